@@ -1,0 +1,255 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/*.npz from the reference itself.
+
+TEST INFRASTRUCTURE (build container only — /root/reference does not exist on the GPU box and
+nothing under tests/ -m gpu, smoke() or bench.py runs this).
+
+What it does: copies /root/reference/pyCamSet into a *temporary* directory (the reference
+code-generates ``template_functions/*.py`` beside its own ``__file__``,
+abstract_function_blocks.py:298-299, :394; matmul_map.py:250-251, and /root/reference is
+read-only), installs the stand-in modules of ``_refstubs.py`` (numba is absent here; njit becomes
+the identity so the reference bodies run as IEEE-754 CPython), runs the reference's own
+function blocks / ``optimisation_function`` / bundle handlers on seeded synthetic problems from
+``pycamset_amd.synthetic`` and stores inputs + outputs.  The temp copy and the files the
+reference generates there are deleted on exit; no reference source enters this repo.
+
+Run:  python tests/golden/make_golden.py     (about a minute)
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import sys
+import tempfile
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+REPO = HERE.parent.parent
+REFERENCE = Path(os.environ.get("PCS_REFERENCE", "/root/reference"))
+sys.path.insert(0, str(REPO))
+sys.path.insert(0, str(HERE))
+
+os.environ.setdefault("MPLBACKEND", "Agg")
+
+import _refstubs  # noqa: E402
+
+from pycamset_amd import synthetic  # noqa: E402
+
+
+class _DuckCamset:
+    """get_names()/get_n_cams() are all the handlers touch (template_handler.py:116-125)."""
+
+    def __init__(self, n):
+        self._names = [f"cam_{i}" for i in range(n)]
+
+    def get_names(self):
+        return list(self._names)
+
+    def get_n_cams(self):
+        return len(self._names)
+
+
+class _DuckTarget:
+    """point_data is all the handlers touch (template_handler.py:120-121, :160-163)."""
+
+    def __init__(self, points):
+        self.point_data = np.array(points, dtype=np.float64)[None]  # (1, K, 3) like ChArUco
+        self.square_size = 1.0
+        self.valid_map = None
+
+
+def unit_vectors(fb, ch):
+    """Known-answer vectors for SURVEY 8a rows a1-a7, including the branch / edge inputs."""
+    rng = np.random.default_rng(7)
+    rvecs = [
+        np.zeros(3), np.array([1e-11, 0.0, 0.0]), np.array([3e-11, -4e-11, 1e-11]),
+        np.array([1e-9, 2e-9, -1e-9]), np.array([1e-5, -2e-5, 3e-5]),
+        np.array([np.pi, 0.0, 0.0]), np.array([0.0, np.pi - 1e-9, 0.0]),
+        np.array([1.2, -2.0, 2.1]), np.array([0.0, 0.0, 1.0]),
+    ] + [rng.normal(0, s, 3) for s in (0.01, 0.1, 0.5, 1.0, 2.0, 3.0)]
+    rvecs = np.array(rvecs)
+    rod = np.empty((len(rvecs), 9))
+    rodj = np.empty((len(rvecs), 27))
+    for i, r in enumerate(rvecs):
+        ch.numba_flat_rodrigues_INPLACE(r.copy(), rod[i])
+        ch.numba_rodrigues_jac(r.copy(), rodj[i])
+
+    n = 40
+    pose6 = np.concatenate([rng.normal(0, 0.6, (n, 3)), rng.normal(0, 0.2, (n, 3))], axis=1)
+    pose6[0, :3] = 0
+    pose6[1, :3] = [2e-11, 0, 0]
+    pts = rng.normal(0, 0.1, (n, 3))
+    e4 = np.empty((n, 12))
+    ht = np.empty((n, 3))
+    rig_fun = np.empty((n, 3))
+    rig_jac = np.empty((n, 27))
+    tmp_jac = np.empty((n, 18))
+    for i in range(n):
+        ch.n_e4x4_flat_INPLACE(pose6[i].copy(), e4[i])
+        ch.n_htform_prealloc(pts[i].copy(), e4[i].copy(), out=ht[i])
+        mem = np.empty(27)
+        fb.rigidTform3d.compute_fun(pose6[i].copy(), pts[i].copy(), rig_fun[i], mem)
+        fb.rigidTform3d.compute_jac(pose6[i].copy(), pts[i].copy(), rig_jac[i], np.empty(27))
+        out18 = np.empty(18)
+        fb.template_points.compute_jac(pose6[i].copy(), pts[i].copy(), out18, np.empty(27))
+        tmp_jac[i] = out18
+
+    intr = np.empty((n, 9))
+    intr[:, 0] = rng.uniform(900, 1100, n)
+    intr[:, 1] = rng.uniform(480, 520, n)
+    intr[:, 2] = rng.uniform(900, 1100, n)
+    intr[:, 3] = rng.uniform(480, 520, n)
+    intr[:, 4] = rng.normal(0, 0.05, n)
+    intr[:, 5] = rng.normal(0, 0.01, n)
+    intr[:, 6:8] = rng.normal(0, 1e-3, (n, 2))
+    intr[:, 8] = rng.normal(0, 1e-3, n)
+    xc = np.stack([rng.normal(0, 0.05, n), rng.normal(0, 0.05, n), rng.uniform(0.1, 0.4, n)], axis=1)
+    xc[0] = [0.3, -0.2, 0.011]     # small z: large normalised radius
+    xc[1] = [0.0, 0.0, 0.25]       # on the axis
+    xc[2] = [0.02, 0.01, -0.3]     # behind the camera: formulas still evaluate
+    xc[3] = [1.0, 1.0, 1.0]        # all-ones point used by abstract_function_block.test_self (afb:750-775)
+    intr[3] = 1.0
+    pj_fun = np.empty((n, 2))
+    pj_jac = np.empty((n, 24))
+    for i in range(n):
+        fb.projection.compute_fun(intr[i].copy(), xc[i].copy(), pj_fun[i], np.empty(1))
+        fb.projection.compute_jac(intr[i].copy(), xc[i].copy(), pj_jac[i], np.empty(1))
+    fp_fun = np.empty(3)
+    fp_jac = np.empty(9)
+    fb.free_point.compute_fun(np.array([0.1, -0.2, 0.3]), np.empty(0), fp_fun, np.empty(0))
+    fb.free_point.compute_jac(np.array([0.1, -0.2, 0.3]), np.empty(0), fp_jac, np.empty(0))
+    return dict(rvecs=rvecs, rodrigues=rod, rodrigues_jac=rodj, pose6=pose6, pts=pts, e4x4=e4, htform=ht,
+                rigid_fun=rig_fun, rigid_jac=rig_jac, template_jac=tmp_jac,
+                intr=intr, xc=xc, proj_fun=pj_fun, proj_jac=pj_jac, free_fun=fp_fun, free_jac=fp_jac)
+
+
+def chain_blocks(fb, chain):
+    if chain == "template":
+        return fb.projection() + fb.extrinsic3D() + fb.template_points()
+    if chain == "self":
+        return fb.projection() + fb.extrinsic3D() + fb.rigidTform3d() + fb.free_point()
+    if chain == "free":
+        return fb.projection() + fb.extrinsic3D() + fb.free_point()
+    raise ValueError(chain)
+
+
+def chain_slabs(rig, chain):
+    if chain == "template":
+        return [rig.intr, rig.extr, rig.poses]
+    if chain == "self":
+        return [rig.intr, rig.extr, rig.poses, rig.points]
+    # free-point chain: the points live directly in the world frame; reuse image 0's frame.
+    return [rig.intr, rig.extr, rig.points]
+
+
+def block_level(fb, rig, chain, threads_list=(1, 3), seed=0):
+    """optimisation_function API (abstract_function_blocks.py:656-681) on a synthetic rig."""
+    rng = np.random.default_rng(seed)
+    out = {}
+    dd = rig.detections
+    template = rig.points if chain == "template" else None
+    op = chain_blocks(fb, chain)
+    param_str = op.build_param_list(*chain_slabs(rig, chain))
+    out["detections"] = dd
+    out["param_str"] = param_str
+    out["points"] = rig.points
+    out["intr"], out["extr"], out["poses"] = rig.intr, rig.extr, rig.poses
+    n_par = param_str.shape[0]
+    unfixed = rng.random(n_par) > 0.25
+    unfixed[:3] = [True, False, True]
+    out["unfixed"] = unfixed
+    for t in threads_list:
+        loss = op.make_full_loss_fn(dd, t)
+        out[f"resid_t{t}"] = np.array(loss(param_str, template)) if template is not None else np.array(loss(param_str))
+        jac_all = op.make_jacobean(dd, t)
+        d, c, rp = jac_all(param_str, template) if template is not None else jac_all(param_str)
+        out[f"data_all_t{t}"], out[f"indices_all_t{t}"], out[f"indptr_all_t{t}"] = np.array(d), np.array(c), np.array(rp)
+        jac_m = op.make_jacobean(dd, t, unfixed_params=unfixed)
+        d, c, rp = jac_m(param_str, template) if template is not None else jac_m(param_str)
+        out[f"data_masked_t{t}"], out[f"indices_masked_t{t}"], out[f"indptr_masked_t{t}"] = np.array(d), np.array(c), np.array(rp)
+    bpi = op.get_block_param_inds(dd, 1, unthreaded=True)
+    out["block_param_inds"] = np.array(bpi).astype(np.int64)
+    return out
+
+
+def handler_level(mods, rig, chain, fixed_cam_ext=True):
+    """ParamHandler surface (template_handler.py:157-193, standard_bundle_handler.py:184-226,
+    free_point_handler.py:145-186): x -> residual vector, csr_array."""
+    th, sbh, fph, TargetDetection = mods
+    camset = _DuckCamset(rig.n_cams)
+    target = _DuckTarget(rig.points)
+    det = TargetDetection(cam_names=camset.get_names(), data=rig.detections.copy())
+    fixed = None
+    if fixed_cam_ext:
+        fixed = {"cam_0": {"ext": rig.extr[0].copy()}, "cam_1": {"int": rig.intr[1].copy()}}
+    cls = {"template": th.TemplateBundleHandler, "self": sbh.SelfBundleHandler, "free": fph.FreePointBundleHandler}[chain]
+    h = cls(camset, target, det, fixed_params=fixed, options={"verbosity": 0})
+    bp = h.bundlePrimitive
+    parts = [rig.intr[bp.intr_unfixed].ravel(), rig.extr[bp.extr_unfixed].ravel()]
+    if chain != "free":
+        parts.append(rig.poses[bp.poses_unfixed].ravel())
+    if chain != "template":
+        parts.append(rig.points.ravel()[bp.bdpt_unfixed])
+    x = np.concatenate(parts)
+    loss = h.make_loss_fun(2)
+    jac = h.make_loss_jac(2)
+    r = np.array(loss(x.copy()))
+    J = jac(x.copy())
+    out = dict(detections=rig.detections, points=rig.points, x=x, resid=r,
+               data=np.array(J.data), indices=np.array(J.indices), indptr=np.array(J.indptr),
+               shape=np.array(J.shape), intr0=rig.intr, extr0=rig.extr, poses0=rig.poses,
+               intr_unfixed=np.array(bp.intr_unfixed), extr_unfixed=np.array(bp.extr_unfixed))
+    if chain != "free":
+        out["poses_unfixed"] = np.array(bp.poses_unfixed)
+    if chain != "template":
+        out["bdpt_unfixed"] = np.array(bp.bdpt_unfixed)
+    if fixed_cam_ext:
+        out["fixed_ext_cam0"] = rig.extr[0].copy()
+        out["fixed_int_cam1"] = rig.intr[1].copy()
+    return out
+
+
+def main():
+    if not (REFERENCE / "pyCamSet").is_dir():
+        raise SystemExit(f"reference not found at {REFERENCE}")
+    tmp = Path(tempfile.mkdtemp(prefix="pcs_ref_"))
+    try:
+        shutil.copytree(REFERENCE / "pyCamSet", tmp / "pyCamSet")
+        for p in (tmp / "pyCamSet").rglob("*"):
+            os.chmod(p, 0o755 if p.is_dir() else 0o644)
+        os.chmod(tmp / "pyCamSet", 0o755)
+        _refstubs.install()
+        sys.path.insert(0, str(tmp))
+        import pyCamSet.optimisation.compiled_helpers as ch
+        import pyCamSet.optimisation.function_block_implementations as fb
+        import pyCamSet.optimisation.template_handler as th
+        import pyCamSet.optimisation.standard_bundle_handler as sbh
+        import pyCamSet.optimisation.free_point_handler as fph
+        from pyCamSet.calibration_targets import TargetDetection
+
+        np.savez_compressed(HERE / "unit_vectors.npz", **unit_vectors(fb, ch))
+        print("unit vectors done")
+
+        tiny = synthetic.tiny_rig(seed=0)
+        medium = synthetic.make_rig("medium", 4, 20, synthetic.ccube_points(), seed=11, visibility=0.026)
+        print("tiny N =", tiny.n_det, " medium N =", medium.n_det)
+        for chain in ("template", "self", "free"):
+            for tag, rig in (("tiny", tiny), ("medium", medium)):
+                res = block_level(fb, rig, chain, threads_list=(1, 3) if tag == "tiny" else (4,))
+                np.savez_compressed(HERE / f"block_{chain}_{tag}.npz", **res)
+                print("block", chain, tag, "nnz_all", res[[k for k in res if k.startswith('data_all')][0]].shape)
+        mods = (th, sbh, fph, TargetDetection)
+        for chain in ("template", "self", "free"):
+            for tag, rig, fx in (("tiny", tiny, True), ("tiny_nofix", tiny, False)):
+                th.DEFAULT_OPTIONS.update({"fixed_pose": 0})
+                res = handler_level(mods, rig, chain, fixed_cam_ext=fx)
+                np.savez_compressed(HERE / f"handler_{chain}_{tag}.npz", **res)
+                print("handler", chain, tag, "J shape", res["shape"], "nnz", res["data"].shape)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    main()
