@@ -1,0 +1,169 @@
+"""Python face of the CPU oracle (TEST INFRASTRUCTURE — see ba_oracle.c header).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+The product package ``pycamset_amd`` never does.
+
+Floating-point work is in ba_oracle.c (ctypes); the integer/index bookkeeping of the reference
+(param-string layout, per-detection column table, static CSR structure, fixed-parameter masking)
+is restated here in NumPy.  Citations: afb = pyCamSet/optimisation/abstract_function_blocks.py,
+th = template_handler.py, sbh = standard_bundle_handler.py, fph = free_point_handler.py.
+
+Parity status: PINNED against tests/golden/*.npz (generated from the reference itself).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+CHAINS = {"template": 0, "self": 1, "free": 2}
+CHAIN_P = {"template": 21, "self": 24, "free": 18}
+
+_c_double_p = ctypes.POINTER(ctypes.c_double)
+_libs: dict[str, ctypes.CDLL] = {}
+
+
+def build(force: bool = False) -> None:
+    """Compile oracle/ba_oracle.c (gcc) if the shared objects are missing."""
+    if force or not (_HERE / "libba_oracle.so").exists() or not (_HERE / "libba_oracle_fast.so").exists():
+        subprocess.run(["make", "-C", str(_HERE)] + (["-B"] if force else []), check=True, capture_output=True)
+
+
+def _lib(fast: bool = False) -> ctypes.CDLL:
+    name = "libba_oracle_fast.so" if fast else "libba_oracle.so"
+    if name not in _libs:
+        build()
+        lib = ctypes.CDLL(str(_HERE / name))
+        i64, dp, ci = ctypes.c_int64, _c_double_p, ctypes.c_int
+        lib.orc_full_loss.argtypes = [ci, i64, dp, dp, i64, i64, dp, dp, ci]
+        lib.orc_full_loss.restype = ci
+        lib.orc_full_jac.argtypes = [ci, i64, dp, dp, i64, i64, dp, dp, dp, ci]
+        lib.orc_full_jac.restype = ci
+        lib.orc_max_threads.restype = ci
+        for fn, n in (("orc_rodrigues", 2), ("orc_rodrigues_jac", 2), ("orc_e4x4_flat", 2), ("orc_htform", 3),
+                      ("orc_projection_fun", 3), ("orc_projection_jac", 3), ("orc_rigid_fun", 3),
+                      ("orc_rigid_jac", 3), ("orc_template_jac", 3)):
+            getattr(lib, fn).argtypes = [dp] * n
+            getattr(lib, fn).restype = None
+        _libs[name] = lib
+    return _libs[name]
+
+
+def _p(a: np.ndarray):
+    return a.ctypes.data_as(_c_double_p)
+
+
+def _f64(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+# ---- unit functions -------------------------------------------------
+def call_unit(name: str, out_len: int, *arrays) -> np.ndarray:
+    """Call one of the small C functions ``orc_<name>(in..., out)``."""
+    ins = [_f64(a) for a in arrays]
+    out = np.empty(out_len)
+    getattr(_lib(), f"orc_{name}")(*[_p(a) for a in ins], _p(out))
+    return out
+
+
+# ---- param-string layout and static structure (a11, a12) -----------------------------------
+def counts_from_detections(det: np.ndarray) -> tuple[int, int, int]:
+    """make_param_struct counts: max index + 1 per link type (afb:793-795)."""
+    return int(det[:, 0].max()) + 1, int(det[:, 1].max()) + 1, int(det[:, 2].max()) + 1
+
+
+def param_struct(chain: str, det: np.ndarray):
+    """(starts, n_params, total) of the unique parameter groups in block order (afb:804-820)."""
+    C, I, K = counts_from_detections(det)
+    groups = {"template": [(9, C), (6, C), (6, I)],
+              "self": [(9, C), (6, C), (6, I), (3, K)],
+              "free": [(9, C), (6, C), (3, K)]}[chain]
+    starts, total = [], 0
+    for n, cnt in groups:
+        starts.append(total)
+        total += n * cnt
+    return np.array(starts), np.array([g[0] for g in groups]), total
+
+
+def block_param_inds(chain: str, det: np.ndarray) -> np.ndarray:
+    """Per-detection global column of every local parameter, (N, P) (afb:211-217, unthreaded)."""
+    starts, npar, _ = param_struct(chain, det)
+    key_col = {"template": [0, 0, 1], "self": [0, 0, 1, 2], "free": [0, 0, 2]}[chain]
+    cols = []
+    for s, n, kc in zip(starts, npar, key_col):
+        idx = det[:, kc].astype(np.int64)
+        cols.append(s + idx[:, None] * n + np.arange(n)[None, :])
+    return np.concatenate(cols, axis=1)
+
+
+def csr_structure(chain: str, det: np.ndarray, unfixed: np.ndarray):
+    """make_jac_CSR_columns_row_pointers (afb:465-489): static indices / indptr."""
+    c = np.repeat(block_param_inds(chain, det), 2, axis=0)
+    unfixed = np.asarray(unfixed, dtype=bool)
+    conversion = np.concatenate([[0], np.cumsum(unfixed)])
+    mask = unfixed[c]
+    indices = conversion[c][mask]
+    indptr = np.concatenate([[0], np.cumsum(mask.sum(axis=1))])
+    return indices.astype(np.int64), indptr.astype(np.int64), mask
+
+
+def build_param_list(*arrays) -> np.ndarray:
+    """afb:669-681: flatten + concatenate in block order."""
+    return np.concatenate([np.asarray(a, dtype=np.float64).ravel() for a in arrays])
+
+
+# ---- drivers (a9, a10) ---------------------------------------------------------------------
+def full_loss(chain: str, det: np.ndarray, param_str: np.ndarray, template=None, threads: int = 1,
+              fast: bool = False) -> np.ndarray:
+    det, param_str = _f64(det), _f64(param_str)
+    C, I, _ = counts_from_detections(det)
+    t = _f64(template) if template is not None else None
+    out = np.empty((det.shape[0], 2))
+    rc = _lib(fast).orc_full_loss(CHAINS[chain], det.shape[0], _p(det), _p(param_str), C, I,
+                                  _p(t) if t is not None else None, _p(out), threads)
+    if rc:
+        raise ValueError("orc_full_loss: bad arguments")
+    return out
+
+
+def full_jac_dense(chain: str, det: np.ndarray, param_str: np.ndarray, template=None, threads: int = 1,
+                   fast: bool = False, with_resid: bool = False):
+    """Dense (2N, P) block rows = generated full_jac output after afb:641."""
+    det, param_str = _f64(det), _f64(param_str)
+    C, I, _ = counts_from_detections(det)
+    t = _f64(template) if template is not None else None
+    P = CHAIN_P[chain]
+    dense = np.empty((2 * det.shape[0], P))
+    res = np.empty((det.shape[0], 2)) if with_resid else None
+    rc = _lib(fast).orc_full_jac(CHAINS[chain], det.shape[0], _p(det), _p(param_str), C, I,
+                                 _p(t) if t is not None else None, _p(dense), _p(res) if with_resid else None, threads)
+    if rc:
+        raise ValueError("orc_full_jac: bad arguments")
+    return (dense, res) if with_resid else dense
+
+
+def jac_csr(chain: str, det: np.ndarray, param_str: np.ndarray, template=None, unfixed=None, threads: int = 1):
+    """jac_fn wrapper (afb:627-652): (data, indices, indptr) with fixed columns dropped."""
+    dense = full_jac_dense(chain, det, param_str, template, threads)
+    if unfixed is None:
+        unfixed = np.ones(param_struct(chain, det)[2], dtype=bool)
+    indices, indptr, mask = csr_structure(chain, det, unfixed)
+    return dense[mask], indices, indptr
+
+
+# ---- handler-level x -> slabs (a13, a14) ----------------------------------------------------
+def scatter_free(x_part: np.ndarray, full: np.ndarray, unfixed: np.ndarray) -> None:
+    """ch.fill_flat (compiled_helpers.py:155-177): write free rows/scalars into the full slab."""
+    full[np.asarray(unfixed, dtype=bool)] = x_part
+
+
+def max_threads() -> int:
+    return int(_lib(True).orc_max_threads())
+
+
+def cpu_count() -> int:
+    return os.cpu_count() or 1

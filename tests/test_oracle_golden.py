@@ -1,0 +1,105 @@
+"""Pin the CPU oracle (oracle/ba_oracle.c + oracle/ba_oracle.py) to the golden vectors that
+tests/golden/make_golden.py produced by running the reference's own Python sources.
+
+Tolerance rule (FP64): |a - b| <= RTOL * max(|ref|, ROW_FLOOR * ||row||_inf), RTOL = 5e-12,
+ROW_FLOOR = 1e-6.  The oracle multiplies out integer powers where CPython called libm pow(), so
+last-bit differences are expected and are amplified on the cancelling chain-rule entries
+(measured: 1.6e-12 element-relative, 5e-16 relative to the row maximum; built with
+-DORC_LIBM_POW 82% of all Jacobian entries are bit-identical to the goldens).  5e-12 is 20x
+tighter than the 1e-10 product tolerance.
+Index / structure arrays must match bit-exactly.
+"""
+import numpy as np
+import pytest
+
+from oracle import ba_oracle as orc
+
+RTOL = 5e-12
+ROW_FLOOR = 1e-6
+
+
+def assert_close(a, b, rtol=RTOL, rows=None):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape
+    if rows is None:
+        scale = np.maximum(np.abs(b), ROW_FLOOR * np.max(np.abs(b))) if b.size else b
+    else:
+        scale = np.maximum(np.abs(b), ROW_FLOOR * rows)
+    err = np.abs(a - b)
+    bad = err > rtol * scale
+    assert not bad.any(), f"max rel err {np.max(err / scale):.3e} at {np.argwhere(bad)[:5]}"
+
+
+@pytest.fixture(scope="module")
+def unit(golden_dir):
+    return np.load(golden_dir / "unit_vectors.npz")
+
+
+def test_rodrigues_and_jacobian_incl_small_angle_branch(unit):
+    for r, R, dR in zip(unit["rvecs"], unit["rodrigues"], unit["rodrigues_jac"]):
+        assert_close(orc.call_unit("rodrigues", 9, r), R)
+        assert_close(orc.call_unit("rodrigues_jac", 27, r), dR)
+    # exact branch outputs (compiled_helpers.py:206-211, :246-254)
+    assert np.array_equal(orc.call_unit("rodrigues", 9, np.zeros(3)), np.eye(3).ravel())
+    g = orc.call_unit("rodrigues_jac", 27, np.array([1e-11, 0, 0]))
+    assert g[5] == -1 and g[7] == 1 and g[11] == 1 and g[15] == -1 and g[19] == -1 and g[21] == 1
+    assert np.count_nonzero(g) == 6
+
+
+def test_se3_helpers(unit):
+    for p6, pt, e4, ht, rf, rj, tj in zip(unit["pose6"], unit["pts"], unit["e4x4"], unit["htform"],
+                                           unit["rigid_fun"], unit["rigid_jac"], unit["template_jac"]):
+        assert_close(orc.call_unit("e4x4_flat", 12, p6), e4)
+        assert_close(orc.call_unit("htform", 3, pt, e4), ht)
+        assert_close(orc.call_unit("rigid_fun", 3, p6, pt), rf)
+        assert_close(orc.call_unit("rigid_jac", 27, p6, pt), rj)
+        assert_close(orc.call_unit("template_jac", 18, p6, pt), tj)
+
+
+def test_projection_fun_and_jac(unit):
+    for prm, xc, f, j in zip(unit["intr"], unit["xc"], unit["proj_fun"], unit["proj_jac"]):
+        assert_close(orc.call_unit("projection_fun", 2, prm, xc), f)
+        assert_close(orc.call_unit("projection_jac", 24, prm, xc), j)
+    # structural constants of the 2x12 block (function_block_implementations.py:58-60, :67, :99-103)
+    j = orc.call_unit("projection_jac", 24, unit["intr"][5], unit["xc"][5])
+    assert j[1] == 1 and j[2] == 0 and j[3] == 0 and j[12] == 0 and j[13] == 0 and j[15] == 1
+
+
+@pytest.mark.parametrize("chain", ["template", "self", "free"])
+@pytest.mark.parametrize("tag", ["tiny", "medium"])
+def test_block_level_chain(golden_dir, chain, tag):
+    g = np.load(golden_dir / f"block_{chain}_{tag}.npz")
+    det, ps = g["detections"], g["param_str"]
+    tmpl = g["points"] if chain == "template" else None
+    threads = [1, 3] if tag == "tiny" else [4]
+    P = orc.CHAIN_P[chain]
+    # layout + structure are integer work: exact
+    assert np.array_equal(orc.block_param_inds(chain, det), g["block_param_inds"])
+    assert orc.param_struct(chain, det)[2] == ps.shape[0]
+    res = orc.full_loss(chain, det, ps, tmpl)
+    dense = orc.full_jac_dense(chain, det, ps, tmpl)
+    rows = np.max(np.abs(dense), axis=1, keepdims=True)
+    for t in threads:
+        # thread count only changes the reference's chunk padding, never the result (afb:281-288, :385, :641)
+        assert_close(res, g[f"resid_t{t}"], rtol=1e-11)
+        assert_close(dense, g[f"data_all_t{t}"].reshape(-1, P), rows=rows)
+        idx, ptr, mask = orc.csr_structure(chain, det, np.ones(ps.shape[0], bool))
+        assert np.array_equal(idx, g[f"indices_all_t{t}"]) and np.array_equal(ptr, g[f"indptr_all_t{t}"])
+        data, idx, ptr = orc.jac_csr(chain, det, ps, tmpl, unfixed=g["unfixed"])
+        assert np.array_equal(idx, g[f"indices_masked_t{t}"]) and np.array_equal(ptr, g[f"indptr_masked_t{t}"])
+        gd = g[f"data_masked_t{t}"]
+        _, _, m = orc.csr_structure(chain, det, g["unfixed"])
+        assert_close(data, gd, rows=np.broadcast_to(rows, dense.shape)[m])
+    # explicit structural entries stay stored: 4 zeros and 2 ones per detection in the intrinsic block
+    d = dense.reshape(-1, 2, P)
+    assert np.all(d[:, 0, 1] == 1) and np.all(d[:, 1, 3] == 1)
+    assert np.all(d[:, 0, 2] == 0) and np.all(d[:, 0, 3] == 0) and np.all(d[:, 1, 0] == 0) and np.all(d[:, 1, 1] == 0)
+
+
+def test_oracle_fast_build_agrees(golden_dir):
+    g = np.load(golden_dir / "block_self_medium.npz")
+    a = orc.full_jac_dense("self", g["detections"], g["param_str"], None, threads=1)
+    b, r = orc.full_jac_dense("self", g["detections"], g["param_str"], None, threads=4, fast=True, with_resid=True)
+    rows = np.max(np.abs(a), axis=1, keepdims=True)
+    assert_close(b, a, rtol=1e-11, rows=rows)
+    assert_close(r, g["resid_t4"], rtol=1e-10)
