@@ -1,0 +1,144 @@
+/*
+ * pcs_hip.h — C ABI of the MI355X bundle-adjustment cost/Jacobian engine (libpcs_hip.so).
+ *
+ * Drop-in boundary for pyCamSet's optimisation hot path.  Every entry point names the
+ * reference interface it replaces (paths relative to the reference repo, pyCamSet/optimisation/
+ * unless stated: afb = abstract_function_blocks.py, th = template_handler.py,
+ * sbh = standard_bundle_handler.py, fph = free_point_handler.py,
+ * td = ../calibration_targets/target_detections.py).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no C++/torch types cross the boundary.
+ *   - every function returns PCS_OK (0) or a negative pcs_status; pcs_last_error() gives text
+ *     for the calling thread's most recent failure.  No exception crosses the ABI.
+ *   - the caller owns every buffer it passes; the engine owns its device buffers for the
+ *     lifetime of the handle.  One handle = one host thread at a time.
+ *   - numerical inf/nan (e.g. a point on the camera plane, z = 0) pass through unchanged,
+ *     as in the reference's numba code.
+ *   - there is NO CPU fallback: without a HIP device pcs_create fails with PCS_ERR_NODEVICE.
+ */
+#ifndef PCS_HIP_H
+#define PCS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pcs_engine pcs_engine;
+
+typedef enum {
+    PCS_OK = 0,
+    PCS_ERR_ARG = -1,      /* null pointer, bad enum, bad size */
+    PCS_ERR_HIP = -2,      /* a HIP runtime call failed (text in pcs_last_error) */
+    PCS_ERR_STATE = -3,    /* detections / template / structure not set yet */
+    PCS_ERR_NODEVICE = -4, /* no usable HIP device */
+    PCS_ERR_RANGE = -5     /* a detection indexes outside [0,n_cams) x [0,n_imgs) x [0,n_keys) */
+} pcs_status;
+
+/* Function-block chains (the three `op_fun` sums the reference handlers build). */
+typedef enum {
+    PCS_CHAIN_TEMPLATE = 0, /* projection + extrinsic3D + template_points          th:152   P = 21 */
+    PCS_CHAIN_SELF = 1,     /* projection + extrinsic3D + rigidTform3d + free_point sbh:182  P = 24 */
+    PCS_CHAIN_FREE = 2      /* projection + extrinsic3D + free_point                fph:143  P = 18 */
+} pcs_chain;
+
+typedef enum { PCS_F64 = 0, PCS_F32 = 1 } pcs_dtype;
+
+/* Library / build identification. */
+int pcs_version(void);
+const char *pcs_last_error(void);
+/* Number of HIP devices visible (0 when none); never fails. */
+int pcs_device_count(void);
+
+/*
+ * Create an engine for one chain on one device.
+ * Replaces: optimisation_function.__init__/_prep_for_computation (afb:111-190) +
+ *           make_param_struct (afb:777-820).  The reference derives the group counts from the
+ *           detection table (max index + 1, afb:793-795); here they are explicit arguments.
+ * Parameter-string layout (same as the reference):
+ *   intr 9*c+j | extr 9*C + 6*c+j | pose 15*C + 6*i+j (chains T,S) | point (15*C+6*I | 15*C) + 3*k+j (S | F)
+ */
+int pcs_create(pcs_engine **out, int chain, int dtype, int64_t n_cams, int64_t n_imgs, int64_t n_keys, int device);
+int pcs_destroy(pcs_engine *h);
+
+int64_t pcs_n_params(const pcs_engine *h);     /* length of the full parameter string */
+int pcs_row_len(const pcs_engine *h);          /* P: dense Jacobian entries per row */
+int64_t pcs_n_detections(const pcs_engine *h); /* N */
+
+/*
+ * Upload the static detection table.
+ * Replaces: the closure state captured by make_full_loss_template / make_full_jac_template
+ *           (_reshape_data_for_parallel afb:281-288, get_block_param_inds afb:192-233).
+ * pcs_set_detections_table takes the reference's own (N,5) float64 table
+ * [cam, im, key, u, v] (td:51-55 after return_flattened_keys td:333-351); indices are cast with
+ * (int) like afb:214 / afb:375.  pcs_set_detections takes the split form.
+ * Indices are range-checked against the counts given to pcs_create -> PCS_ERR_RANGE.
+ */
+int pcs_set_detections_table(pcs_engine *h, const double *det5, int64_t n);
+int pcs_set_detections(pcs_engine *h, const int32_t *cam, const int32_t *img, const int32_t *key,
+                       const double *uv /* n x 2 */, int64_t n);
+
+/*
+ * Upload the constant template points (chain TEMPLATE only), (n_keys, 3) float64.
+ * Replaces: the `template` argument of the generated loss/jac (afb:352-354, afb:374-375;
+ *           th:160, th:174 `target.point_data.reshape((-1, 3))`).
+ */
+int pcs_set_template(pcs_engine *h, const double *points);
+
+/*
+ * One evaluation at a full parameter string (host buffers, synchronous).
+ * Replaces: generated full_loss (afb:350-387) and full_jac (afb:552-599) + the [:n_elements]
+ *           truncation (afb:641).
+ *   resid : (N,2) row-major  = projected - measured            (afb:384) or NULL
+ *   jac   : (2N,P) row-major dense block rows, u row then v row (afb:591-594) or NULL
+ * Both are float64 on the host whatever the engine dtype (an F32 engine computes and stores
+ * float32 on the device and widens on the way out).
+ */
+int pcs_eval(pcs_engine *h, const double *param_str, double *resid, double *jac);
+
+/*
+ * Same evaluation, asynchronous, outputs left in device memory (engine dtype), launched on
+ * `stream` (a hipStream_t passed as void*, NULL = the engine's own stream).
+ *   d_resid : device pointer, N*2 elements, or NULL
+ *   d_jac   : device pointer, 2N*P elements, or NULL
+ * param_str is a host pointer (copied through a pinned staging buffer); use
+ * pcs_eval_device_resident when the parameter string already lives on the device.
+ */
+int pcs_eval_device(pcs_engine *h, const double *param_str, void *d_resid, void *d_jac, void *stream);
+int pcs_eval_device_resident(pcs_engine *h, const double *d_param_str, void *d_resid, void *d_jac, void *stream);
+
+/*
+ * Static CSR structure for a given fixed-parameter mask.
+ * Replaces: make_jac_CSR_columns_row_pointers (afb:465-489).
+ *   unfixed : n_params bytes (non-zero = free), NULL = all free
+ *   indices : nnz int64 (pass NULL to only query nnz), indptr : 2N+1 int64 (may be NULL)
+ */
+int pcs_csr_structure(pcs_engine *h, const uint8_t *unfixed, int64_t *indices, int64_t *indptr, int64_t *nnz);
+/* Per-detection global column table (N,P) int64.  Replaces: get_block_param_inds(unthreaded) afb:192-233. */
+int pcs_block_param_inds(pcs_engine *h, int64_t *out);
+
+/*
+ * Fixed-parameter compaction on the device.
+ * Replaces: `data[:n_elements][good_mask]` (afb:627-651) — the reference's per-call host
+ * boolean-mask copy.  pcs_set_unfixed prepares the static per-row offsets; pcs_eval_compact
+ * writes only the unfixed entries, in CSR data order.
+ */
+int pcs_set_unfixed(pcs_engine *h, const uint8_t *unfixed, int64_t *nnz);
+int pcs_eval_compact(pcs_engine *h, const double *param_str, double *resid, double *data /* nnz */);
+int pcs_eval_compact_device(pcs_engine *h, const double *param_str, void *d_resid, void *d_data, void *stream);
+
+/* Block until everything queued on `stream` (NULL = engine stream) has finished. */
+int pcs_synchronize(pcs_engine *h, void *stream);
+/* Duration of the most recent evaluation's kernels (HIP events on the launch stream), ms. */
+int pcs_last_kernel_ms(pcs_engine *h, float *slab_prep_ms, float *eval_ms);
+/* Tuning knobs (launch geometry); see DESIGN.md.  Unknown keys -> PCS_ERR_ARG. */
+int pcs_set_option(pcs_engine *h, const char *key, int64_t value);
+/* Engine-owned device scratch for outputs (engine dtype); valid until the next set_detections. */
+int pcs_device_buffers(pcs_engine *h, void **d_resid, void **d_jac);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCS_HIP_H */

@@ -118,9 +118,11 @@ def build_param_list(*arrays) -> np.ndarray:
 
 # ---- drivers (a9, a10) ---------------------------------------------------------------------
 def full_loss(chain: str, det: np.ndarray, param_str: np.ndarray, template=None, threads: int = 1,
-              fast: bool = False) -> np.ndarray:
+              fast: bool = False, counts=None) -> np.ndarray:
+    """``counts`` = (n_cams, n_imgs[, n_keys]) overrides the max-index+1 rule (for evaluating a
+    slice of a larger table against the full parameter string)."""
     det, param_str = _f64(det), _f64(param_str)
-    C, I, _ = counts_from_detections(det)
+    C, I = counts[:2] if counts is not None else counts_from_detections(det)[:2]
     t = _f64(template) if template is not None else None
     out = np.empty((det.shape[0], 2))
     rc = _lib(fast).orc_full_loss(CHAINS[chain], det.shape[0], _p(det), _p(param_str), C, I,
@@ -131,10 +133,10 @@ def full_loss(chain: str, det: np.ndarray, param_str: np.ndarray, template=None,
 
 
 def full_jac_dense(chain: str, det: np.ndarray, param_str: np.ndarray, template=None, threads: int = 1,
-                   fast: bool = False, with_resid: bool = False):
+                   fast: bool = False, with_resid: bool = False, counts=None):
     """Dense (2N, P) block rows = generated full_jac output after afb:641."""
     det, param_str = _f64(det), _f64(param_str)
-    C, I, _ = counts_from_detections(det)
+    C, I = counts[:2] if counts is not None else counts_from_detections(det)[:2]
     t = _f64(template) if template is not None else None
     P = CHAIN_P[chain]
     dense = np.empty((2 * det.shape[0], P))

@@ -1,0 +1,206 @@
+// ba_device.hpp — per-entity and per-detection device math of the bundle-adjustment hot path.
+//
+// gfx950 (CDNA4) only.  Everything is templated on the scalar type (double / float).
+//
+// What the reference evaluates per detection (pyCamSet/optimisation/, fbi =
+// function_block_implementations.py, ch = compiled_helpers.py, mm = matmul_map.py):
+//     pose  SE3 (fbi:150-155, :188-211)  ->  extrinsic SE3 (fbi:184-185, :157-182)  ->
+//     pinhole + Brown-Conrady (fbi:27-140)  ->  chain rule `matflow` (generator mm:147-243)
+// including Rodrigues (ch:197-235) and its Jacobian (ch:237-286) three resp. two times per
+// detection.  Here the transcendental part is hoisted: `slab_prep` evaluates R, t, dR/dr once
+// per camera and once per pose ("slabs"), and the per-detection code is FMAs plus one divide.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace pcs {
+
+constexpr int CHAIN_TEMPLATE = 0;
+constexpr int CHAIN_SELF = 1;
+constexpr int CHAIN_FREE = 2;
+
+__host__ __device__ constexpr int chain_P(int chain) { return chain == CHAIN_TEMPLATE ? 21 : chain == CHAIN_SELF ? 24 : 18; }
+
+// Slab layouts, in scalars.  Strides are multiples of 16 bytes for both dtypes.
+//   camera slab : [0,9) intr fx,px,fy,py,k0,k1,p0,p1,k2 | [9,18) R_e row-major | [18,21) t_e |
+//                 [21,48) dR_e[a*9 + row*3 + col] = d R_e[row][col] / d r_a
+//   pose slab   : [0,9) R_p | [9,12) t_p | [12,39) dR_p | [39] pad
+constexpr int CAM_STRIDE = 48;
+constexpr int POSE_STRIDE = 40;
+constexpr int CAM_R = 9, CAM_T = 18, CAM_DR = 21;
+constexpr int POSE_R = 0, POSE_T = 9, POSE_DR = 12;
+
+// Rodrigues rotation and its derivative from a rotation vector, in double whatever the slab
+// dtype.  Same formulas and the same theta < 1e-10 branches as ch:205-234 and ch:244-286
+// (pose 0 is exactly zero by default, template_handler.py:134-137, so the branch is live).
+__device__ inline void rodrigues_and_jac(const double r0, const double r1, const double r2, double (&R)[9], double (&dR)[27]) {
+    const double theta = sqrt(r0 * r0 + r1 * r1 + r2 * r2);
+    if (theta < 1e-10) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) R[i] = 0.0;
+        R[0] = 1.0; R[4] = 1.0; R[8] = 1.0;
+#pragma unroll
+        for (int i = 0; i < 27; ++i) dR[i] = 0.0;
+        dR[5] = -1.0; dR[15] = -1.0; dR[19] = -1.0;
+        dR[7] = 1.0; dR[11] = 1.0; dR[21] = 1.0;
+        return;
+    }
+    const double it = 1.0 / theta;
+    double st, ct;
+    sincos(theta, &st, &ct);
+    const double r[3] = {r0, r1, r2};
+    {   // R = ct*I + (1-ct)/theta^2 * r r^T + st/theta * [r]x      (un-normalised r, ch:213-234)
+        const double f = (1.0 - ct) * (it * it);
+        const double s = st * it;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) R[3 * i + j] = (r[i] * r[j]) * f;
+        R[0] += ct; R[4] += ct; R[8] += ct;
+        R[1] -= r2 * s; R[3] += r2 * s;
+        R[2] += r1 * s; R[6] -= r1 * s;
+        R[5] -= r0 * s; R[7] += r0 * s;
+    }
+    {   // dR/dr_a = a0*I + a1*rr^T + a2*d(rr^T)/dr_a + a3*[r]x + a4*d[r]x/dr_a on the unit axis (ch:256-286)
+        const double x = r0 * it, y = r1 * it, z = r2 * it;
+        const double ct_1 = 1.0 - ct;
+        const double rrt[9] = {x * x, x * y, x * z, x * y, y * y, y * z, x * z, y * z, z * z};
+        const double r_x[9] = {0, -z, y, z, 0, -x, -y, x, 0};
+        const double drrt[27] = {x + x, y, z, y, 0, 0, z, 0, 0, 0, x, 0, x, y + y, z, 0, z, 0, 0, 0, x, 0, 0, y, x, y, z + z};
+        const double drx[27] = {0, 0, 0, 0, 0, -1, 0, 1, 0, 0, 0, 1, 0, 0, 0, -1, 0, 0, 0, -1, 0, 1, 0, 0, 0, 0, 0};
+        const double ax[3] = {x, y, z};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const double ri = ax[a];
+            const double a0 = -st * ri;
+            const double a1 = (st - 2 * ct_1 * it) * ri;
+            const double a2 = ct_1 * it;
+            const double a3 = (ct - st * it) * ri;
+            const double a4 = st * it;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const double eye = (k == 0 || k == 4 || k == 8) ? 1.0 : 0.0;
+                dR[a * 9 + k] = a0 * eye + a1 * rrt[k] + a2 * drrt[a * 9 + k] + a3 * r_x[k] + a4 * drx[a * 9 + k];
+            }
+        }
+    }
+}
+
+// One detection through the chain.
+//   cs : camera slab (CAM_STRIDE scalars), ps : pose slab (POSE_STRIDE scalars, unused for CHAIN_FREE)
+//   X  : template point (CHAIN_TEMPLATE) or free 3-D point (CHAIN_SELF / CHAIN_FREE)
+// Outputs: projected pixel (u,v) and, when JAC, the dense 2 x P block `J` row-major with the
+// reference's column order:
+//   T: [A_p(9) | A_x.E_r(3) | A_x(3) | S.Q_r(3) | S(3)]                S = A_x.R_e
+//   S: [A_p | A_x.E_r | A_x | S.G_r | S | S.R_p]
+//   F: [A_p | A_x.E_r | A_x | S]
+// The projection Jacobian is evaluated in normalised coordinates a = x/z, b = y/z; it is the
+// same rational function as fbi:62-134 (which carries z**7, z**8 denominators).
+template <int CHAIN, typename T, bool JAC, typename SlabPtrC, typename SlabPtrP>
+__device__ __forceinline__ void eval_detection(SlabPtrC cs, SlabPtrP ps, const T X0, const T X1, const T X2, T &u, T &v,
+                                               T (&J)[2 * chain_P(CHAIN)]) {
+    constexpr int P = chain_P(CHAIN);
+    T Xw0, Xw1, Xw2;
+    T Qr[9];  // Qr[c*3 + a] = (dR_p[a] X)[c]
+    if constexpr (CHAIN != CHAIN_FREE) {
+        const T r0 = ps[POSE_R + 0], r1 = ps[POSE_R + 1], r2 = ps[POSE_R + 2];
+        const T r3 = ps[POSE_R + 3], r4 = ps[POSE_R + 4], r5 = ps[POSE_R + 5];
+        const T r6 = ps[POSE_R + 6], r7 = ps[POSE_R + 7], r8 = ps[POSE_R + 8];
+        Xw0 = r0 * X0 + r1 * X1 + r2 * X2 + ps[POSE_T + 0];
+        Xw1 = r3 * X0 + r4 * X1 + r5 * X2 + ps[POSE_T + 1];
+        Xw2 = r6 * X0 + r7 * X1 + r8 * X2 + ps[POSE_T + 2];
+        if constexpr (JAC) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    Qr[c * 3 + a] = ps[POSE_DR + a * 9 + c * 3 + 0] * X0 + ps[POSE_DR + a * 9 + c * 3 + 1] * X1 +
+                                    ps[POSE_DR + a * 9 + c * 3 + 2] * X2;
+        }
+    } else {
+        Xw0 = X0; Xw1 = X1; Xw2 = X2;
+    }
+    const T e0 = cs[CAM_R + 0], e1 = cs[CAM_R + 1], e2 = cs[CAM_R + 2];
+    const T e3 = cs[CAM_R + 3], e4 = cs[CAM_R + 4], e5 = cs[CAM_R + 5];
+    const T e6 = cs[CAM_R + 6], e7 = cs[CAM_R + 7], e8 = cs[CAM_R + 8];
+    const T x = e0 * Xw0 + e1 * Xw1 + e2 * Xw2 + cs[CAM_T + 0];
+    const T y = e3 * Xw0 + e4 * Xw1 + e5 * Xw2 + cs[CAM_T + 1];
+    const T z = e6 * Xw0 + e7 * Xw1 + e8 * Xw2 + cs[CAM_T + 2];
+
+    const T fx = cs[0], px = cs[1], fy = cs[2], py = cs[3];
+    const T k0 = cs[4], k1 = cs[5], p0 = cs[6], p1 = cs[7], k2 = cs[8];
+    const T iz = T(1) / z;
+    const T a = x * iz, b = y * iz;
+    const T a2 = a * a, b2 = b * b, ab = a * b;
+    const T r2 = a2 + b2;
+    const T r4 = r2 * r2;
+    const T r6 = r4 * r2;
+    const T kup = T(1) + k0 * r2 + k1 * r4 + k2 * r6;                  // fbi:37
+    const T xD = a * kup + T(2) * p0 * ab + p1 * (r2 + T(2) * a2);     // fbi:39-42
+    const T yD = b * kup + p0 * (r2 + T(2) * b2) + T(2) * p1 * ab;     // fbi:40-43
+    u = xD * fx + px;                                                  // fbi:45
+    v = yD * fy + py;                                                  // fbi:46
+    if constexpr (JAC) {
+        const T dk = k0 + T(2) * k1 * r2 + T(3) * k2 * r4;             // d kup / d r2
+        // d(u,v)/d(a,b)
+        const T ua = fx * (kup + T(2) * a2 * dk + T(2) * p0 * b + T(6) * p1 * a);
+        const T cross = T(2) * (ab * dk + p0 * a + p1 * b);
+        const T ub = fx * cross;
+        const T va = fy * cross;
+        const T vb = fy * (kup + T(2) * b2 * dk + T(6) * p0 * b + T(2) * p1 * a);
+        // A_x = d(u,v)/d(x,y,z) (fbi:79-97, fbi:120-134)
+        T Ax[2][3];
+        Ax[0][0] = ua * iz; Ax[0][1] = ub * iz; Ax[0][2] = -(a * ua + b * ub) * iz;
+        Ax[1][0] = va * iz; Ax[1][1] = vb * iz; Ax[1][2] = -(a * va + b * vb) * iz;
+        // A_p: intrinsics + distortion (fbi:58-77, fbi:99-118); the explicit 0 / 1 entries are stored
+        // like the reference's CSR does (mm:231, mm:237-242).
+        J[0] = xD;            J[1] = T(1); J[2] = T(0);          J[3] = T(0);
+        J[4] = fx * a * r2;   J[5] = fx * a * r4;  J[6] = T(2) * fx * ab;  J[7] = fx * (r2 + T(2) * a2);  J[8] = fx * a * r6;
+        J[P + 0] = T(0);      J[P + 1] = T(0);     J[P + 2] = yD;          J[P + 3] = T(1);
+        J[P + 4] = fy * b * r2; J[P + 5] = fy * b * r4; J[P + 6] = fy * (r2 + T(2) * b2); J[P + 7] = T(2) * fy * ab; J[P + 8] = fy * b * r6;
+        // extrinsic rotation columns: A_x . E_r, E_r[:,a] = dR_e[a] X_w     (fbi:163-170)
+        T Er[9];
+#pragma unroll
+        for (int aa = 0; aa < 3; ++aa)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                Er[c * 3 + aa] = cs[CAM_DR + aa * 9 + c * 3 + 0] * Xw0 + cs[CAM_DR + aa * 9 + c * 3 + 1] * Xw1 +
+                                 cs[CAM_DR + aa * 9 + c * 3 + 2] * Xw2;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int aa = 0; aa < 3; ++aa) J[i * P + 9 + aa] = Ax[i][0] * Er[0 * 3 + aa] + Ax[i][1] * Er[1 * 3 + aa] + Ax[i][2] * Er[2 * 3 + aa];
+#pragma unroll
+            for (int aa = 0; aa < 3; ++aa) J[i * P + 12 + aa] = Ax[i][aa];     // E_t = I (fbi:172-174)
+        }
+        // S = A_x . R_e  (fbi:177-181)
+        T S[2][3];
+        const T Re[9] = {e0, e1, e2, e3, e4, e5, e6, e7, e8};
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) S[i][c] = Ax[i][0] * Re[0 * 3 + c] + Ax[i][1] * Re[1 * 3 + c] + Ax[i][2] * Re[2 * 3 + c];
+        if constexpr (CHAIN == CHAIN_FREE) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) J[i * P + 15 + c] = S[i][c];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                for (int aa = 0; aa < 3; ++aa) J[i * P + 15 + aa] = S[i][0] * Qr[0 * 3 + aa] + S[i][1] * Qr[1 * 3 + aa] + S[i][2] * Qr[2 * 3 + aa];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) J[i * P + 18 + c] = S[i][c];
+            }
+            if constexpr (CHAIN == CHAIN_SELF) {  // point columns: S . R_p   (free_point Jacobian = I, fbi:234-240)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+                        J[i * P + 21 + c] = S[i][0] * ps[POSE_R + 0 * 3 + c] + S[i][1] * ps[POSE_R + 1 * 3 + c] + S[i][2] * ps[POSE_R + 2 * 3 + c];
+            }
+        }
+    }
+}
+
+}  // namespace pcs

@@ -1,0 +1,870 @@
+// pcs_engine.hip — HIP kernels + C ABI of the MI355X bundle-adjustment cost/Jacobian engine.
+//
+// gfx950 (CDNA4) only: wave64, 256 CUs in 8 XCDs, 160 KiB LDS per CU, HBM3E.
+// The path is an HBM-write-bound stream (380 B/detection for the FP64 template chain, of which
+// 352 B are stores); there is no dense contraction, so no MFMA.  See DESIGN.md.
+//
+// Kernels
+//   slab_prep_kernel   K0: one thread per camera / pose -> R, t, dR/dr slabs (ba_device.hpp);
+//                      also narrows / copies the 3-D points of chains SELF / FREE.
+//   ba_eval_kernel     K1-K4: fused residual + dense 2xP Jacobian block per detection.
+//                      One lane owns one detection of a 64-detection tile; slabs + points are
+//                      staged in LDS (or read through L1/L2 when they do not fit); the
+//                      Jacobian tile is transposed through LDS so that every store instruction
+//                      writes 1 KiB of consecutive addresses.
+//   ba_compact_kernel  same maths, writes only unfixed columns at static CSR offsets.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/pcs_hip.h"
+#include "ba_device.hpp"
+
+namespace pcs {
+
+// ---------------------------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------------------------
+// clang ext vectors (the nontemporal builtins reject HIP's double2 / float2 structs)
+template <typename T> struct Vec2 { using type = __attribute__((ext_vector_type(2))) T; };
+
+// widest naturally aligned chunk the Jacobian row of one detection allows
+//   double: row = 2P*8 B, always a multiple of 16 -> 16-byte chunks (2 scalars)
+//   float : row = 2P*4 B, multiple of 8 only (P = 21)   ->  8-byte chunks (2 scalars)
+template <typename T> using Chunk = typename Vec2<T>::type;
+
+constexpr int MODE_RESID = 1;
+constexpr int MODE_JAC = 2;
+
+constexpr int VAR_SLAB_LDS = 1;   // stage slabs + points in LDS
+constexpr int VAR_TRANSPOSE = 2;  // transpose the Jacobian tile through LDS, coalesced stores
+constexpr int VAR_NT = 4;         // non-temporal output stores
+
+constexpr int WG_THREADS = 256;
+constexpr int WAVES_PER_WG = WG_THREADS / 64;
+constexpr int TILE = 64;       // detections per wave tile
+constexpr int HALF = 32;       // detections per transpose pass
+
+struct EvalArgs {
+    const int32_t *cam, *img, *key;
+    const void *uv;         // N x 2 scalars
+    const void *cam_slab;   // n_cams x CAM_STRIDE
+    const void *pose_slab;  // n_imgs x POSE_STRIDE
+    const void *points;     // n_keys x 3 (padded)
+    void *resid;            // N x 2
+    void *jac;              // 2N x P
+    int64_t n;
+    int32_t n_cams, n_imgs, n_keys;
+    int32_t tiles_per_wg;
+    int64_t n_tiles;
+    // compaction (ba_compact_kernel only)
+    const uint32_t *keep;    // per detection: bit j set = local column j is free
+    const int64_t *row_off;  // per detection: offset of its u row in the CSR data array
+};
+
+template <typename T, bool NT>
+__device__ __forceinline__ void store_out(T *p, T v) {
+    if constexpr (NT) __builtin_nontemporal_store(v, p); else *p = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K0  slab preparation
+// ---------------------------------------------------------------------------------------------
+// param_str layout: afb make_param_struct (abstract_function_blocks.py:777-820), see pcs_hip.h.
+template <typename T>
+__global__ void slab_prep_kernel(const double *__restrict__ prm, T *__restrict__ cam_slab, T *__restrict__ pose_slab,
+                                 T *__restrict__ points, int n_cams, int n_imgs, int n_keys, int64_t extr_off,
+                                 int64_t pose_off, int64_t point_off, int has_pose, int copy_points) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n_cams + (has_pose ? n_imgs : 0)) {
+        const bool is_cam = e < n_cams;
+        const double *p6 = is_cam ? prm + extr_off + 6 * (int64_t)e : prm + pose_off + 6 * (int64_t)(e - n_cams);
+        double R[9], dR[27];
+        rodrigues_and_jac(p6[0], p6[1], p6[2], R, dR);
+        if (is_cam) {
+            T *o = cam_slab + (int64_t)e * CAM_STRIDE;
+#pragma unroll
+            for (int j = 0; j < 9; ++j) o[j] = (T)prm[9 * (int64_t)e + j];
+#pragma unroll
+            for (int j = 0; j < 9; ++j) o[CAM_R + j] = (T)R[j];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) o[CAM_T + j] = (T)p6[3 + j];
+#pragma unroll
+            for (int j = 0; j < 27; ++j) o[CAM_DR + j] = (T)dR[j];
+        } else {
+            T *o = pose_slab + (int64_t)(e - n_cams) * POSE_STRIDE;
+#pragma unroll
+            for (int j = 0; j < 9; ++j) o[POSE_R + j] = (T)R[j];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) o[POSE_T + j] = (T)p6[3 + j];
+#pragma unroll
+            for (int j = 0; j < 27; ++j) o[POSE_DR + j] = (T)dR[j];
+            o[39] = T(0);
+        }
+    }
+    if (copy_points) {
+        const int total = n_keys * 3;
+        for (int j = e; j < total; j += gridDim.x * blockDim.x) points[j] = (T)prm[point_off + j];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1-K4  fused residual + Jacobian
+// ---------------------------------------------------------------------------------------------
+template <int CHAIN, typename T, int MODE, int VARIANT>
+__global__ __launch_bounds__(WG_THREADS) void ba_eval_kernel(const EvalArgs a) {
+    constexpr int P = chain_P(CHAIN);
+    constexpr int P2 = 2 * P;
+    constexpr bool SLAB_LDS = (VARIANT & VAR_SLAB_LDS) != 0;
+    constexpr bool TRANSPOSE = (VARIANT & VAR_TRANSPOSE) != 0;
+    constexpr bool NT = (VARIANT & VAR_NT) != 0;
+    constexpr bool JAC = (MODE & MODE_JAC) != 0;
+    constexpr bool RES = (MODE & MODE_RESID) != 0;
+    using V2 = typename Vec2<T>::type;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T *smem = reinterpret_cast<T *>(smem_raw);
+
+    const T *cam_slab = static_cast<const T *>(a.cam_slab);
+    const T *pose_slab = static_cast<const T *>(a.pose_slab);
+    const T *points = static_cast<const T *>(a.points);
+    int lds_used = 0;  // scalars
+    if constexpr (SLAB_LDS) {
+        const int n_cam_sc = a.n_cams * CAM_STRIDE;
+        const int n_pose_sc = (CHAIN != CHAIN_FREE) ? a.n_imgs * POSE_STRIDE : 0;
+        const int n_pt_sc = (a.n_keys * 3 + 3) & ~3;  // device buffer is padded to a multiple of 4 scalars
+        // 16-byte cooperative copies (all three regions are multiples of 16 bytes)
+        constexpr int VS = 16 / sizeof(T);
+        using V16 = __attribute__((ext_vector_type(VS))) T;
+        const V16 *g0 = reinterpret_cast<const V16 *>(cam_slab);
+        V16 *l0 = reinterpret_cast<V16 *>(smem);
+        for (int i = threadIdx.x; i < n_cam_sc / VS; i += WG_THREADS) l0[i] = g0[i];
+        const V16 *g1 = reinterpret_cast<const V16 *>(pose_slab);
+        V16 *l1 = reinterpret_cast<V16 *>(smem + n_cam_sc);
+        for (int i = threadIdx.x; i < n_pose_sc / VS; i += WG_THREADS) l1[i] = g1[i];
+        const V16 *g2 = reinterpret_cast<const V16 *>(points);
+        V16 *l2 = reinterpret_cast<V16 *>(smem + n_cam_sc + n_pose_sc);
+        for (int i = threadIdx.x; i < n_pt_sc / VS; i += WG_THREADS) l2[i] = g2[i];
+        cam_slab = smem;
+        pose_slab = smem + n_cam_sc;
+        points = smem + n_cam_sc + n_pose_sc;
+        lds_used = n_cam_sc + n_pose_sc + n_pt_sc;
+        __syncthreads();
+    }
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    T *tr = smem + lds_used + wave * (HALF * P2);  // wave-private transpose region (TRANSPOSE only)
+
+    const int64_t tile0 = (int64_t)blockIdx.x * a.tiles_per_wg;
+    const int64_t tile1 = min(tile0 + (int64_t)a.tiles_per_wg, a.n_tiles);
+    const V2 *uv = static_cast<const V2 *>(a.uv);
+    T *resid = static_cast<T *>(a.resid);
+    T *jac = static_cast<T *>(a.jac);
+    const int64_t total_jac = a.n * (int64_t)P2;
+
+    for (int64_t tile = tile0 + wave; tile < tile1; tile += WAVES_PER_WG) {
+        const int64_t i = tile * TILE + lane;
+        const bool valid = i < a.n;
+        const int64_t ic = valid ? i : a.n - 1;  // tail lanes recompute the last detection, store nothing
+        const int c = a.cam[ic], im = a.img[ic], k = a.key[ic];
+        const V2 m = uv[ic];
+        const T *cs = cam_slab + c * CAM_STRIDE;
+        const T *ps = pose_slab + im * POSE_STRIDE;
+        const T X0 = points[3 * k], X1 = points[3 * k + 1], X2 = points[3 * k + 2];
+        T u, v;
+        T J[P2];
+        eval_detection<CHAIN, T, JAC>(cs, ps, X0, X1, X2, u, v, J);
+        if constexpr (RES) {
+            if (valid) {
+                V2 r;
+                r.x = u - m.x;   // afb:384  losses = projected - measured
+                r.y = v - m.y;
+                if constexpr (NT) __builtin_nontemporal_store(r, reinterpret_cast<V2 *>(resid) + i);
+                else reinterpret_cast<V2 *>(resid)[i] = r;
+            }
+        }
+        if constexpr (JAC) {
+            if constexpr (!TRANSPOSE) {
+                if (valid) {
+                    V2 *row = reinterpret_cast<V2 *>(jac + i * P2);
+#pragma unroll
+                    for (int j = 0; j < P; ++j) {
+                        V2 w;
+                        w.x = J[2 * j];
+                        w.y = J[2 * j + 1];
+                        if constexpr (NT) __builtin_nontemporal_store(w, row + j); else row[j] = w;
+                    }
+                }
+            } else {
+                // Two passes of 32 detections: the active half writes its 2P values row-major into
+                // the wave-private LDS region, then all 64 lanes stream the region out in 16-byte
+                // units at consecutive addresses.  Same-wave LDS ops execute in order; the
+                // wavefront-scope fences only stop the compiler from reordering across them.
+                constexpr int VS = 16 / sizeof(T);  // scalars per 16-byte unit
+                using V16 = __attribute__((ext_vector_type(VS))) T;
+                constexpr int UNITS = HALF * P2 / VS;
+                static_assert((HALF * P2) % VS == 0, "half tile must be a whole number of 16-byte units");
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    if ((lane >> 5) == h) {
+                        V2 *dst = reinterpret_cast<V2 *>(tr + (lane & 31) * P2);
+#pragma unroll
+                        for (int j = 0; j < P; ++j) {
+                            V2 w;
+                            w.x = J[2 * j];
+                            w.y = J[2 * j + 1];
+                            dst[j] = w;
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    const int64_t base = (tile * TILE + h * HALF) * (int64_t)P2;  // scalar offset, multiple of VS
+#pragma unroll
+                    for (int q0 = 0; q0 < UNITS; q0 += 64) {
+                        const int q = q0 + lane;
+                        if (q < UNITS) {
+                            const int64_t e = base + (int64_t)q * VS;
+                            if (e + VS <= total_jac) {
+                                const V16 w = reinterpret_cast<const V16 *>(tr)[q];
+                                if constexpr (NT) __builtin_nontemporal_store(w, reinterpret_cast<V16 *>(jac + e));
+                                else *reinterpret_cast<V16 *>(jac + e) = w;
+                            } else {
+                                for (int s = 0; s < VS; ++s)
+                                    if (e + s < total_jac) jac[e + s] = tr[q * VS + s];
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                }
+            }
+        }
+    }
+}
+
+// Fixed-parameter compaction (replaces `data[:n_elements][good_mask]`, afb:627-651): every lane
+// writes the kept entries of its two rows at the static CSR offsets.  Reads slabs through L1/L2.
+template <int CHAIN, typename T, int MODE>
+__global__ __launch_bounds__(WG_THREADS) void ba_compact_kernel(const EvalArgs a) {
+    constexpr int P = chain_P(CHAIN);
+    constexpr int P2 = 2 * P;
+    using V2 = typename Vec2<T>::type;
+    const T *cam_slab = static_cast<const T *>(a.cam_slab);
+    const T *pose_slab = static_cast<const T *>(a.pose_slab);
+    const T *points = static_cast<const T *>(a.points);
+    const V2 *uv = static_cast<const V2 *>(a.uv);
+    T *resid = static_cast<T *>(a.resid);
+    T *data = static_cast<T *>(a.jac);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += stride) {
+        const int c = a.cam[i], im = a.img[i], k = a.key[i];
+        const V2 m = uv[i];
+        T u, v;
+        T J[P2];
+        eval_detection<CHAIN, T, (MODE & MODE_JAC) != 0>(cam_slab + c * CAM_STRIDE, pose_slab + im * POSE_STRIDE, points[3 * k],
+                                                          points[3 * k + 1], points[3 * k + 2], u, v, J);
+        if constexpr ((MODE & MODE_RESID) != 0) {
+            V2 r;
+            r.x = u - m.x;
+            r.y = v - m.y;
+            reinterpret_cast<V2 *>(resid)[i] = r;
+        }
+        if constexpr ((MODE & MODE_JAC) != 0) {
+            const uint32_t keep = a.keep[i];
+            const int cnt = __popc(keep);
+            T *ru = data + a.row_off[i];
+            T *rv = ru + cnt;
+            int o = 0;
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+                if (keep & (1u << j)) {
+                    ru[o] = J[j];
+                    rv[o] = J[P + j];
+                    ++o;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace pcs
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+using namespace pcs;
+
+static thread_local std::string g_err;
+
+static int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess) return fail(PCS_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+struct pcs_engine {
+    int chain = 0, dtype = 0, device = 0, P = 0;
+    int64_t n_cams = 0, n_imgs = 0, n_keys = 0, n_params = 0, n = 0;
+    int64_t extr_off = 0, pose_off = 0, point_off = 0;
+    size_t esize = 8;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    bool events_valid = false;
+    hipStream_t last_stream = nullptr;
+    // static inputs
+    int32_t *d_cam = nullptr, *d_img = nullptr, *d_key = nullptr;
+    void *d_uv = nullptr;
+    std::vector<int32_t> h_cam, h_img, h_key;
+    bool have_template = false;
+    // per-step
+    double *d_param = nullptr;
+    double *h_param = nullptr;  // pinned staging
+    void *d_cam_slab = nullptr, *d_pose_slab = nullptr, *d_points = nullptr;
+    // scratch outputs for the host-buffer entry points
+    void *d_resid = nullptr, *d_jac = nullptr;
+    int64_t jac_capacity = 0, resid_capacity = 0;
+    // compaction
+    uint32_t *d_keep = nullptr;
+    int64_t *d_row_off = nullptr;
+    int64_t nnz = -1;
+    void *d_data = nullptr;
+    int64_t data_capacity = 0;
+    // launch geometry
+    int n_cu = 256;
+    int variant = VAR_SLAB_LDS | VAR_TRANSPOSE;
+    int64_t wgs_per_cu = 2;
+    int64_t tiles_per_wg = 0;  // 0 = derive from wgs_per_cu
+    size_t lds_limit = 160 * 1024;
+};
+
+static int64_t padded_points(int64_t n_keys) { return (n_keys * 3 + 3) & ~(int64_t)3; }
+
+extern "C" {
+
+int pcs_version(void) { return 100; }
+const char *pcs_last_error(void) { return g_err.c_str(); }
+
+int pcs_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int pcs_create(pcs_engine **out, int chain, int dtype, int64_t n_cams, int64_t n_imgs, int64_t n_keys, int device) {
+    if (!out) return fail(PCS_ERR_ARG, "pcs_create: out is NULL");
+    *out = nullptr;
+    if (chain < 0 || chain > 2) return fail(PCS_ERR_ARG, "pcs_create: chain %d not in {0,1,2}", chain);
+    if (dtype != PCS_F64 && dtype != PCS_F32) return fail(PCS_ERR_ARG, "pcs_create: dtype %d not in {0,1}", dtype);
+    if (n_cams <= 0 || n_keys <= 0 || (chain != PCS_CHAIN_FREE && n_imgs <= 0))
+        return fail(PCS_ERR_ARG, "pcs_create: counts must be positive (cams %lld imgs %lld keys %lld)", (long long)n_cams,
+                    (long long)n_imgs, (long long)n_keys);
+    if (n_cams > (1 << 24) || n_imgs > (1 << 24) || n_keys > (1 << 26)) return fail(PCS_ERR_ARG, "pcs_create: counts too large");
+    int ndev = pcs_device_count();
+    if (ndev <= 0) return fail(PCS_ERR_NODEVICE, "pcs_create: no HIP device visible (this engine has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(PCS_ERR_ARG, "pcs_create: device %d out of range [0,%d)", device, ndev);
+    HIPCHK(hipSetDevice(device));
+    pcs_engine *h = new pcs_engine();
+    h->chain = chain;
+    h->dtype = dtype;
+    h->device = device;
+    h->P = chain_P(chain);
+    h->esize = dtype == PCS_F64 ? 8 : 4;
+    h->n_cams = n_cams;
+    h->n_imgs = chain == PCS_CHAIN_FREE ? 0 : n_imgs;
+    h->n_keys = n_keys;
+    h->extr_off = 9 * n_cams;
+    h->pose_off = 15 * n_cams;
+    h->point_off = chain == PCS_CHAIN_SELF ? 15 * n_cams + 6 * n_imgs : 15 * n_cams;
+    h->n_params = chain == PCS_CHAIN_TEMPLATE ? 15 * n_cams + 6 * n_imgs
+                  : chain == PCS_CHAIN_SELF   ? 15 * n_cams + 6 * n_imgs + 3 * n_keys
+                                              : 15 * n_cams + 3 * n_keys;
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    h->lds_limit = prop.maxSharedMemoryPerMultiProcessor > 0 ? prop.maxSharedMemoryPerMultiProcessor
+                   : prop.sharedMemPerBlock > 0            ? prop.sharedMemPerBlock
+                                                           : 64 * 1024;
+    HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    for (auto &e : h->ev) HIPCHK(hipEventCreate(&e));
+    HIPCHK(hipMalloc(&h->d_param, sizeof(double) * h->n_params));
+    HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&h->h_param), sizeof(double) * h->n_params, hipHostMallocDefault));
+    HIPCHK(hipMalloc(&h->d_cam_slab, h->esize * n_cams * CAM_STRIDE));
+    HIPCHK(hipMalloc(&h->d_pose_slab, h->esize * std::max<int64_t>(1, h->n_imgs) * POSE_STRIDE));
+    HIPCHK(hipMalloc(&h->d_points, h->esize * padded_points(n_keys)));
+    HIPCHK(hipMemset(h->d_points, 0, h->esize * padded_points(n_keys)));
+    *out = h;
+    return PCS_OK;
+}
+
+int pcs_destroy(pcs_engine *h) {
+    if (!h) return PCS_OK;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    void *bufs[] = {h->d_cam, h->d_img, h->d_key, h->d_uv, h->d_param, h->d_cam_slab, h->d_pose_slab, h->d_points,
+                    h->d_resid, h->d_jac, h->d_keep, h->d_row_off, h->d_data};
+    for (void *b : bufs)
+        if (b) (void)hipFree(b);
+    if (h->h_param) (void)hipHostFree(h->h_param);
+    for (auto &e : h->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return PCS_OK;
+}
+
+int64_t pcs_n_params(const pcs_engine *h) { return h ? h->n_params : -1; }
+int pcs_row_len(const pcs_engine *h) { return h ? h->P : -1; }
+int64_t pcs_n_detections(const pcs_engine *h) { return h ? h->n : -1; }
+
+static int upload_detections(pcs_engine *h, const double *uv, int64_t n) {
+    // range check: an out-of-range index would be an out-of-bounds slab read on the device
+    for (int64_t i = 0; i < n; ++i) {
+        const int32_t c = h->h_cam[i], im = h->h_img[i], k = h->h_key[i];
+        if (c < 0 || c >= h->n_cams || k < 0 || k >= h->n_keys || (h->chain != PCS_CHAIN_FREE && (im < 0 || im >= h->n_imgs)))
+            return fail(PCS_ERR_RANGE, "detection %lld = (cam %d, im %d, key %d) outside (%lld, %lld, %lld)", (long long)i, c, im, k,
+                        (long long)h->n_cams, (long long)h->n_imgs, (long long)h->n_keys);
+    }
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (void **b : {(void **)&h->d_cam, (void **)&h->d_img, (void **)&h->d_key, &h->d_uv, &h->d_resid, &h->d_jac,
+                     (void **)&h->d_keep, (void **)&h->d_row_off, &h->d_data}) {
+        if (*b) HIPCHK(hipFree(*b));
+        *b = nullptr;
+    }
+    h->jac_capacity = h->resid_capacity = h->data_capacity = 0;
+    h->nnz = -1;
+    h->n = n;
+    if (n == 0) return PCS_OK;
+    HIPCHK(hipMalloc(&h->d_cam, sizeof(int32_t) * n));
+    HIPCHK(hipMalloc(&h->d_img, sizeof(int32_t) * n));
+    HIPCHK(hipMalloc(&h->d_key, sizeof(int32_t) * n));
+    HIPCHK(hipMalloc(&h->d_uv, h->esize * 2 * n));
+    HIPCHK(hipMemcpy(h->d_cam, h->h_cam.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_img, h->h_img.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_key, h->h_key.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice));
+    if (h->dtype == PCS_F64) {
+        HIPCHK(hipMemcpy(h->d_uv, uv, sizeof(double) * 2 * n, hipMemcpyHostToDevice));
+    } else {
+        std::vector<float> f(2 * n);
+        for (int64_t i = 0; i < 2 * n; ++i) f[i] = (float)uv[i];
+        HIPCHK(hipMemcpy(h->d_uv, f.data(), sizeof(float) * 2 * n, hipMemcpyHostToDevice));
+    }
+    return PCS_OK;
+}
+
+int pcs_set_detections_table(pcs_engine *h, const double *det5, int64_t n) {
+    if (!h || (!det5 && n > 0) || n < 0) return fail(PCS_ERR_ARG, "pcs_set_detections_table: bad arguments");
+    h->h_cam.resize(n); h->h_img.resize(n); h->h_key.resize(n);
+    std::vector<double> uv(2 * n);
+    for (int64_t i = 0; i < n; ++i) {
+        h->h_cam[i] = (int32_t)det5[5 * i + 0];  // int() cast like afb:214 / afb:375
+        h->h_img[i] = (int32_t)det5[5 * i + 1];
+        h->h_key[i] = (int32_t)det5[5 * i + 2];
+        uv[2 * i] = det5[5 * i + 3];
+        uv[2 * i + 1] = det5[5 * i + 4];
+    }
+    return upload_detections(h, uv.data(), n);
+}
+
+int pcs_set_detections(pcs_engine *h, const int32_t *cam, const int32_t *img, const int32_t *key, const double *uv, int64_t n) {
+    if (!h || n < 0 || (n > 0 && (!cam || !key || !uv || (!img && h->chain != PCS_CHAIN_FREE))))
+        return fail(PCS_ERR_ARG, "pcs_set_detections: bad arguments");
+    h->h_cam.assign(cam, cam + n);
+    if (img) h->h_img.assign(img, img + n); else h->h_img.assign(n, 0);
+    h->h_key.assign(key, key + n);
+    return upload_detections(h, uv, n);
+}
+
+int pcs_set_template(pcs_engine *h, const double *points) {
+    if (!h || !points) return fail(PCS_ERR_ARG, "pcs_set_template: bad arguments");
+    if (h->chain != PCS_CHAIN_TEMPLATE) return fail(PCS_ERR_ARG, "pcs_set_template: only the template chain has constant points");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const int64_t cnt = 3 * h->n_keys;
+    if (h->dtype == PCS_F64) {
+        HIPCHK(hipMemcpy(h->d_points, points, sizeof(double) * cnt, hipMemcpyHostToDevice));
+    } else {
+        std::vector<float> f(cnt);
+        for (int64_t i = 0; i < cnt; ++i) f[i] = (float)points[i];
+        HIPCHK(hipMemcpy(h->d_points, f.data(), sizeof(float) * cnt, hipMemcpyHostToDevice));
+    }
+    h->have_template = true;
+    return PCS_OK;
+}
+
+int pcs_set_option(pcs_engine *h, const char *key, int64_t value) {
+    if (!h || !key) return fail(PCS_ERR_ARG, "pcs_set_option: bad arguments");
+    if (!strcmp(key, "variant")) {
+        if (value < 0 || value > 7) return fail(PCS_ERR_ARG, "variant must be in [0,7]");
+        h->variant = (int)value;
+    } else if (!strcmp(key, "wgs_per_cu")) {
+        if (value < 1 || value > 64) return fail(PCS_ERR_ARG, "wgs_per_cu must be in [1,64]");
+        h->wgs_per_cu = value;
+        h->tiles_per_wg = 0;
+    } else if (!strcmp(key, "tiles_per_wg")) {
+        if (value < 0 || value > (1 << 20)) return fail(PCS_ERR_ARG, "tiles_per_wg out of range");
+        h->tiles_per_wg = value;
+    } else {
+        return fail(PCS_ERR_ARG, "pcs_set_option: unknown key '%s'", key);
+    }
+    return PCS_OK;
+}
+
+}  // extern "C"
+
+// ---- launch plumbing ---------------------------------------------------------------------------
+template <int CHAIN, typename T, int MODE, int VARIANT>
+static hipError_t launch_eval_v(const EvalArgs &a, dim3 grid, size_t lds, hipStream_t s) {
+    auto kern = ba_eval_kernel<CHAIN, T, MODE, VARIANT>;
+    static size_t configured[64] = {0};  // per device: largest dynamic-LDS size already enabled for this kernel
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (lds > 48 * 1024 && lds > configured[dev & 63]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        configured[dev & 63] = lds;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(WG_THREADS), lds, s, a);
+    return hipGetLastError();
+}
+
+template <int CHAIN, typename T, int MODE>
+static hipError_t launch_eval_m(int variant, const EvalArgs &a, dim3 grid, size_t lds, hipStream_t s) {
+    switch (variant) {
+        case 0: return launch_eval_v<CHAIN, T, MODE, 0>(a, grid, lds, s);
+        case 1: return launch_eval_v<CHAIN, T, MODE, 1>(a, grid, lds, s);
+        case 2: return launch_eval_v<CHAIN, T, MODE, 2>(a, grid, lds, s);
+        case 3: return launch_eval_v<CHAIN, T, MODE, 3>(a, grid, lds, s);
+        case 4: return launch_eval_v<CHAIN, T, MODE, 4>(a, grid, lds, s);
+        case 5: return launch_eval_v<CHAIN, T, MODE, 5>(a, grid, lds, s);
+        case 6: return launch_eval_v<CHAIN, T, MODE, 6>(a, grid, lds, s);
+        default: return launch_eval_v<CHAIN, T, MODE, 7>(a, grid, lds, s);
+    }
+}
+
+template <int CHAIN, typename T>
+static hipError_t launch_eval_c(int mode, int variant, const EvalArgs &a, dim3 grid, size_t lds, hipStream_t s) {
+    switch (mode) {
+        case MODE_RESID: return launch_eval_m<CHAIN, T, MODE_RESID>(variant & ~VAR_TRANSPOSE, a, grid, lds, s);
+        case MODE_JAC: return launch_eval_m<CHAIN, T, MODE_JAC>(variant, a, grid, lds, s);
+        default: return launch_eval_m<CHAIN, T, MODE_RESID | MODE_JAC>(variant, a, grid, lds, s);
+    }
+}
+
+template <typename T>
+static hipError_t launch_eval_t(int chain, int mode, int variant, const EvalArgs &a, dim3 grid, size_t lds, hipStream_t s) {
+    switch (chain) {
+        case CHAIN_TEMPLATE: return launch_eval_c<CHAIN_TEMPLATE, T>(mode, variant, a, grid, lds, s);
+        case CHAIN_SELF: return launch_eval_c<CHAIN_SELF, T>(mode, variant, a, grid, lds, s);
+        default: return launch_eval_c<CHAIN_FREE, T>(mode, variant, a, grid, lds, s);
+    }
+}
+
+template <int CHAIN, typename T>
+static hipError_t launch_compact_c(int mode, const EvalArgs &a, dim3 grid, hipStream_t s) {
+    if (mode == MODE_RESID) hipLaunchKernelGGL((ba_compact_kernel<CHAIN, T, MODE_RESID>), grid, dim3(WG_THREADS), 0, s, a);
+    else if (mode == MODE_JAC) hipLaunchKernelGGL((ba_compact_kernel<CHAIN, T, MODE_JAC>), grid, dim3(WG_THREADS), 0, s, a);
+    else hipLaunchKernelGGL((ba_compact_kernel<CHAIN, T, MODE_RESID | MODE_JAC>), grid, dim3(WG_THREADS), 0, s, a);
+    return hipGetLastError();
+}
+
+template <typename T>
+static hipError_t launch_compact_t(int chain, int mode, const EvalArgs &a, dim3 grid, hipStream_t s) {
+    switch (chain) {
+        case CHAIN_TEMPLATE: return launch_compact_c<CHAIN_TEMPLATE, T>(mode, a, grid, s);
+        case CHAIN_SELF: return launch_compact_c<CHAIN_SELF, T>(mode, a, grid, s);
+        default: return launch_compact_c<CHAIN_FREE, T>(mode, a, grid, s);
+    }
+}
+
+// Queue slab_prep + the evaluation kernel on `s`.  d_prm must already hold the parameter string.
+static int enqueue_eval(pcs_engine *h, const double *d_prm, void *d_resid, void *d_out, bool compact, hipStream_t s) {
+    if (h->n <= 0) return fail(PCS_ERR_STATE, "no detections set");
+    if (h->chain == PCS_CHAIN_TEMPLATE && !h->have_template) return fail(PCS_ERR_STATE, "template points not set");
+    const int mode = (d_resid ? MODE_RESID : 0) | (d_out ? MODE_JAC : 0);
+    if (!mode) return PCS_OK;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipEventRecord(h->ev[0], s));
+    {
+        const int has_pose = h->chain != PCS_CHAIN_FREE;
+        const int copy_points = h->chain != PCS_CHAIN_TEMPLATE;
+        const int64_t ents = h->n_cams + (has_pose ? h->n_imgs : 0);
+        int64_t threads = ents;
+        if (copy_points) threads = std::max<int64_t>(threads, std::min<int64_t>(3 * h->n_keys, 1 << 16));
+        const dim3 grid((unsigned)((threads + 127) / 128));
+        if (h->dtype == PCS_F64)
+            hipLaunchKernelGGL(slab_prep_kernel<double>, grid, dim3(128), 0, s, d_prm, (double *)h->d_cam_slab, (double *)h->d_pose_slab,
+                               (double *)h->d_points, (int)h->n_cams, (int)h->n_imgs, (int)h->n_keys, h->extr_off, h->pose_off,
+                               h->point_off, has_pose, copy_points);
+        else
+            hipLaunchKernelGGL(slab_prep_kernel<float>, grid, dim3(128), 0, s, d_prm, (float *)h->d_cam_slab, (float *)h->d_pose_slab,
+                               (float *)h->d_points, (int)h->n_cams, (int)h->n_imgs, (int)h->n_keys, h->extr_off, h->pose_off,
+                               h->point_off, has_pose, copy_points);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipEventRecord(h->ev[1], s));
+    EvalArgs a{};
+    a.cam = h->d_cam; a.img = h->d_img; a.key = h->d_key; a.uv = h->d_uv;
+    a.cam_slab = h->d_cam_slab; a.pose_slab = h->d_pose_slab; a.points = h->d_points;
+    a.resid = d_resid; a.jac = d_out;
+    a.n = h->n; a.n_cams = (int32_t)h->n_cams; a.n_imgs = (int32_t)h->n_imgs; a.n_keys = (int32_t)h->n_keys;
+    a.n_tiles = (h->n + TILE - 1) / TILE;
+    if (compact) {
+        a.keep = h->d_keep; a.row_off = h->d_row_off;
+        const int64_t blocks = std::min<int64_t>((h->n + WG_THREADS - 1) / WG_THREADS, (int64_t)h->n_cu * 8);
+        hipError_t e = h->dtype == PCS_F64 ? launch_compact_t<double>(h->chain, mode, a, dim3((unsigned)blocks), s)
+                                           : launch_compact_t<float>(h->chain, mode, a, dim3((unsigned)blocks), s);
+        if (e != hipSuccess) return fail(PCS_ERR_HIP, "compact kernel launch failed: %s", hipGetErrorString(e));
+    } else {
+        int variant = h->variant;
+        if (!(mode & MODE_JAC)) variant &= ~VAR_TRANSPOSE;
+        // LDS budget: slabs + points (+ 4 wave-private transpose regions)
+        const size_t slab_bytes = h->esize * (size_t)(h->n_cams * CAM_STRIDE + h->n_imgs * POSE_STRIDE + padded_points(h->n_keys));
+        const size_t tr_bytes = (variant & VAR_TRANSPOSE) ? h->esize * (size_t)WAVES_PER_WG * HALF * 2 * h->P : 0;
+        if ((variant & VAR_SLAB_LDS) && slab_bytes + tr_bytes > h->lds_limit) variant &= ~VAR_SLAB_LDS;  // read slabs through L1/L2
+        const size_t lds = ((variant & VAR_SLAB_LDS) ? slab_bytes : 0) + tr_bytes;
+        int64_t tpw = h->tiles_per_wg;
+        if (tpw <= 0) {
+            const int64_t target_wgs = (int64_t)h->n_cu * h->wgs_per_cu;
+            tpw = (a.n_tiles + target_wgs - 1) / target_wgs;
+            tpw = std::max<int64_t>(WAVES_PER_WG, (tpw + WAVES_PER_WG - 1) / WAVES_PER_WG * WAVES_PER_WG);
+        }
+        a.tiles_per_wg = (int32_t)tpw;
+        const int64_t grid = (a.n_tiles + tpw - 1) / tpw;
+        hipError_t e = h->dtype == PCS_F64 ? launch_eval_t<double>(h->chain, mode, variant, a, dim3((unsigned)grid), lds, s)
+                                           : launch_eval_t<float>(h->chain, mode, variant, a, dim3((unsigned)grid), lds, s);
+        if (e != hipSuccess) return fail(PCS_ERR_HIP, "eval kernel launch failed: %s", hipGetErrorString(e));
+    }
+    HIPCHK(hipEventRecord(h->ev[2], s));
+    h->events_valid = true;
+    h->last_stream = s;
+    return PCS_OK;
+}
+
+static int stage_params(pcs_engine *h, const double *param_str, hipStream_t s) {
+    // the pinned staging buffer is reused: wait until the previous copy out of it has been consumed
+    HIPCHK(hipStreamSynchronize(h->last_stream ? h->last_stream : s));
+    memcpy(h->h_param, param_str, sizeof(double) * h->n_params);
+    HIPCHK(hipMemcpyAsync(h->d_param, h->h_param, sizeof(double) * h->n_params, hipMemcpyHostToDevice, s));
+    return PCS_OK;
+}
+
+static int ensure_scratch(pcs_engine *h, bool want_resid, bool want_jac, bool want_data) {
+    HIPCHK(hipSetDevice(h->device));
+    if (want_resid && h->resid_capacity < 2 * h->n) {
+        if (h->d_resid) HIPCHK(hipFree(h->d_resid));
+        HIPCHK(hipMalloc(&h->d_resid, h->esize * 2 * h->n));
+        h->resid_capacity = 2 * h->n;
+    }
+    if (want_jac && h->jac_capacity < 2 * h->n * h->P) {
+        if (h->d_jac) HIPCHK(hipFree(h->d_jac));
+        HIPCHK(hipMalloc(&h->d_jac, h->esize * 2 * h->n * h->P));
+        h->jac_capacity = 2 * h->n * h->P;
+    }
+    if (want_data && h->data_capacity < std::max<int64_t>(1, h->nnz)) {
+        if (h->d_data) HIPCHK(hipFree(h->d_data));
+        HIPCHK(hipMalloc(&h->d_data, h->esize * std::max<int64_t>(1, h->nnz)));
+        h->data_capacity = std::max<int64_t>(1, h->nnz);
+    }
+    return PCS_OK;
+}
+
+static int download(pcs_engine *h, double *dst, const void *d_src, int64_t count, hipStream_t s) {
+    if (h->dtype == PCS_F64) {
+        HIPCHK(hipMemcpyAsync(dst, d_src, sizeof(double) * count, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+    } else {
+        std::vector<float> f(count);
+        HIPCHK(hipMemcpyAsync(f.data(), d_src, sizeof(float) * count, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        for (int64_t i = 0; i < count; ++i) dst[i] = (double)f[i];
+    }
+    return PCS_OK;
+}
+
+extern "C" {
+
+int pcs_eval_device_resident(pcs_engine *h, const double *d_param_str, void *d_resid, void *d_jac, void *stream) {
+    if (!h || !d_param_str) return fail(PCS_ERR_ARG, "pcs_eval_device_resident: bad arguments");
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    return enqueue_eval(h, d_param_str, d_resid, d_jac, false, s);
+}
+
+int pcs_eval_device(pcs_engine *h, const double *param_str, void *d_resid, void *d_jac, void *stream) {
+    if (!h || !param_str) return fail(PCS_ERR_ARG, "pcs_eval_device: bad arguments");
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    HIPCHK(hipSetDevice(h->device));
+    int rc = stage_params(h, param_str, s);
+    if (rc) return rc;
+    return enqueue_eval(h, h->d_param, d_resid, d_jac, false, s);
+}
+
+int pcs_eval(pcs_engine *h, const double *param_str, double *resid, double *jac) {
+    if (!h || !param_str) return fail(PCS_ERR_ARG, "pcs_eval: bad arguments");
+    if (h->n <= 0) return fail(PCS_ERR_STATE, "no detections set");
+    int rc = ensure_scratch(h, resid != nullptr, jac != nullptr, false);
+    if (rc) return rc;
+    rc = pcs_eval_device(h, param_str, resid ? h->d_resid : nullptr, jac ? h->d_jac : nullptr, nullptr);
+    if (rc) return rc;
+    if (resid && (rc = download(h, resid, h->d_resid, 2 * h->n, h->stream))) return rc;
+    if (jac && (rc = download(h, jac, h->d_jac, 2 * h->n * h->P, h->stream))) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return PCS_OK;
+}
+
+int pcs_device_buffers(pcs_engine *h, void **d_resid, void **d_jac) {
+    if (!h) return fail(PCS_ERR_ARG, "pcs_device_buffers: bad arguments");
+    if (h->n <= 0) return fail(PCS_ERR_STATE, "no detections set");
+    int rc = ensure_scratch(h, d_resid != nullptr, d_jac != nullptr, false);
+    if (rc) return rc;
+    if (d_resid) *d_resid = h->d_resid;
+    if (d_jac) *d_jac = h->d_jac;
+    return PCS_OK;
+}
+
+int pcs_block_param_inds(pcs_engine *h, int64_t *out) {
+    if (!h || !out) return fail(PCS_ERR_ARG, "pcs_block_param_inds: bad arguments");
+    const int P = h->P;
+    for (int64_t i = 0; i < h->n; ++i) {
+        int64_t *o = out + i * P;
+        const int64_t c = h->h_cam[i], im = h->h_img[i], k = h->h_key[i];
+        int j = 0;
+        for (int q = 0; q < 9; ++q) o[j++] = 9 * c + q;
+        for (int q = 0; q < 6; ++q) o[j++] = h->extr_off + 6 * c + q;
+        if (h->chain != PCS_CHAIN_FREE)
+            for (int q = 0; q < 6; ++q) o[j++] = h->pose_off + 6 * im + q;
+        if (h->chain != PCS_CHAIN_TEMPLATE)
+            for (int q = 0; q < 3; ++q) o[j++] = h->point_off + 3 * k + q;
+    }
+    return PCS_OK;
+}
+
+// keep-mask of one detection's local columns under `unfixed`
+static inline uint32_t keep_mask(const pcs_engine *h, const uint8_t *unfixed, int64_t i) {
+    if (!unfixed) return (1u << h->P) - 1u;
+    const int64_t c = h->h_cam[i], im = h->h_img[i], k = h->h_key[i];
+    uint32_t m = 0;
+    int j = 0;
+    for (int q = 0; q < 9; ++q, ++j) m |= (uint32_t)(unfixed[9 * c + q] != 0) << j;
+    for (int q = 0; q < 6; ++q, ++j) m |= (uint32_t)(unfixed[h->extr_off + 6 * c + q] != 0) << j;
+    if (h->chain != PCS_CHAIN_FREE)
+        for (int q = 0; q < 6; ++q, ++j) m |= (uint32_t)(unfixed[h->pose_off + 6 * im + q] != 0) << j;
+    if (h->chain != PCS_CHAIN_TEMPLATE)
+        for (int q = 0; q < 3; ++q, ++j) m |= (uint32_t)(unfixed[h->point_off + 3 * k + q] != 0) << j;
+    return m;
+}
+
+int pcs_csr_structure(pcs_engine *h, const uint8_t *unfixed, int64_t *indices, int64_t *indptr, int64_t *nnz_out) {
+    if (!h) return fail(PCS_ERR_ARG, "pcs_csr_structure: bad arguments");
+    // conversion = [0, cumsum(unfixed)]: full column -> free column (afb:482)
+    std::vector<int64_t> conv(h->n_params + 1, 0);
+    for (int64_t p = 0; p < h->n_params; ++p) conv[p + 1] = conv[p] + ((!unfixed || unfixed[p]) ? 1 : 0);
+    std::vector<int64_t> cols(h->P);
+    int64_t pos = 0;
+    if (indptr) indptr[0] = 0;
+    for (int64_t i = 0; i < h->n; ++i) {
+        const int64_t c = h->h_cam[i], im = h->h_img[i], k = h->h_key[i];
+        int j = 0;
+        for (int q = 0; q < 9; ++q) cols[j++] = 9 * c + q;
+        for (int q = 0; q < 6; ++q) cols[j++] = h->extr_off + 6 * c + q;
+        if (h->chain != PCS_CHAIN_FREE)
+            for (int q = 0; q < 6; ++q) cols[j++] = h->pose_off + 6 * im + q;
+        if (h->chain != PCS_CHAIN_TEMPLATE)
+            for (int q = 0; q < 3; ++q) cols[j++] = h->point_off + 3 * k + q;
+        for (int row = 0; row < 2; ++row) {  // each detection's index row is used for u and for v (afb:475-479)
+            for (int q = 0; q < h->P; ++q) {
+                if (!unfixed || unfixed[cols[q]]) {
+                    if (indices) indices[pos] = conv[cols[q]];
+                    ++pos;
+                }
+            }
+            if (indptr) indptr[2 * i + row + 1] = pos;
+        }
+    }
+    if (nnz_out) *nnz_out = pos;
+    return PCS_OK;
+}
+
+int pcs_set_unfixed(pcs_engine *h, const uint8_t *unfixed, int64_t *nnz_out) {
+    if (!h) return fail(PCS_ERR_ARG, "pcs_set_unfixed: bad arguments");
+    if (h->n <= 0) return fail(PCS_ERR_STATE, "no detections set");
+    std::vector<uint32_t> keep(h->n);
+    std::vector<int64_t> off(h->n);
+    int64_t pos = 0;
+    for (int64_t i = 0; i < h->n; ++i) {
+        keep[i] = keep_mask(h, unfixed, i);
+        off[i] = pos;
+        pos += 2 * __builtin_popcount(keep[i]);
+    }
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (!h->d_keep) HIPCHK(hipMalloc(&h->d_keep, sizeof(uint32_t) * h->n));
+    if (!h->d_row_off) HIPCHK(hipMalloc(&h->d_row_off, sizeof(int64_t) * h->n));
+    HIPCHK(hipMemcpy(h->d_keep, keep.data(), sizeof(uint32_t) * h->n, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_row_off, off.data(), sizeof(int64_t) * h->n, hipMemcpyHostToDevice));
+    h->nnz = pos;
+    if (nnz_out) *nnz_out = pos;
+    return PCS_OK;
+}
+
+int pcs_eval_compact_device(pcs_engine *h, const double *param_str, void *d_resid, void *d_data, void *stream) {
+    if (!h || !param_str) return fail(PCS_ERR_ARG, "pcs_eval_compact_device: bad arguments");
+    if (h->nnz < 0) return fail(PCS_ERR_STATE, "pcs_set_unfixed has not been called");
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    HIPCHK(hipSetDevice(h->device));
+    int rc = stage_params(h, param_str, s);
+    if (rc) return rc;
+    return enqueue_eval(h, h->d_param, d_resid, d_data, true, s);
+}
+
+int pcs_eval_compact(pcs_engine *h, const double *param_str, double *resid, double *data) {
+    if (!h || !param_str) return fail(PCS_ERR_ARG, "pcs_eval_compact: bad arguments");
+    if (h->nnz < 0) return fail(PCS_ERR_STATE, "pcs_set_unfixed has not been called");
+    int rc = ensure_scratch(h, resid != nullptr, false, data != nullptr);
+    if (rc) return rc;
+    rc = pcs_eval_compact_device(h, param_str, resid ? h->d_resid : nullptr, data ? h->d_data : nullptr, nullptr);
+    if (rc) return rc;
+    if (resid && (rc = download(h, resid, h->d_resid, 2 * h->n, h->stream))) return rc;
+    if (data && h->nnz > 0 && (rc = download(h, data, h->d_data, h->nnz, h->stream))) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return PCS_OK;
+}
+
+int pcs_synchronize(pcs_engine *h, void *stream) {
+    if (!h) return fail(PCS_ERR_ARG, "pcs_synchronize: bad arguments");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(stream ? (hipStream_t)stream : h->stream));
+    return PCS_OK;
+}
+
+int pcs_last_kernel_ms(pcs_engine *h, float *slab_prep_ms, float *eval_ms) {
+    if (!h) return fail(PCS_ERR_ARG, "pcs_last_kernel_ms: bad arguments");
+    if (!h->events_valid) return fail(PCS_ERR_STATE, "no evaluation has been queued yet");
+    HIPCHK(hipEventSynchronize(h->ev[2]));
+    float a = 0, b = 0;
+    HIPCHK(hipEventElapsedTime(&a, h->ev[0], h->ev[1]));
+    HIPCHK(hipEventElapsedTime(&b, h->ev[1], h->ev[2]));
+    if (slab_prep_ms) *slab_prep_ms = a;
+    if (eval_ms) *eval_ms = b;
+    return PCS_OK;
+}
+
+}  // extern "C"

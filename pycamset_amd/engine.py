@@ -1,0 +1,171 @@
+"""``Engine`` — thin Python owner of one ``pcs_engine`` handle (include/pcs_hip.h).
+
+NumPy in / NumPy out for the drop-in closures; raw device pointers (e.g. ``tensor.data_ptr()``)
+for callers that keep the residual / Jacobian in HBM (bench.py, the sharded multi-GPU path).
+All arithmetic happens in the HIP kernels behind the C ABI; nothing here computes.
+"""
+from __future__ import annotations
+
+import ctypes
+from ctypes import POINTER, byref, c_double, c_float, c_int32, c_int64, c_uint8, c_void_p
+
+import numpy as np
+
+from . import _capi
+from ._capi import CHAIN_IDS, CHAIN_P, DTYPE_IDS, check, lib
+
+
+def _dp(a: np.ndarray):
+    return a.ctypes.data_as(POINTER(c_double))
+
+
+def _f64c(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class Engine:
+    """One chain ('template' | 'self' | 'free') on one device.
+
+    Counts follow the reference's ``make_param_struct`` (abstract_function_blocks.py:793-795):
+    callers that mirror the reference pass ``max index + 1`` of the detection table.
+    """
+
+    def __init__(self, chain: str, n_cams: int, n_imgs: int, n_keys: int, *, dtype: str = "f64", device: int = 0):
+        if chain not in CHAIN_IDS:
+            raise ValueError(f"chain must be one of {sorted(CHAIN_IDS)}")
+        if dtype not in DTYPE_IDS:
+            raise ValueError("dtype must be 'f64' or 'f32'")
+        self.chain, self.dtype, self.device = chain, dtype, device
+        self.P = CHAIN_P[chain]
+        self._h = c_void_p()
+        check(lib().pcs_create(byref(self._h), CHAIN_IDS[chain], DTYPE_IDS[dtype], int(n_cams), int(n_imgs), int(n_keys), int(device)))
+        self.n_params = int(lib().pcs_n_params(self._h))
+        self.n = 0
+        self.nnz = None
+        self.np_dtype = np.float64 if dtype == "f64" else np.float32
+
+    # -- lifetime -----------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            lib().pcs_destroy(self._h)
+            self._h = c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- static inputs ------------------------------------------------------------------------
+    def set_detections_table(self, det5: np.ndarray):
+        """(N,5) float64 [cam, im, key, u, v] — the reference's flattened detection table."""
+        det5 = _f64c(det5)
+        if det5.ndim != 2 or det5.shape[1] != 5:
+            raise ValueError("detections must have shape (N, 5)")
+        check(lib().pcs_set_detections_table(self._h, _dp(det5), det5.shape[0]))
+        self.n = det5.shape[0]
+        self.nnz = None
+
+    def set_detections(self, cam, img, key, uv):
+        cam = np.ascontiguousarray(cam, dtype=np.int32)
+        img = np.ascontiguousarray(img, dtype=np.int32)
+        key = np.ascontiguousarray(key, dtype=np.int32)
+        uv = _f64c(uv)
+        n = cam.shape[0]
+        if not (img.shape[0] == key.shape[0] == n and uv.shape == (n, 2)):
+            raise ValueError("cam/img/key must have length N and uv shape (N,2)")
+        i32 = POINTER(c_int32)
+        check(lib().pcs_set_detections(self._h, cam.ctypes.data_as(i32), img.ctypes.data_as(i32), key.ctypes.data_as(i32), _dp(uv), n))
+        self.n = n
+        self.nnz = None
+
+    def set_template(self, points: np.ndarray):
+        points = _f64c(points).reshape(-1, 3)
+        check(lib().pcs_set_template(self._h, _dp(points)))
+
+    def set_option(self, key: str, value: int):
+        check(lib().pcs_set_option(self._h, key.encode(), int(value)))
+
+    # -- evaluation: host buffers -------------------------------------------------------------
+    def _check_params(self, param_str) -> np.ndarray:
+        p = _f64c(param_str).ravel()
+        if p.shape[0] != self.n_params:
+            raise ValueError(f"parameter string has {p.shape[0]} entries, engine expects {self.n_params}")
+        return p
+
+    def eval(self, param_str, want_resid: bool = True, want_jac: bool = True):
+        """-> (resid (N,2) | None, jac (2N,P) | None), float64 NumPy."""
+        p = self._check_params(param_str)
+        r = np.empty((self.n, 2)) if want_resid else None
+        j = np.empty((2 * self.n, self.P)) if want_jac else None
+        check(lib().pcs_eval(self._h, _dp(p), _dp(r) if want_resid else None, _dp(j) if want_jac else None))
+        return r, j
+
+    def set_unfixed(self, unfixed) -> int:
+        m = None if unfixed is None else np.ascontiguousarray(unfixed, dtype=np.uint8)
+        if m is not None and m.shape[0] != self.n_params:
+            raise ValueError("unfixed mask must have one entry per parameter")
+        nnz = c_int64()
+        check(lib().pcs_set_unfixed(self._h, m.ctypes.data_as(POINTER(c_uint8)) if m is not None else None, byref(nnz)))
+        self.nnz = int(nnz.value)
+        return self.nnz
+
+    def eval_compact(self, param_str, want_resid: bool = False):
+        """-> (resid | None, data (nnz,)) with the fixed columns removed on the device."""
+        if self.nnz is None:
+            raise RuntimeError("call set_unfixed() first")
+        p = self._check_params(param_str)
+        r = np.empty((self.n, 2)) if want_resid else None
+        d = np.empty(self.nnz)
+        check(lib().pcs_eval_compact(self._h, _dp(p), _dp(r) if want_resid else None, _dp(d)))
+        return r, d
+
+    # -- evaluation: device buffers -----------------------------------------------------------
+    def eval_device(self, param_str, d_resid: int | None, d_jac: int | None, stream: int | None = None):
+        """Asynchronous; ``d_resid`` / ``d_jac`` are raw device addresses in the engine dtype."""
+        p = self._check_params(param_str)
+        check(lib().pcs_eval_device(self._h, _dp(p), c_void_p(d_resid or 0), c_void_p(d_jac or 0), c_void_p(stream or 0)))
+
+    def eval_device_resident(self, d_param_str: int, d_resid: int | None, d_jac: int | None, stream: int | None = None):
+        """Parameter string already in HBM (float64, n_params entries)."""
+        check(lib().pcs_eval_device_resident(self._h, c_void_p(d_param_str), c_void_p(d_resid or 0), c_void_p(d_jac or 0), c_void_p(stream or 0)))
+
+    def eval_compact_device(self, param_str, d_resid: int | None, d_data: int | None, stream: int | None = None):
+        p = self._check_params(param_str)
+        check(lib().pcs_eval_compact_device(self._h, _dp(p), c_void_p(d_resid or 0), c_void_p(d_data or 0), c_void_p(stream or 0)))
+
+    def synchronize(self, stream: int | None = None):
+        check(lib().pcs_synchronize(self._h, c_void_p(stream or 0)))
+
+    def last_kernel_ms(self) -> tuple[float, float]:
+        """(slab_prep ms, eval kernel ms) of the most recent evaluation, from HIP events on its stream."""
+        a, b = c_float(), c_float()
+        check(lib().pcs_last_kernel_ms(self._h, byref(a), byref(b)))
+        return float(a.value), float(b.value)
+
+    def device_buffers(self) -> tuple[int, int]:
+        r, j = c_void_p(), c_void_p()
+        check(lib().pcs_device_buffers(self._h, byref(r), byref(j)))
+        return int(r.value), int(j.value)
+
+    # -- static structure ---------------------------------------------------------------------
+    def csr_structure(self, unfixed=None):
+        """(indices int64 (nnz,), indptr int64 (2N+1,)) — abstract_function_blocks.py:465-489."""
+        m = None if unfixed is None else np.ascontiguousarray(unfixed, dtype=np.uint8)
+        mp = m.ctypes.data_as(POINTER(c_uint8)) if m is not None else None
+        nnz = c_int64()
+        check(lib().pcs_csr_structure(self._h, mp, None, None, byref(nnz)))
+        indices = np.empty(nnz.value, dtype=np.int64)
+        indptr = np.empty(2 * self.n + 1, dtype=np.int64)
+        i64 = POINTER(c_int64)
+        check(lib().pcs_csr_structure(self._h, mp, indices.ctypes.data_as(i64), indptr.ctypes.data_as(i64), byref(nnz)))
+        return indices, indptr
+
+    def block_param_inds(self) -> np.ndarray:
+        out = np.empty((self.n, self.P), dtype=np.int64)
+        check(lib().pcs_block_param_inds(self._h, out.ctypes.data_as(POINTER(c_int64))))
+        return out
+
+
+def device_count() -> int:
+    return int(lib().pcs_device_count())
