@@ -1,0 +1,275 @@
+#!/usr/bin/env python3
+"""bench.py — residual + Jacobian rows/s of the bundle-adjustment hot path on N MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A *step* is one LM-step evaluation of the hot path over the whole detection table: slab
+preparation (K0) + the fused residual/Jacobian kernel (K1), with the parameter string and the
+detection table already resident in HBM and the residual / dense Jacobian blocks left in HBM.
+
+Workload at N = 1: BASELINE.json configs[2], "rig-32" — 32 cameras, Ccube target (486 keys),
+200 poses, ~1.0e6 detections, template chain, FP64.  For N > 1 (one process
+per GPU, launched by torch.distributed.run, RCCL backend) scaling is *weak*: rank r evaluates an
+independent rig-32 block (same shape, seed + 1000 r) — together a 32N-camera / 200N-pose rig whose
+visibility is block diagonal — with no data-path collective in the timed region (the path
+partitions by observation).  The all-gather of residual + Jacobian blocks that a
+host-side consumer would need is link-bound; it is timed separately and reported under
+"allgather" (never inside `value` unless --collective allgather is given).
+
+Rank 0 prints ONE JSON line (schema: task contract + "roofline" + "cpu_baseline").
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+REPO = Path(__file__).resolve().parent
+if str(REPO) not in sys.path:
+    sys.path.insert(0, str(REPO))
+
+BYTES_PER_DET = {("template", "f64"): 380, ("self", "f64"): 428, ("free", "f64"): 332,
+                 ("template", "f32"): 196, ("self", "f32"): 220, ("free", "f32"): 172}
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+CONFIG_CHAIN = {1: "template", 2: "template", 3: "template", 4: "self", 5: "template"}
+CONFIG_DTYPE = {1: "f64", 2: "f64", 3: "f64", 4: "f64", 5: "f32"}
+
+
+def chain_slabs(rig, chain):
+    if chain == "template":
+        return [rig.intr, rig.extr, rig.poses]
+    if chain == "self":
+        return [rig.intr, rig.extr, rig.poses, rig.points]
+    return [rig.intr, rig.extr, rig.points]
+
+
+def cpu_baseline(rig, chain, param_str, budget_s: float):
+    """Time the CPU oracle (the repo's C restatement of the reference's per-detection algorithm,
+    -O3 AVX2/FMA + OpenMP) on the host cores, on the same workload.  kind = "port"."""
+    from oracle import ba_oracle as orc
+
+    orc.build()
+    threads = os.cpu_count() or 1
+    tm = rig.points if chain == "template" else None
+    counts = (rig.n_cams, rig.n_imgs, rig.n_keys)
+    n_sample = min(rig.n_det, 1_000_000)
+    det = rig.detections[:n_sample]
+    orc.full_jac_dense(chain, det[:50_000], param_str, tm, threads=threads, fast=True, with_resid=True, counts=counts)  # warm
+    passes, t0 = 0, time.perf_counter()
+    while True:
+        orc.full_jac_dense(chain, det, param_str, tm, threads=threads, fast=True, with_resid=True, counts=counts)
+        passes += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or passes >= 200:
+            break
+    return {
+        "value": 2.0 * n_sample * passes / el,
+        "unit": "rows/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"{passes} full residual+Jacobian passes over the first {n_sample} detections of the same rig "
+                  f"({el:.1f} s, oracle/libba_oracle_fast.so, OpenMP static schedule)",
+    }
+
+
+def pmc_traffic(workload_key: str):
+    """HBM bytes per launch from the committed rocprofv3 PMC summary of this same command, if any."""
+    f = REPO / "profiles" / "pmc_traffic.json"
+    if f.exists():
+        try:
+            return json.loads(f.read_text()).get(workload_key, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            return None
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", type=int, default=3, help="BASELINE.md config number (3 = headline rig-32)")
+    ap.add_argument("--chain", default=None)
+    ap.add_argument("--dtype", default=None)
+    ap.add_argument("--scale", type=float, default=1.0, help="visibility scale (<1: smaller N, for quick checks)")
+    ap.add_argument("--collective", default="none", choices=["none", "allgather"],
+                    help="'allgather' puts the RCCL all-gather of residual+Jacobian blocks inside the timed step")
+    ap.add_argument("--variant", type=int, default=None)
+    ap.add_argument("--wgs-per-cu", type=int, default=None)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-allgather-probe", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit(f"--gpus {args.gpus} needs one process per GPU: launch with "
+                             f"python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} "
+                             f"--master-addr 127.0.0.1 --master-port P bench.py --gpus {args.gpus} ...")
+        raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
+
+    import torch
+    import torch.distributed as dist
+
+    from pycamset_amd import synthetic
+    from pycamset_amd.engine import Engine
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    chain = args.chain or CONFIG_CHAIN[args.config]
+    dtype = args.dtype or CONFIG_DTYPE[args.config]
+    rig = synthetic.config_rig(args.config, scale=args.scale, block=rank)
+    N = rig.n_det
+    ps = np.concatenate([np.asarray(a, dtype=np.float64).ravel() for a in chain_slabs(rig, chain)])
+
+    eng = Engine(chain, rig.n_cams, rig.n_imgs, rig.n_keys, dtype=dtype, device=local_rank)
+    eng.set_detections_table(rig.detections)
+    if chain == "template":
+        eng.set_template(rig.points)
+    if args.variant is not None:
+        eng.set_option("variant", args.variant)
+    if args.wgs_per_cu is not None:
+        eng.set_option("wgs_per_cu", args.wgs_per_cu)
+    P = eng.P
+    tdt = torch.float64 if dtype == "f64" else torch.float32
+    d_r = torch.empty((N, 2), dtype=tdt, device=dev)
+    d_j = torch.empty((2 * N, P), dtype=tdt, device=dev)
+    d_p = torch.from_numpy(ps).to(dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    gather = None
+    if world > 1 and (args.collective == "allgather" or not args.no_allgather_probe):
+        counts = torch.tensor([N], device=dev)
+        dist.all_reduce(counts, op=dist.ReduceOp.MAX)
+        per = int(counts.item())
+        pad_r = torch.zeros((per, 2), dtype=tdt, device=dev)
+        pad_j = torch.zeros((2 * per, P), dtype=tdt, device=dev)
+        g_r = torch.empty((world * per, 2), dtype=tdt, device=dev)
+        g_j = torch.empty((world * 2 * per, P), dtype=tdt, device=dev)
+
+        def gather():
+            # equal counts per rank (pad like afb:281-288); outputs land in the padded send buffers
+            dist.all_gather_into_tensor(g_r, pad_r)
+            dist.all_gather_into_tensor(g_j, pad_j)
+
+    use_gather_in_step = args.collective == "allgather" and world > 1
+    out_r, out_j = (pad_r, pad_j) if use_gather_in_step else (d_r, d_j)
+
+    def step():
+        eng.eval_device_resident(d_p.data_ptr(), out_r.data_ptr(), out_j.data_ptr(), stream)
+        if use_gather_in_step:
+            gather()
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    eng.set_option("event_ring", max(1, args.steps))  # keep the HIP events of every timed launch
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    n_all = torch.tensor([float(N)], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(n_all, op=dist.ReduceOp.SUM)
+    elapsed = float(t.item())
+    n_total = float(n_all.item())
+    n_ev, prep_ms, eval_ms = eng.kernel_ms_mean()
+
+    allgather_info = None
+    if gather is not None and not use_gather_in_step:
+        pad_r[:N].copy_(d_r)
+        pad_j[: 2 * N].copy_(d_j)
+        for _ in range(3):
+            gather()
+        fence()
+        reps = 10
+        g0 = time.perf_counter()
+        for _ in range(reps):
+            gather()
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        gt = torch.tensor([(time.perf_counter() - g0) / reps], dtype=torch.float64, device=dev)
+        dist.all_reduce(gt, op=dist.ReduceOp.MAX)
+        sent = (pad_r.numel() + pad_j.numel()) * pad_r.element_size()
+        allgather_info = {"ms": float(gt.item()) * 1e3, "bytes_sent_per_gpu": sent,
+                          "bytes_received_per_gpu": sent * (world - 1),
+                          "recv_GBps_per_gpu": sent * (world - 1) / float(gt.item()) / 1e9,
+                          "note": "RCCL all_gather_into_tensor of residual+Jacobian blocks, timed outside the step"}
+
+    if rank == 0:
+        bpd = BYTES_PER_DET[(chain, dtype)]
+        achieved = N * bpd / (eval_ms * 1e-3) / 1e9
+        key = f"{rig.name.split('/')[0]}/{chain}/{dtype}"
+        line = {
+            "metric": "residual+Jacobian rows/sec",
+            "value": 2.0 * n_total * args.steps / elapsed,
+            "unit": "rows/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": dtype,
+            "data": "synthetic",
+            "config": {
+                "workload": f"{rig.name.split('/')[0]} (BASELINE config {args.config}): {rig.n_cams} cams x {rig.n_imgs} poses x "
+                            f"{rig.n_keys} keys, {N} detections per GPU, chain {chain}, slab_prep + fused residual/Jacobian kernel per step",
+                "detections_per_gpu": N,
+                "rows_per_step": 2.0 * n_total,
+                "row_len_P": P,
+                "collective_in_step": args.collective if world > 1 else "none",
+                "parallelism": f"obs-shard x{world}",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS,
+                "traffic": pmc_traffic(key),
+                "kernel": "ba_eval_kernel",
+                "kernel_ms": eval_ms,
+                "slab_prep_ms": prep_ms,
+                "launches_timed": n_ev,
+                "algorithmic_bytes_per_detection": bpd,
+                "frac_of_measured_copy_peak_6290": achieved / 6290.0,
+            },
+        }
+        if allgather_info:
+            line["allgather"] = allgather_info
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(rig, chain, ps, args.cpu_seconds)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

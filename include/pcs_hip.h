@@ -133,7 +133,12 @@ int pcs_eval_compact_device(pcs_engine *h, const double *param_str, void *d_resi
 int pcs_synchronize(pcs_engine *h, void *stream);
 /* Duration of the most recent evaluation's kernels (HIP events on the launch stream), ms. */
 int pcs_last_kernel_ms(pcs_engine *h, float *slab_prep_ms, float *eval_ms);
-/* Tuning knobs (launch geometry); see DESIGN.md.  Unknown keys -> PCS_ERR_ARG. */
+/* Mean kernel durations over the evaluations kept in the event ring (option "event_ring" = R keeps
+ * the last R evaluations; the ring is reset when the option is set).  Used by bench.py for the
+ * roofline figure: live HIP-event timing of every launch of the timed region. */
+int pcs_kernel_ms_mean(pcs_engine *h, int64_t *count, float *slab_prep_ms, float *eval_ms);
+/* Tuning knobs ("variant", "wgs_per_cu", "tiles_per_wg", "event_ring"); see DESIGN.md.
+ * Unknown keys -> PCS_ERR_ARG. */
 int pcs_set_option(pcs_engine *h, const char *key, int64_t value);
 /* Engine-owned device scratch for outputs (engine dtype); valid until the next set_detections. */
 int pcs_device_buffers(pcs_engine *h, void **d_resid, void **d_jac);

@@ -326,7 +326,9 @@ struct pcs_engine {
     int64_t extr_off = 0, pose_off = 0, point_off = 0;
     size_t esize = 8;
     hipStream_t stream = nullptr;
-    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    std::vector<hipEvent_t> ev;  // ring of (start, after slab_prep, after eval) triples
+    int64_t ev_ring = 1;         // triples in the ring
+    int64_t ev_count = 0;        // evaluations recorded since the ring was (re)created
     bool events_valid = false;
     hipStream_t last_stream = nullptr;
     // static inputs
@@ -349,8 +351,10 @@ struct pcs_engine {
     int64_t data_capacity = 0;
     // launch geometry
     int n_cu = 256;
-    int variant = VAR_SLAB_LDS | VAR_TRANSPOSE;
-    int64_t wgs_per_cu = 2;
+    // defaults from the MI355X sweep in profiles/ (round 1): transposed + non-temporal stores, slabs
+    // through L1/L2 (the cam -> image -> key ordered table makes slab reads wave-uniform)
+    int variant = VAR_TRANSPOSE | VAR_NT;
+    int64_t wgs_per_cu = 8;
     int64_t tiles_per_wg = 0;  // 0 = derive from wgs_per_cu
     size_t lds_limit = 160 * 1024;
 };
@@ -403,6 +407,7 @@ int pcs_create(pcs_engine **out, int chain, int dtype, int64_t n_cams, int64_t n
                    : prop.sharedMemPerBlock > 0            ? prop.sharedMemPerBlock
                                                            : 64 * 1024;
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    h->ev.assign(3, nullptr);
     for (auto &e : h->ev) HIPCHK(hipEventCreate(&e));
     HIPCHK(hipMalloc(&h->d_param, sizeof(double) * h->n_params));
     HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&h->h_param), sizeof(double) * h->n_params, hipHostMallocDefault));
@@ -519,6 +524,18 @@ int pcs_set_option(pcs_engine *h, const char *key, int64_t value) {
         if (value < 1 || value > 64) return fail(PCS_ERR_ARG, "wgs_per_cu must be in [1,64]");
         h->wgs_per_cu = value;
         h->tiles_per_wg = 0;
+    } else if (!strcmp(key, "event_ring")) {
+        // keep the HIP-event triples of the last `value` evaluations (pcs_kernel_ms_mean averages them)
+        if (value < 1 || value > 100000) return fail(PCS_ERR_ARG, "event_ring must be in [1,100000]");
+        HIPCHK(hipSetDevice(h->device));
+        HIPCHK(hipStreamSynchronize(h->last_stream ? h->last_stream : h->stream));
+        for (auto &e : h->ev)
+            if (e) (void)hipEventDestroy(e);
+        h->ev.assign(3 * value, nullptr);
+        for (auto &e : h->ev) HIPCHK(hipEventCreate(&e));
+        h->ev_ring = value;
+        h->ev_count = 0;
+        h->events_valid = false;
     } else if (!strcmp(key, "tiles_per_wg")) {
         if (value < 0 || value > (1 << 20)) return fail(PCS_ERR_ARG, "tiles_per_wg out of range");
         h->tiles_per_wg = value;
@@ -602,7 +619,8 @@ static int enqueue_eval(pcs_engine *h, const double *d_prm, void *d_resid, void 
     const int mode = (d_resid ? MODE_RESID : 0) | (d_out ? MODE_JAC : 0);
     if (!mode) return PCS_OK;
     HIPCHK(hipSetDevice(h->device));
-    HIPCHK(hipEventRecord(h->ev[0], s));
+    hipEvent_t *ev = h->ev.data() + 3 * (h->ev_count % h->ev_ring);
+    HIPCHK(hipEventRecord(ev[0], s));
     {
         const int has_pose = h->chain != PCS_CHAIN_FREE;
         const int copy_points = h->chain != PCS_CHAIN_TEMPLATE;
@@ -620,7 +638,7 @@ static int enqueue_eval(pcs_engine *h, const double *d_prm, void *d_resid, void 
                                h->point_off, has_pose, copy_points);
         HIPCHK(hipGetLastError());
     }
-    HIPCHK(hipEventRecord(h->ev[1], s));
+    HIPCHK(hipEventRecord(ev[1], s));
     EvalArgs a{};
     a.cam = h->d_cam; a.img = h->d_img; a.key = h->d_key; a.uv = h->d_uv;
     a.cam_slab = h->d_cam_slab; a.pose_slab = h->d_pose_slab; a.points = h->d_points;
@@ -653,7 +671,8 @@ static int enqueue_eval(pcs_engine *h, const double *d_prm, void *d_resid, void 
                                            : launch_eval_t<float>(h->chain, mode, variant, a, dim3((unsigned)grid), lds, s);
         if (e != hipSuccess) return fail(PCS_ERR_HIP, "eval kernel launch failed: %s", hipGetErrorString(e));
     }
-    HIPCHK(hipEventRecord(h->ev[2], s));
+    HIPCHK(hipEventRecord(ev[2], s));
+    ++h->ev_count;
     h->events_valid = true;
     h->last_stream = s;
     return PCS_OK;
@@ -858,12 +877,33 @@ int pcs_synchronize(pcs_engine *h, void *stream) {
 int pcs_last_kernel_ms(pcs_engine *h, float *slab_prep_ms, float *eval_ms) {
     if (!h) return fail(PCS_ERR_ARG, "pcs_last_kernel_ms: bad arguments");
     if (!h->events_valid) return fail(PCS_ERR_STATE, "no evaluation has been queued yet");
-    HIPCHK(hipEventSynchronize(h->ev[2]));
+    hipEvent_t *ev = h->ev.data() + 3 * ((h->ev_count - 1) % h->ev_ring);
+    HIPCHK(hipEventSynchronize(ev[2]));
     float a = 0, b = 0;
-    HIPCHK(hipEventElapsedTime(&a, h->ev[0], h->ev[1]));
-    HIPCHK(hipEventElapsedTime(&b, h->ev[1], h->ev[2]));
+    HIPCHK(hipEventElapsedTime(&a, ev[0], ev[1]));
+    HIPCHK(hipEventElapsedTime(&b, ev[1], ev[2]));
     if (slab_prep_ms) *slab_prep_ms = a;
     if (eval_ms) *eval_ms = b;
+    return PCS_OK;
+}
+
+int pcs_kernel_ms_mean(pcs_engine *h, int64_t *count, float *slab_prep_ms, float *eval_ms) {
+    if (!h) return fail(PCS_ERR_ARG, "pcs_kernel_ms_mean: bad arguments");
+    if (!h->events_valid) return fail(PCS_ERR_STATE, "no evaluation has been queued yet");
+    const int64_t n = std::min<int64_t>(h->ev_count, h->ev_ring);
+    double sa = 0, sb = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        hipEvent_t *ev = h->ev.data() + 3 * i;
+        HIPCHK(hipEventSynchronize(ev[2]));
+        float a = 0, b = 0;
+        HIPCHK(hipEventElapsedTime(&a, ev[0], ev[1]));
+        HIPCHK(hipEventElapsedTime(&b, ev[1], ev[2]));
+        sa += a;
+        sb += b;
+    }
+    if (count) *count = n;
+    if (slab_prep_ms) *slab_prep_ms = (float)(sa / n);
+    if (eval_ms) *eval_ms = (float)(sb / n);
     return PCS_OK;
 }
 

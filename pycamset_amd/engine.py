@@ -42,6 +42,7 @@ class Engine:
         self.n_params = int(lib().pcs_n_params(self._h))
         self.n = 0
         self.nnz = None
+        self.mask_key = None
         self.np_dtype = np.float64 if dtype == "f64" else np.float32
 
     # -- lifetime -----------------------------------------------------------------------------
@@ -108,6 +109,7 @@ class Engine:
         nnz = c_int64()
         check(lib().pcs_set_unfixed(self._h, m.ctypes.data_as(POINTER(c_uint8)) if m is not None else None, byref(nnz)))
         self.nnz = int(nnz.value)
+        self.mask_key = None if m is None else hash(m.astype(bool).tobytes())
         return self.nnz
 
     def eval_compact(self, param_str, want_resid: bool = False):
@@ -142,6 +144,13 @@ class Engine:
         a, b = c_float(), c_float()
         check(lib().pcs_last_kernel_ms(self._h, byref(a), byref(b)))
         return float(a.value), float(b.value)
+
+    def kernel_ms_mean(self) -> tuple[int, float, float]:
+        """(count, mean slab_prep ms, mean eval ms) over the evaluations kept in the event ring
+        (``set_option('event_ring', R)``)."""
+        n, a, b = c_int64(), c_float(), c_float()
+        check(lib().pcs_kernel_ms_mean(self._h, byref(n), byref(a), byref(b)))
+        return int(n.value), float(a.value), float(b.value)
 
     def device_buffers(self) -> tuple[int, int]:
         r, j = c_void_p(), c_void_p()

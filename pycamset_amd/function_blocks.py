@@ -1,0 +1,209 @@
+"""Host-side mirror of pyCamSet's operator API for the bundle-adjustment hot path.
+
+Same names, argument meaning and return layouts as
+``pyCamSet/optimisation/abstract_function_blocks.py`` (afb) and
+``pyCamSet/optimisation/function_block_implementations.py`` (fbi), so that a pyCamSet
+``ParamHandler`` can swap its ``self.op_fun`` for one built from these blocks:
+
+    op_fun = projection() + extrinsic3D() + template_points()          # template_handler.py:152
+    loss = op_fun.make_full_loss_fn(detections, threads)                # afb:656-658
+    jac  = op_fun.make_jacobean(detections, threads, unfixed_params)    # afb:661-667
+    param_str = op_fun.build_param_list(intr, extr, poses)              # afb:669-681
+    loss(param_str, template) -> (N, 2)
+    jac(param_str, template)  -> (data, indices, indptr)
+
+The blocks here are *declarations*: the arithmetic of every block (and the chain rule the
+reference code-generates with matmul_map.py) lives in the fused HIP kernels behind the C ABI
+(csrc/ba_device.hpp).  Only the three chains the reference's handlers build are available; any
+other combination raises, loudly — there is no interpreter fallback.
+"""
+from __future__ import annotations
+
+from enum import IntEnum
+
+import numpy as np
+
+from .engine import Engine
+
+
+class key_type(IntEnum):  # afb:42-46
+    PER_CAM = 0
+    PER_IMG = 1
+    PER_KEY = 2
+    SINGLE = 3
+
+
+class param_type:  # afb:50-70
+    def __init__(self, link_type: key_type, n_params: int, mod_function=None) -> None:
+        self.link_type = link_type
+        self.n_params = n_params
+        self.sparse_param = False
+        self.mod_function = mod_function
+
+
+class abstract_function_block:  # afb:689-748
+    array_memory: int = 0
+    template = False
+    num_inp: int = 0
+    num_out: int = 0
+    params: param_type = None
+
+    def __add__(self, other):
+        if isinstance(other, abstract_function_block):
+            return optimisation_function([self, other])
+        if isinstance(other, optimisation_function):
+            return optimisation_function([self] + other.function_blocks)
+        raise ValueError(f"could not combine function block with {other}")
+
+    def __radd__(self, other):
+        if isinstance(other, abstract_function_block):
+            return optimisation_function([other, self])
+        if isinstance(other, optimisation_function):
+            return optimisation_function(other.function_blocks + [self])
+        raise ValueError(f"could not combine function block with {other}")
+
+
+class projection(abstract_function_block):  # fbi:21-140
+    num_inp, num_out, array_memory = 3, 2, 1
+    params = param_type(key_type.PER_CAM, 9)
+
+
+class rigidTform3d(abstract_function_block):  # fbi:143-182
+    num_inp, num_out, array_memory = 3, 3, 27
+    params = param_type(key_type.PER_IMG, 6)
+
+
+class extrinsic3D(rigidTform3d):  # fbi:184-185
+    params = param_type(key_type.PER_CAM, 6)
+
+
+class template_points(rigidTform3d):  # fbi:188-211
+    template = True
+    num_inp, num_out = 0, 3
+    params = param_type(key_type.PER_IMG, 6)
+
+
+class free_point(abstract_function_block):  # fbi:216-240
+    num_inp, num_out, array_memory = 0, 3, 0
+    params = param_type(key_type.PER_KEY, 3)
+
+
+_CHAINS = {
+    (projection, extrinsic3D, template_points): "template",
+    (projection, extrinsic3D, rigidTform3d, free_point): "self",
+    (projection, extrinsic3D, free_point): "free",
+}
+
+
+def _counts(detections: np.ndarray) -> tuple[int, int, int]:
+    """make_param_struct's group counts: max index + 1 per link type (afb:793-795)."""
+    if detections.shape[0] == 0:
+        raise ValueError("empty detection table")
+    return (int(np.max(detections[:, 0])) + 1, int(np.max(detections[:, 1])) + 1, int(np.max(detections[:, 2])) + 1)
+
+
+class optimisation_function:  # afb:111-685
+    """A chain of function blocks evaluated by the MI355X engine."""
+
+    def __init__(self, function_blocks, *, dtype: str = "f64", device: int = 0) -> None:
+        self.function_blocks = list(function_blocks)
+        self.n_blocks = len(self.function_blocks)
+        self.dtype, self.device = dtype, device
+        self.templated = self.function_blocks[-1].template
+        self.n_params = np.array([b.params.n_params for b in self.function_blocks])
+        self.param_line_length = int(self.n_params.sum())  # P
+        self._engine: Engine | None = None
+        self._engine_key = None
+        self._template_key = None
+
+    @property
+    def chain(self) -> str:
+        """Which fused kernel family evaluates this chain.  `a + b + c` builds intermediate
+        partial chains (afb:735-748), so the check happens on use, not on construction."""
+        kinds = tuple(type(b) for b in self.function_blocks)
+        if kinds not in _CHAINS:
+            names = " + ".join(k.__name__ for k in kinds)
+            raise NotImplementedError(
+                f"chain '{names}' has no fused HIP kernel; supported: "
+                + "; ".join(" + ".join(k.__name__ for k in c) for c in _CHAINS)
+            )
+        return _CHAINS[kinds]
+
+    # -- engine sharing between the loss and the Jacobian closures ---------------------------
+    def _engine_for(self, detections: np.ndarray) -> Engine:
+        det = np.ascontiguousarray(detections, dtype=np.float64)
+        if det.ndim != 2 or det.shape[1] != 5:
+            raise ValueError("detections must be the flattened (N, 5) table [cam, im, key, u, v]")
+        key = (det.shape, hash(det.tobytes()))
+        if self._engine is None or key != self._engine_key:
+            C, I, K = _counts(det)
+            eng = Engine(self.chain, C, I, K, dtype=self.dtype, device=self.device)
+            eng.set_detections_table(det)
+            self._engine, self._engine_key, self._template_key = eng, key, None
+        return self._engine
+
+    def _bind_template(self, eng: Engine, template) -> None:
+        if self.chain != "template":
+            return
+        if template is None:
+            raise ValueError("the template chain needs the template points (target.point_data.reshape(-1, 3))")
+        t = np.ascontiguousarray(template, dtype=np.float64).reshape(-1, 3)
+        key = hash(t.tobytes())
+        if key != self._template_key:
+            eng.set_template(t)
+            self._template_key = key
+
+    # -- reference API -------------------------------------------------------------------------
+    def can_make_jac(self) -> bool:  # afb:683-684
+        return True
+
+    def build_param_list(self, *args) -> np.ndarray:  # afb:669-681
+        return np.concatenate([np.asarray(a, dtype=np.float64).flatten() for a in args], axis=0)
+
+    def make_full_loss_fn(self, detections, threads=None):  # afb:656-658 -> afb:290-419
+        """``threads`` is accepted for signature compatibility and ignored (the GPU grid replaces
+        the reference's prange chunks; its np.resize padding never reaches the output, afb:385)."""
+        eng = self._engine_for(detections)
+
+        def loss_fn(param, template=None):
+            self._bind_template(eng, template)
+            r, _ = eng.eval(param, want_resid=True, want_jac=False)
+            return r
+
+        return loss_fn
+
+    def make_jacobean(self, detections, threads=None, unfixed_params=None):  # afb:661-667 -> afb:492-652
+        eng = self._engine_for(detections)
+        if unfixed_params is None:
+            unfixed = np.ones(eng.n_params, dtype=bool)
+        else:
+            unfixed = np.asarray(unfixed_params, dtype=bool)
+            if unfixed.shape[0] != eng.n_params:
+                raise ValueError(f"unfixed_params has {unfixed.shape[0]} entries, expected {eng.n_params}")
+        indices, indptr = eng.csr_structure(unfixed)  # static, built once (afb:619)
+        all_free = bool(np.all(unfixed))
+        mask_key = hash(unfixed.tobytes())
+        if not all_free:
+            eng.set_unfixed(unfixed)
+
+        def jac_fn(param, template=None):
+            self._bind_template(eng, template)
+            if all_free:  # afb:633-642
+                _, j = eng.eval(param, want_resid=False, want_jac=True)
+                return j.reshape(-1), indices, indptr
+            if eng.mask_key != mask_key:  # another closure re-bound the engine's mask
+                eng.set_unfixed(unfixed)
+            _, data = eng.eval_compact(param)  # afb:644-651, masked on the device
+            return data, indices, indptr
+
+        return jac_fn
+
+    def get_block_param_inds(self, detections, threads=None, unthreaded=True) -> np.ndarray:  # afb:192-233
+        return self._engine_for(detections).block_param_inds()
+
+    def make_jac_CSR_columns_row_pointers(self, detections, threads, unfixed_params):  # afb:465-489
+        return self._engine_for(detections).csr_structure(np.asarray(unfixed_params, dtype=bool))
+
+    @property
+    def engine(self) -> Engine | None:
+        return self._engine

@@ -199,18 +199,29 @@ def make_rig(name: str, n_cams: int, n_imgs: int, points: np.ndarray, *, seed: i
 # --------------------------------------------------------------------------------------
 # the BASELINE.json configs
 # --------------------------------------------------------------------------------------
-def config_rig(number: int, *, scale: float = 1.0, order: str = "cam", n_imgs: int | None = None) -> SyntheticRig:
-    """BASELINE.md section 3 configs; ``scale`` < 1 shrinks the visibility (smaller N, same shapes)."""
+def config_rig(number: int, *, scale: float = 1.0, order: str = "cam", n_imgs: int | None = None,
+               block: int = 0) -> SyntheticRig:
+    """BASELINE.md section 3 configs; ``scale`` < 1 shrinks the visibility (smaller N, same shapes).
+    ``block`` > 0 draws an independent rig of the same shape (seed + 1000 * block): rank r of a
+    weak-scaling run evaluates block r."""
+    if block:
+        rig = _config_rig(number, scale, order, n_imgs, 1000 * block)
+        rig.name += f"/block{block}"
+        return rig
+    return _config_rig(number, scale, order, n_imgs, 0)
+
+
+def _config_rig(number, scale, order, n_imgs, seed_off) -> SyntheticRig:
     if number == 1:   # ccube-plumbing: 3 cams x 24 images, Ccube 486 keys, N ~ 7e3
-        return make_rig("ccube-plumbing", 3, n_imgs or 24, ccube_points(), seed=1, visibility=0.2 * scale)
+        return make_rig("ccube-plumbing", 3, n_imgs or 24, ccube_points(), seed=1 + seed_off, visibility=0.2 * scale)
     if number == 2:   # ring-8: planar ChArUco 17x17 -> 256 corners, 50 poses, all visible, N = 102400
-        return make_rig("ring-8", 8, n_imgs or 50, charuco_points(17, 4.0), seed=2,
+        return make_rig("ring-8", 8, n_imgs or 50, charuco_points(17, 4.0), seed=2 + seed_off,
                         visibility=1.0 if scale >= 1 else scale)
     if number in (3, 4):   # rig-32 (headline) / rig-32-self: 32 cams on two rings, Ccube, 200 poses, N ~ 1e6
         return make_rig("rig-32" if number == 3 else "rig-32-self", 32, n_imgs or 200, ccube_points(),
-                        seed=number, visibility=0.3215 * scale, n_rings=2, order=order)
+                        seed=number + seed_off, visibility=0.3215 * scale, n_rings=2, order=order)
     if number == 5:   # rig-128: 128 cams, 500 poses, N ~ 1e7
-        return make_rig("rig-128", 128, n_imgs or 500, ccube_points(), seed=5, visibility=0.3215 * scale,
+        return make_rig("rig-128", 128, n_imgs or 500, ccube_points(), seed=5 + seed_off, visibility=0.3215 * scale,
                         n_rings=4, order=order)
     raise ValueError(f"unknown config {number}")
 

@@ -1,0 +1,43 @@
+"""Shared helpers for the test-suite (tolerance rules, slab selection)."""
+import numpy as np
+
+# Product tolerance (BASELINE.json north_star: 1e-10 relative FP64):
+#   Jacobian:  |a - b| <= 1e-10 * max(|ref|, 1e-6 * ||row||_inf)
+#   residual:  |a - b| <= 1e-10 * max(|ref|, 1e-3 * max(|u|,|v|))   (a residual is the difference of
+#              two ~500 px coordinates; its relative accuracy is meaningful on the projection)
+JAC_RTOL = 1e-10
+ROW_FLOOR = 1e-6
+RES_RTOL = 1e-10
+# FP32 engine (config 5): single-precision arithmetic on ~1e3 px projections, cancelling chain-rule sums
+F32_JAC_RTOL = 5e-3
+F32_RES_ATOL = 2e-3  # pixels
+
+
+def chain_slabs(rig, chain):
+    if chain == "template":
+        return [rig.intr, rig.extr, rig.poses]
+    if chain == "self":
+        return [rig.intr, rig.extr, rig.poses, rig.points]
+    return [rig.intr, rig.extr, rig.points]
+
+
+def jac_rel_err(a, ref, rows=None):
+    a, ref = np.asarray(a), np.asarray(ref)
+    if rows is None:
+        rows = np.max(np.abs(ref), axis=1, keepdims=True)
+    return float(np.max(np.abs(a - ref) / np.maximum(np.abs(ref), ROW_FLOOR * rows))) if ref.size else 0.0
+
+
+def resid_rel_err(r, ref, uv):
+    scale = np.maximum(np.abs(ref), 1e-3 * np.max(np.abs(uv), axis=1, keepdims=True))
+    return float(np.max(np.abs(r - ref) / scale)) if ref.size else 0.0
+
+
+def assert_jac_close(a, ref, rtol=JAC_RTOL, rows=None):
+    err = jac_rel_err(a, ref, rows)
+    assert err <= rtol, f"Jacobian max rel err {err:.3e} > {rtol:.1e}"
+
+
+def assert_resid_close(r, ref, uv, rtol=RES_RTOL):
+    err = resid_rel_err(r, ref, uv)
+    assert err <= rtol, f"residual max rel err {err:.3e} > {rtol:.1e}"

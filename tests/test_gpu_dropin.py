@@ -1,0 +1,128 @@
+"""Drop-in boundary on the GPU: the optimisation_function adapter and the ParamHandler closures
+against the goldens produced by the reference's own handlers, and scipy.least_squares driven by
+the HIP closures."""
+import numpy as np
+import pytest
+from scipy.optimize import least_squares
+from scipy.sparse import csr_array
+
+from oracle import ba_oracle as orc
+from pycamset_amd import function_blocks as fb
+from pycamset_amd import handlers, synthetic
+from pycamset_amd.detections import TargetDetection
+from tests import helpers as H
+from tests.test_host_logic import DuckCamset, DuckTarget, make_handler
+
+pytestmark = pytest.mark.gpu
+
+
+def chain_op(chain):
+    if chain == "template":
+        return fb.projection() + fb.extrinsic3D() + fb.template_points()
+    if chain == "self":
+        return fb.projection() + fb.extrinsic3D() + fb.rigidTform3d() + fb.free_point()
+    return fb.projection() + fb.extrinsic3D() + fb.free_point()
+
+
+@pytest.mark.parametrize("chain", ["template", "self", "free"])
+def test_operator_api_matches_reference_goldens(golden_dir, chain):
+    g = np.load(golden_dir / f"block_{chain}_medium.npz")
+    det, ps = g["detections"], g["param_str"]
+    tm = g["points"] if chain == "template" else None
+    op = chain_op(chain)
+    assert op.can_make_jac()
+    loss = op.make_full_loss_fn(det, 4)
+    r = loss(ps, tm) if tm is not None else loss(ps)
+    assert r.shape == (det.shape[0], 2)
+    H.assert_resid_close(r, g["resid_t4"], det[:, 3:])
+    jac = op.make_jacobean(det, 4)
+    d, c, rp = jac(ps, tm) if tm is not None else jac(ps)
+    P = op.param_line_length
+    H.assert_jac_close(d.reshape(-1, P), g["data_all_t4"].reshape(-1, P))
+    assert np.array_equal(c, g["indices_all_t4"]) and np.array_equal(rp, g["indptr_all_t4"])
+    jac_m = op.make_jacobean(det, 4, unfixed_params=g["unfixed"])
+    dm, cm, rpm = jac_m(ps, tm) if tm is not None else jac_m(ps)
+    assert np.array_equal(cm, g["indices_masked_t4"]) and np.array_equal(rpm, g["indptr_masked_t4"])
+    assert dm.shape == g["data_masked_t4"].shape
+    assert np.max(np.abs(dm - g["data_masked_t4"])) <= 1e-10 * np.max(np.abs(g["data_masked_t4"]))
+    # the all-free closure still works after the masked one re-bound the engine
+    d2, _, _ = jac(ps, tm) if tm is not None else jac(ps)
+    assert np.array_equal(d2, d)
+    assert np.array_equal(op.build_param_list(g["intr"], g["extr"]), np.concatenate([g["intr"].ravel(), g["extr"].ravel()]))
+    assert np.array_equal(op.get_block_param_inds(det, 4), g["block_param_inds"])
+
+
+@pytest.mark.parametrize("chain", ["template", "self", "free"])
+@pytest.mark.parametrize("tag,fixed", [("tiny", True), ("tiny_nofix", False)])
+def test_handler_closures_match_reference_goldens(golden_dir, chain, tag, fixed):
+    g = np.load(golden_dir / f"handler_{chain}_{tag}.npz")
+    h = make_handler(g, chain, fixed)
+    x = g["x"].copy()
+    loss_fn = h.make_loss_fun(2)
+    jac_fn = h.make_loss_jac(2)
+    r = loss_fn(x)
+    assert r.shape == g["resid"].shape and r.flags.c_contiguous
+    uv = np.repeat(np.max(np.abs(g["detections"][:, 3:]), axis=1), 2)
+    assert np.max(np.abs(r - g["resid"]) / np.maximum(np.abs(g["resid"]), 1e-3 * uv)) <= H.RES_RTOL
+    J = jac_fn(x)
+    assert isinstance(J, csr_array) and tuple(J.shape) == tuple(g["shape"])
+    assert np.array_equal(J.indices, g["indices"]) and np.array_equal(J.indptr, g["indptr"])
+    ref = csr_array((g["data"], g["indices"], g["indptr"]), shape=tuple(g["shape"]))
+    rows = np.repeat(np.max(np.abs(ref).toarray(), axis=1), np.diff(g["indptr"]))
+    err = np.max(np.abs(J.data - g["data"]) / np.maximum(np.abs(g["data"]), H.ROW_FLOOR * rows))
+    assert err <= H.JAC_RTOL
+    # rows of the fixed pose 0 lose their 6 pose columns
+    if chain == "template" and not fixed:
+        per_row = np.diff(J.indptr)
+        on_pose0 = np.repeat(g["detections"][:, 1] == 0, 2)
+        assert set(per_row[on_pose0]) == {15} and set(per_row[~on_pose0]) == {21}
+
+
+def _oracle_closures(h, chain):
+    det = h._flat_detections()
+    tmpl = h._template_arg()
+    mask = h._jac_mask()
+    idx, ptr, m = orc.csr_structure(chain, det, mask)
+
+    def loss(x):
+        ps = orc.build_param_list(*h.get_bundle_adjustment_inputs(x))
+        return orc.full_loss(chain, det, ps, tmpl, threads=8, fast=True).flatten()
+
+    def jac(x):
+        ps = orc.build_param_list(*h.get_bundle_adjustment_inputs(x))
+        dense = orc.full_jac_dense(chain, det, ps, tmpl, threads=8, fast=True)
+        return csr_array((dense[m], idx, ptr), shape=(2 * det.shape[0], x.shape[0]))
+
+    return loss, jac
+
+
+@pytest.mark.parametrize("chain", ["template", "self"])
+def test_least_squares_with_hip_closures_converges_like_the_cpu_path(chain):
+    """optimisation_handling.py:88-98: least_squares(loss_fn, x0, jac=jac_fn, x_scale='jac') on a
+    synthetic 8-camera ring; the HIP closures and CPU-oracle closures must walk to the same x."""
+    rig = synthetic.make_rig("ring-8-small", 8, 12, synthetic.charuco_points(9, 8.0), seed=21, visibility=0.8)
+    names = [f"cam_{i}" for i in range(rig.n_cams)]
+    cls = handlers.TemplateBundleHandler if chain == "template" else handlers.SelfBundleHandler
+    fixed = {"cam_0": {"ext": rig.extr_true[0].copy()}}
+
+    def build():
+        return cls(DuckCamset(rig.n_cams), DuckTarget(rig.points), TargetDetection(names, rig.detections),
+                   fixed_params={k: dict(v) for k, v in fixed.items()}, options={"verbosity": 0, "max_nfev": 12})
+
+    h = build()
+    bp = h.bundlePrimitive
+    parts = [rig.intr[bp.intr_unfixed].ravel(), rig.extr[bp.extr_unfixed].ravel(), rig.poses[bp.poses_unfixed].ravel()]
+    if chain == "self":
+        parts.append(rig.points.ravel()[bp.bdpt_unfixed])
+    x0 = np.concatenate(parts)
+    loss_fn, jac_fn = h.make_loss_fun(1), h.make_loss_jac(1)
+    res = least_squares(loss_fn, x0.copy(), jac=jac_fn, x_scale="jac", max_nfev=12, verbose=0)
+    h2 = build()
+    o_loss, o_jac = _oracle_closures(h2, chain)
+    ref = least_squares(o_loss, x0.copy(), jac=o_jac, x_scale="jac", max_nfev=12, verbose=0)
+    e0 = np.mean(np.linalg.norm(loss_fn(x0).reshape(-1, 2), axis=1))
+    e1 = np.mean(np.linalg.norm(res.fun.reshape(-1, 2), axis=1))
+    assert e1 < 0.6 and e1 < e0  # noise floor is 0.3 px per axis
+    assert res.nfev == ref.nfev and res.njev == ref.njev
+    assert abs(res.cost - ref.cost) <= 1e-8 * ref.cost
+    assert np.max(np.abs(res.x - ref.x)) <= 1e-6 * max(1.0, np.max(np.abs(ref.x)))

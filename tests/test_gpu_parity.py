@@ -1,0 +1,267 @@
+"""Parity tests proper (MI355X): every call goes through the C ABI (libpcs_hip.so) and is checked
+against the CPU oracle, the golden fixtures generated from the reference, or a size-independent
+property.  Tolerances are stated in tests/helpers.py."""
+import numpy as np
+import pytest
+
+from oracle import ba_oracle as orc
+from pycamset_amd import _capi, synthetic
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+CHAINS = ["template", "self", "free"]
+
+
+@pytest.fixture(scope="module")
+def Engine():
+    from pycamset_amd.engine import Engine as E
+    assert _capi.lib().pcs_device_count() > 0, "no HIP device: the GPU tests must run on an MI355X"
+    return E
+
+
+def make_engine(Engine, rig, chain, dtype="f64", det=None):
+    e = Engine(chain, rig.n_cams, rig.n_imgs, rig.n_keys, dtype=dtype)
+    e.set_detections_table(rig.detections if det is None else det)
+    if chain == "template":
+        e.set_template(rig.points)
+    return e
+
+
+def oracle_eval(rig, chain, det=None, threads=8):
+    det = rig.detections if det is None else det
+    ps = orc.build_param_list(*H.chain_slabs(rig, chain))
+    tm = rig.points if chain == "template" else None
+    counts = (rig.n_cams, rig.n_imgs, rig.n_keys)
+    j, r = orc.full_jac_dense(chain, det, ps, tm, threads=threads, fast=False, with_resid=True, counts=counts)
+    return ps, r, j
+
+
+# ---- golden fixtures (reference outputs) -------------------------------------------------------
+@pytest.mark.parametrize("chain", CHAINS)
+@pytest.mark.parametrize("tag", ["tiny", "medium"])
+def test_hip_against_reference_goldens(Engine, golden_dir, chain, tag):
+    g = np.load(golden_dir / f"block_{chain}_{tag}.npz")
+    t = "t1" if tag == "tiny" else "t4"
+    det, ps = g["detections"], g["param_str"]
+    C, I, K = orc.counts_from_detections(det)
+    e = Engine(chain, C, I, K)
+    e.set_detections_table(det)
+    if chain == "template":
+        e.set_template(g["points"])
+    r, j = e.eval(ps)
+    H.assert_resid_close(r, g[f"resid_{t}"], det[:, 3:])
+    H.assert_jac_close(j, g[f"data_all_{t}"].reshape(j.shape))
+    idx, ptr = e.csr_structure(None)
+    assert np.array_equal(idx, g[f"indices_all_{t}"]) and np.array_equal(ptr, g[f"indptr_all_{t}"])
+    assert np.array_equal(e.block_param_inds(), g["block_param_inds"])
+    # fixed-parameter compaction on the device == data[:n][good_mask] (afb:627-651)
+    unfixed = g["unfixed"]
+    idx, ptr = e.csr_structure(unfixed)
+    assert np.array_equal(idx, g[f"indices_masked_{t}"]) and np.array_equal(ptr, g[f"indptr_masked_{t}"])
+    assert e.set_unfixed(unfixed) == g[f"data_masked_{t}"].shape[0]
+    rc, data = e.eval_compact(ps, want_resid=True)
+    assert np.array_equal(rc, r)
+    _, _, m = orc.csr_structure(chain, det, unfixed)
+    rows = np.broadcast_to(np.max(np.abs(j), axis=1, keepdims=True), j.shape)[m]
+    err = np.max(np.abs(data - g[f"data_masked_{t}"]) / np.maximum(np.abs(g[f"data_masked_{t}"]), H.ROW_FLOOR * rows))
+    assert err <= H.JAC_RTOL
+    assert np.array_equal(data, j[m])  # same kernel maths, only the store pattern differs
+    e.close()
+
+
+# ---- oracle on seeded synthetic rigs: every chain, every kernel variant ------------------------
+@pytest.mark.parametrize("chain", CHAINS)
+def test_all_kernel_variants_agree_with_oracle(Engine, chain):
+    rig = synthetic.config_rig(1)
+    ps, ref_r, ref_j = oracle_eval(rig, chain)
+    e = make_engine(Engine, rig, chain)
+    outs = []
+    for variant in range(8):
+        e.set_option("variant", variant)
+        r, j = e.eval(ps)
+        H.assert_resid_close(r, ref_r, rig.detections[:, 3:])
+        H.assert_jac_close(j, ref_j)
+        outs.append((r, j))
+    for r, j in outs[1:]:  # LDS staging / transposed stores / non-temporal stores never change a bit
+        assert np.array_equal(r, outs[0][0]) and np.array_equal(j, outs[0][1])
+    for wpc in (1, 3, 16):
+        e.set_option("wgs_per_cu", wpc)
+        r, j = e.eval(ps)
+        assert np.array_equal(j, outs[0][1])
+    e.set_option("tiles_per_wg", 4)
+    assert np.array_equal(e.eval(ps)[1], outs[0][1])
+    r_only, none = e.eval(ps, want_jac=False)
+    none2, j_only = e.eval(ps, want_resid=False)
+    assert none is None and none2 is None
+    assert np.array_equal(r_only, outs[0][0]) and np.array_equal(j_only, outs[0][1])
+    e.close()
+
+
+@pytest.mark.parametrize("chain", CHAINS)
+def test_fp32_engine(Engine, chain):
+    rig = synthetic.config_rig(1)
+    ps, ref_r, ref_j = oracle_eval(rig, chain)
+    e = make_engine(Engine, rig, chain, dtype="f32")
+    for variant in (0, 3, 6, 7):
+        e.set_option("variant", variant)
+        r, j = e.eval(ps)
+        assert np.max(np.abs(r - ref_r)) <= H.F32_RES_ATOL
+        assert H.jac_rel_err(j, ref_j) <= H.F32_JAC_RTOL
+    e.close()
+
+
+# ---- ragged / edge inputs ----------------------------------------------------------------------
+@pytest.mark.parametrize("n", [1, 2, 31, 32, 33, 63, 64, 65, 127, 129, 255, 257, 1000])
+def test_ragged_sizes(Engine, n):
+    rig = synthetic.config_rig(1)
+    det = rig.detections[:n].copy()
+    det[-1, :3] = [rig.n_cams - 1, rig.n_imgs - 1, rig.n_keys - 1]
+    for chain in CHAINS:
+        ps, ref_r, ref_j = oracle_eval(rig, chain, det)
+        e = make_engine(Engine, rig, chain, det=det)
+        for variant in (0, 7):
+            e.set_option("variant", variant)
+            r, j = e.eval(ps)
+            assert r.shape == (n, 2) and j.shape == (2 * n, e.P)
+            H.assert_resid_close(r, ref_r, det[:, 3:])
+            H.assert_jac_close(j, ref_j)
+        e.close()
+
+
+def test_error_paths(Engine):
+    rig = synthetic.tiny_rig()
+    e = Engine("template", rig.n_cams, rig.n_imgs, rig.n_keys)
+    ps = orc.build_param_list(rig.intr, rig.extr, rig.poses)
+    with pytest.raises(_capi.PcsError) as ex:   # nothing uploaded yet
+        e.eval(ps)
+    assert ex.value.code == _capi.PCS_ERR_STATE
+    e.set_detections_table(rig.detections)
+    with pytest.raises(_capi.PcsError) as ex:   # template missing
+        e.eval(ps)
+    assert ex.value.code == _capi.PCS_ERR_STATE
+    bad = rig.detections.copy()
+    bad[3, 0] = rig.n_cams                      # camera index out of range -> refused on the host
+    with pytest.raises(_capi.PcsError) as ex:
+        e.set_detections_table(bad)
+    assert ex.value.code == _capi.PCS_ERR_RANGE
+    bad = rig.detections.copy()
+    bad[0, 2] = -1
+    with pytest.raises(_capi.PcsError):
+        e.set_detections_table(bad)
+    with pytest.raises(ValueError):
+        e.eval(ps[:-1])
+    with pytest.raises(_capi.PcsError):
+        e.set_option("no_such_option", 1)
+    with pytest.raises(_capi.PcsError):          # empty table: nothing to evaluate
+        e.set_detections_table(np.zeros((0, 5)))
+        e.eval(ps)
+    e.close()
+    f = Engine("free", rig.n_cams, 0, rig.n_keys)
+    with pytest.raises(_capi.PcsError):
+        f.set_template(rig.points)
+    f.close()
+
+
+def test_zero_pose_and_nonfinite_passthrough(Engine):
+    """theta < 1e-10 Rodrigues branches (pose 0 is exactly zero by default) and IEEE inf/nan for a
+    point on the camera plane, like the reference's numba code (no trap, no clamping)."""
+    rig = synthetic.config_rig(1)
+    assert np.all(rig.poses[0] == 0)
+    sel = rig.detections[:, 1] == 0
+    assert sel.sum() > 50
+    det = rig.detections[sel].copy()
+    det[-1, :3] = [rig.n_cams - 1, 0, rig.n_keys - 1]
+    rig1 = synthetic.SyntheticRig("p0", det, rig.intr, rig.extr, rig.poses[:1].copy(), rig.points)
+    rig1.poses[0, :3] = [3e-11, -2e-11, 1e-11]  # inside the small-angle branch, not exactly zero
+    for chain in ("template", "self"):
+        ps, ref_r, ref_j = oracle_eval(rig1, chain)
+        e = make_engine(Engine, rig1, chain)
+        r, j = e.eval(ps)
+        H.assert_resid_close(r, ref_r, det[:, 3:])
+        H.assert_jac_close(j, ref_j)
+        e.close()
+    # put one point exactly on a camera plane: z = 0 -> inf / nan in that detection only
+    rig2 = synthetic.tiny_rig(seed=5)
+    rig2.extr[:, :3] = 0
+    rig2.extr[:, 3:] = 0
+    rig2.points[0] = [0.01, 0.02, 0.0]
+    ps = orc.build_param_list(rig2.intr, rig2.extr, rig2.points)
+    e = make_engine(Engine, rig2, "free")
+    r, j = e.eval(ps)
+    ref_j, ref_r = orc.full_jac_dense("free", rig2.detections, ps, None, with_resid=True)
+    hit = rig2.detections[:, 2] == 0
+    assert hit.any() and not np.isfinite(r[hit]).all() and not np.isfinite(ref_r[hit]).all()
+    assert np.isfinite(r[~hit]).all()
+    assert np.array_equal(np.isfinite(r), np.isfinite(ref_r))
+    H.assert_resid_close(r[~hit], ref_r[~hit], rig2.detections[~hit, 3:])
+    e.close()
+
+
+# ---- full-size configs: sampled oracle comparison + size-independent properties ------------------
+@pytest.mark.parametrize("number,chain", [(2, "template"), (3, "template"), (4, "self")])
+def test_full_size_config(Engine, number, chain):
+    rig = synthetic.config_rig(number)
+    N = rig.n_det
+    assert N > 1e5
+    ps = orc.build_param_list(*H.chain_slabs(rig, chain))
+    e = make_engine(Engine, rig, chain)
+    r, j = e.eval(ps)
+    assert np.isfinite(r).all() and np.isfinite(j).all()
+    # (1) oracle on a strided sample plus the head and the ragged tail of the table
+    idx = np.unique(np.concatenate([np.arange(0, N, 37), np.arange(200), np.arange(N - 200, N)]))
+    tm = rig.points if chain == "template" else None
+    counts = (rig.n_cams, rig.n_imgs, rig.n_keys)
+    ref_j, ref_r = orc.full_jac_dense(chain, rig.detections[idx], ps, tm, threads=8, with_resid=True, counts=counts)
+    P = e.P
+    H.assert_resid_close(r[idx], ref_r, rig.detections[idx, 3:])
+    H.assert_jac_close(j.reshape(N, 2 * P)[idx].reshape(-1, P), ref_j)
+    # (2) permutation equivariance: evaluating a shuffled table gives the shuffled rows, bit for bit
+    perm = np.random.default_rng(0).permutation(N)
+    e2 = make_engine(Engine, rig, chain, det=rig.detections[perm])
+    r2, j2 = e2.eval(ps)
+    assert np.array_equal(r2, r[perm])
+    assert np.array_equal(j2.reshape(N, 2 * P), j.reshape(N, 2 * P)[perm])
+    e2.close()
+    # (3) the Jacobian is the derivative of the residual: central difference along a random direction
+    rng = np.random.default_rng(1)
+    dx = rng.standard_normal(ps.shape[0]) * np.maximum(np.abs(ps), 1e-3)
+    dx /= np.linalg.norm(dx)
+    h = 1e-6
+    rp, _ = e.eval(ps + h * dx, want_jac=False)
+    rm, _ = e.eval(ps - h * dx, want_jac=False)
+    fd = ((rp - rm) / (2 * h)).reshape(-1)
+    cols = e.block_param_inds()
+    jv = np.einsum("nrp,np->nr", j.reshape(N, 2, P), dx[cols]).reshape(-1)
+    assert np.max(np.abs(fd - jv)) <= 2e-5 * max(1.0, np.max(np.abs(jv)))
+    # (4) sharding: evaluating two contiguous halves and concatenating == the full evaluation
+    half = N // 2
+    ea = make_engine(Engine, rig, chain, det=rig.detections[:half])
+    eb = make_engine(Engine, rig, chain, det=rig.detections[half:])
+    ja = ea.eval(ps, want_resid=False)[1]
+    jb = eb.eval(ps, want_resid=False)[1]
+    assert np.array_equal(np.concatenate([ja, jb]), j)
+    for x in (e, ea, eb):
+        x.close()
+
+
+def test_device_resident_outputs_and_kernel_timer(Engine):
+    import torch
+    rig = synthetic.config_rig(2)
+    ps = orc.build_param_list(rig.intr, rig.extr, rig.poses)
+    e = make_engine(Engine, rig, "template")
+    r_host, j_host = e.eval(ps)
+    d_r = torch.zeros((rig.n_det, 2), dtype=torch.float64, device="cuda")
+    d_j = torch.zeros((2 * rig.n_det, 21), dtype=torch.float64, device="cuda")
+    d_p = torch.from_numpy(ps).cuda()
+    stream = torch.cuda.current_stream().cuda_stream
+    e.eval_device_resident(d_p.data_ptr(), d_r.data_ptr(), d_j.data_ptr(), stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_r.cpu().numpy(), r_host) and np.array_equal(d_j.cpu().numpy(), j_host)
+    d_j.zero_()
+    e.eval_device(ps, None, d_j.data_ptr(), stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_j.cpu().numpy(), j_host)
+    prep_ms, eval_ms = e.last_kernel_ms()
+    assert 0 < eval_ms < 50 and 0 <= prep_ms < 50
+    e.close()

@@ -1,0 +1,139 @@
+"""Host logic of the drop-in boundary (no GPU): free-vector <-> slab scatter, fixed-parameter masks,
+key flattening, synthetic rig layout.  The handler goldens come from the reference's own handlers
+(tests/golden/make_golden.py); the arithmetic here is done by the CPU oracle."""
+import numpy as np
+import pytest
+
+from oracle import ba_oracle as orc
+from pycamset_amd import handlers, synthetic
+from pycamset_amd.detections import TargetDetection
+from tests.test_oracle_golden import assert_close
+
+
+class DuckCamset:
+    def __init__(self, n):
+        self._names = [f"cam_{i}" for i in range(n)]
+
+    def get_names(self):
+        return list(self._names)
+
+    def get_n_cams(self):
+        return len(self._names)
+
+
+class DuckTarget:
+    def __init__(self, points):
+        self.point_data = np.array(points, dtype=np.float64)[None]
+
+
+HANDLERS = {"template": handlers.TemplateBundleHandler, "self": handlers.SelfBundleHandler,
+            "free": handlers.FreePointBundleHandler}
+
+
+def make_handler(g, chain, fixed):
+    n_cams = g["intr0"].shape[0]
+    det = TargetDetection([f"cam_{i}" for i in range(n_cams)], g["detections"])
+    fp = None
+    if fixed:
+        fp = {"cam_0": {"ext": g["fixed_ext_cam0"].copy()}, "cam_1": {"int": g["fixed_int_cam1"].copy()}}
+    return HANDLERS[chain](DuckCamset(n_cams), DuckTarget(g["points"]), det, fixed_params=fp, options={"verbosity": 0})
+
+
+@pytest.mark.parametrize("chain", ["template", "self", "free"])
+@pytest.mark.parametrize("tag,fixed", [("tiny", True), ("tiny_nofix", False)])
+def test_handler_host_logic_against_reference_goldens(golden_dir, chain, tag, fixed):
+    g = np.load(golden_dir / f"handler_{chain}_{tag}.npz")
+    h = make_handler(g, chain, fixed)
+    bp = h.bundlePrimitive
+    assert np.array_equal(bp.intr_unfixed, g["intr_unfixed"]) and np.array_equal(bp.extr_unfixed, g["extr_unfixed"])
+    if chain != "free":
+        assert np.array_equal(bp.poses_unfixed, g["poses_unfixed"])
+        assert not bp.poses_unfixed[0]  # fixed_pose = 0 (template_handler.py:134-137)
+    if chain != "template":
+        assert np.array_equal(bp.bdpt_unfixed, g["bdpt_unfixed"])
+    x = g["x"]
+    assert x.shape[0] == g["shape"][1]
+    slabs = h.get_bundle_adjustment_inputs(x.copy())
+    param_str = h.op_fun.build_param_list(*slabs)
+    mask = h._jac_mask()
+    assert mask.shape[0] == param_str.shape[0] and int(mask.sum()) == x.shape[0]
+    det = h._flat_detections()
+    tmpl = h._template_arg()
+    # structure (integer work) is exact; values go through the oracle
+    idx, ptr, m = orc.csr_structure(chain, det, mask)
+    assert np.array_equal(idx, g["indices"]) and np.array_equal(ptr, g["indptr"])
+    res = orc.full_loss(chain, det, param_str, tmpl).flatten()
+    assert_close(res, g["resid"], rtol=1e-11)
+    dense = orc.full_jac_dense(chain, det, param_str, tmpl)
+    rows = np.broadcast_to(np.max(np.abs(dense), axis=1, keepdims=True), dense.shape)
+    assert_close(dense[m], g["data"], rows=rows[m])
+
+
+def test_fill_flat_scatter_and_layout():
+    rng = np.random.default_rng(0)
+    full = np.zeros((5, 6))
+    unf = np.array([True, False, True, True, False])
+    src = rng.random((3, 6))
+    handlers.fill_flat(src, full, unf)
+    assert np.array_equal(full[unf], src) and np.all(full[~unf] == 0)
+    flat = np.zeros(7)
+    handlers.fill_flat(np.array([1.0, 2.0]), flat, np.array([0, 1, 0, 0, 1, 0, 0], bool))
+    assert flat.tolist() == [0, 1, 0, 0, 2, 0, 0]
+
+
+def test_return_flattened_keys_matches_row_major_reshape():
+    # Ccube-style keys (face, index) flatten like point_data.reshape(-1, 3) (target_detections.py:333-351)
+    data = np.array([[0, 0, 2, 5, 10.0, 20.0], [1, 3, 5, 80, 1.0, 2.0], [1, 3, 0, 0, 3.0, 4.0]])
+    td = TargetDetection(["a", "b"], data)
+    flat = td.return_flattened_keys((6, 81)).get_data()
+    assert flat.shape == (3, 5)
+    assert flat[:, 2].tolist() == [2 * 81 + 5, 5 * 81 + 80, 0]
+    assert np.array_equal(flat[:, 3:], data[:, 4:])
+    assert td.max_ims == 4
+    td5 = TargetDetection(["a", "b"], flat)
+    assert td5.return_flattened_keys((6, 81)) is td5
+    with pytest.raises(ValueError):
+        TargetDetection(["a", "a"], flat)
+
+
+def test_unsupported_chain_raises():
+    from pycamset_amd import function_blocks as fb
+    op = fb.projection() + fb.rigidTform3d()
+    with pytest.raises(NotImplementedError):
+        op.make_full_loss_fn(np.zeros((1, 5)), 1)
+
+
+def test_initial_params_must_be_supplied():
+    rig = synthetic.tiny_rig()
+    det = TargetDetection([f"cam_{i}" for i in range(rig.n_cams)], rig.detections)
+    h = handlers.TemplateBundleHandler(DuckCamset(rig.n_cams), DuckTarget(rig.points), det)
+    with pytest.raises(NotImplementedError):
+        h.get_initial_params()
+    h.set_initial_params(np.ones(3))
+    assert h.get_initial_params().shape == (3,)
+
+
+@pytest.mark.parametrize("number,expect", [(1, (3, 24, 486)), (2, (8, 50, 256))])
+def test_synthetic_config_shapes(number, expect):
+    rig = synthetic.config_rig(number)
+    assert (rig.n_cams, rig.n_imgs, rig.n_keys) == expect
+    d = rig.detections
+    if number == 2:
+        assert d.shape == (102400, 5)
+    # ordered cam -> image -> key (camera_calibrator.py:314-317) and covering the last cam / image / key
+    order = np.lexsort((d[:, 2], d[:, 1], d[:, 0]))
+    assert np.array_equal(order, np.arange(d.shape[0]))
+    assert orc.counts_from_detections(d) == expect
+    assert np.all(rig.poses[0] == 0)
+    # measurements sit within a few pixels of the projection at the evaluation point
+    r = orc.full_loss("template", d, orc.build_param_list(rig.intr, rig.extr, rig.poses), rig.points, threads=4, fast=True)
+    assert np.isfinite(r).all() and np.median(np.abs(r)) < 50
+
+
+def test_synthetic_headline_scaled_down():
+    rig = synthetic.config_rig(3, scale=0.01)
+    assert (rig.n_cams, rig.n_imgs, rig.n_keys) == (32, 200, 486)
+    assert 5000 < rig.n_det < 20000
+    rig_im = synthetic.config_rig(3, scale=0.01, order="im")
+    assert rig_im.n_det == rig.n_det
+    assert np.all(np.diff(rig_im.detections[:, 1]) >= 0)
