@@ -48,13 +48,38 @@ def chain_slabs(rig, chain):
     return [rig.intr, rig.extr, rig.points]
 
 
+def usable_cpus() -> int:
+    """Host threads this process may actually use: min(affinity mask, cgroup CPU quota, cpu_count).
+    (A GPU box hands each job a CPU share well below os.cpu_count().)"""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = Path(path).read_text().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                quota = int(txt[0])
+                period = int(Path("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read_text())
+                if quota > 0:
+                    n = min(n, max(1, int(quota / period + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
+
 def cpu_baseline(rig, chain, param_str, budget_s: float):
     """Time the CPU oracle (the repo's C restatement of the reference's per-detection algorithm,
     -O3 AVX2/FMA + OpenMP) on the host cores, on the same workload.  kind = "port"."""
     from oracle import ba_oracle as orc
 
     orc.build()
-    threads = os.cpu_count() or 1
+    threads = int(os.environ.get("PCS_CPU_THREADS", "0")) or usable_cpus()
     tm = rig.points if chain == "template" else None
     counts = (rig.n_cams, rig.n_imgs, rig.n_keys)
     n_sample = min(rig.n_det, 1_000_000)
@@ -72,6 +97,7 @@ def cpu_baseline(rig, chain, param_str, budget_s: float):
         "unit": "rows/s",
         "cores": threads,
         "kind": "port",
+        "host_cpu_count": os.cpu_count(),
         "sample": f"{passes} full residual+Jacobian passes over the first {n_sample} detections of the same rig "
                   f"({el:.1f} s, oracle/libba_oracle_fast.so, OpenMP static schedule)",
     }

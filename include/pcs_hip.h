@@ -140,6 +140,10 @@ int pcs_kernel_ms_mean(pcs_engine *h, int64_t *count, float *slab_prep_ms, float
 /* Tuning knobs ("variant", "wgs_per_cu", "tiles_per_wg", "event_ring"); see DESIGN.md.
  * Unknown keys -> PCS_ERR_ARG. */
 int pcs_set_option(pcs_engine *h, const char *key, int64_t value);
+/* Streaming probe of the device's achievable HBM rate with this engine's access shape (16 B per lane):
+ * kind 0 fill, 1 non-temporal fill, 2 copy, 3 non-temporal copy; `bytes` per launch (per buffer).
+ * Measurement aid for DESIGN.md / bench.py --membench; not on the evaluation path. */
+int pcs_membench(int device, int kind, int64_t bytes, int iters, int blocks_per_cu, float *mean_ms);
 /* Engine-owned device scratch for outputs (engine dtype); valid until the next set_detections. */
 int pcs_device_buffers(pcs_engine *h, void **d_resid, void **d_jac);
 

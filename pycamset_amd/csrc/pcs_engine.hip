@@ -295,6 +295,23 @@ __global__ __launch_bounds__(WG_THREADS) void ba_compact_kernel(const EvalArgs a
     }
 }
 
+// Streaming probes used to measure the box's achievable HBM rate for THIS access shape
+// (16 B per lane, 1 KiB per wave-instruction): kind 0 plain fill, 1 non-temporal fill, 2 plain copy,
+// 3 non-temporal copy.  Reported next to the 8 TB/s spec figure in DESIGN.md.
+template <int KIND>
+__global__ __launch_bounds__(256) void membench_kernel(const double2 *__restrict__ src, double2 *__restrict__ dst, int64_t n16) {
+    using V = __attribute__((ext_vector_type(2))) double;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    V *d = reinterpret_cast<V *>(dst);
+    const V *s = reinterpret_cast<const V *>(src);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) {
+        V v;
+        if constexpr (KIND >= 2) v = (KIND == 3) ? __builtin_nontemporal_load(s + i) : s[i];
+        else { v.x = (double)i; v.y = 1.0; }
+        if constexpr (KIND == 1 || KIND == 3) __builtin_nontemporal_store(v, d + i); else d[i] = v;
+    }
+}
+
 }  // namespace pcs
 
 // ---------------------------------------------------------------------------------------------
@@ -351,10 +368,14 @@ struct pcs_engine {
     int64_t data_capacity = 0;
     // launch geometry
     int n_cu = 256;
-    // defaults from the MI355X sweep in profiles/ (round 1): transposed + non-temporal stores, slabs
-    // through L1/L2 (the cam -> image -> key ordered table makes slab reads wave-uniform)
-    int variant = VAR_TRANSPOSE | VAR_NT;
-    int64_t wgs_per_cu = 8;
+    // Launch geometry.  variant < 0 / wgs_per_cu <= 0 = automatic, from the MI355X sweeps in
+    // profiles/r01/sweeps.md: transposed + non-temporal stores always; for a table whose 64-detection
+    // tiles are (cam, image)-uniform (the reference's cam -> image -> key order) slabs are read
+    // through L1/L2 with many small workgroups; for scattered tables slabs are staged in LDS by
+    // few long-lived workgroups.
+    int variant = -1;
+    int64_t wgs_per_cu = 0;
+    double tile_locality = 1.0;  // fraction of 64-detection tiles touching <= 2 distinct (cam, image) pairs
     int64_t tiles_per_wg = 0;  // 0 = derive from wgs_per_cu
     size_t lds_limit = 160 * 1024;
 };
@@ -365,6 +386,45 @@ extern "C" {
 
 int pcs_version(void) { return 100; }
 const char *pcs_last_error(void) { return g_err.c_str(); }
+
+int pcs_membench(int device, int kind, int64_t bytes, int iters, int blocks_per_cu, float *mean_ms) {
+    if (kind < 0 || kind > 3 || bytes < 4096 || iters < 1 || !mean_ms) return fail(PCS_ERR_ARG, "pcs_membench: bad arguments");
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    void *src = nullptr, *dst = nullptr;
+    HIPCHK(hipMalloc(&dst, bytes));
+    if (kind >= 2) {
+        HIPCHK(hipMalloc(&src, bytes));
+        HIPCHK(hipMemset(src, 1, bytes));
+    }
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    const int64_t n16 = bytes / 16;
+    const dim3 grid((unsigned)std::min<int64_t>((n16 + 255) / 256, (int64_t)prop.multiProcessorCount * std::max(1, blocks_per_cu)));
+    auto launch = [&]() {
+        switch (kind) {
+            case 0: hipLaunchKernelGGL(membench_kernel<0>, grid, dim3(256), 0, nullptr, (const double2 *)src, (double2 *)dst, n16); break;
+            case 1: hipLaunchKernelGGL(membench_kernel<1>, grid, dim3(256), 0, nullptr, (const double2 *)src, (double2 *)dst, n16); break;
+            case 2: hipLaunchKernelGGL(membench_kernel<2>, grid, dim3(256), 0, nullptr, (const double2 *)src, (double2 *)dst, n16); break;
+            default: hipLaunchKernelGGL(membench_kernel<3>, grid, dim3(256), 0, nullptr, (const double2 *)src, (double2 *)dst, n16); break;
+        }
+    };
+    for (int i = 0; i < 3; ++i) launch();
+    HIPCHK(hipEventRecord(e0, nullptr));
+    for (int i = 0; i < iters; ++i) launch();
+    HIPCHK(hipEventRecord(e1, nullptr));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    *mean_ms = ms / iters;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (src) (void)hipFree(src);
+    (void)hipFree(dst);
+    return PCS_OK;
+}
 
 int pcs_device_count(void) {
     int n = 0;
@@ -447,6 +507,21 @@ static int upload_detections(pcs_engine *h, const double *uv, int64_t n) {
             return fail(PCS_ERR_RANGE, "detection %lld = (cam %d, im %d, key %d) outside (%lld, %lld, %lld)", (long long)i, c, im, k,
                         (long long)h->n_cams, (long long)h->n_imgs, (long long)h->n_keys);
     }
+    {   // slab-read locality of the table, per 64-detection tile (drives the automatic variant choice)
+        int64_t tiles = 0, good = 0;
+        for (int64_t t0 = 0; t0 < n; t0 += TILE, ++tiles) {
+            const int64_t t1 = std::min<int64_t>(t0 + TILE, n);
+            int64_t p0 = -1, p1 = -1;
+            bool ok = true;
+            for (int64_t i = t0; i < t1 && ok; ++i) {
+                const int64_t pr = ((int64_t)h->h_cam[i] << 32) | (uint32_t)h->h_img[i];
+                if (pr == p0 || pr == p1) continue;
+                if (p0 < 0) p0 = pr; else if (p1 < 0) p1 = pr; else ok = false;
+            }
+            good += ok;
+        }
+        h->tile_locality = tiles ? (double)good / (double)tiles : 1.0;
+    }
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(h->stream));
     for (void **b : {(void **)&h->d_cam, (void **)&h->d_img, (void **)&h->d_key, &h->d_uv, &h->d_resid, &h->d_jac,
@@ -518,10 +593,10 @@ int pcs_set_template(pcs_engine *h, const double *points) {
 int pcs_set_option(pcs_engine *h, const char *key, int64_t value) {
     if (!h || !key) return fail(PCS_ERR_ARG, "pcs_set_option: bad arguments");
     if (!strcmp(key, "variant")) {
-        if (value < 0 || value > 7) return fail(PCS_ERR_ARG, "variant must be in [0,7]");
+        if (value < -1 || value > 7) return fail(PCS_ERR_ARG, "variant must be in [-1,7] (-1 = automatic)");
         h->variant = (int)value;
     } else if (!strcmp(key, "wgs_per_cu")) {
-        if (value < 1 || value > 64) return fail(PCS_ERR_ARG, "wgs_per_cu must be in [1,64]");
+        if (value < 0 || value > 64) return fail(PCS_ERR_ARG, "wgs_per_cu must be in [0,64] (0 = automatic)");
         h->wgs_per_cu = value;
         h->tiles_per_wg = 0;
     } else if (!strcmp(key, "event_ring")) {
@@ -652,7 +727,8 @@ static int enqueue_eval(pcs_engine *h, const double *d_prm, void *d_resid, void 
                                            : launch_compact_t<float>(h->chain, mode, a, dim3((unsigned)blocks), s);
         if (e != hipSuccess) return fail(PCS_ERR_HIP, "compact kernel launch failed: %s", hipGetErrorString(e));
     } else {
-        int variant = h->variant;
+        const bool local = h->tile_locality >= 0.5;
+        int variant = h->variant >= 0 ? h->variant : (VAR_TRANSPOSE | VAR_NT | (local ? 0 : VAR_SLAB_LDS));
         if (!(mode & MODE_JAC)) variant &= ~VAR_TRANSPOSE;
         // LDS budget: slabs + points (+ 4 wave-private transpose regions)
         const size_t slab_bytes = h->esize * (size_t)(h->n_cams * CAM_STRIDE + h->n_imgs * POSE_STRIDE + padded_points(h->n_keys));
@@ -661,7 +737,8 @@ static int enqueue_eval(pcs_engine *h, const double *d_prm, void *d_resid, void 
         const size_t lds = ((variant & VAR_SLAB_LDS) ? slab_bytes : 0) + tr_bytes;
         int64_t tpw = h->tiles_per_wg;
         if (tpw <= 0) {
-            const int64_t target_wgs = (int64_t)h->n_cu * h->wgs_per_cu;
+            const int64_t wpc = h->wgs_per_cu > 0 ? h->wgs_per_cu : ((variant & VAR_SLAB_LDS) ? 2 : 16);
+            const int64_t target_wgs = (int64_t)h->n_cu * wpc;
             tpw = (a.n_tiles + target_wgs - 1) / target_wgs;
             tpw = std::max<int64_t>(WAVES_PER_WG, (tpw + WAVES_PER_WG - 1) / WAVES_PER_WG * WAVES_PER_WG);
         }
