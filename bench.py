@@ -130,6 +130,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-allgather-probe", action="store_true")
+    ap.add_argument("--host-path", action="store_true",
+                    help="also time the host-buffer boundary (pcs_eval: H2D params + kernels + D2H of residual and Jacobian); "
+                         "reported under 'host_boundary', never in 'value'")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -288,6 +291,15 @@ def main():
         }
         if allgather_info:
             line["allgather"] = allgather_info
+        if args.host_path:
+            eng.eval(ps)  # allocate scratch, warm
+            reps, h0 = 3, time.perf_counter()
+            for _ in range(reps):
+                eng.eval(ps)
+            hs = (time.perf_counter() - h0) / reps
+            line["host_boundary"] = {"ms_per_call": hs * 1e3, "rows_per_s": 2.0 * N / hs,
+                                     "d2h_GBps": (2 * N * (P + 1)) * 8 / hs / 1e9,
+                                     "note": "Engine.eval: pageable NumPy outputs, PCIe D2H of the dense Jacobian dominates"}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(rig, chain, ps, args.cpu_seconds)
         print(json.dumps(line), flush=True)
