@@ -153,10 +153,16 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    # PCS_BENCH_BACKEND=gloo lets the N > 1 code path be rehearsed on a one-GPU box (ranks share the card)
+    backend = os.environ.get("PCS_BENCH_BACKEND", "nccl")
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     chain = args.chain or CONFIG_CHAIN[args.config]
     dtype = args.dtype or CONFIG_DTYPE[args.config]
@@ -180,6 +186,8 @@ def main():
     stream = torch.cuda.current_stream(dev).cuda_stream
 
     gather = None
+    if world > 1 and backend != "nccl" and args.collective == "none":
+        args.no_allgather_probe = True  # gloo rehearsal: no device all-gather
     if world > 1 and (args.collective == "allgather" or not args.no_allgather_probe):
         counts = torch.tensor([N], device=dev)
         dist.all_reduce(counts, op=dist.ReduceOp.MAX)
