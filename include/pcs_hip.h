@@ -140,6 +140,11 @@ int pcs_kernel_ms_mean(pcs_engine *h, int64_t *count, float *slab_prep_ms, float
 /* Tuning knobs ("variant", "wgs_per_cu", "tiles_per_wg", "event_ring"); see DESIGN.md.
  * Unknown keys -> PCS_ERR_ARG. */
 int pcs_set_option(pcs_engine *h, const char *key, int64_t value);
+/* Page-locked host memory for outputs: pcs_eval / pcs_eval_compact copy device -> host at PCIe rate
+ * into such buffers (a pageable destination is several times slower).  Replaces nothing in the
+ * reference (NumPy owns every array there, afb:561); SURVEY 8 f1 "zero-copy hand-off". */
+int pcs_host_alloc(void **out, int64_t bytes);
+int pcs_host_free(void *p);
 /* Streaming probe of the device's achievable HBM rate with this engine's access shape (16 B per lane):
  * kind 0 fill, 1 non-temporal fill, 2 copy, 3 non-temporal copy; `bytes` per launch (per buffer).
  * Measurement aid for DESIGN.md / bench.py --membench; not on the evaluation path. */

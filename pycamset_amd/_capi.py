@@ -44,6 +44,8 @@ SYMBOLS = {
     "pcs_synchronize": (c_int, [_P, _P]),
     "pcs_last_kernel_ms": (c_int, [_P, POINTER(c_float), POINTER(c_float)]),
     "pcs_kernel_ms_mean": (c_int, [_P, POINTER(c_int64), POINTER(c_float), POINTER(c_float)]),
+    "pcs_host_alloc": (c_int, [POINTER(_P), c_int64]),
+    "pcs_host_free": (c_int, [_P]),
     "pcs_membench": (c_int, [c_int, c_int, c_int64, c_int, c_int, POINTER(c_float)]),
     "pcs_set_option": (c_int, [_P, c_char_p, c_int64]),
     "pcs_device_buffers": (c_int, [_P, POINTER(_P), POINTER(_P)]),

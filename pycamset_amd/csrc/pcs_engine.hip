@@ -295,6 +295,85 @@ __global__ __launch_bounds__(WG_THREADS) void ba_compact_kernel(const EvalArgs a
     }
 }
 
+// Coalesced fixed-parameter compaction: tile-per-wave like ba_eval_kernel.  The kept entries of a
+// tile form one contiguous range of the CSR data array ([row_off[first], row_off[last] + 2*cnt));
+// every lane packs its two rows into the wave-private LDS region at its offset inside that range
+// (two passes of 32 detections), then the wave streams the range out at consecutive addresses
+// (8-byte units: a row offset need not be 16-byte aligned).
+template <int CHAIN, typename T, int MODE>
+__global__ __launch_bounds__(WG_THREADS) void ba_compact_tile_kernel(const EvalArgs a) {
+    constexpr int P = chain_P(CHAIN);
+    constexpr int P2 = 2 * P;
+    constexpr bool JAC = (MODE & MODE_JAC) != 0;
+    using V2 = typename Vec2<T>::type;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    T *tr = reinterpret_cast<T *>(smem_raw) + wave * (HALF * P2);
+    const T *cam_slab = static_cast<const T *>(a.cam_slab);
+    const T *pose_slab = static_cast<const T *>(a.pose_slab);
+    const T *points = static_cast<const T *>(a.points);
+    const V2 *uv = static_cast<const V2 *>(a.uv);
+    T *resid = static_cast<T *>(a.resid);
+    T *data = static_cast<T *>(a.jac);
+    const int64_t tile0 = (int64_t)blockIdx.x * a.tiles_per_wg;
+    const int64_t tile1 = min(tile0 + (int64_t)a.tiles_per_wg, a.n_tiles);
+    for (int64_t tile = tile0 + wave; tile < tile1; tile += WAVES_PER_WG) {
+        const int64_t i = tile * TILE + lane;
+        const bool valid = i < a.n;
+        const int64_t ic = valid ? i : a.n - 1;
+        const int c = a.cam[ic], im = a.img[ic], k = a.key[ic];
+        const V2 m = uv[ic];
+        T u, v;
+        T J[P2];
+        eval_detection<CHAIN, T, JAC>(cam_slab + c * CAM_STRIDE, pose_slab + im * POSE_STRIDE, points[3 * k], points[3 * k + 1],
+                                      points[3 * k + 2], u, v, J);
+        if constexpr ((MODE & MODE_RESID) != 0) {
+            if (valid) {
+                V2 r;
+                r.x = u - m.x;
+                r.y = v - m.y;
+                __builtin_nontemporal_store(r, reinterpret_cast<V2 *>(resid) + i);
+            }
+        }
+        if constexpr (JAC) {
+            const uint32_t keep = valid ? a.keep[ic] : 0u;
+            const int cnt = __popc(keep);
+            const int64_t off = a.row_off[ic] + (valid ? 0 : 2 * (int64_t)__popc(a.keep[ic]));  // tail lanes: end of data
+            const int64_t off0 = __shfl(off, 0);                  // first entry of the tile
+            const int lo = (int)(off - off0);                     // this detection's offset inside the tile range
+            const int mid = __shfl(lo, HALF);                     // pass boundary
+            const int end = __shfl(lo + 2 * cnt, TILE - 1);       // tile range length
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int s0 = h ? mid : 0;
+                const int s1 = h ? end : mid;
+                if ((lane >> 5) == h) {
+                    T *ru = tr + (lo - s0);
+                    T *rv = ru + cnt;
+                    int o = 0;
+#pragma unroll
+                    for (int j = 0; j < P; ++j) {
+                        if (keep & (1u << j)) {
+                            ru[o] = J[j];
+                            rv[o] = J[P + j];
+                            ++o;
+                        }
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                T *dst = data + off0 + s0;
+                for (int e = lane; e < s1 - s0; e += 64) __builtin_nontemporal_store(tr[e], dst + e);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+        }
+    }
+}
+
 // Streaming probes used to measure the box's achievable HBM rate for THIS access shape
 // (16 B per lane, 1 KiB per wave-instruction): kind 0 plain fill, 1 non-temporal fill, 2 plain copy,
 // 3 non-temporal copy.  Reported next to the 8 TB/s spec figure in DESIGN.md.
@@ -375,6 +454,7 @@ struct pcs_engine {
     // few long-lived workgroups.
     int variant = -1;
     int64_t wgs_per_cu = 0;
+    int compact_variant = 1;     // 1 = tile kernel with coalesced stores, 0 = per-lane stores
     double tile_locality = 1.0;  // fraction of 64-detection tiles touching <= 2 distinct (cam, image) pairs
     int64_t tiles_per_wg = 0;  // 0 = derive from wgs_per_cu
     size_t lds_limit = 160 * 1024;
@@ -386,6 +466,18 @@ extern "C" {
 
 int pcs_version(void) { return 100; }
 const char *pcs_last_error(void) { return g_err.c_str(); }
+
+int pcs_host_alloc(void **out, int64_t bytes) {
+    if (!out || bytes <= 0) return fail(PCS_ERR_ARG, "pcs_host_alloc: bad arguments");
+    *out = nullptr;
+    HIPCHK(hipHostMalloc(out, (size_t)bytes, hipHostMallocDefault));
+    return PCS_OK;
+}
+
+int pcs_host_free(void *p) {
+    if (p) HIPCHK(hipHostFree(p));
+    return PCS_OK;
+}
 
 int pcs_membench(int device, int kind, int64_t bytes, int iters, int blocks_per_cu, float *mean_ms) {
     if (kind < 0 || kind > 3 || bytes < 4096 || iters < 1 || !mean_ms) return fail(PCS_ERR_ARG, "pcs_membench: bad arguments");
@@ -599,6 +691,9 @@ int pcs_set_option(pcs_engine *h, const char *key, int64_t value) {
         if (value < 0 || value > 64) return fail(PCS_ERR_ARG, "wgs_per_cu must be in [0,64] (0 = automatic)");
         h->wgs_per_cu = value;
         h->tiles_per_wg = 0;
+    } else if (!strcmp(key, "compact_variant")) {
+        if (value < 0 || value > 1) return fail(PCS_ERR_ARG, "compact_variant must be 0 or 1");
+        h->compact_variant = (int)value;
     } else if (!strcmp(key, "event_ring")) {
         // keep the HIP-event triples of the last `value` evaluations (pcs_kernel_ms_mean averages them)
         if (value < 1 || value > 100000) return fail(PCS_ERR_ARG, "event_ring must be in [1,100000]");
@@ -671,6 +766,23 @@ static hipError_t launch_eval_t(int chain, int mode, int variant, const EvalArgs
 }
 
 template <int CHAIN, typename T>
+static hipError_t launch_compact_tile_c(int mode, const EvalArgs &a, dim3 grid, size_t lds, hipStream_t s) {
+    if (mode == MODE_RESID) hipLaunchKernelGGL((ba_compact_tile_kernel<CHAIN, T, MODE_RESID>), grid, dim3(WG_THREADS), lds, s, a);
+    else if (mode == MODE_JAC) hipLaunchKernelGGL((ba_compact_tile_kernel<CHAIN, T, MODE_JAC>), grid, dim3(WG_THREADS), lds, s, a);
+    else hipLaunchKernelGGL((ba_compact_tile_kernel<CHAIN, T, MODE_RESID | MODE_JAC>), grid, dim3(WG_THREADS), lds, s, a);
+    return hipGetLastError();
+}
+
+template <typename T>
+static hipError_t launch_compact_tile_t(int chain, int mode, const EvalArgs &a, dim3 grid, size_t lds, hipStream_t s) {
+    switch (chain) {
+        case CHAIN_TEMPLATE: return launch_compact_tile_c<CHAIN_TEMPLATE, T>(mode, a, grid, lds, s);
+        case CHAIN_SELF: return launch_compact_tile_c<CHAIN_SELF, T>(mode, a, grid, lds, s);
+        default: return launch_compact_tile_c<CHAIN_FREE, T>(mode, a, grid, lds, s);
+    }
+}
+
+template <int CHAIN, typename T>
 static hipError_t launch_compact_c(int mode, const EvalArgs &a, dim3 grid, hipStream_t s) {
     if (mode == MODE_RESID) hipLaunchKernelGGL((ba_compact_kernel<CHAIN, T, MODE_RESID>), grid, dim3(WG_THREADS), 0, s, a);
     else if (mode == MODE_JAC) hipLaunchKernelGGL((ba_compact_kernel<CHAIN, T, MODE_JAC>), grid, dim3(WG_THREADS), 0, s, a);
@@ -722,9 +834,22 @@ static int enqueue_eval(pcs_engine *h, const double *d_prm, void *d_resid, void 
     a.n_tiles = (h->n + TILE - 1) / TILE;
     if (compact) {
         a.keep = h->d_keep; a.row_off = h->d_row_off;
-        const int64_t blocks = std::min<int64_t>((h->n + WG_THREADS - 1) / WG_THREADS, (int64_t)h->n_cu * 8);
-        hipError_t e = h->dtype == PCS_F64 ? launch_compact_t<double>(h->chain, mode, a, dim3((unsigned)blocks), s)
-                                           : launch_compact_t<float>(h->chain, mode, a, dim3((unsigned)blocks), s);
+        hipError_t e;
+        if (h->compact_variant == 0) {  // per-lane stores (first version, kept for A/B)
+            const int64_t blocks = std::min<int64_t>((h->n + WG_THREADS - 1) / WG_THREADS, (int64_t)h->n_cu * 8);
+            e = h->dtype == PCS_F64 ? launch_compact_t<double>(h->chain, mode, a, dim3((unsigned)blocks), s)
+                                    : launch_compact_t<float>(h->chain, mode, a, dim3((unsigned)blocks), s);
+        } else {
+            const int64_t wpc = h->wgs_per_cu > 0 ? h->wgs_per_cu : 16;
+            const int64_t target_wgs = (int64_t)h->n_cu * wpc;
+            int64_t tpw = (a.n_tiles + target_wgs - 1) / target_wgs;
+            tpw = std::max<int64_t>(WAVES_PER_WG, (tpw + WAVES_PER_WG - 1) / WAVES_PER_WG * WAVES_PER_WG);
+            a.tiles_per_wg = (int32_t)tpw;
+            const int64_t grid = (a.n_tiles + tpw - 1) / tpw;
+            const size_t lds = (mode & MODE_JAC) ? h->esize * (size_t)WAVES_PER_WG * HALF * 2 * h->P : 0;
+            e = h->dtype == PCS_F64 ? launch_compact_tile_t<double>(h->chain, mode, a, dim3((unsigned)grid), lds, s)
+                                    : launch_compact_tile_t<float>(h->chain, mode, a, dim3((unsigned)grid), lds, s);
+        }
         if (e != hipSuccess) return fail(PCS_ERR_HIP, "compact kernel launch failed: %s", hipGetErrorString(e));
     } else {
         const bool local = h->tile_locality >= 0.5;

@@ -23,6 +23,34 @@ def _f64c(a) -> np.ndarray:
     return np.ascontiguousarray(a, dtype=np.float64)
 
 
+class _PinnedBlock:
+    """Owner of one page-locked host allocation; NumPy views keep it alive through ``base``."""
+
+    def __init__(self, nbytes: int):
+        self.ptr = c_void_p()
+        check(lib().pcs_host_alloc(byref(self.ptr), int(nbytes)))
+        self.nbytes = nbytes
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                lib().pcs_host_free(self.ptr)
+                self.ptr = c_void_p()
+        except Exception:
+            pass
+
+
+def pinned_empty(shape, dtype=np.float64) -> np.ndarray:
+    """``np.empty`` in page-locked host memory (freed when the last view dies)."""
+    shape = tuple(int(x) for x in np.atleast_1d(shape))
+    n = int(np.prod(shape)) if shape else 1
+    nbytes = max(1, n) * np.dtype(dtype).itemsize
+    block = _PinnedBlock(nbytes)
+    buf = (ctypes.c_char * nbytes).from_address(block.ptr.value)
+    buf._pcs_owner = block  # ctypes object keeps the owner; the ndarray keeps the ctypes object
+    return np.frombuffer(buf, dtype=dtype, count=n).reshape(shape)
+
+
 class Engine:
     """One chain ('template' | 'self' | 'free') on one device.
 
@@ -43,10 +71,12 @@ class Engine:
         self.n = 0
         self.nnz = None
         self.mask_key = None
+        self._rings = {}
         self.np_dtype = np.float64 if dtype == "f64" else np.float32
 
     # -- lifetime -----------------------------------------------------------------------------
     def close(self):
+        self._rings = {}
         if getattr(self, "_h", None) is not None and self._h:
             lib().pcs_destroy(self._h)
             self._h = c_void_p()
@@ -94,11 +124,23 @@ class Engine:
             raise ValueError(f"parameter string has {p.shape[0]} entries, engine expects {self.n_params}")
         return p
 
-    def eval(self, param_str, want_resid: bool = True, want_jac: bool = True):
+    def _out(self, name: str, shape, pinned_ring: int):
+        """Output array: fresh pageable memory (reference semantics), or the next buffer of a ring of
+        ``pinned_ring`` page-locked buffers (valid until ``pinned_ring`` further calls)."""
+        if pinned_ring <= 0:
+            return np.empty(shape)
+        ring = self._rings.setdefault((name, tuple(shape), pinned_ring), {"bufs": [], "next": 0})
+        if len(ring["bufs"]) < pinned_ring:
+            ring["bufs"].append(pinned_empty(shape))
+            return ring["bufs"][-1]
+        ring["next"] = (ring["next"] + 1) % pinned_ring
+        return ring["bufs"][ring["next"]]
+
+    def eval(self, param_str, want_resid: bool = True, want_jac: bool = True, pinned_ring: int = 0):
         """-> (resid (N,2) | None, jac (2N,P) | None), float64 NumPy."""
         p = self._check_params(param_str)
-        r = np.empty((self.n, 2)) if want_resid else None
-        j = np.empty((2 * self.n, self.P)) if want_jac else None
+        r = self._out("resid", (self.n, 2), pinned_ring) if want_resid else None
+        j = self._out("jac", (2 * self.n, self.P), pinned_ring) if want_jac else None
         check(lib().pcs_eval(self._h, _dp(p), _dp(r) if want_resid else None, _dp(j) if want_jac else None))
         return r, j
 
@@ -112,13 +154,13 @@ class Engine:
         self.mask_key = None if m is None else hash(m.astype(bool).tobytes())
         return self.nnz
 
-    def eval_compact(self, param_str, want_resid: bool = False):
+    def eval_compact(self, param_str, want_resid: bool = False, pinned_ring: int = 0):
         """-> (resid | None, data (nnz,)) with the fixed columns removed on the device."""
         if self.nnz is None:
             raise RuntimeError("call set_unfixed() first")
         p = self._check_params(param_str)
-        r = np.empty((self.n, 2)) if want_resid else None
-        d = np.empty(self.nnz)
+        r = self._out("resid", (self.n, 2), pinned_ring) if want_resid else None
+        d = self._out("data", (self.nnz,), pinned_ring)
         check(lib().pcs_eval_compact(self._h, _dp(p), _dp(r) if want_resid else None, _dp(d)))
         return r, d
 

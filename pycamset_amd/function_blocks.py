@@ -105,7 +105,12 @@ def _counts(detections: np.ndarray) -> tuple[int, int, int]:
 class optimisation_function:  # afb:111-685
     """A chain of function blocks evaluated by the MI355X engine."""
 
-    def __init__(self, function_blocks, *, dtype: str = "f64", device: int = 0) -> None:
+    def __init__(self, function_blocks, *, dtype: str = "f64", device: int = 0, pinned_ring: int = 0) -> None:
+        """``pinned_ring`` = R > 0 returns the Jacobian ``data`` array from a ring of R page-locked
+        host buffers (PCIe-rate device -> host copy, wrapped by ``csr_array`` without a copy); an
+        array handed out stays valid for R further Jacobian calls.  0 = a fresh NumPy array per
+        call, exactly like the reference (afb:561)."""
+        self.pinned_ring = int(pinned_ring)
         self.function_blocks = list(function_blocks)
         self.n_blocks = len(self.function_blocks)
         self.dtype, self.device = dtype, device
@@ -189,11 +194,11 @@ class optimisation_function:  # afb:111-685
         def jac_fn(param, template=None):
             self._bind_template(eng, template)
             if all_free:  # afb:633-642
-                _, j = eng.eval(param, want_resid=False, want_jac=True)
+                _, j = eng.eval(param, want_resid=False, want_jac=True, pinned_ring=self.pinned_ring)
                 return j.reshape(-1), indices, indptr
             if eng.mask_key != mask_key:  # another closure re-bound the engine's mask
                 eng.set_unfixed(unfixed)
-            _, data = eng.eval_compact(param)  # afb:644-651, masked on the device
+            _, data = eng.eval_compact(param, pinned_ring=self.pinned_ring)  # afb:644-651, masked on the device
             return data, indices, indptr
 
         return jac_fn

@@ -150,7 +150,8 @@ class TemplateBundleHandler:  # th:80-240
     """Target-pose based bundle adjustment against a constant template (chain T)."""
 
     def __init__(self, camset, target, detection: TargetDetection, fixed_params: dict | None = None,
-                 options: dict | None = None, missing_poses: list | None = None, *, dtype: str = "f64", device: int = 0):
+                 options: dict | None = None, missing_poses: list | None = None, *, dtype: str = "f64", device: int = 0,
+                 pinned_ring: int = 0):
         self.problem_opts = dict(DEFAULT_OPTIONS)  # the reference aliases and mutates the module global (th:108-110)
         if options is not None:
             self.problem_opts.update(options)
@@ -164,7 +165,7 @@ class TemplateBundleHandler:  # th:80-240
         self.point_data = deepcopy(target.point_data)
         self.target_point_shape = np.array(target.point_data.shape)
         self.initial_params = None
-        self._dtype, self._device = dtype, device
+        self._dtype, self._device, self._pinned_ring = dtype, device, pinned_ring
 
         n_poses = detection.max_ims
         n_cams = camset.get_n_cams()
@@ -185,7 +186,8 @@ class TemplateBundleHandler:  # th:80-240
         self.jac_mask = None
         self.missing_poses = missing_poses
         self.op_fun = fb.optimisation_function(
-            [fb.projection(), fb.extrinsic3D(), fb.template_points()], dtype=dtype, device=device)  # th:152
+            [fb.projection(), fb.extrinsic3D(), fb.template_points()], dtype=dtype, device=device,
+            pinned_ring=pinned_ring)  # th:152
 
     # -- the path ------------------------------------------------------------------------------
     def can_make_jac(self):  # th:154-155
@@ -280,8 +282,9 @@ class SelfBundleHandler(TemplateBundleHandler):  # sbh:109-260
     """Self-calibration: the 3-D target points are free too (chain S), 7-DoF gauge fixed."""
 
     def __init__(self, camset, target, detection, fixed_params=None, options=None, missing_poses=None,
-                 *, dtype: str = "f64", device: int = 0):
-        super().__init__(camset, target, detection, fixed_params, options, missing_poses, dtype=dtype, device=device)
+                 *, dtype: str = "f64", device: int = 0, pinned_ring: int = 0):
+        super().__init__(camset, target, detection, fixed_params, options, missing_poses, dtype=dtype, device=device,
+                         pinned_ring=pinned_ring)
         self.flat_point_data = np.copy(self.point_data.reshape((-1)))
         self.fixed_inds = find_not_colinear_pts(self.flat_point_data.reshape((-1, 3)))  # sbh:153-158
         i0, i1, i2 = self.fixed_inds
@@ -300,7 +303,8 @@ class SelfBundleHandler(TemplateBundleHandler):  # sbh:109-260
             sup.poses, self.flat_point_data, sup.extr, sup.intr, extr_unfixed=sup.extr_unfixed,
             intr_unfixed=sup.intr_unfixed, poses_unfixed=sup.poses_unfixed, bundle_points_unfixed=self.feat_unfixed)
         self.op_fun = fb.optimisation_function(
-            [fb.projection(), fb.extrinsic3D(), fb.rigidTform3d(), fb.free_point()], dtype=dtype, device=device)  # sbh:182
+            [fb.projection(), fb.extrinsic3D(), fb.rigidTform3d(), fb.free_point()], dtype=dtype, device=device,
+            pinned_ring=pinned_ring)  # sbh:182
 
     def _jac_mask(self):  # sbh:211-218
         return np.concatenate((
@@ -318,8 +322,9 @@ class FreePointBundleHandler(TemplateBundleHandler):  # fph:102-201
     """Classic bundle adjustment of world points without a target pose (chain F)."""
 
     def __init__(self, camset, target, detection, fixed_params=None, options=None, missing_poses=None,
-                 *, dtype: str = "f64", device: int = 0):
-        super().__init__(camset, target, detection, fixed_params, options, missing_poses, dtype=dtype, device=device)
+                 *, dtype: str = "f64", device: int = 0, pinned_ring: int = 0):
+        super().__init__(camset, target, detection, fixed_params, options, missing_poses, dtype=dtype, device=device,
+                         pinned_ring=pinned_ring)
         self.flat_point_data = np.copy(self.point_data.reshape((-1)))
         self.feat_unfixed = np.ones(self.flat_point_data.shape[0], dtype=bool)
         self.super_primitive = self.bundlePrimitive
@@ -328,7 +333,8 @@ class FreePointBundleHandler(TemplateBundleHandler):  # fph:102-201
             extr_unfixed=self.super_primitive.extr_unfixed, intr_unfixed=self.super_primitive.intr_unfixed,
             bundle_points_unfixed=self.feat_unfixed)
         self.op_fun = fb.optimisation_function(
-            [fb.projection(), fb.extrinsic3D(), fb.free_point()], dtype=dtype, device=device)  # fph:143
+            [fb.projection(), fb.extrinsic3D(), fb.free_point()], dtype=dtype, device=device,
+            pinned_ring=pinned_ring)  # fph:143
 
     def _jac_mask(self):  # fph:172-178
         return np.concatenate((

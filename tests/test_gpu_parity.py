@@ -269,3 +269,62 @@ def test_device_resident_outputs_and_kernel_timer(Engine):
     prep_ms, eval_ms = e.last_kernel_ms()
     assert 0 < eval_ms < 50 and 0 <= prep_ms < 50
     e.close()
+
+
+# ---- fixed-parameter compaction --------------------------------------------------------
+@pytest.mark.parametrize("chain", CHAINS)
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_compaction_kernels_match_masked_dense(Engine, chain, dtype):
+    """Both compaction kernels (per-lane stores, tile-coalesced stores) must reproduce
+    ``dense[:n][good_mask]`` (afb:627-651) bit for bit, for scattered per-scalar masks, for
+    entity-wise masks like the handlers', for all-fixed and all-free rows, on ragged sizes."""
+    rig = synthetic.config_rig(1)
+    rng = np.random.default_rng(5)
+    ps = orc.build_param_list(*H.chain_slabs(rig, chain))
+    n_par = ps.shape[0]
+    masks = {
+        "scattered": rng.random(n_par) > 0.4,
+        "all_free": np.ones(n_par, bool),
+        "all_fixed": np.zeros(n_par, bool),
+        "entity": np.concatenate([np.repeat(rng.random(rig.n_cams) > 0.3, 9), np.repeat(rng.random(rig.n_cams) > 0.3, 6),
+                                  np.ones(n_par - 15 * rig.n_cams, bool)]),
+    }
+    masks["entity"][15 * rig.n_cams: 15 * rig.n_cams + 6] = chain == "free"  # pose 0 fixed (th:134-137)
+    for n in (rig.n_det, 1000, 65, 33, 1):
+        det = rig.detections[:n].copy()
+        det[-1, :3] = [rig.n_cams - 1, rig.n_imgs - 1, rig.n_keys - 1]
+        e = make_engine(Engine, rig, chain, dtype=dtype, det=det)
+        r_ref, j = e.eval(ps)
+        for name, mask in masks.items():
+            idx, ptr, m = orc.csr_structure(chain, det, mask)
+            assert e.set_unfixed(mask) == int(m.sum())
+            gi, gp = e.csr_structure(mask)
+            assert np.array_equal(gi, idx) and np.array_equal(gp, ptr)
+            for cv in (0, 1):
+                e.set_option("compact_variant", cv)
+                r, data = e.eval_compact(ps, want_resid=True)
+                assert np.array_equal(data, j[m]), (name, n, cv)
+                assert np.array_equal(r, r_ref)
+        e.close()
+
+
+def test_pinned_output_ring(Engine):
+    from pycamset_amd.engine import pinned_empty
+    a = pinned_empty((5, 3))
+    a[:] = 7.0
+    assert a.shape == (5, 3) and a.dtype == np.float64 and float(a.sum()) == 105.0
+    del a
+    rig = synthetic.config_rig(2)
+    ps = orc.build_param_list(rig.intr, rig.extr, rig.poses)
+    e = make_engine(Engine, rig, "template")
+    r0, j0 = e.eval(ps)
+    outs = [e.eval(ps, pinned_ring=2) for _ in range(4)]
+    assert outs[0][1] is outs[2][1] and outs[1][1] is outs[3][1] and outs[0][1] is not outs[1][1]
+    for r, j in outs:
+        assert np.array_equal(r, r0) and np.array_equal(j, j0)
+    e.set_unfixed(np.arange(ps.shape[0]) % 3 != 0)
+    _, d0 = e.eval_compact(ps)
+    _, d1 = e.eval_compact(ps, pinned_ring=3)
+    assert np.array_equal(d0, d1)
+    e.close()
+    assert np.array_equal(outs[0][1], j0)  # views outlive the engine
