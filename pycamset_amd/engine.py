@@ -129,12 +129,12 @@ class Engine:
         ``pinned_ring`` page-locked buffers (valid until ``pinned_ring`` further calls)."""
         if pinned_ring <= 0:
             return np.empty(shape)
-        ring = self._rings.setdefault((name, tuple(shape), pinned_ring), {"bufs": [], "next": 0})
-        if len(ring["bufs"]) < pinned_ring:
+        ring = self._rings.setdefault((name, tuple(shape), pinned_ring), {"bufs": [], "count": 0})
+        idx = ring["count"] % pinned_ring
+        ring["count"] += 1
+        if idx >= len(ring["bufs"]):
             ring["bufs"].append(pinned_empty(shape))
-            return ring["bufs"][-1]
-        ring["next"] = (ring["next"] + 1) % pinned_ring
-        return ring["bufs"][ring["next"]]
+        return ring["bufs"][idx]
 
     def eval(self, param_str, want_resid: bool = True, want_jac: bool = True, pinned_ring: int = 0):
         """-> (resid (N,2) | None, jac (2N,P) | None), float64 NumPy."""

@@ -303,8 +303,13 @@ def test_compaction_kernels_match_masked_dense(Engine, chain, dtype):
             for cv in (0, 1):
                 e.set_option("compact_variant", cv)
                 r, data = e.eval_compact(ps, want_resid=True)
-                assert np.array_equal(data, j[m]), (name, n, cv)
-                assert np.array_equal(r, r_ref)
+                if dtype == "f64":
+                    assert np.array_equal(data, j[m]), (name, n, cv)
+                    assert np.array_equal(r, r_ref)
+                else:  # separately compiled f32 kernels contract FMAs differently: last-bit differences
+                    rows = np.broadcast_to(np.max(np.abs(j), axis=1, keepdims=True), j.shape)[m]
+                    assert np.all(np.abs(data - j[m]) <= 2 * H.F32_JAC_RTOL * np.maximum(np.abs(j[m]), H.ROW_FLOOR * rows)), (name, n, cv)
+                    assert np.max(np.abs(r - r_ref), initial=0.0) <= 1e-3
         e.close()
 
 
