@@ -129,6 +129,22 @@ int pcs_set_unfixed(pcs_engine *h, const uint8_t *unfixed, int64_t *nnz);
 int pcs_eval_compact(pcs_engine *h, const double *param_str, double *resid, double *data /* nnz */);
 int pcs_eval_compact_device(pcs_engine *h, const double *param_str, void *d_resid, void *d_data, void *stream);
 
+/*
+ * Matrix-free products with the Jacobian at a linearisation point: J is never
+ * materialised.  Replaces what scipy does with the reference's CSR Jacobian
+ * (optimisation_handling.py:88-98: x_scale='jac' column norms, J^T f, lsmr mat-vecs).
+ * pcs_linearize prepares the slabs at `param_str` (any pcs_eval* call does so too).
+ * pcs_matfree ops (vectors on the host, FULL parameter-string space, float64):
+ *   0 JV    in: n_params            out: 2N        out = J in
+ *   1 JTU   in: 2N                  out: n_params  out = J^T in
+ *   2 JTJV  in: n_params            out: n_params  out = J^T (J in)
+ *   3 DIAG  in: NULL                out: n_params  out = diag(J^T J)
+ *   4 GRAD  in: NULL                out: n_params  out = J^T r,  *cost = sum r^2 (cost may be NULL)
+ * Sums use f64 atomics: their last bits depend on arrival order.
+ */
+int pcs_linearize(pcs_engine *h, const double *param_str);
+int pcs_matfree(pcs_engine *h, int op, const double *in, double *out, double *cost);
+
 /* Block until everything queued on `stream` (NULL = engine stream) has finished. */
 int pcs_synchronize(pcs_engine *h, void *stream);
 /* Duration of the most recent evaluation's kernels (HIP events on the launch stream), ms. */

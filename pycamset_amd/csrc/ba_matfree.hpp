@@ -1,0 +1,159 @@
+// ba_matfree.hpp — matrix-free products with the bundle-adjustment Jacobian.
+//
+// What scipy does with the CSR Jacobian the reference hands it (optimisation_handling.py:88-98:
+// x_scale='jac' column norms, J^T f gradient, lsmr mat-vecs) needs J only through products.  These
+// kernels recompute each detection's 2 x P block from the slabs (FMAs are ~6x under the memory
+// budget of the dense kernel) and apply it on the fly, so J is never written to HBM:
+//     OP_JV    out[2i..2i+1] = J_i v                       (2N outputs, coalesced)
+//     OP_JTU   out += J_i^T u_i                            (n_params accumulators)
+//     OP_JTJV  out += J_i^T (J_i v)                        (normal-equation operator, one pass)
+//     OP_DIAG  out += diag(J_i^T J_i)                      (column square norms: x_scale='jac', Jacobi)
+//     OP_GRAD  out += J_i^T r_i,  cost += |r_i|^2          (gradient + cost at the linearisation point)
+// Vectors live in the FULL parameter-string space (afb:777-820 layout); fixed parameters are handled
+// by the caller (zeros in v, ignored entries of out).  Traffic: 28 B per detection in (+16 B for
+// OP_JTU / out of OP_JV) — the n_params-sized vectors stay in L1/L2.
+//
+// Accumulation: a tile of 64 detections in the reference's cam -> image -> key order shares its
+// camera and pose, so the 15 camera columns and 6 pose columns are summed across the wave
+// (6 xor-shuffle steps) and added with ONE f64 atomic per column per tile; tiles that are not
+// uniform, and the 3 point columns, use per-lane atomics.  Atomic order makes the last bits of the
+// sums run-to-run dependent (documented; the tests compare with a tolerance).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "ba_device.hpp"
+
+namespace pcs {
+
+constexpr int OP_JV = 0;
+constexpr int OP_JTU = 1;
+constexpr int OP_JTJV = 2;
+constexpr int OP_DIAG = 3;
+constexpr int OP_GRAD = 4;
+
+struct MatfreeArgs {
+    const int32_t *cam, *img, *key;
+    const void *uv;
+    const void *cam_slab, *pose_slab, *points;
+    const double *vin;   // OP_JV / OP_JTJV: n_params; OP_JTU: 2N
+    double *vout;        // OP_JV: 2N; others: n_params (zeroed by the host before the launch)
+    double *cost;        // OP_GRAD: 1 accumulator (zeroed by the host)
+    int64_t n, n_tiles;
+    int64_t extr_off, pose_off, point_off;
+    int32_t tiles_per_wg;
+};
+
+__device__ __forceinline__ double wave_sum(double x) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
+    return x;
+}
+
+// Add `count` per-detection contributions g[first .. first+count) into out[base(key) + j].
+template <int COUNT>
+__device__ __forceinline__ void accumulate_group(const double *g, const int key, const int64_t base_off, const int stride,
+                                                 const bool valid, const int lane, double *__restrict__ out) {
+    const int k0 = __builtin_amdgcn_readfirstlane(key);
+    const bool uniform = __all(!valid || key == k0);
+    if (uniform) {
+        double *dst = out + base_off + (int64_t)k0 * stride;
+#pragma unroll
+        for (int j = 0; j < COUNT; ++j) {
+            const double s = wave_sum(valid ? g[j] : 0.0);
+            if (lane == 0) unsafeAtomicAdd(dst + j, s);
+        }
+    } else if (valid) {
+        double *dst = out + base_off + (int64_t)key * stride;
+#pragma unroll
+        for (int j = 0; j < COUNT; ++j) unsafeAtomicAdd(dst + j, g[j]);
+    }
+}
+
+template <int CHAIN, typename T, int OP>
+__global__ __launch_bounds__(256) void ba_matfree_kernel(const MatfreeArgs a) {
+    constexpr int P = chain_P(CHAIN);
+    constexpr int P2 = 2 * P;
+    using V2 = __attribute__((ext_vector_type(2))) T;
+    using D2 = __attribute__((ext_vector_type(2))) double;
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const T *cam_slab = static_cast<const T *>(a.cam_slab);
+    const T *pose_slab = static_cast<const T *>(a.pose_slab);
+    const T *points = static_cast<const T *>(a.points);
+    const V2 *uv = static_cast<const V2 *>(a.uv);
+    const int64_t tile0 = (int64_t)blockIdx.x * a.tiles_per_wg;
+    const int64_t tile1 = min(tile0 + (int64_t)a.tiles_per_wg, a.n_tiles);
+    double cost_acc = 0.0;
+    for (int64_t tile = tile0 + wave; tile < tile1; tile += 4) {
+        const int64_t i = tile * 64 + lane;
+        const bool valid = i < a.n;
+        const int64_t ic = valid ? i : a.n - 1;
+        const int c = a.cam[ic], im = a.img[ic], k = a.key[ic];
+        const V2 m = uv[ic];
+        T u, v;
+        T J[P2];
+        eval_detection<CHAIN, T, true>(cam_slab + c * CAM_STRIDE, pose_slab + im * POSE_STRIDE, points[3 * k], points[3 * k + 1],
+                                       points[3 * k + 2], u, v, J);
+        // global columns of this detection's P local parameters
+        const int64_t cI = 9 * (int64_t)c, cE = a.extr_off + 6 * (int64_t)c;
+        const int64_t cP = a.pose_off + 6 * (int64_t)im, cX = a.point_off + 3 * (int64_t)k;
+        double w0 = 0.0, w1 = 0.0;
+        if constexpr (OP == OP_JV || OP == OP_JTJV) {
+            const double *vin = a.vin;
+#pragma unroll
+            for (int j = 0; j < 9; ++j) { const double x = vin[cI + j]; w0 += (double)J[j] * x; w1 += (double)J[P + j] * x; }
+#pragma unroll
+            for (int j = 0; j < 6; ++j) { const double x = vin[cE + j]; w0 += (double)J[9 + j] * x; w1 += (double)J[P + 9 + j] * x; }
+            if constexpr (CHAIN != CHAIN_FREE) {
+#pragma unroll
+                for (int j = 0; j < 6; ++j) { const double x = vin[cP + j]; w0 += (double)J[15 + j] * x; w1 += (double)J[P + 15 + j] * x; }
+            }
+            if constexpr (CHAIN != CHAIN_TEMPLATE) {
+                constexpr int o = (CHAIN == CHAIN_SELF) ? 21 : 15;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) { const double x = vin[cX + j]; w0 += (double)J[o + j] * x; w1 += (double)J[P + o + j] * x; }
+            }
+        }
+        if constexpr (OP == OP_JV) {
+            if (valid) {
+                D2 q;
+                q.x = w0;
+                q.y = w1;
+                reinterpret_cast<D2 *>(a.vout)[i] = q;
+            }
+            continue;
+        }
+        if constexpr (OP == OP_JTU) {
+            const D2 q = reinterpret_cast<const D2 *>(a.vin)[ic];
+            w0 = q.x;
+            w1 = q.y;
+        }
+        if constexpr (OP == OP_GRAD) {
+            w0 = (double)(u - m.x);
+            w1 = (double)(v - m.y);
+            if (valid) cost_acc += w0 * w0 + w1 * w1;
+        }
+        double g[P];
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+            if constexpr (OP == OP_DIAG) g[j] = (double)J[j] * (double)J[j] + (double)J[P + j] * (double)J[P + j];
+            else g[j] = (double)J[j] * w0 + (double)J[P + j] * w1;
+        }
+        accumulate_group<9>(g, c, 0, 9, valid, lane, a.vout);
+        accumulate_group<6>(g + 9, c, a.extr_off, 6, valid, lane, a.vout);
+        if constexpr (CHAIN != CHAIN_FREE) accumulate_group<6>(g + 15, im, a.pose_off, 6, valid, lane, a.vout);
+        if constexpr (CHAIN != CHAIN_TEMPLATE) {
+            constexpr int o = (CHAIN == CHAIN_SELF) ? 21 : 15;
+            if (valid) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) unsafeAtomicAdd(a.vout + cX + j, g[o + j]);
+            }
+        }
+    }
+    if constexpr (OP == OP_GRAD) {
+        const double s = wave_sum(cost_acc);
+        if (lane == 0) unsafeAtomicAdd(a.cost, s);
+    }
+}
+
+}  // namespace pcs

@@ -25,6 +25,7 @@
 
 #include "../../include/pcs_hip.h"
 #include "ba_device.hpp"
+#include "ba_matfree.hpp"
 
 namespace pcs {
 
@@ -445,6 +446,10 @@ struct pcs_engine {
     int64_t nnz = -1;
     void *d_data = nullptr;
     int64_t data_capacity = 0;
+    // matrix-free operators (f2)
+    double *d_vin = nullptr, *d_vout = nullptr, *d_cost = nullptr;
+    int64_t vin_capacity = 0, vout_capacity = 0;
+    bool linearized = false;
     // launch geometry
     int n_cu = 256;
     // Launch geometry.  variant < 0 / wgs_per_cu <= 0 = automatic, from the MI355X sweeps in
@@ -576,7 +581,7 @@ int pcs_destroy(pcs_engine *h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     void *bufs[] = {h->d_cam, h->d_img, h->d_key, h->d_uv, h->d_param, h->d_cam_slab, h->d_pose_slab, h->d_points,
-                    h->d_resid, h->d_jac, h->d_keep, h->d_row_off, h->d_data};
+                    h->d_resid, h->d_jac, h->d_keep, h->d_row_off, h->d_data, h->d_vin, h->d_vout, h->d_cost};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (h->h_param) (void)hipHostFree(h->h_param);
@@ -799,6 +804,47 @@ static hipError_t launch_compact_t(int chain, int mode, const EvalArgs &a, dim3 
     }
 }
 
+static int launch_slab_prep(pcs_engine *h, const double *d_prm, hipStream_t s) {
+    const int has_pose = h->chain != PCS_CHAIN_FREE;
+    const int copy_points = h->chain != PCS_CHAIN_TEMPLATE;
+    const int64_t ents = h->n_cams + (has_pose ? h->n_imgs : 0);
+    int64_t threads = ents;
+    if (copy_points) threads = std::max<int64_t>(threads, std::min<int64_t>(3 * h->n_keys, 1 << 16));
+    const dim3 grid((unsigned)((threads + 127) / 128));
+    if (h->dtype == PCS_F64)
+        hipLaunchKernelGGL(slab_prep_kernel<double>, grid, dim3(128), 0, s, d_prm, (double *)h->d_cam_slab, (double *)h->d_pose_slab,
+                           (double *)h->d_points, (int)h->n_cams, (int)h->n_imgs, (int)h->n_keys, h->extr_off, h->pose_off,
+                           h->point_off, has_pose, copy_points);
+    else
+        hipLaunchKernelGGL(slab_prep_kernel<float>, grid, dim3(128), 0, s, d_prm, (float *)h->d_cam_slab, (float *)h->d_pose_slab,
+                           (float *)h->d_points, (int)h->n_cams, (int)h->n_imgs, (int)h->n_keys, h->extr_off, h->pose_off,
+                           h->point_off, has_pose, copy_points);
+    HIPCHK(hipGetLastError());
+    h->linearized = true;
+    return PCS_OK;
+}
+
+template <int CHAIN, typename T>
+static hipError_t launch_matfree_c(int op, const MatfreeArgs &a, dim3 grid, hipStream_t s) {
+    switch (op) {
+        case OP_JV: hipLaunchKernelGGL((ba_matfree_kernel<CHAIN, T, OP_JV>), grid, dim3(256), 0, s, a); break;
+        case OP_JTU: hipLaunchKernelGGL((ba_matfree_kernel<CHAIN, T, OP_JTU>), grid, dim3(256), 0, s, a); break;
+        case OP_JTJV: hipLaunchKernelGGL((ba_matfree_kernel<CHAIN, T, OP_JTJV>), grid, dim3(256), 0, s, a); break;
+        case OP_DIAG: hipLaunchKernelGGL((ba_matfree_kernel<CHAIN, T, OP_DIAG>), grid, dim3(256), 0, s, a); break;
+        default: hipLaunchKernelGGL((ba_matfree_kernel<CHAIN, T, OP_GRAD>), grid, dim3(256), 0, s, a); break;
+    }
+    return hipGetLastError();
+}
+
+template <typename T>
+static hipError_t launch_matfree_t(int chain, int op, const MatfreeArgs &a, dim3 grid, hipStream_t s) {
+    switch (chain) {
+        case CHAIN_TEMPLATE: return launch_matfree_c<CHAIN_TEMPLATE, T>(op, a, grid, s);
+        case CHAIN_SELF: return launch_matfree_c<CHAIN_SELF, T>(op, a, grid, s);
+        default: return launch_matfree_c<CHAIN_FREE, T>(op, a, grid, s);
+    }
+}
+
 // Queue slab_prep + the evaluation kernel on `s`.  d_prm must already hold the parameter string.
 static int enqueue_eval(pcs_engine *h, const double *d_prm, void *d_resid, void *d_out, bool compact, hipStream_t s) {
     if (h->n <= 0) return fail(PCS_ERR_STATE, "no detections set");
@@ -809,22 +855,10 @@ static int enqueue_eval(pcs_engine *h, const double *d_prm, void *d_resid, void 
     hipEvent_t *ev = h->ev.data() + 3 * (h->ev_count % h->ev_ring);
     HIPCHK(hipEventRecord(ev[0], s));
     {
-        const int has_pose = h->chain != PCS_CHAIN_FREE;
-        const int copy_points = h->chain != PCS_CHAIN_TEMPLATE;
-        const int64_t ents = h->n_cams + (has_pose ? h->n_imgs : 0);
-        int64_t threads = ents;
-        if (copy_points) threads = std::max<int64_t>(threads, std::min<int64_t>(3 * h->n_keys, 1 << 16));
-        const dim3 grid((unsigned)((threads + 127) / 128));
-        if (h->dtype == PCS_F64)
-            hipLaunchKernelGGL(slab_prep_kernel<double>, grid, dim3(128), 0, s, d_prm, (double *)h->d_cam_slab, (double *)h->d_pose_slab,
-                               (double *)h->d_points, (int)h->n_cams, (int)h->n_imgs, (int)h->n_keys, h->extr_off, h->pose_off,
-                               h->point_off, has_pose, copy_points);
-        else
-            hipLaunchKernelGGL(slab_prep_kernel<float>, grid, dim3(128), 0, s, d_prm, (float *)h->d_cam_slab, (float *)h->d_pose_slab,
-                               (float *)h->d_points, (int)h->n_cams, (int)h->n_imgs, (int)h->n_keys, h->extr_off, h->pose_off,
-                               h->point_off, has_pose, copy_points);
-        HIPCHK(hipGetLastError());
+        int rc0 = launch_slab_prep(h, d_prm, s);
+        if (rc0) return rc0;
     }
+    h->linearized = true;
     HIPCHK(hipEventRecord(ev[1], s));
     EvalArgs a{};
     a.cam = h->d_cam; a.img = h->d_img; a.key = h->d_key; a.uv = h->d_uv;
@@ -1066,6 +1100,67 @@ int pcs_eval_compact(pcs_engine *h, const double *param_str, double *resid, doub
     if (resid && (rc = download(h, resid, h->d_resid, 2 * h->n, h->stream))) return rc;
     if (data && h->nnz > 0 && (rc = download(h, data, h->d_data, h->nnz, h->stream))) return rc;
     HIPCHK(hipStreamSynchronize(h->stream));
+    return PCS_OK;
+}
+
+int pcs_linearize(pcs_engine *h, const double *param_str) {
+    if (!h || !param_str) return fail(PCS_ERR_ARG, "pcs_linearize: bad arguments");
+    if (h->n <= 0) return fail(PCS_ERR_STATE, "no detections set");
+    if (h->chain == PCS_CHAIN_TEMPLATE && !h->have_template) return fail(PCS_ERR_STATE, "template points not set");
+    HIPCHK(hipSetDevice(h->device));
+    int rc = stage_params(h, param_str, h->stream);
+    if (rc) return rc;
+    h->last_stream = h->stream;
+    return launch_slab_prep(h, h->d_param, h->stream);
+}
+
+int pcs_matfree(pcs_engine *h, int op, const double *in, double *out, double *cost) {
+    if (!h || op < OP_JV || op > OP_GRAD || !out) return fail(PCS_ERR_ARG, "pcs_matfree: bad arguments");
+    if ((op == OP_JV || op == OP_JTU || op == OP_JTJV) && !in) return fail(PCS_ERR_ARG, "pcs_matfree: this operator needs an input vector");
+    if (!h->linearized) return fail(PCS_ERR_STATE, "pcs_matfree: call pcs_linearize (or an evaluation) first");
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    if (h->last_stream && h->last_stream != s) HIPCHK(hipStreamSynchronize(h->last_stream));  // slabs may come from a caller stream
+    const int64_t n_in = (op == OP_JTU) ? 2 * h->n : (op == OP_JV || op == OP_JTJV) ? h->n_params : 0;
+    const int64_t n_out = (op == OP_JV) ? 2 * h->n : h->n_params;
+    if (n_in > h->vin_capacity) {
+        if (h->d_vin) HIPCHK(hipFree(h->d_vin));
+        HIPCHK(hipMalloc(&h->d_vin, sizeof(double) * n_in));
+        h->vin_capacity = n_in;
+    }
+    if (n_out > h->vout_capacity) {
+        if (h->d_vout) HIPCHK(hipFree(h->d_vout));
+        HIPCHK(hipMalloc(&h->d_vout, sizeof(double) * n_out));
+        h->vout_capacity = n_out;
+    }
+    if (!h->d_cost) HIPCHK(hipMalloc(&h->d_cost, sizeof(double)));
+    if (n_in) HIPCHK(hipMemcpyAsync(h->d_vin, in, sizeof(double) * n_in, hipMemcpyHostToDevice, s));
+    if (op != OP_JV) HIPCHK(hipMemsetAsync(h->d_vout, 0, sizeof(double) * n_out, s));
+    if (op == OP_GRAD) HIPCHK(hipMemsetAsync(h->d_cost, 0, sizeof(double), s));
+    MatfreeArgs a{};
+    a.cam = h->d_cam; a.img = h->d_img; a.key = h->d_key; a.uv = h->d_uv;
+    a.cam_slab = h->d_cam_slab; a.pose_slab = h->d_pose_slab; a.points = h->d_points;
+    a.vin = h->d_vin; a.vout = h->d_vout; a.cost = h->d_cost;
+    a.n = h->n; a.n_tiles = (h->n + TILE - 1) / TILE;
+    a.extr_off = h->extr_off; a.pose_off = h->pose_off; a.point_off = h->point_off;
+    const int64_t wpc = h->wgs_per_cu > 0 ? h->wgs_per_cu : 8;
+    const int64_t target_wgs = (int64_t)h->n_cu * wpc;
+    int64_t tpw = (a.n_tiles + target_wgs - 1) / target_wgs;
+    tpw = std::max<int64_t>(WAVES_PER_WG, (tpw + WAVES_PER_WG - 1) / WAVES_PER_WG * WAVES_PER_WG);
+    a.tiles_per_wg = (int32_t)tpw;
+    const dim3 grid((unsigned)((a.n_tiles + tpw - 1) / tpw));
+    hipEvent_t *ev = h->ev.data() + 3 * (h->ev_count % h->ev_ring);
+    HIPCHK(hipEventRecord(ev[0], s));
+    HIPCHK(hipEventRecord(ev[1], s));
+    hipError_t e = h->dtype == PCS_F64 ? launch_matfree_t<double>(h->chain, op, a, grid, s) : launch_matfree_t<float>(h->chain, op, a, grid, s);
+    if (e != hipSuccess) return fail(PCS_ERR_HIP, "matfree kernel launch failed: %s", hipGetErrorString(e));
+    HIPCHK(hipEventRecord(ev[2], s));
+    ++h->ev_count;
+    h->events_valid = true;
+    h->last_stream = s;
+    HIPCHK(hipMemcpyAsync(out, h->d_vout, sizeof(double) * n_out, hipMemcpyDeviceToHost, s));
+    if (op == OP_GRAD && cost) HIPCHK(hipMemcpyAsync(cost, h->d_cost, sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
     return PCS_OK;
 }
 

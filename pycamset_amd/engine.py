@@ -164,6 +164,41 @@ class Engine:
         check(lib().pcs_eval_compact(self._h, _dp(p), _dp(r) if want_resid else None, _dp(d)))
         return r, d
 
+    # -- matrix-free Jacobian products (J never materialised) -------------------------------------
+    OP_JV, OP_JTU, OP_JTJV, OP_DIAG, OP_GRAD = 0, 1, 2, 3, 4
+
+    def linearize(self, param_str):
+        """Prepare the slabs at ``param_str``; the products below refer to this point."""
+        check(lib().pcs_linearize(self._h, _dp(self._check_params(param_str))))
+
+    def _matfree(self, op: int, vin, n_out: int, want_cost: bool = False):
+        out = np.empty(n_out)
+        cost = c_double(0.0)
+        vin_p = _dp(vin) if vin is not None else None
+        check(lib().pcs_matfree(self._h, op, vin_p, _dp(out), byref(cost) if want_cost else None))
+        return (out, float(cost.value)) if want_cost else out
+
+    def jv(self, v) -> np.ndarray:
+        """J v, shape (2N,); ``v`` in the full parameter-string space."""
+        return self._matfree(self.OP_JV, self._check_params(v), 2 * self.n)
+
+    def jtu(self, u) -> np.ndarray:
+        u = _f64c(u).ravel()
+        if u.shape[0] != 2 * self.n:
+            raise ValueError("u must have 2N entries")
+        return self._matfree(self.OP_JTU, u, self.n_params)
+
+    def jtjv(self, v) -> np.ndarray:
+        """J^T (J v) in one pass over the detections."""
+        return self._matfree(self.OP_JTJV, self._check_params(v), self.n_params)
+
+    def jtj_diag(self) -> np.ndarray:
+        return self._matfree(self.OP_DIAG, None, self.n_params)
+
+    def grad(self) -> tuple[np.ndarray, float]:
+        """(J^T r, sum r^2) at the linearisation point."""
+        return self._matfree(self.OP_GRAD, None, self.n_params, want_cost=True)
+
     # -- evaluation: device buffers -----------------------------------------------------------
     def eval_device(self, param_str, d_resid: int | None, d_jac: int | None, stream: int | None = None):
         """Asynchronous; ``d_resid`` / ``d_jac`` are raw device addresses in the engine dtype."""

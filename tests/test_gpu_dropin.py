@@ -132,3 +132,79 @@ def test_least_squares_with_hip_closures_converges_like_the_cpu_path(chain):
     assert abs(e1 - e_ref) <= 1e-4
     # same first step: one evaluation from the common start must agree to rounding
     assert np.max(np.abs(loss_fn(x0) - o_loss(x0))) <= 1e-9
+
+
+# ---- Jacobian kept on the device -------------------------------------------------------
+@pytest.mark.parametrize("chain", ["template", "self", "free"])
+def test_matrix_free_products_match_sparse_products_of_the_oracle_jacobian(chain):
+    """J v, J^T u, J^T J v, diag(J^T J), J^T r and the cost, against scipy.sparse products of the
+    oracle's Jacobian.  f64 atomics reorder the sums: |a - b| <= 1e-10 * max|ref|."""
+    from pycamset_amd.engine import Engine
+    rig = synthetic.config_rig(1)
+    ps = orc.build_param_list(*H.chain_slabs(rig, chain))
+    tm = rig.points if chain == "template" else None
+    dense, r = orc.full_jac_dense(chain, rig.detections, ps, tm, with_resid=True)
+    idx, ptr, _ = orc.csr_structure(chain, rig.detections, np.ones(ps.shape[0], bool))
+    J = csr_array((dense.reshape(-1), idx, ptr), shape=(2 * rig.n_det, ps.shape[0]))
+    rng = np.random.default_rng(3)
+    v = rng.standard_normal(ps.shape[0])
+    u = rng.standard_normal(2 * rig.n_det)
+    for order in ("sorted", "shuffled"):  # wave-uniform fast path and per-lane atomic path
+        det = rig.detections if order == "sorted" else rig.detections[np.random.default_rng(0).permutation(rig.n_det)]
+        Jo = J if order == "sorted" else None
+        e = Engine(chain, rig.n_cams, rig.n_imgs, rig.n_keys)
+        e.set_detections_table(det)
+        if tm is not None:
+            e.set_template(tm)
+        e.linearize(ps)
+
+        def close(a, b):
+            assert a.shape == b.shape
+            assert np.max(np.abs(a - b)) <= 1e-10 * np.max(np.abs(b)), float(np.max(np.abs(a - b)) / np.max(np.abs(b)))
+
+        if Jo is not None:
+            close(e.jv(v), Jo @ v)
+            close(e.jtu(u), Jo.T @ u)
+        close(e.jtjv(v), J.T @ (J @ v))
+        close(e.jtj_diag(), np.asarray(J.multiply(J).sum(axis=0)).ravel())
+        g, cost = e.grad()
+        close(g, J.T @ r.reshape(-1))
+        assert abs(cost - float(np.sum(r * r))) <= 1e-10 * float(np.sum(r * r))
+        # an evaluation re-linearises too
+        e.eval(ps * (1 + 1e-3), want_jac=False)
+        e.linearize(ps)
+        close(e.jtjv(v), J.T @ (J @ v))
+        e.close()
+
+
+@pytest.mark.parametrize("chain", ["template", "self"])
+def test_device_lm_reaches_the_scipy_solution(chain):
+    from pycamset_amd.device_solver import JacobianOperator, lm_solve
+    rig = synthetic.make_rig("ring-8-small", 8, 12, synthetic.charuco_points(9, 8.0), seed=21, visibility=0.8)
+    names = [f"cam_{i}" for i in range(rig.n_cams)]
+    cls = handlers.TemplateBundleHandler if chain == "template" else handlers.SelfBundleHandler
+    h = cls(DuckCamset(rig.n_cams), DuckTarget(rig.points), TargetDetection(names, rig.detections),
+            fixed_params={"cam_0": {"ext": rig.extr_true[0].copy()}}, options={"verbosity": 0})
+    bp = h.bundlePrimitive
+    parts = [rig.intr[bp.intr_unfixed].ravel(), rig.extr[bp.extr_unfixed].ravel(), rig.poses[bp.poses_unfixed].ravel()]
+    if chain == "self":
+        parts.append(rig.points.ravel()[bp.bdpt_unfixed])
+    x0 = np.concatenate(parts)
+    loss_fn, jac_fn = h.make_loss_fun(1), h.make_loss_jac(1)
+    ref = least_squares(loss_fn, x0.copy(), jac=jac_fn, x_scale="jac", max_nfev=30, verbose=0)
+    res = lm_solve(h, x0.copy(), max_iter=30)
+    assert res.history == sorted(res.history, reverse=True)           # monotone decrease
+    assert res.cost <= ref.cost * (1 + 1e-3)                           # at least as low as scipy's trf+lsmr
+    assert abs(0.5 * np.sum(loss_fn(res.x) ** 2) - res.cost) <= 1e-9 * res.cost   # device cost == residual kernel
+    e_dev = np.mean(np.linalg.norm(loss_fn(res.x).reshape(-1, 2), axis=1))
+    e_ref = np.mean(np.linalg.norm(ref.fun.reshape(-1, 2), axis=1))
+    assert e_dev <= e_ref + 1e-3
+    # the operator view agrees with the CSR closure
+    op = JacobianOperator(h.op_fun.engine, h._jac_mask())
+    ps = h.op_fun.build_param_list(*h.get_bundle_adjustment_inputs(res.x))
+    op.linearize(ps)
+    Jc = jac_fn(res.x)
+    v = np.random.default_rng(0).standard_normal(res.x.shape[0])
+    assert np.max(np.abs(op.jtjv(v) - Jc.T @ (Jc @ v))) <= 1e-9 * np.max(np.abs(Jc.T @ (Jc @ v)))
+    L = op.as_linear_operator()
+    assert L.shape == Jc.shape and np.max(np.abs(L @ v - Jc @ v)) <= 1e-9 * np.max(np.abs(Jc @ v))
