@@ -13,11 +13,16 @@
 // by the caller (zeros in v, ignored entries of out).  Traffic: 28 B per detection in (+16 B for
 // OP_JTU / out of OP_JV) — the n_params-sized vectors stay in L1/L2.
 //
-// Accumulation: a tile of 64 detections in the reference's cam -> image -> key order shares its
-// camera and pose, so the 15 camera columns and 6 pose columns are summed across the wave
-// (6 xor-shuffle steps) and added with ONE f64 atomic per column per tile; tiles that are not
-// uniform, and the 3 point columns, use per-lane atomics.  Atomic order makes the last bits of the
-// sums run-to-run dependent (documented; the tests compare with a tolerance).
+// Accumulation (three levels): a tile of 64 detections in the reference's cam -> image -> key order
+// shares its camera and pose, so the 15 camera columns and 6 pose columns are first summed across
+// the wave (6 xor-shuffle steps); the wave sums (and the per-lane contributions of non-uniform tiles
+// and of the 3 point columns) are added into a workgroup-private n_params accumulator in LDS
+// (ds_add_f64); at the end each workgroup flushes its non-zero accumulators with one global f64
+// atomic each.  Going straight to global atomics costs 480 us at N = 1e6 (488 tiles per camera all
+// hit the same 15 addresses, which serialise at the memory side); through LDS it is compute-bound.
+// Parameter strings too large for LDS (> 64 KiB) fall back to direct global atomics.
+// Atomic order makes the last bits of the sums run-to-run dependent (documented; the tests compare
+// with a tolerance).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -41,6 +46,7 @@ struct MatfreeArgs {
     int64_t n, n_tiles;
     int64_t extr_off, pose_off, point_off;
     int32_t tiles_per_wg;
+    int32_t n_params;
 };
 
 __device__ __forceinline__ double wave_sum(double x) {
@@ -69,8 +75,13 @@ __device__ __forceinline__ void accumulate_group(const double *g, const int key,
     }
 }
 
-template <int CHAIN, typename T, int OP>
+template <int CHAIN, typename T, int OP, bool LDS_ACC>
 __global__ __launch_bounds__(256) void ba_matfree_kernel(const MatfreeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double lds_acc[];
+    if constexpr (LDS_ACC && OP != OP_JV) {
+        for (int j = threadIdx.x; j < a.n_params; j += 256) lds_acc[j] = 0.0;
+        __syncthreads();
+    }
     constexpr int P = chain_P(CHAIN);
     constexpr int P2 = 2 * P;
     using V2 = __attribute__((ext_vector_type(2))) T;
@@ -139,15 +150,35 @@ __global__ __launch_bounds__(256) void ba_matfree_kernel(const MatfreeArgs a) {
             if constexpr (OP == OP_DIAG) g[j] = (double)J[j] * (double)J[j] + (double)J[P + j] * (double)J[P + j];
             else g[j] = (double)J[j] * w0 + (double)J[P + j] * w1;
         }
-        accumulate_group<9>(g, c, 0, 9, valid, lane, a.vout);
-        accumulate_group<6>(g + 9, c, a.extr_off, 6, valid, lane, a.vout);
-        if constexpr (CHAIN != CHAIN_FREE) accumulate_group<6>(g + 15, im, a.pose_off, 6, valid, lane, a.vout);
-        if constexpr (CHAIN != CHAIN_TEMPLATE) {
-            constexpr int o = (CHAIN == CHAIN_SELF) ? 21 : 15;
-            if (valid) {
+        if constexpr (LDS_ACC) {
+            accumulate_group<9>(g, c, 0, 9, valid, lane, lds_acc);
+            accumulate_group<6>(g + 9, c, a.extr_off, 6, valid, lane, lds_acc);
+            if constexpr (CHAIN != CHAIN_FREE) accumulate_group<6>(g + 15, im, a.pose_off, 6, valid, lane, lds_acc);
+            if constexpr (CHAIN != CHAIN_TEMPLATE) {
+                constexpr int o = (CHAIN == CHAIN_SELF) ? 21 : 15;
+                if (valid) {
 #pragma unroll
-                for (int j = 0; j < 3; ++j) unsafeAtomicAdd(a.vout + cX + j, g[o + j]);
+                    for (int j = 0; j < 3; ++j) unsafeAtomicAdd(lds_acc + cX + j, g[o + j]);
+                }
             }
+        } else {
+            accumulate_group<9>(g, c, 0, 9, valid, lane, a.vout);
+            accumulate_group<6>(g + 9, c, a.extr_off, 6, valid, lane, a.vout);
+            if constexpr (CHAIN != CHAIN_FREE) accumulate_group<6>(g + 15, im, a.pose_off, 6, valid, lane, a.vout);
+            if constexpr (CHAIN != CHAIN_TEMPLATE) {
+                constexpr int o = (CHAIN == CHAIN_SELF) ? 21 : 15;
+                if (valid) {
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) unsafeAtomicAdd(a.vout + cX + j, g[o + j]);
+                }
+            }
+        }
+    }
+    if constexpr (LDS_ACC && OP != OP_JV) {
+        __syncthreads();
+        for (int j = threadIdx.x; j < a.n_params; j += 256) {
+            const double x = lds_acc[j];
+            if (x != 0.0) unsafeAtomicAdd(a.vout + j, x);
         }
     }
     if constexpr (OP == OP_GRAD) {

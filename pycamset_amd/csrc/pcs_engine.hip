@@ -450,6 +450,7 @@ struct pcs_engine {
     double *d_vin = nullptr, *d_vout = nullptr, *d_cost = nullptr;
     int64_t vin_capacity = 0, vout_capacity = 0;
     bool linearized = false;
+    bool matfree_lds = true;  // accumulate J^T products in workgroup-private LDS before the global atomics
     // launch geometry
     int n_cu = 256;
     // Launch geometry.  variant < 0 / wgs_per_cu <= 0 = automatic, from the MI355X sweeps in
@@ -696,6 +697,8 @@ int pcs_set_option(pcs_engine *h, const char *key, int64_t value) {
         if (value < 0 || value > 64) return fail(PCS_ERR_ARG, "wgs_per_cu must be in [0,64] (0 = automatic)");
         h->wgs_per_cu = value;
         h->tiles_per_wg = 0;
+    } else if (!strcmp(key, "matfree_lds")) {
+        h->matfree_lds = value != 0;
     } else if (!strcmp(key, "compact_variant")) {
         if (value < 0 || value > 1) return fail(PCS_ERR_ARG, "compact_variant must be 0 or 1");
         h->compact_variant = (int)value;
@@ -824,24 +827,31 @@ static int launch_slab_prep(pcs_engine *h, const double *d_prm, hipStream_t s) {
     return PCS_OK;
 }
 
-template <int CHAIN, typename T>
-static hipError_t launch_matfree_c(int op, const MatfreeArgs &a, dim3 grid, hipStream_t s) {
+template <int CHAIN, typename T, bool LDS_ACC>
+static hipError_t launch_matfree_c(int op, const MatfreeArgs &a, dim3 grid, size_t lds, hipStream_t s) {
     switch (op) {
-        case OP_JV: hipLaunchKernelGGL((ba_matfree_kernel<CHAIN, T, OP_JV>), grid, dim3(256), 0, s, a); break;
-        case OP_JTU: hipLaunchKernelGGL((ba_matfree_kernel<CHAIN, T, OP_JTU>), grid, dim3(256), 0, s, a); break;
-        case OP_JTJV: hipLaunchKernelGGL((ba_matfree_kernel<CHAIN, T, OP_JTJV>), grid, dim3(256), 0, s, a); break;
-        case OP_DIAG: hipLaunchKernelGGL((ba_matfree_kernel<CHAIN, T, OP_DIAG>), grid, dim3(256), 0, s, a); break;
-        default: hipLaunchKernelGGL((ba_matfree_kernel<CHAIN, T, OP_GRAD>), grid, dim3(256), 0, s, a); break;
+        case OP_JV: hipLaunchKernelGGL((ba_matfree_kernel<CHAIN, T, OP_JV, false>), grid, dim3(256), 0, s, a); break;
+        case OP_JTU: hipLaunchKernelGGL((ba_matfree_kernel<CHAIN, T, OP_JTU, LDS_ACC>), grid, dim3(256), lds, s, a); break;
+        case OP_JTJV: hipLaunchKernelGGL((ba_matfree_kernel<CHAIN, T, OP_JTJV, LDS_ACC>), grid, dim3(256), lds, s, a); break;
+        case OP_DIAG: hipLaunchKernelGGL((ba_matfree_kernel<CHAIN, T, OP_DIAG, LDS_ACC>), grid, dim3(256), lds, s, a); break;
+        default: hipLaunchKernelGGL((ba_matfree_kernel<CHAIN, T, OP_GRAD, LDS_ACC>), grid, dim3(256), lds, s, a); break;
     }
     return hipGetLastError();
 }
 
 template <typename T>
-static hipError_t launch_matfree_t(int chain, int op, const MatfreeArgs &a, dim3 grid, hipStream_t s) {
+static hipError_t launch_matfree_t(int chain, int op, bool lds_acc, const MatfreeArgs &a, dim3 grid, size_t lds, hipStream_t s) {
+    if (lds_acc) {
+        switch (chain) {
+            case CHAIN_TEMPLATE: return launch_matfree_c<CHAIN_TEMPLATE, T, true>(op, a, grid, lds, s);
+            case CHAIN_SELF: return launch_matfree_c<CHAIN_SELF, T, true>(op, a, grid, lds, s);
+            default: return launch_matfree_c<CHAIN_FREE, T, true>(op, a, grid, lds, s);
+        }
+    }
     switch (chain) {
-        case CHAIN_TEMPLATE: return launch_matfree_c<CHAIN_TEMPLATE, T>(op, a, grid, s);
-        case CHAIN_SELF: return launch_matfree_c<CHAIN_SELF, T>(op, a, grid, s);
-        default: return launch_matfree_c<CHAIN_FREE, T>(op, a, grid, s);
+        case CHAIN_TEMPLATE: return launch_matfree_c<CHAIN_TEMPLATE, T, false>(op, a, grid, 0, s);
+        case CHAIN_SELF: return launch_matfree_c<CHAIN_SELF, T, false>(op, a, grid, 0, s);
+        default: return launch_matfree_c<CHAIN_FREE, T, false>(op, a, grid, 0, s);
     }
 }
 
@@ -1143,7 +1153,11 @@ int pcs_matfree(pcs_engine *h, int op, const double *in, double *out, double *co
     a.vin = h->d_vin; a.vout = h->d_vout; a.cost = h->d_cost;
     a.n = h->n; a.n_tiles = (h->n + TILE - 1) / TILE;
     a.extr_off = h->extr_off; a.pose_off = h->pose_off; a.point_off = h->point_off;
-    const int64_t wpc = h->wgs_per_cu > 0 ? h->wgs_per_cu : 8;
+    a.n_params = (int32_t)h->n_params;
+    // workgroup-private LDS accumulators when the parameter string fits 64 KiB (default dynamic-LDS cap)
+    const bool lds_acc = h->matfree_lds && op != OP_JV && sizeof(double) * (size_t)h->n_params <= 64 * 1024;
+    const size_t lds = lds_acc ? sizeof(double) * (size_t)h->n_params : 0;
+    const int64_t wpc = h->wgs_per_cu > 0 ? h->wgs_per_cu : (op == OP_JV ? 8 : 2);
     const int64_t target_wgs = (int64_t)h->n_cu * wpc;
     int64_t tpw = (a.n_tiles + target_wgs - 1) / target_wgs;
     tpw = std::max<int64_t>(WAVES_PER_WG, (tpw + WAVES_PER_WG - 1) / WAVES_PER_WG * WAVES_PER_WG);
@@ -1152,7 +1166,8 @@ int pcs_matfree(pcs_engine *h, int op, const double *in, double *out, double *co
     hipEvent_t *ev = h->ev.data() + 3 * (h->ev_count % h->ev_ring);
     HIPCHK(hipEventRecord(ev[0], s));
     HIPCHK(hipEventRecord(ev[1], s));
-    hipError_t e = h->dtype == PCS_F64 ? launch_matfree_t<double>(h->chain, op, a, grid, s) : launch_matfree_t<float>(h->chain, op, a, grid, s);
+    hipError_t e = h->dtype == PCS_F64 ? launch_matfree_t<double>(h->chain, op, lds_acc, a, grid, lds, s)
+                                       : launch_matfree_t<float>(h->chain, op, lds_acc, a, grid, lds, s);
     if (e != hipSuccess) return fail(PCS_ERR_HIP, "matfree kernel launch failed: %s", hipGetErrorString(e));
     HIPCHK(hipEventRecord(ev[2], s));
     ++h->ev_count;

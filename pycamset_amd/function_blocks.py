@@ -105,12 +105,15 @@ def _counts(detections: np.ndarray) -> tuple[int, int, int]:
 class optimisation_function:  # afb:111-685
     """A chain of function blocks evaluated by the MI355X engine."""
 
-    def __init__(self, function_blocks, *, dtype: str = "f64", device: int = 0, pinned_ring: int = 0) -> None:
+    def __init__(self, function_blocks, *, dtype: str = "f64", device: int = 0, pinned_ring: int = 0, counts=None) -> None:
         """``pinned_ring`` = R > 0 returns the Jacobian ``data`` array from a ring of R page-locked
         host buffers (PCIe-rate device -> host copy, wrapped by ``csr_array`` without a copy); an
         array handed out stays valid for R further Jacobian calls.  0 = a fresh NumPy array per
         call, exactly like the reference (afb:561)."""
         self.pinned_ring = int(pinned_ring)
+        # (n_cams, n_imgs, n_keys) override of the max-index+1 rule (afb:793-795): a rank that holds
+        # only a shard of the detections must still lay out the GLOBAL parameter string.
+        self.counts = None if counts is None else tuple(int(c) for c in counts)
         self.function_blocks = list(function_blocks)
         self.n_blocks = len(self.function_blocks)
         self.dtype, self.device = dtype, device
@@ -141,7 +144,7 @@ class optimisation_function:  # afb:111-685
             raise ValueError("detections must be the flattened (N, 5) table [cam, im, key, u, v]")
         key = (det.shape, hash(det.tobytes()))
         if self._engine is None or key != self._engine_key:
-            C, I, K = _counts(det)
+            C, I, K = self.counts if self.counts is not None else _counts(det)
             eng = Engine(self.chain, C, I, K, dtype=self.dtype, device=self.device)
             eng.set_detections_table(det)
             self._engine, self._engine_key, self._template_key = eng, key, None

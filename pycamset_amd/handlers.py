@@ -151,7 +151,7 @@ class TemplateBundleHandler:  # th:80-240
 
     def __init__(self, camset, target, detection: TargetDetection, fixed_params: dict | None = None,
                  options: dict | None = None, missing_poses: list | None = None, *, dtype: str = "f64", device: int = 0,
-                 pinned_ring: int = 0):
+                 pinned_ring: int = 0, counts=None):
         self.problem_opts = dict(DEFAULT_OPTIONS)  # the reference aliases and mutates the module global (th:108-110)
         if options is not None:
             self.problem_opts.update(options)
@@ -165,7 +165,7 @@ class TemplateBundleHandler:  # th:80-240
         self.point_data = deepcopy(target.point_data)
         self.target_point_shape = np.array(target.point_data.shape)
         self.initial_params = None
-        self._dtype, self._device, self._pinned_ring = dtype, device, pinned_ring
+        self._dtype, self._device, self._pinned_ring, self._counts = dtype, device, pinned_ring, counts
 
         n_poses = detection.max_ims
         n_cams = camset.get_n_cams()
@@ -187,7 +187,7 @@ class TemplateBundleHandler:  # th:80-240
         self.missing_poses = missing_poses
         self.op_fun = fb.optimisation_function(
             [fb.projection(), fb.extrinsic3D(), fb.template_points()], dtype=dtype, device=device,
-            pinned_ring=pinned_ring)  # th:152
+            pinned_ring=pinned_ring, counts=counts)  # th:152
 
     # -- the path ------------------------------------------------------------------------------
     def can_make_jac(self):  # th:154-155
@@ -282,9 +282,9 @@ class SelfBundleHandler(TemplateBundleHandler):  # sbh:109-260
     """Self-calibration: the 3-D target points are free too (chain S), 7-DoF gauge fixed."""
 
     def __init__(self, camset, target, detection, fixed_params=None, options=None, missing_poses=None,
-                 *, dtype: str = "f64", device: int = 0, pinned_ring: int = 0):
+                 *, dtype: str = "f64", device: int = 0, pinned_ring: int = 0, counts=None):
         super().__init__(camset, target, detection, fixed_params, options, missing_poses, dtype=dtype, device=device,
-                         pinned_ring=pinned_ring)
+                         pinned_ring=pinned_ring, counts=counts)
         self.flat_point_data = np.copy(self.point_data.reshape((-1)))
         self.fixed_inds = find_not_colinear_pts(self.flat_point_data.reshape((-1, 3)))  # sbh:153-158
         i0, i1, i2 = self.fixed_inds
@@ -304,7 +304,7 @@ class SelfBundleHandler(TemplateBundleHandler):  # sbh:109-260
             intr_unfixed=sup.intr_unfixed, poses_unfixed=sup.poses_unfixed, bundle_points_unfixed=self.feat_unfixed)
         self.op_fun = fb.optimisation_function(
             [fb.projection(), fb.extrinsic3D(), fb.rigidTform3d(), fb.free_point()], dtype=dtype, device=device,
-            pinned_ring=pinned_ring)  # sbh:182
+            pinned_ring=pinned_ring, counts=counts)  # sbh:182
 
     def _jac_mask(self):  # sbh:211-218
         return np.concatenate((
@@ -322,9 +322,9 @@ class FreePointBundleHandler(TemplateBundleHandler):  # fph:102-201
     """Classic bundle adjustment of world points without a target pose (chain F)."""
 
     def __init__(self, camset, target, detection, fixed_params=None, options=None, missing_poses=None,
-                 *, dtype: str = "f64", device: int = 0, pinned_ring: int = 0):
+                 *, dtype: str = "f64", device: int = 0, pinned_ring: int = 0, counts=None):
         super().__init__(camset, target, detection, fixed_params, options, missing_poses, dtype=dtype, device=device,
-                         pinned_ring=pinned_ring)
+                         pinned_ring=pinned_ring, counts=counts)
         self.flat_point_data = np.copy(self.point_data.reshape((-1)))
         self.feat_unfixed = np.ones(self.flat_point_data.shape[0], dtype=bool)
         self.super_primitive = self.bundlePrimitive
@@ -334,7 +334,7 @@ class FreePointBundleHandler(TemplateBundleHandler):  # fph:102-201
             bundle_points_unfixed=self.feat_unfixed)
         self.op_fun = fb.optimisation_function(
             [fb.projection(), fb.extrinsic3D(), fb.free_point()], dtype=dtype, device=device,
-            pinned_ring=pinned_ring)  # fph:143
+            pinned_ring=pinned_ring, counts=counts)  # fph:143
 
     def _jac_mask(self):  # fph:172-178
         return np.concatenate((

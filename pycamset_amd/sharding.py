@@ -106,3 +106,23 @@ def make_engine_eval(chain: str, det_full: np.ndarray, counts, template=None, *,
 
     local_eval.engine = eng
     return local_eval
+
+
+def allreduce_sum_fn(group=None, device=None):
+    """``reduce_fn`` for ``device_solver.JacobianOperator``: sum an n-vector (J^T J v, diag, J^T r,
+    cost — a few KB) over the ranks.  This replaces the all-gather of J: with the
+    Jacobian kept on each GPU only parameter-sized vectors cross xGMI.  ``device`` = a torch CUDA
+    device for the RCCL backend; None keeps the tensor on the host (gloo)."""
+    import torch
+    import torch.distributed as dist
+
+    def reduce_fn(vec: np.ndarray) -> np.ndarray:
+        if not dist.is_initialized() or dist.get_world_size(group) == 1:
+            return vec
+        t = torch.from_numpy(np.ascontiguousarray(vec, dtype=np.float64))
+        if device is not None:
+            t = t.to(device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        return t.cpu().numpy()
+
+    return reduce_fn

@@ -67,3 +67,75 @@ def test_padded_shard_rule():
     assert np.array_equal(s0, det[:4])
     assert np.array_equal(s1, np.concatenate([det[4:], det[:1]]))  # cyclic repetition like np.resize (afb:281-288)
     assert np.array_equal(np.concatenate([s0, s1])[:7], det)
+
+
+class _OracleEngine:
+    """CPU stand-in with the Engine's matrix-free interface, built from the oracle's Jacobian of one
+    shard (tests only): lets the sharded normal-equation algebra run under gloo without a GPU."""
+
+    def __init__(self, chain, det, counts, template):
+        from oracle import ba_oracle as orc
+        self.orc, self.chain, self.det, self.counts, self.template = orc, chain, det, counts, template
+        self.n = det.shape[0]
+        self.n_params = 15 * counts[0] + 6 * counts[1]
+
+    def linearize(self, ps):
+        from scipy.sparse import csr_array
+        orc = self.orc
+        dense, r = orc.full_jac_dense(self.chain, self.det, ps, self.template, with_resid=True, counts=self.counts)
+        cols = np.repeat(self._cols(), 2, axis=0)
+        ptr = np.arange(0, dense.size + 1, dense.shape[1])
+        self.J = csr_array((dense.reshape(-1), cols.reshape(-1), ptr), shape=(2 * self.n, self.n_params))
+        self.r = r.reshape(-1)
+
+    def _cols(self):
+        C = self.counts[0]
+        c, i = self.det[:, 0].astype(np.int64), self.det[:, 1].astype(np.int64)
+        return np.concatenate([9 * c[:, None] + np.arange(9), 9 * C + 6 * c[:, None] + np.arange(6),
+                               15 * C + 6 * i[:, None] + np.arange(6)], axis=1)
+
+    def jtjv(self, v):
+        return self.J.T @ (self.J @ v)
+
+    def jtj_diag(self):
+        return np.asarray(self.J.multiply(self.J).sum(axis=0)).ravel()
+
+    def grad(self):
+        return self.J.T @ self.r, float(self.r @ self.r)
+
+
+def _worker_normal_eq(rank, world, port, out_dir):
+    sys.path.insert(0, str(REPO))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import ba_oracle as orc
+        from pycamset_amd import sharding, synthetic
+        from pycamset_amd.device_solver import JacobianOperator
+
+        rig = synthetic.tiny_rig(seed=4, n_cams=3, n_imgs=5, n_keys=9)
+        det = rig.detections
+        counts = orc.counts_from_detections(det)
+        ps = orc.build_param_list(rig.intr, rig.extr, rig.poses)
+        per = sharding.shard_rows(det.shape[0], world)
+        mine = det[rank * per: (rank + 1) * per]           # unpadded shard: sums must not double count
+        mask = np.ones(ps.shape[0], bool)
+        mask[15 * counts[0]: 15 * counts[0] + 6] = False   # pose 0 fixed
+        op = JacobianOperator(_OracleEngine("template", mine, counts, rig.points), mask, reduce_fn=sharding.allreduce_sum_fn())
+        op.linearize(ps)
+        full = JacobianOperator(_OracleEngine("template", det, counts, rig.points), mask)
+        full.linearize(ps)
+        v = np.random.default_rng(0).standard_normal(op.n_free)
+        for a, b in ((op.jtjv(v), full.jtjv(v)), (op.diag(), full.diag()), (op.grad()[0], full.grad()[0])):
+            assert np.max(np.abs(a - b)) <= 1e-12 * np.max(np.abs(b))
+        assert abs(op.grad()[1] - full.grad()[1]) <= 1e-12 * full.grad()[1]
+        Path(out_dir, f"ok{rank}").write_text("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_normal_equations_allreduce(tmp_path):
+    """ranks all-reduce J^T J v / diag / J^T r (parameter-sized) instead of gathering J."""
+    world = 2
+    mp.spawn(_worker_normal_eq, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(world))

@@ -19,7 +19,7 @@ for cfg, chain in ((3, "template"), (4, "self")):
     v = np.random.default_rng(0).standard_normal(ps.shape[0]); u = np.random.default_rng(1).standard_normal(2 * rig.n_det)
     print(f"# {rig.name} chain {chain} N={rig.n_det} n_params={ps.shape[0]}")
     for name, fn in (("jv", lambda: e.jv(v)), ("jtu", lambda: e.jtu(u)), ("jtjv", lambda: e.jtjv(v)), ("diag", e.jtj_diag), ("grad", e.grad)):
-        for wpc in (0, 2, 4, 16):
+        for wpc in (0, 1, 2, 4, 8):
             e.set_option("wgs_per_cu", wpc)
             fn(); fn()
             ks, t0 = [], time.perf_counter()
