@@ -217,7 +217,11 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    eng.set_option("event_ring", max(1, args.steps))  # keep the HIP events of every timed launch
+    # HIP start/stop events on every 10th launch of the timed region (a timed launch costs ~12 us of
+    # extra dispatch gaps, profiles/r01/step_overhead.log; untimed ones run back to back)
+    every = max(1, min(10, args.steps))
+    eng.set_option("timing_every", every)
+    eng.set_option("event_ring", max(1, -(-args.steps // every)))
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -293,6 +297,7 @@ def main():
                 "kernel_ms": eval_ms,
                 "slab_prep_ms": prep_ms,
                 "launches_timed": n_ev,
+                "timed_every": every,
                 "algorithmic_bytes_per_detection": bpd,
                 "frac_of_measured_copy_peak_6290": achieved / 6290.0,
             },

@@ -153,7 +153,8 @@ int pcs_last_kernel_ms(pcs_engine *h, float *slab_prep_ms, float *eval_ms);
  * the last R evaluations; the ring is reset when the option is set).  Used by bench.py for the
  * roofline figure: live HIP-event timing of every launch of the timed region. */
 int pcs_kernel_ms_mean(pcs_engine *h, int64_t *count, float *slab_prep_ms, float *eval_ms);
-/* Tuning knobs ("variant", "wgs_per_cu", "tiles_per_wg", "event_ring"); see DESIGN.md.
+/* Tuning knobs ("variant", "wgs_per_cu", "tiles_per_wg", "event_ring", "timing_every",
+ * "compact_variant", "matfree_lds"); see DESIGN.md.
  * Unknown keys -> PCS_ERR_ARG. */
 int pcs_set_option(pcs_engine *h, const char *key, int64_t value);
 /* Page-locked host memory for outputs: pcs_eval / pcs_eval_compact copy device -> host at PCIe rate
