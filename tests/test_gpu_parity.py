@@ -333,3 +333,37 @@ def test_pinned_output_ring(Engine):
     assert np.array_equal(d0, d1)
     e.close()
     assert np.array_equal(outs[0][1], j0)  # views outlive the engine
+
+
+def test_slabs_too_large_for_lds_fall_back_to_l2(Engine):
+    """Config 5 shape (128 cameras x 500 poses): the FP64 slabs (49 KB + 160 KB) exceed the 160 KiB
+    LDS, so a forced LDS-staging variant must fall back to reading them through L1/L2 — same bits."""
+    rig = synthetic.config_rig(5, scale=0.02)
+    assert (rig.n_cams, rig.n_imgs) == (128, 500) and rig.n_det > 1e5
+    ps = orc.build_param_list(rig.intr, rig.extr, rig.poses)
+    idx = np.unique(np.concatenate([np.arange(0, rig.n_det, 53), np.arange(rig.n_det - 100, rig.n_det)]))
+    ref_j, ref_r = orc.full_jac_dense("template", rig.detections[idx], ps, rig.points, threads=8, with_resid=True,
+                                      counts=(rig.n_cams, rig.n_imgs, rig.n_keys))
+    shuffled = rig.detections[np.random.default_rng(2).permutation(rig.n_det)]
+    for dtype in ("f64", "f32"):
+        e = make_engine(Engine, rig, "template", dtype=dtype)
+        outs = []
+        for variant in (6, 7, -1):
+            e.set_option("variant", variant)
+            r, j = e.eval(ps)
+            outs.append(j)
+            if dtype == "f64":
+                H.assert_resid_close(r[idx], ref_r, rig.detections[idx, 3:])
+                H.assert_jac_close(j.reshape(rig.n_det, 42)[idx].reshape(-1, 21), ref_j)
+            else:
+                assert H.jac_rel_err(j.reshape(rig.n_det, 42)[idx].reshape(-1, 21), ref_j) <= H.F32_JAC_RTOL
+        assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+        e.close()
+        # scattered table: the automatic choice stages slabs in LDS when they fit (f32) or falls back (f64)
+        e = make_engine(Engine, rig, "template", dtype=dtype, det=shuffled)
+        r, j = e.eval(ps)
+        inv = np.empty(rig.n_det, dtype=np.int64)
+        perm = np.random.default_rng(2).permutation(rig.n_det)
+        inv[perm] = np.arange(rig.n_det)
+        assert np.array_equal(j.reshape(rig.n_det, 42)[inv], outs[0].reshape(rig.n_det, 42))
+        e.close()
