@@ -145,6 +145,18 @@ int pcs_eval_compact_device(pcs_engine *h, const double *param_str, void *d_resi
 int pcs_linearize(pcs_engine *h, const double *param_str);
 int pcs_matfree(pcs_engine *h, int op, const double *in, double *out, double *cost);
 
+/*
+ * Legacy residual-only cost.
+ * Replaces: bundle_adjustment_costfn / numpy_bundle_adjustment_costfn (compiled_helpers.py:518-549),
+ * called once per candidate pose set during initialisation (template_handler.py:535-592).
+ *   im_points  (n_imgs, n_keys, 3)  target points already transformed by each image's pose
+ *   proj       (n_cams, 3, 4)       K [R|t] per camera
+ *   intrinsics (n_cams, 3, 3), dists (n_cams, 5) = [k0, k1, p0, p1, k2]
+ *   errors     (2N)                 [u0 err, v0 err, u1 err, ...] for the engine's detection table
+ */
+int pcs_legacy_cost(pcs_engine *h, const double *im_points, const double *proj, const double *intrinsics, const double *dists,
+                    double *errors);
+
 /* Block until everything queued on `stream` (NULL = engine stream) has finished. */
 int pcs_synchronize(pcs_engine *h, void *stream);
 /* Duration of the most recent evaluation's kernels (HIP events on the launch stream), ms. */

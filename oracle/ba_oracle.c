@@ -352,6 +352,50 @@ int orc_full_jac(int chain, int64_t N, const double *det, const double *param_st
     return 0;
 }
 
+/* ---------------------------------------------------------------------------------------------
+ * Legacy residual-only cost: numpy_bundle_adjustment_costfn / bundle_adjustment_costfn
+ * (ch:518-549), used by the initial pose selection (template_handler.py:535-592).  Pre-multiplied
+ * 3x4 projection matrices, pre-transformed points im_points[image, key], pinhole intrinsics 3x3 and
+ * 5 distortion coefficients per camera.
+ * ------------------------------------------------------------------------------------------- */
+/* ch:443-466 nb_distort_prealloc: pts (pixels) are distorted in place; k = [k0,k1,p0,p1,k2] */
+void orc_distort(double *pts, const double *intrinsics /*3x3*/, const double *k /*5*/) {
+    double centre_0 = intrinsics[2], centre_1 = intrinsics[5];
+    double focal_0 = intrinsics[0], focal_1 = intrinsics[4];
+    double x = (pts[0] - centre_0) / focal_0, y = (pts[1] - centre_1) / focal_1; /* ch:455 */
+    double r2 = ipow(x, 2) + ipow(y, 2);
+    double kup = (1 + k[0] * r2 + k[1] * ipow(r2, 2) + k[4] * ipow(r2, 3));
+    double xD = x * kup;
+    double yD = y * kup;
+    xD += 2 * k[2] * x * y + k[3] * (r2 + 2 * ipow(x, 2));
+    yD += k[2] * (r2 + 2 * ipow(y, 2)) + 2 * k[3] * x * y;
+    pts[0] = xD * focal_0 + centre_0; /* ch:465-466 */
+    pts[1] = yD * focal_1 + centre_1;
+}
+
+/* ch:518-547: error[2i], error[2i+1] for every detection row [cam, im, key, u, v] */
+int orc_legacy_cost(int64_t N, const double *dct /*N x 5*/, const double *im_points /*I x K x 3*/, int64_t n_keys,
+                    const double *proj /*C x 3 x 4*/, const double *intrinsics /*C x 3 x 3*/, const double *dists /*C x 5*/,
+                    double *error /*2N*/, int threads) {
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(threads > 0 ? threads : 1)
+#endif
+    for (int64_t idx = 0; idx < N; ++idx) {
+        const double *d = dct + 5 * idx;
+        const int64_t cam = (int64_t)d[0];                                        /* ch:533 */
+        const double *X = im_points + 3 * ((int64_t)d[1] * n_keys + (int64_t)d[2]); /* ch:535-537 */
+        const double *P = proj + 12 * cam;
+        double puv[3];
+        for (int r = 0; r < 3; ++r) puv[r] = P[4 * r] * X[0] + P[4 * r + 1] * X[1] + P[4 * r + 2] * X[2] + P[4 * r + 3] * 1.0; /* ch:538 */
+        puv[0] = puv[0] / puv[2];                                                 /* ch:539 */
+        puv[1] = puv[1] / puv[2];
+        orc_distort(puv, intrinsics + 9 * cam, dists + 5 * cam);                  /* ch:540 */
+        error[2 * idx] = puv[0] - d[3];                                           /* ch:541-542 */
+        error[2 * idx + 1] = puv[1] - d[4];
+    }
+    return 0;
+}
+
 int orc_max_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

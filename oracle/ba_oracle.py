@@ -44,6 +44,8 @@ def _lib(fast: bool = False) -> ctypes.CDLL:
         lib.orc_full_jac.argtypes = [ci, i64, dp, dp, i64, i64, dp, dp, dp, ci]
         lib.orc_full_jac.restype = ci
         lib.orc_max_threads.restype = ci
+        lib.orc_legacy_cost.argtypes = [i64, dp, dp, i64, dp, dp, dp, dp, ci]
+        lib.orc_legacy_cost.restype = ci
         for fn, n in (("orc_rodrigues", 2), ("orc_rodrigues_jac", 2), ("orc_e4x4_flat", 2), ("orc_htform", 3),
                       ("orc_projection_fun", 3), ("orc_projection_jac", 3), ("orc_rigid_fun", 3),
                       ("orc_rigid_jac", 3), ("orc_template_jac", 3)):
@@ -155,6 +157,38 @@ def jac_csr(chain: str, det: np.ndarray, param_str: np.ndarray, template=None, u
         unfixed = np.ones(param_struct(chain, det)[2], dtype=bool)
     indices, indptr, mask = csr_structure(chain, det, unfixed)
     return dense[mask], indices, indptr
+
+
+# ---- legacy residual-only cost -----------------------------------------------------
+def legacy_cost(dct, im_points, projection_matrixes, intrinsics, dists, threads: int = 1, fast: bool = False) -> np.ndarray:
+    """numpy_bundle_adjustment_costfn (compiled_helpers.py:518-547): (2N,) errors."""
+    dct, im = _f64(dct), _f64(im_points)
+    n_keys = int(np.prod(im.shape[1:-1]))
+    P, Kc, D = _f64(projection_matrixes), _f64(intrinsics), _f64(dists)
+    out = np.empty(2 * dct.shape[0])
+    _lib(fast).orc_legacy_cost(dct.shape[0], _p(dct), _p(im), n_keys, _p(P), _p(Kc), _p(D), _p(out), threads)
+    return out
+
+
+def legacy_inputs(intr, extr, poses, points):
+    """Build the legacy cost's inputs from the parameter slabs with the oracle's own SE3 helpers:
+    im_points (I,K,3) like template_handler.py:231-237, projection matrices K [R|t] (C,3,4),
+    intrinsic matrices (C,3,3), distortion (C,5) = [k0,k1,p0,p1,k2]."""
+    intr, extr, poses, points = _f64(intr), _f64(extr), _f64(poses), _f64(points)
+    C, I, K = intr.shape[0], poses.shape[0], points.shape[0]
+    im_points = np.empty((I, K, 3))
+    for i in range(I):
+        T = call_unit("e4x4_flat", 12, poses[i])
+        for k in range(K):
+            im_points[i, k] = call_unit("htform", 3, points[k], T)
+    Kc = np.zeros((C, 3, 3))
+    Kc[:, 0, 0], Kc[:, 0, 2], Kc[:, 1, 1], Kc[:, 1, 2], Kc[:, 2, 2] = intr[:, 0], intr[:, 1], intr[:, 2], intr[:, 3], 1.0
+    proj = np.empty((C, 3, 4))
+    for c in range(C):
+        T = call_unit("e4x4_flat", 12, extr[c])
+        Rt = np.concatenate([T[:9].reshape(3, 3), T[9:].reshape(3, 1)], axis=1)
+        proj[c] = Kc[c] @ Rt
+    return im_points, proj, Kc, np.ascontiguousarray(intr[:, 4:9])
 
 
 # ---- handler-level x -> slabs (a13, a14) ----------------------------------------------------

@@ -41,6 +41,7 @@ SYMBOLS = {
     "pcs_set_unfixed": (c_int, [_P, POINTER(c_uint8), POINTER(c_int64)]),
     "pcs_eval_compact": (c_int, [_P, POINTER(c_double), POINTER(c_double), POINTER(c_double)]),
     "pcs_eval_compact_device": (c_int, [_P, POINTER(c_double), _P, _P, _P]),
+    "pcs_legacy_cost": (c_int, [_P, POINTER(c_double), POINTER(c_double), POINTER(c_double), POINTER(c_double), POINTER(c_double)]),
     "pcs_linearize": (c_int, [_P, POINTER(c_double)]),
     "pcs_matfree": (c_int, [_P, c_int, POINTER(c_double), POINTER(c_double), POINTER(c_double)]),
     "pcs_synchronize": (c_int, [_P, _P]),

@@ -376,6 +376,42 @@ __global__ __launch_bounds__(WG_THREADS) void ba_compact_tile_kernel(const EvalA
     }
 }
 
+// Legacy residual-only cost (compiled_helpers.py:518-549, used by the initial pose
+// selection template_handler.py:535-592): pre-multiplied 3x4 projection matrices and pre-transformed
+// points im_points[image, key].  cam_tab row (24 scalars): P row-major 12 | fx cx fy cy | k0 k1 p0 p1 k2 | pad.
+constexpr int LEGACY_STRIDE = 24;
+template <typename T>
+__global__ __launch_bounds__(256) void legacy_cost_kernel(const int32_t *__restrict__ cam, const int32_t *__restrict__ img,
+                                                          const int32_t *__restrict__ key, const void *__restrict__ uv_,
+                                                          const T *__restrict__ im_points, const T *__restrict__ cam_tab,
+                                                          T *__restrict__ errors, int64_t n, int64_t n_keys) {
+    using V2 = typename Vec2<T>::type;
+    const V2 *uv = static_cast<const V2 *>(uv_);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const T *ct = cam_tab + (int64_t)cam[i] * LEGACY_STRIDE;
+        const T *X = im_points + 3 * ((int64_t)img[i] * n_keys + key[i]);
+        const T X0 = X[0], X1 = X[1], X2 = X[2];
+        const V2 m = uv[i];
+        T p0 = ct[0] * X0 + ct[1] * X1 + ct[2] * X2 + ct[3];        // ch:538  P [X;1]
+        T p1 = ct[4] * X0 + ct[5] * X1 + ct[6] * X2 + ct[7];
+        const T p2 = ct[8] * X0 + ct[9] * X1 + ct[10] * X2 + ct[11];
+        p0 = p0 / p2;                                               // ch:539
+        p1 = p1 / p2;
+        const T fx = ct[12], cx = ct[13], fy = ct[14], cy = ct[15];
+        const T k0 = ct[16], k1 = ct[17], q0 = ct[18], q1 = ct[19], k2 = ct[20];
+        const T x = (p0 - cx) / fx, y = (p1 - cy) / fy;             // ch:455
+        const T r2 = x * x + y * y;
+        const T kup = T(1) + k0 * r2 + k1 * (r2 * r2) + k2 * (r2 * r2 * r2);
+        const T xD = x * kup + T(2) * q0 * x * y + q1 * (r2 + T(2) * x * x);
+        const T yD = y * kup + q0 * (r2 + T(2) * y * y) + T(2) * q1 * x * y;
+        V2 e;
+        e.x = (xD * fx + cx) - m.x;                                  // ch:541-542
+        e.y = (yD * fy + cy) - m.y;
+        __builtin_nontemporal_store(e, reinterpret_cast<V2 *>(errors) + i);
+    }
+}
+
 // Streaming probes used to measure the box's achievable HBM rate for THIS access shape
 // (16 B per lane, 1 KiB per wave-instruction): kind 0 plain fill, 1 non-temporal fill, 2 plain copy,
 // 3 non-temporal copy.  Reported next to the 8 TB/s spec figure in DESIGN.md.
@@ -455,6 +491,9 @@ struct pcs_engine {
     // matrix-free operators (f2)
     double *d_vin = nullptr, *d_vout = nullptr, *d_cost = nullptr;
     int64_t vin_capacity = 0, vout_capacity = 0;
+    // legacy cost (f3)
+    void *d_im_points = nullptr, *d_cam_tab = nullptr;
+    int64_t im_points_capacity = 0;
     bool linearized = false;
     bool matfree_lds = true;  // accumulate J^T products in workgroup-private LDS before the global atomics
     // launch geometry
@@ -588,7 +627,7 @@ int pcs_destroy(pcs_engine *h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     void *bufs[] = {h->d_cam, h->d_img, h->d_key, h->d_uv, h->d_param, h->d_cam_slab, h->d_pose_slab, h->d_points,
-                    h->d_resid, h->d_jac, h->d_keep, h->d_row_off, h->d_data, h->d_vin, h->d_vout, h->d_cost};
+                    h->d_resid, h->d_jac, h->d_keep, h->d_row_off, h->d_data, h->d_vin, h->d_vout, h->d_cost, h->d_im_points, h->d_cam_tab};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (h->h_param) (void)hipHostFree(h->h_param);
@@ -1128,6 +1167,59 @@ int pcs_eval_compact(pcs_engine *h, const double *param_str, double *resid, doub
     if (data && h->nnz > 0 && (rc = download(h, data, h->d_data, h->nnz, h->stream))) return rc;
     HIPCHK(hipStreamSynchronize(h->stream));
     return PCS_OK;
+}
+
+int pcs_legacy_cost(pcs_engine *h, const double *im_points, const double *proj, const double *intrinsics, const double *dists,
+                    double *errors) {
+    if (!h || !im_points || !proj || !intrinsics || !dists || !errors) return fail(PCS_ERR_ARG, "pcs_legacy_cost: bad arguments");
+    if (h->n <= 0) return fail(PCS_ERR_STATE, "no detections set");
+    if (h->chain == PCS_CHAIN_FREE) return fail(PCS_ERR_ARG, "pcs_legacy_cost: needs an engine with images (template or self chain)");
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    const int64_t n_pts = h->n_imgs * h->n_keys * 3;
+    if (n_pts > h->im_points_capacity) {
+        if (h->d_im_points) HIPCHK(hipFree(h->d_im_points));
+        HIPCHK(hipMalloc(&h->d_im_points, h->esize * n_pts));
+        h->im_points_capacity = n_pts;
+    }
+    if (!h->d_cam_tab) HIPCHK(hipMalloc(&h->d_cam_tab, h->esize * h->n_cams * LEGACY_STRIDE));
+    int rc = ensure_scratch(h, true, false, false);
+    if (rc) return rc;
+    std::vector<double> tab((size_t)h->n_cams * LEGACY_STRIDE, 0.0);
+    for (int64_t c = 0; c < h->n_cams; ++c) {
+        double *t = tab.data() + c * LEGACY_STRIDE;
+        for (int j = 0; j < 12; ++j) t[j] = proj[12 * c + j];
+        const double *K = intrinsics + 9 * c;
+        t[12] = K[0]; t[13] = K[2]; t[14] = K[4]; t[15] = K[5];  // focal_0, centre_0, focal_1, centre_1 (ch:453-454)
+        for (int j = 0; j < 5; ++j) t[16 + j] = dists[5 * c + j];
+    }
+    HIPCHK(hipStreamSynchronize(s));
+    if (h->dtype == PCS_F64) {
+        HIPCHK(hipMemcpyAsync(h->d_im_points, im_points, sizeof(double) * n_pts, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(h->d_cam_tab, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice, s));
+        HIPCHK(hipStreamSynchronize(s));
+    } else {
+        std::vector<float> f(n_pts), g(tab.size());
+        for (int64_t i = 0; i < n_pts; ++i) f[i] = (float)im_points[i];
+        for (size_t i = 0; i < tab.size(); ++i) g[i] = (float)tab[i];
+        HIPCHK(hipMemcpyAsync(h->d_im_points, f.data(), sizeof(float) * n_pts, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(h->d_cam_tab, g.data(), sizeof(float) * g.size(), hipMemcpyHostToDevice, s));
+        HIPCHK(hipStreamSynchronize(s));
+    }
+    const dim3 grid((unsigned)std::min<int64_t>((h->n + 255) / 256, (int64_t)h->n_cu * 16));
+    hipEvent_t *ev = h->ev.data() + 3 * (h->ev_count % h->ev_ring);
+    HIPCHK(hipEventRecord(ev[0], s));  // keeps (ev0, ev1) a valid pair for pcs_last_kernel_ms
+    if (h->dtype == PCS_F64)
+        hipExtLaunchKernelGGL(legacy_cost_kernel<double>, grid, dim3(256), 0, s, ev[1], ev[2], 0, h->d_cam, h->d_img, h->d_key, h->d_uv,
+                              (const double *)h->d_im_points, (const double *)h->d_cam_tab, (double *)h->d_resid, h->n, h->n_keys);
+    else
+        hipExtLaunchKernelGGL(legacy_cost_kernel<float>, grid, dim3(256), 0, s, ev[1], ev[2], 0, h->d_cam, h->d_img, h->d_key, h->d_uv,
+                              (const float *)h->d_im_points, (const float *)h->d_cam_tab, (float *)h->d_resid, h->n, h->n_keys);
+    HIPCHK(hipGetLastError());
+    ++h->ev_count;
+    h->events_valid = true;
+    h->last_stream = s;
+    return download(h, errors, h->d_resid, 2 * h->n, s);
 }
 
 int pcs_linearize(pcs_engine *h, const double *param_str) {

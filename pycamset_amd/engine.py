@@ -164,6 +164,19 @@ class Engine:
         check(lib().pcs_eval_compact(self._h, _dp(p), _dp(r) if want_resid else None, _dp(d)))
         return r, d
 
+    # -- legacy residual-only cost (compiled_helpers.py:518-549) ----------------------------------------
+    def legacy_cost(self, im_points, projection_matrixes, intrinsics, dists) -> np.ndarray:
+        im = _f64c(im_points)
+        P, K, D = _f64c(projection_matrixes), _f64c(intrinsics), _f64c(dists)
+        if im.size != 3 * im.shape[0] * (im.size // (3 * im.shape[0])) or im.shape[-1] != 3:
+            raise ValueError("im_points must have shape (n_imgs, ..., 3)")
+        n_cams = P.shape[0]
+        if P.shape[1:] != (3, 4) or K.shape != (n_cams, 3, 3) or D.reshape(n_cams, -1).shape[1] != 5:
+            raise ValueError("expected proj (C,3,4), intrinsics (C,3,3), dists (C,5)")
+        out = np.empty(2 * self.n)
+        check(lib().pcs_legacy_cost(self._h, _dp(im), _dp(P), _dp(K), _dp(D), _dp(out)))
+        return out
+
     # -- matrix-free Jacobian products (J never materialised) -------------------------------------
     OP_JV, OP_JTU, OP_JTJV, OP_DIAG, OP_GRAD = 0, 1, 2, 3, 4
 

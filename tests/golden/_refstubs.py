@@ -72,7 +72,7 @@ _rng = np.random.default_rng(12345)
 def _njit(*args, **kwargs):
     """Identity decorator in all three spellings used by the reference:
     ``@njit``, ``@njit(cache=True, ...)``, ``@njit("sig", cache=True)`` and ``njit(lambda)``."""
-    if len(args) == 1 and callable(args[0]) and not kwargs:
+    if len(args) == 1 and callable(args[0]):  # @njit, njit(lambda), njit(fn, fastmath=True, cache=True)
         return args[0]
     signature = args[0] if args and isinstance(args[0], str) else None
 

@@ -211,6 +211,34 @@ def handler_level(mods, rig, chain, fixed_cam_ext=True):
     return out
 
 
+def legacy_cost_vectors(ch, rig):
+    """the reference's legacy residual-only cost (compiled_helpers.py:493-549) on inputs
+    assembled with the reference's own helpers (template_handler.py:231-237)."""
+    C, I, K = rig.n_cams, rig.n_imgs, rig.n_keys
+    im_points = np.empty((I, K, 3))
+    for i in range(I):
+        blank = np.zeros(12)
+        ch.n_e4x4_flat_INPLACE(rig.poses[i].copy(), blank)
+        ch.n_htform_broadcast_prealloc(rig.points.copy(), blank, im_points[i])
+    Kc = np.zeros((C, 3, 3))
+    Kc[:, 0, 0], Kc[:, 0, 2], Kc[:, 1, 1], Kc[:, 1, 2], Kc[:, 2, 2] = rig.intr[:, 0], rig.intr[:, 1], rig.intr[:, 2], rig.intr[:, 3], 1.0
+    proj = np.empty((C, 3, 4))
+    for c in range(C):
+        blank = np.zeros(12)
+        ch.n_e4x4_flat_INPLACE(rig.extr[c].copy(), blank)
+        proj[c] = Kc[c] @ np.concatenate([blank[:9].reshape(3, 3), blank[9:].reshape(3, 1)], axis=1)
+    dists = np.ascontiguousarray(rig.intr[:, 4:9])
+    err = ch.numpy_bundle_adjustment_costfn(rig.detections, im_points, proj, Kc, dists)
+    err_jit = ch.bundle_adjustment_costfn(rig.detections, im_points, proj, Kc, dists)
+    n = (rig.n_det // 3) * 3
+    err_par = ch.bundle_adj_parrallel_solver(rig.detections[:n].reshape(3, n // 3, 5), im_points, proj, Kc, dists)
+    pts = rig.detections[:20, 3:].copy()
+    dist_out = np.array([ch.nb_distort(p.copy(), Kc[0], dists[0]) for p in pts])
+    return dict(detections=rig.detections, im_points=im_points, proj=proj, intrinsics=Kc, dists=dists,
+                errors=np.array(err), errors_njit_alias=np.array(err_jit), errors_parallel=np.array(err_par),
+                intr=rig.intr, extr=rig.extr, poses=rig.poses, points=rig.points, distort_in=pts, distort_out=dist_out)
+
+
 def main():
     if not (REFERENCE / "pyCamSet").is_dir():
         raise SystemExit(f"reference not found at {REFERENCE}")
@@ -240,6 +268,8 @@ def main():
                 res = block_level(fb, rig, chain, threads_list=(1, 3) if tag == "tiny" else (4,))
                 np.savez_compressed(HERE / f"block_{chain}_{tag}.npz", **res)
                 print("block", chain, tag, "nnz_all", res[[k for k in res if k.startswith('data_all')][0]].shape)
+        np.savez_compressed(HERE / "legacy_cost_medium.npz", **legacy_cost_vectors(ch, medium))
+        print("legacy cost done")
         mods = (th, sbh, fph, TargetDetection)
         for chain in ("template", "self", "free"):
             for tag, rig, fx in (("tiny", tiny, True), ("tiny_nofix", tiny, False)):

@@ -208,3 +208,31 @@ def test_device_lm_reaches_the_scipy_solution(chain):
     assert np.max(np.abs(op.jtjv(v) - Jc.T @ (Jc @ v))) <= 1e-9 * np.max(np.abs(Jc.T @ (Jc @ v)))
     L = op.as_linear_operator()
     assert L.shape == Jc.shape and np.max(np.abs(L @ v - Jc @ v)) <= 1e-9 * np.max(np.abs(Jc @ v))
+
+
+# ---- legacy residual-only cost -----------------------------------------------------------
+def test_legacy_cost_kernel(golden_dir):
+    from pycamset_amd import compiled_helpers as hip_ch
+    g = np.load(golden_dir / "legacy_cost_medium.npz")
+    e = hip_ch.bundle_adjustment_costfn(g["detections"], g["im_points"], g["proj"], g["intrinsics"], g["dists"])
+    assert e.shape == g["errors"].shape
+    assert np.max(np.abs(e - g["errors"])) <= 1e-10 * 1e3          # 1e-10 relative on ~1e3 px projections
+    n = (g["detections"].shape[0] // 3) * 3
+    par = hip_ch.bundle_adj_parrallel_solver(g["detections"][:n].reshape(3, n // 3, 5), g["im_points"], g["proj"], g["intrinsics"], g["dists"])
+    assert par.shape == g["errors_parallel"].shape and np.max(np.abs(par - g["errors_parallel"])) <= 1e-7
+    # full size: agrees with the oracle on a sample and with the chain-T residual kernel everywhere
+    from pycamset_amd.engine import Engine
+    rig = synthetic.config_rig(3)
+    im, P, K, D = orc.legacy_inputs(rig.intr, rig.extr, rig.poses, rig.points)
+    eng = Engine("template", rig.n_cams, rig.n_imgs, rig.n_keys)
+    eng.set_detections_table(rig.detections)
+    eng.set_template(rig.points)
+    err = eng.legacy_cost(im, P, K, D)
+    prep_ms, k_ms = eng.last_kernel_ms()
+    idx = np.arange(0, rig.n_det, 97)
+    ref = orc.legacy_cost(rig.detections[idx], im, P, K, D, threads=8)
+    assert np.max(np.abs(err.reshape(-1, 2)[idx].reshape(-1) - ref)) <= 1e-9
+    r, _ = eng.eval(orc.build_param_list(rig.intr, rig.extr, rig.poses), want_jac=False)
+    assert np.max(np.abs(r.reshape(-1) - err)) <= 1e-9
+    assert 0 < k_ms < 5
+    eng.close()

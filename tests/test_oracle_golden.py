@@ -103,3 +103,19 @@ def test_oracle_fast_build_agrees(golden_dir):
     rows = np.max(np.abs(a), axis=1, keepdims=True)
     assert_close(b, a, rtol=1e-11, rows=rows)
     assert_close(r, g["resid_t4"], rtol=1e-10)
+
+
+def test_legacy_cost_oracle_against_reference(golden_dir):
+    """numpy_bundle_adjustment_costfn (compiled_helpers.py:518-547)."""
+    g = np.load(golden_dir / "legacy_cost_medium.npz")
+    assert np.array_equal(g["errors"], g["errors_njit_alias"])
+    e = orc.legacy_cost(g["detections"], g["im_points"], g["proj"], g["intrinsics"], g["dists"])
+    assert np.max(np.abs(e - g["errors"])) <= 1e-11          # pixels; projections are ~500 px
+    e4 = orc.legacy_cost(g["detections"], g["im_points"], g["proj"], g["intrinsics"], g["dists"], threads=4, fast=True)
+    assert np.max(np.abs(e4 - g["errors"])) <= 1e-10
+    im, P, K, D = orc.legacy_inputs(g["intr"], g["extr"], g["poses"], g["points"])
+    assert np.max(np.abs(im - g["im_points"])) <= 1e-15 and np.array_equal(K, g["intrinsics"]) and np.array_equal(D, g["dists"])
+    assert np.max(np.abs(P - g["proj"])) <= 1e-12 * np.max(np.abs(g["proj"]))
+    # the legacy cost and the block chain describe the same projection
+    r = orc.full_loss("template", g["detections"], orc.build_param_list(g["intr"], g["extr"], g["poses"]), g["points"])
+    assert np.max(np.abs(r.reshape(-1) - g["errors"])) <= 1e-10
