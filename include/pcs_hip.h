@@ -169,6 +169,20 @@ int pcs_kernel_ms_mean(pcs_engine *h, int64_t *count, float *slab_prep_ms, float
  * "compact_variant", "matfree_lds"); see DESIGN.md.
  * Unknown keys -> PCS_ERR_ARG. */
 int pcs_set_option(pcs_engine *h, const char *key, int64_t value);
+/*
+ * Batched n-view triangulation; stateless.
+ * Replaces: nb_triangulate_full (compiled_helpers.py:609-643) = per point nb_undistort (ch:409-431) +
+ *           nb_triangulate_nviews (ch:645-663, smallest right singular vector of the 3n x (4+n) DLT
+ *           matrix); front end CameraSet.multi_cam_triangulate (cameras/camera_set.py:343-402).
+ *   cam (n_obs) int32, uv (n_obs,2): observations sorted by point; point j owns rows
+ *   [start_inds[j], start_inds[j+1]) (start_inds has n_pts+1 entries, like the reference's).
+ *   proj (n_cams,3,4), intrinsics (n_cams,3,3), dists (n_cams,5) = [k0,k1,p0,p1,k2].
+ *   pts (n_pts,3) out; kernel_ms (optional) = duration of the kernel by HIP events.
+ */
+int pcs_triangulate(int device, int64_t n_obs, const int32_t *cam, const double *uv, int64_t n_pts, const int64_t *start_inds,
+                    int64_t n_cams, const double *proj, const double *intrinsics, const double *dists, double *pts,
+                    float *kernel_ms);
+
 /* Page-locked host memory for outputs: pcs_eval / pcs_eval_compact copy device -> host at PCIe rate
  * into such buffers (a pageable destination is several times slower).  Replaces nothing in the
  * reference (NumPy owns every array there, afb:561); SURVEY 8 f1 "zero-copy hand-off". */

@@ -191,6 +191,54 @@ def legacy_inputs(intr, extr, poses, points):
     return im_points, proj, Kc, np.ascontiguousarray(intr[:, 4:9])
 
 
+# ---- batched triangulation -----------------------------------------------------------
+def undistort(pts, intrinsics, dist_coef):
+    """nb_undistort (compiled_helpers.py:409-431): 5 fixed-point iterations, one point (2,)."""
+    centre = intrinsics[:2, -1]
+    focal = np.diag(intrinsics)[:2]
+    x0, y0 = (pts - centre) / focal
+    k = np.reshape(dist_coef, (-1))
+    x, y = x0, y0
+    for _ in range(5):
+        r2 = x ** 2 + y ** 2
+        k_inv = 1 / (1 + k[0] * r2 + k[1] * (r2 ** 2) + k[4] * (r2 ** 3))
+        xD = 2 * k[2] * x * y + k[3] * (r2 + 2 * (x ** 2))
+        yD = k[2] * (r2 + 2 * (y ** 2)) + 2 * k[3] * x * y
+        x = (x0 - xD) * k_inv
+        y = (y0 - yD) * k_inv
+    return np.array([x, y]) * focal + centre
+
+
+def triangulate_nviews(P, ip):
+    """nb_triangulate_nviews (compiled_helpers.py:645-663): DLT matrix + LAPACK SVD."""
+    n = len(P)
+    M = np.zeros((3 * n, 4 + n))
+    for i, (x, p) in enumerate(zip(ip, P)):
+        M[3 * i:3 * i + 3, :4] = p
+        M[3 * i:3 * i + 3, 4 + i] = -x
+    V = np.linalg.svd(M, full_matrices=False)[-1]
+    X = V[-1, :4]
+    return X[:3] / X[3]
+
+
+def triangulate_full(data, proj, start_inds, intr, dist):
+    """nb_triangulate_full (compiled_helpers.py:609-643)."""
+    data = np.asarray(data, dtype=np.float64)
+    pts = np.empty((len(start_inds) - 1, 3))
+    for idx in range(len(start_inds) - 1):
+        s, e = int(start_inds[idx]), int(start_inds[idx + 1])
+        uvh = np.empty((e - s, 3))
+        Ps = np.empty((e - s, 3, 4))
+        for t in range(e - s):
+            datum = data[s + t]
+            cam = int(datum[0])
+            ud = undistort(datum[-2:], intr[cam], dist[cam])
+            uvh[t] = [ud[0], ud[1], 1]
+            Ps[t] = proj[cam]
+        pts[idx] = triangulate_nviews(Ps, uvh)
+    return pts
+
+
 # ---- handler-level x -> slabs (a13, a14) ----------------------------------------------------
 def scatter_free(x_part: np.ndarray, full: np.ndarray, unfixed: np.ndarray) -> None:
     """ch.fill_flat (compiled_helpers.py:155-177): write free rows/scalars into the full slab."""

@@ -27,6 +27,7 @@
 #include "../../include/pcs_hip.h"
 #include "ba_device.hpp"
 #include "ba_matfree.hpp"
+#include "ba_triangulate.hpp"
 
 namespace pcs {
 
@@ -517,6 +518,76 @@ extern "C" {
 
 int pcs_version(void) { return 100; }
 const char *pcs_last_error(void) { return g_err.c_str(); }
+
+int pcs_triangulate(int device, int64_t n_obs, const int32_t *cam, const double *uv, int64_t n_pts, const int64_t *start_inds,
+                    int64_t n_cams, const double *proj, const double *intrinsics, const double *dists, double *pts,
+                    float *kernel_ms) {
+    if (n_obs < 0 || n_pts < 0 || n_cams <= 0 || !start_inds || !proj || !intrinsics || !dists || (n_pts > 0 && !pts) ||
+        (n_obs > 0 && (!cam || !uv)))
+        return fail(PCS_ERR_ARG, "pcs_triangulate: bad arguments");
+    if (n_pts == 0) return PCS_OK;
+    if (start_inds[0] != 0 || start_inds[n_pts] != n_obs) return fail(PCS_ERR_ARG, "pcs_triangulate: start_inds must run from 0 to n_obs");
+    for (int64_t j = 0; j < n_pts; ++j)
+        if (start_inds[j + 1] < start_inds[j]) return fail(PCS_ERR_ARG, "pcs_triangulate: start_inds must be non-decreasing");
+    for (int64_t r = 0; r < n_obs; ++r)
+        if (cam[r] < 0 || cam[r] >= n_cams) return fail(PCS_ERR_RANGE, "observation %lld has camera %d outside [0,%lld)", (long long)r, cam[r], (long long)n_cams);
+    int ndev = pcs_device_count();
+    if (ndev <= 0) return fail(PCS_ERR_NODEVICE, "pcs_triangulate: no HIP device visible (no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(PCS_ERR_ARG, "pcs_triangulate: device out of range");
+    HIPCHK(hipSetDevice(device));
+    std::vector<double> tab((size_t)n_cams * TRI_CAM_STRIDE, 0.0);
+    for (int64_t c = 0; c < n_cams; ++c) {
+        double *t = tab.data() + c * TRI_CAM_STRIDE;
+        const double *P = proj + 12 * c;
+        for (int k = 0; k < 12; ++k) t[k] = P[k];
+        int o = 12;
+        for (int a = 0; a < 4; ++a)
+            for (int b = a; b < 4; ++b) t[o++] = P[a] * P[b] + P[4 + a] * P[4 + b] + P[8 + a] * P[8 + b];  // (P^T P)[a][b]
+        const double *K = intrinsics + 9 * c;
+        t[22] = K[0]; t[23] = K[2]; t[24] = K[4]; t[25] = K[5];
+        for (int k = 0; k < 5; ++k) t[26 + k] = dists[5 * c + k];
+    }
+    int32_t *d_cam = nullptr; double *d_uv = nullptr, *d_tab = nullptr, *d_pts = nullptr; int64_t *d_start = nullptr; void *d_scr = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = PCS_OK;
+    auto cleanup = [&]() {
+        for (void *b : {(void *)d_cam, (void *)d_uv, (void *)d_tab, (void *)d_pts, (void *)d_start, d_scr})
+            if (b) (void)hipFree(b);
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+    };
+#define TRICHK(expr)                                                                                       \
+    do {                                                                                                   \
+        hipError_t _e = (expr);                                                                            \
+        if (_e != hipSuccess) { rc = fail(PCS_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); cleanup(); return rc; } \
+    } while (0)
+    TRICHK(hipMalloc(&d_cam, sizeof(int32_t) * std::max<int64_t>(1, n_obs)));
+    TRICHK(hipMalloc(&d_uv, sizeof(double) * 2 * std::max<int64_t>(1, n_obs)));
+    TRICHK(hipMalloc(&d_scr, sizeof(double) * 2 * std::max<int64_t>(1, n_obs)));
+    TRICHK(hipMalloc(&d_tab, sizeof(double) * tab.size()));
+    TRICHK(hipMalloc(&d_pts, sizeof(double) * 3 * n_pts));
+    TRICHK(hipMalloc(&d_start, sizeof(int64_t) * (n_pts + 1)));
+    TRICHK(hipEventCreate(&e0));
+    TRICHK(hipEventCreate(&e1));
+    if (n_obs) {
+        TRICHK(hipMemcpy(d_cam, cam, sizeof(int32_t) * n_obs, hipMemcpyHostToDevice));
+        TRICHK(hipMemcpy(d_uv, uv, sizeof(double) * 2 * n_obs, hipMemcpyHostToDevice));
+    }
+    TRICHK(hipMemcpy(d_tab, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice));
+    TRICHK(hipMemcpy(d_start, start_inds, sizeof(int64_t) * (n_pts + 1), hipMemcpyHostToDevice));
+    const dim3 grid((unsigned)((n_pts + 255) / 256));
+    hipExtLaunchKernelGGL(triangulate_kernel, grid, dim3(256), 0, nullptr, e0, e1, 0, (const int32_t *)d_cam, (const double2 *)d_uv,
+                          (const int64_t *)d_start, (const double *)d_tab, (double2 *)d_scr, d_pts, n_pts);
+    TRICHK(hipGetLastError());
+    TRICHK(hipMemcpy(pts, d_pts, sizeof(double) * 3 * n_pts, hipMemcpyDeviceToHost));
+    if (kernel_ms) {
+        TRICHK(hipEventSynchronize(e1));
+        TRICHK(hipEventElapsedTime(kernel_ms, e0, e1));
+    }
+#undef TRICHK
+    cleanup();
+    return PCS_OK;
+}
 
 int pcs_host_alloc(void **out, int64_t bytes) {
     if (!out || bytes <= 0) return fail(PCS_ERR_ARG, "pcs_host_alloc: bad arguments");

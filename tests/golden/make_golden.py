@@ -239,6 +239,39 @@ def legacy_cost_vectors(ch, rig):
                 intr=rig.intr, extr=rig.extr, poses=rig.poses, points=rig.points, distort_in=pts, distort_out=dist_out)
 
 
+def triangulation_vectors(ch, seed=9):
+    """the reference's nb_triangulate_full (compiled_helpers.py:609-663) on observations of a
+    synthetic rig, sorted by (image, key, camera) as the reference's front end requires."""
+    rig = synthetic.make_rig("tri", 12, 3, synthetic.charuco_points(7, 6.0), seed=seed, visibility=0.55, n_rings=2, noise_px=0.3)
+    C, I, K = rig.n_cams, rig.n_imgs, rig.n_keys
+    Kc = np.zeros((C, 3, 3))
+    it = rig.intr_true
+    Kc[:, 0, 0], Kc[:, 0, 2], Kc[:, 1, 1], Kc[:, 1, 2], Kc[:, 2, 2] = it[:, 0], it[:, 1], it[:, 2], it[:, 3], 1.0
+    proj = np.empty((C, 3, 4))
+    for c in range(C):
+        blank = np.zeros(12)
+        ch.n_e4x4_flat_INPLACE(rig.extr_true[c].copy(), blank)
+        proj[c] = Kc[c] @ np.concatenate([blank[:9].reshape(3, 3), blank[9:].reshape(3, 1)], axis=1)
+    dists = np.ascontiguousarray(it[:, 4:9])
+    d = rig.detections
+    d = d[np.lexsort((d[:, 0], d[:, 2], d[:, 1]))]
+    # grouping of CameraSet.multi_cam_triangulate (cameras/camera_set.py:371-378)
+    _, inv, count = np.unique(d[:, 1:-2], axis=0, return_inverse=True, return_counts=True)
+    rec = d[(count > 1)[inv].squeeze()]
+    _, im_index, im_counts = np.unique(rec[:, 1:-2], axis=0, return_index=True, return_counts=True)
+    start = np.append(0, np.cumsum(im_counts[np.argsort(im_index)]))
+    pts = ch.nb_triangulate_full(rec, proj, start, Kc, dists)
+    und = np.array([ch.nb_undistort(r[-2:].copy(), Kc[int(r[0])], dists[int(r[0])]) for r in rec[:40]])
+    # ground truth for a sanity bound: pose-transformed template points
+    truth = np.empty((I, K, 3))
+    for i in range(I):
+        blank = np.zeros(12)
+        ch.n_e4x4_flat_INPLACE(rig.poses_true[i].copy(), blank)
+        ch.n_htform_broadcast_prealloc(rig.points.copy(), blank, truth[i])
+    return dict(data=rec, start_inds=start, proj=proj, intrinsics=Kc, dists=dists, points=np.array(pts),
+                undistorted_first40=und, unsorted_detections=rig.detections, truth=truth)
+
+
 def main():
     if not (REFERENCE / "pyCamSet").is_dir():
         raise SystemExit(f"reference not found at {REFERENCE}")
@@ -270,6 +303,8 @@ def main():
                 print("block", chain, tag, "nnz_all", res[[k for k in res if k.startswith('data_all')][0]].shape)
         np.savez_compressed(HERE / "legacy_cost_medium.npz", **legacy_cost_vectors(ch, medium))
         print("legacy cost done")
+        np.savez_compressed(HERE / "triangulation.npz", **triangulation_vectors(ch))
+        print("triangulation done")
         mods = (th, sbh, fph, TargetDetection)
         for chain in ("template", "self", "free"):
             for tag, rig, fx in (("tiny", tiny, True), ("tiny_nofix", tiny, False)):

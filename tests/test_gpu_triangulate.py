@@ -1,0 +1,79 @@
+"""SURVEY f4 on the GPU: batched n-view triangulation through the C ABI against the golden vectors
+(reference output) and the NumPy/LAPACK oracle.  Tolerance: 1e-10 relative to the point norm
+(the kernel solves the 4x4 secular equation instead of an SVD of the 3n x (4+n) matrix; measured
+agreement is ~1e-13)."""
+import numpy as np
+import pytest
+
+from oracle import ba_oracle as orc
+from pycamset_amd import _capi, synthetic
+from pycamset_amd import compiled_helpers as hip_ch
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_err(a, b):
+    return float(np.max(np.linalg.norm(a - b, axis=1) / np.linalg.norm(b, axis=1)))
+
+
+def test_triangulation_matches_reference_goldens(golden_dir):
+    g = np.load(golden_dir / "triangulation.npz")
+    pts = hip_ch.nb_triangulate_full(g["data"], g["proj"], g["start_inds"], g["intrinsics"], g["dists"])
+    assert pts.shape == g["points"].shape
+    assert rel_err(pts, g["points"]) <= 1e-10
+    assert hip_ch.last_triangulate_kernel_ms > 0
+
+
+def rig_inputs(rig):
+    im, P, K, D = orc.legacy_inputs(rig.intr_true, rig.extr_true, rig.poses_true, rig.points)
+    d = rig.detections
+    d = d[np.lexsort((d[:, 0], d[:, 2], d[:, 1]))]
+    rec, start = hip_ch.group_reconstructable(d)
+    return rec, start, P, K, D, im
+
+
+@pytest.mark.parametrize("n_cams,vis", [(2, 1.0), (5, 0.7), (32, 0.5), (32, 1.0)])
+def test_triangulation_matches_svd_oracle(n_cams, vis):
+    rig = synthetic.make_rig("tri", n_cams, 4, synthetic.ccube_points(6, 30.0), seed=40 + n_cams, visibility=vis,
+                             n_rings=2 if n_cams >= 4 else 1)
+    rec, start, P, K, D, im = rig_inputs(rig)
+    views = np.diff(start)
+    assert views.min() >= 2 and views.max() <= n_cams
+    pts = hip_ch.nb_triangulate_full(rec, P, start, K, D)
+    ref = orc.triangulate_full(rec, P, start, K, D)
+    assert rel_err(pts, ref) <= 1e-10, rel_err(pts, ref)
+    first = rec[start[:-1]]
+    truth = im[first[:, 1].astype(int), first[:, 2].astype(int)]
+    assert np.median(np.linalg.norm(pts - truth, axis=1)) < 5e-4      # 0.3 px noise at 0.2 m
+    # distortion switched off (multi_cam_triangulate(distort=False), camera_set.py:384-385)
+    pts0 = hip_ch.nb_triangulate_full(rec, P, start, K, np.zeros_like(D))
+    assert rel_err(pts0, orc.triangulate_full(rec, P, start, K, np.zeros_like(D))) <= 1e-10
+
+
+def test_triangulation_at_scale_and_errors():
+    rig = synthetic.make_rig("tri-big", 32, 40, synthetic.ccube_points(), seed=77, visibility=0.3215, n_rings=2)
+    rec, start, P, K, D, im = rig_inputs(rig)
+    n_pts = start.shape[0] - 1
+    assert n_pts > 15000 and rec.shape[0] > 1.5e5
+    pts = hip_ch.nb_triangulate_full(rec, P, start, K, D)
+    ms = hip_ch.last_triangulate_kernel_ms
+    sel = np.arange(0, n_pts, 41)
+    sub_rows = np.concatenate([np.arange(start[j], start[j + 1]) for j in sel])
+    sub_start = np.append(0, np.cumsum(np.diff(start)[sel]))
+    ref = orc.triangulate_full(rec[sub_rows], P, sub_start, K, D)
+    assert rel_err(pts[sel], ref) <= 1e-10
+    assert np.isfinite(pts).all() and 0 < ms < 50
+    # permuting the points permutes the output (each lane owns one point)
+    perm = np.random.default_rng(0).permutation(n_pts)
+    rows = np.concatenate([np.arange(start[j], start[j + 1]) for j in perm])
+    pstart = np.append(0, np.cumsum(np.diff(start)[perm]))
+    assert np.array_equal(hip_ch.nb_triangulate_full(rec[rows], P, pstart, K, D), pts[perm])
+    # argument checks
+    with pytest.raises(_capi.PcsError):
+        hip_ch.nb_triangulate_full(rec, P, start[:-1], K, D)           # start_inds does not end at n_obs
+    bad = rec.copy()
+    bad[5, 0] = 99
+    with pytest.raises(_capi.PcsError) as e:
+        hip_ch.nb_triangulate_full(bad, P, start, K, D)
+    assert e.value.code == _capi.PCS_ERR_RANGE
+    assert hip_ch.nb_triangulate_full(rec[:0], P, np.array([0]), K, D).shape == (0, 3)
