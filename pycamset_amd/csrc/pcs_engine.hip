@@ -540,18 +540,15 @@ int pcs_triangulate(int device, int64_t n_obs, const int32_t *cam, const double 
         double *t = tab.data() + c * TRI_CAM_STRIDE;
         const double *P = proj + 12 * c;
         for (int k = 0; k < 12; ++k) t[k] = P[k];
-        int o = 12;
-        for (int a = 0; a < 4; ++a)
-            for (int b = a; b < 4; ++b) t[o++] = P[a] * P[b] + P[4 + a] * P[4 + b] + P[8 + a] * P[8 + b];  // (P^T P)[a][b]
         const double *K = intrinsics + 9 * c;
         t[22] = K[0]; t[23] = K[2]; t[24] = K[4]; t[25] = K[5];
         for (int k = 0; k < 5; ++k) t[26 + k] = dists[5 * c + k];
     }
-    int32_t *d_cam = nullptr; double *d_uv = nullptr, *d_tab = nullptr, *d_pts = nullptr; int64_t *d_start = nullptr; void *d_scr = nullptr;
+    int32_t *d_cam = nullptr; double *d_uv = nullptr, *d_tab = nullptr, *d_pts = nullptr, *d_scl = nullptr; int64_t *d_start = nullptr; void *d_scr = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     int rc = PCS_OK;
     auto cleanup = [&]() {
-        for (void *b : {(void *)d_cam, (void *)d_uv, (void *)d_tab, (void *)d_pts, (void *)d_start, d_scr})
+        for (void *b : {(void *)d_cam, (void *)d_uv, (void *)d_tab, (void *)d_pts, (void *)d_start, d_scr, (void *)d_scl})
             if (b) (void)hipFree(b);
         if (e0) (void)hipEventDestroy(e0);
         if (e1) (void)hipEventDestroy(e1);
@@ -564,6 +561,7 @@ int pcs_triangulate(int device, int64_t n_obs, const int32_t *cam, const double 
     TRICHK(hipMalloc(&d_cam, sizeof(int32_t) * std::max<int64_t>(1, n_obs)));
     TRICHK(hipMalloc(&d_uv, sizeof(double) * 2 * std::max<int64_t>(1, n_obs)));
     TRICHK(hipMalloc(&d_scr, sizeof(double) * 2 * std::max<int64_t>(1, n_obs)));
+    TRICHK(hipMalloc(&d_scl, sizeof(double) * std::max<int64_t>(1, n_obs)));
     TRICHK(hipMalloc(&d_tab, sizeof(double) * tab.size()));
     TRICHK(hipMalloc(&d_pts, sizeof(double) * 3 * n_pts));
     TRICHK(hipMalloc(&d_start, sizeof(int64_t) * (n_pts + 1)));
@@ -577,7 +575,7 @@ int pcs_triangulate(int device, int64_t n_obs, const int32_t *cam, const double 
     TRICHK(hipMemcpy(d_start, start_inds, sizeof(int64_t) * (n_pts + 1), hipMemcpyHostToDevice));
     const dim3 grid((unsigned)((n_pts + 255) / 256));
     hipExtLaunchKernelGGL(triangulate_kernel, grid, dim3(256), 0, nullptr, e0, e1, 0, (const int32_t *)d_cam, (const double2 *)d_uv,
-                          (const int64_t *)d_start, (const double *)d_tab, (double2 *)d_scr, d_pts, n_pts);
+                          (const int64_t *)d_start, (const double *)d_tab, (double2 *)d_scr, d_scl, d_pts, n_pts);
     TRICHK(hipGetLastError());
     TRICHK(hipMemcpy(pts, d_pts, sizeof(double) * 3 * n_pts, hipMemcpyDeviceToHost));
     if (kernel_ms) {

@@ -1,7 +1,10 @@
 """SURVEY f4 on the GPU: batched n-view triangulation through the C ABI against the golden vectors
-(reference output) and the NumPy/LAPACK oracle.  Tolerance: 1e-10 relative to the point norm
-(the kernel solves the 4x4 secular equation instead of an SVD of the 3n x (4+n) matrix; measured
-agreement is ~1e-13)."""
+(reference output) and the NumPy/LAPACK oracle.
+
+Tolerance: |X - X_ref| <= tol * |X_ref| with tol = max(1e-10, 1e3 * eps * sigma_1 / (sigma_{m-1} - sigma_m))
+per point: the smallest right singular vector is only determined to eps * sigma_1 / gap by ANY backward
+stable algorithm (the reference's LAPACK SVD included), and two-view points near the baseline have
+gaps of 1e-4.  Well-conditioned points (10-30 views) agree to ~2e-13."""
 import numpy as np
 import pytest
 
@@ -14,6 +17,28 @@ pytestmark = pytest.mark.gpu
 
 def rel_err(a, b):
     return float(np.max(np.linalg.norm(a - b, axis=1) / np.linalg.norm(b, axis=1)))
+
+
+def svd_tolerances(rec, start, P, K, D):
+    """Per-point conditioning bound of the reference's own SVD."""
+    tol = np.empty(len(start) - 1)
+    for j in range(len(start) - 1):
+        rows = rec[start[j]:start[j + 1]]
+        n = len(rows)
+        M = np.zeros((3 * n, 4 + n))
+        for i, r in enumerate(rows):
+            c = int(r[0])
+            M[3 * i:3 * i + 3, :4] = P[c]
+            M[3 * i:3 * i + 2, 4 + i] = -orc.undistort(r[-2:], K[c], D[c])
+            M[3 * i + 2, 4 + i] = -1.0
+        S = np.linalg.svd(M, compute_uv=False)
+        tol[j] = max(1e-10, 1e3 * np.finfo(float).eps * S[0] / (S[-2] - S[-1]))
+    return tol
+
+
+def assert_points_close(pts, ref, tol):
+    err = np.linalg.norm(pts - ref, axis=1) / np.linalg.norm(ref, axis=1)
+    assert np.all(err <= tol), (float(np.max(err / tol)), float(err.max()))
 
 
 def test_triangulation_matches_reference_goldens(golden_dir):
@@ -41,13 +66,16 @@ def test_triangulation_matches_svd_oracle(n_cams, vis):
     assert views.min() >= 2 and views.max() <= n_cams
     pts = hip_ch.nb_triangulate_full(rec, P, start, K, D)
     ref = orc.triangulate_full(rec, P, start, K, D)
-    assert rel_err(pts, ref) <= 1e-10, rel_err(pts, ref)
+    tol = svd_tolerances(rec, start, P, K, D)
+    assert_points_close(pts, ref, tol)
+    if n_cams >= 32:
+        assert tol.max() == 1e-10 and rel_err(pts, ref) <= 1e-11
     first = rec[start[:-1]]
     truth = im[first[:, 1].astype(int), first[:, 2].astype(int)]
     assert np.median(np.linalg.norm(pts - truth, axis=1)) < 5e-4      # 0.3 px noise at 0.2 m
     # distortion switched off (multi_cam_triangulate(distort=False), camera_set.py:384-385)
     pts0 = hip_ch.nb_triangulate_full(rec, P, start, K, np.zeros_like(D))
-    assert rel_err(pts0, orc.triangulate_full(rec, P, start, K, np.zeros_like(D))) <= 1e-10
+    assert_points_close(pts0, orc.triangulate_full(rec, P, start, K, np.zeros_like(D)), 10 * tol)
 
 
 def test_triangulation_at_scale_and_errors():
