@@ -203,4 +203,90 @@ __device__ __forceinline__ void eval_detection(SlabPtrC cs, SlabPtrP ps, const T
     }
 }
 
+// Row-split form: the same chain for ONE of the two rows (u when !second, v when second) of a
+// detection.  Two lanes share a detection, so a lane carries P instead of 2P Jacobian values (half
+// the registers -> more waves per SIMD).  Both lanes run the same instruction stream; the row only
+// enters through selects, never through a branch.  Values are identical to eval_detection's.
+template <int CHAIN, typename T, typename SlabPtrC, typename SlabPtrP>
+__device__ __forceinline__ void eval_detection_row(SlabPtrC cs, SlabPtrP ps, const T X0, const T X1, const T X2, const bool second,
+                                                   T &proj, T (&Jr)[chain_P(CHAIN)]) {
+    T Xw0, Xw1, Xw2;
+    T Qr[9];
+    if constexpr (CHAIN != CHAIN_FREE) {
+        Xw0 = ps[POSE_R + 0] * X0 + ps[POSE_R + 1] * X1 + ps[POSE_R + 2] * X2 + ps[POSE_T + 0];
+        Xw1 = ps[POSE_R + 3] * X0 + ps[POSE_R + 4] * X1 + ps[POSE_R + 5] * X2 + ps[POSE_T + 1];
+        Xw2 = ps[POSE_R + 6] * X0 + ps[POSE_R + 7] * X1 + ps[POSE_R + 8] * X2 + ps[POSE_T + 2];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                Qr[c * 3 + a] = ps[POSE_DR + a * 9 + c * 3 + 0] * X0 + ps[POSE_DR + a * 9 + c * 3 + 1] * X1 +
+                                ps[POSE_DR + a * 9 + c * 3 + 2] * X2;
+    } else {
+        Xw0 = X0; Xw1 = X1; Xw2 = X2;
+    }
+    const T e0 = cs[CAM_R + 0], e1 = cs[CAM_R + 1], e2 = cs[CAM_R + 2];
+    const T e3 = cs[CAM_R + 3], e4 = cs[CAM_R + 4], e5 = cs[CAM_R + 5];
+    const T e6 = cs[CAM_R + 6], e7 = cs[CAM_R + 7], e8 = cs[CAM_R + 8];
+    const T x = e0 * Xw0 + e1 * Xw1 + e2 * Xw2 + cs[CAM_T + 0];
+    const T y = e3 * Xw0 + e4 * Xw1 + e5 * Xw2 + cs[CAM_T + 1];
+    const T z = e6 * Xw0 + e7 * Xw1 + e8 * Xw2 + cs[CAM_T + 2];
+    const T fx = cs[0], px = cs[1], fy = cs[2], py = cs[3];
+    const T k0 = cs[4], k1 = cs[5], p0 = cs[6], p1 = cs[7], k2 = cs[8];
+    const T iz = T(1) / z;
+    const T a = x * iz, b = y * iz;
+    const T a2 = a * a, b2 = b * b, ab = a * b;
+    const T r2 = a2 + b2;
+    const T r4 = r2 * r2;
+    const T r6 = r4 * r2;
+    const T kup = T(1) + k0 * r2 + k1 * r4 + k2 * r6;
+    const T xD = a * kup + T(2) * p0 * ab + p1 * (r2 + T(2) * a2);
+    const T yD = b * kup + p0 * (r2 + T(2) * b2) + T(2) * p1 * ab;
+    const T u = xD * fx + px;
+    const T v = yD * fy + py;
+    proj = second ? v : u;
+    const T dk = k0 + T(2) * k1 * r2 + T(3) * k2 * r4;
+    const T ua = fx * (kup + T(2) * a2 * dk + T(2) * p0 * b + T(6) * p1 * a);
+    const T cross = T(2) * (ab * dk + p0 * a + p1 * b);
+    const T ub = fx * cross;
+    const T va = fy * cross;
+    const T vb = fy * (kup + T(2) * b2 * dk + T(6) * p0 * b + T(2) * p1 * a);
+    const T da = second ? va : ua;
+    const T db = second ? vb : ub;
+    const T Ax0 = da * iz, Ax1 = db * iz, Ax2 = -(a * da + b * db) * iz;
+    const T f = second ? fy : fx;
+    const T ar = second ? b : a;
+    Jr[0] = second ? T(0) : xD;
+    Jr[1] = second ? T(0) : T(1);
+    Jr[2] = second ? yD : T(0);
+    Jr[3] = second ? T(1) : T(0);
+    Jr[4] = f * ar * r2;
+    Jr[5] = f * ar * r4;
+    Jr[6] = second ? fy * (r2 + T(2) * b2) : T(2) * fx * ab;
+    Jr[7] = second ? T(2) * fy * ab : fx * (r2 + T(2) * a2);
+    Jr[8] = f * ar * r6;
+#pragma unroll
+    for (int aa = 0; aa < 3; ++aa) {
+        const T er0 = cs[CAM_DR + aa * 9 + 0] * Xw0 + cs[CAM_DR + aa * 9 + 1] * Xw1 + cs[CAM_DR + aa * 9 + 2] * Xw2;
+        const T er1 = cs[CAM_DR + aa * 9 + 3] * Xw0 + cs[CAM_DR + aa * 9 + 4] * Xw1 + cs[CAM_DR + aa * 9 + 5] * Xw2;
+        const T er2 = cs[CAM_DR + aa * 9 + 6] * Xw0 + cs[CAM_DR + aa * 9 + 7] * Xw1 + cs[CAM_DR + aa * 9 + 8] * Xw2;
+        Jr[9 + aa] = Ax0 * er0 + Ax1 * er1 + Ax2 * er2;
+    }
+    Jr[12] = Ax0; Jr[13] = Ax1; Jr[14] = Ax2;
+    const T S0 = Ax0 * e0 + Ax1 * e3 + Ax2 * e6;
+    const T S1 = Ax0 * e1 + Ax1 * e4 + Ax2 * e7;
+    const T S2 = Ax0 * e2 + Ax1 * e5 + Ax2 * e8;
+    if constexpr (CHAIN == CHAIN_FREE) {
+        Jr[15] = S0; Jr[16] = S1; Jr[17] = S2;
+    } else {
+#pragma unroll
+        for (int aa = 0; aa < 3; ++aa) Jr[15 + aa] = S0 * Qr[0 * 3 + aa] + S1 * Qr[1 * 3 + aa] + S2 * Qr[2 * 3 + aa];
+        Jr[18] = S0; Jr[19] = S1; Jr[20] = S2;
+        if constexpr (CHAIN == CHAIN_SELF) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) Jr[21 + c] = S0 * ps[POSE_R + 0 * 3 + c] + S1 * ps[POSE_R + 1 * 3 + c] + S2 * ps[POSE_R + 2 * 3 + c];
+        }
+    }
+}
+
 }  // namespace pcs

@@ -67,6 +67,7 @@ struct EvalArgs {
     int32_t tiles_per_wg;
     int64_t n_tiles;
     // compaction (ba_compact_kernel only)
+    void *sink;              // 64 B scratch: tail lanes store their (unused) residual here, so the store needs no branch
     const uint32_t *keep;    // per detection: bit j set = local column j is free
     const int64_t *row_off;  // per detection: offset of its u row in the CSR data array
 };
@@ -184,13 +185,14 @@ __global__ __launch_bounds__(WG_THREADS) void ba_eval_kernel(const EvalArgs a) {
         T J[P2];
         eval_detection<CHAIN, T, JAC>(cs, ps, X0, X1, X2, u, v, J);
         if constexpr (RES) {
-            if (valid) {
-                V2 r;
-                r.x = u - m.x;   // afb:384  losses = projected - measured
-                r.y = v - m.y;
-                if constexpr (NT) __builtin_nontemporal_store(r, reinterpret_cast<V2 *>(resid) + i);
-                else reinterpret_cast<V2 *>(resid)[i] = r;
-            }
+            // Branch-free: a conditional block here splits the basic block and makes hipcc keep the whole
+            // slab + Jacobian live across it (226 VGPRs instead of 150); tail lanes write to a sink.
+            V2 r;
+            r.x = u - m.x;   // afb:384  losses = projected - measured
+            r.y = v - m.y;
+            V2 *rp = valid ? reinterpret_cast<V2 *>(resid) + i : static_cast<V2 *>(a.sink);
+            if constexpr (NT) __builtin_nontemporal_store(r, rp);
+            else *rp = r;
         }
         if constexpr (JAC) {
             if constexpr (!TRANSPOSE) {
@@ -250,6 +252,77 @@ __global__ __launch_bounds__(WG_THREADS) void ba_eval_kernel(const EvalArgs a) {
                 }
             }
         }
+    }
+}
+
+// Row-split variant of the fused kernel (option "rowsplit"): a wave tile is 32 detections and lanes
+// l / l+32 compute the u / v row of the same detection (eval_detection_row).  Half the Jacobian
+// registers per lane -> 3 waves per SIMD instead of 2, and the transposed store needs one LDS pass
+// instead of two.  Costs ~50 % more VALU work (the shared part of the chain is evaluated by both
+// lanes), which this HBM-bound kernel has to spare.  Slabs are read through L1/L2.
+template <int CHAIN, typename T, int MODE, bool NT>
+__global__ __launch_bounds__(WG_THREADS, 3) void ba_eval_rowsplit_kernel(const EvalArgs a) {
+    constexpr int P = chain_P(CHAIN);
+    constexpr int P2 = 2 * P;
+    constexpr bool RES = (MODE & MODE_RESID) != 0;
+    using V2 = typename Vec2<T>::type;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int d = lane & 31;
+    const bool second = lane >= 32;
+    T *tr = reinterpret_cast<T *>(smem_raw) + wave * (HALF * P2);
+    const T *cam_slab = static_cast<const T *>(a.cam_slab);
+    const T *pose_slab = static_cast<const T *>(a.pose_slab);
+    const T *points = static_cast<const T *>(a.points);
+    const V2 *uv = static_cast<const V2 *>(a.uv);
+    T *resid = static_cast<T *>(a.resid);
+    T *jac = static_cast<T *>(a.jac);
+    const int64_t total_jac = a.n * (int64_t)P2;
+    const int64_t tile0 = (int64_t)blockIdx.x * a.tiles_per_wg;   // tiles of HALF = 32 detections here
+    const int64_t tile1 = min(tile0 + (int64_t)a.tiles_per_wg, a.n_tiles);
+    for (int64_t tile = tile0 + wave; tile < tile1; tile += WAVES_PER_WG) {
+        const int64_t i = tile * HALF + d;
+        const bool valid = i < a.n;
+        const int64_t ic = valid ? i : a.n - 1;
+        const int c = a.cam[ic], im = a.img[ic], k = a.key[ic];
+        const V2 m = uv[ic];
+        T proj;
+        T Jr[P];
+        eval_detection_row<CHAIN, T>(cam_slab + c * CAM_STRIDE, pose_slab + im * POSE_STRIDE, points[3 * k], points[3 * k + 1],
+                                     points[3 * k + 2], second, proj, Jr);
+        if constexpr (RES) {  // branch-free (see ba_eval_kernel)
+            T *rp = valid ? resid + 2 * i + (second ? 1 : 0) : static_cast<T *>(a.sink) + (second ? 1 : 0);
+            store_out<T, NT>(rp, proj - (second ? m.y : m.x));
+        }
+        T *dst = tr + d * P2 + (second ? P : 0);
+#pragma unroll
+        for (int j = 0; j < P; ++j) dst[j] = Jr[j];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        constexpr int VS = 16 / sizeof(T);
+        using V16 = __attribute__((ext_vector_type(VS))) T;
+        constexpr int UNITS = HALF * P2 / VS;
+        const int64_t base = tile * HALF * (int64_t)P2;
+#pragma unroll
+        for (int q0 = 0; q0 < UNITS; q0 += 64) {
+            const int q = q0 + lane;
+            if (q < UNITS) {
+                const int64_t e = base + (int64_t)q * VS;
+                if (e + VS <= total_jac) {
+                    const V16 w = reinterpret_cast<const V16 *>(tr)[q];
+                    if constexpr (NT) __builtin_nontemporal_store(w, reinterpret_cast<V16 *>(jac + e));
+                    else *reinterpret_cast<V16 *>(jac + e) = w;
+                } else {
+                    for (int s = 0; s < VS; ++s)
+                        if (e + s < total_jac) jac[e + s] = tr[q * VS + s];
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 }
 
@@ -331,13 +404,11 @@ __global__ __launch_bounds__(WG_THREADS) void ba_compact_tile_kernel(const EvalA
         T J[P2];
         eval_detection<CHAIN, T, JAC>(cam_slab + c * CAM_STRIDE, pose_slab + im * POSE_STRIDE, points[3 * k], points[3 * k + 1],
                                       points[3 * k + 2], u, v, J);
-        if constexpr ((MODE & MODE_RESID) != 0) {
-            if (valid) {
-                V2 r;
-                r.x = u - m.x;
-                r.y = v - m.y;
-                __builtin_nontemporal_store(r, reinterpret_cast<V2 *>(resid) + i);
-            }
+        if constexpr ((MODE & MODE_RESID) != 0) {  // branch-free (see ba_eval_kernel)
+            V2 r;
+            r.x = u - m.x;
+            r.y = v - m.y;
+            __builtin_nontemporal_store(r, valid ? reinterpret_cast<V2 *>(resid) + i : static_cast<V2 *>(a.sink));
         }
         if constexpr (JAC) {
             const uint32_t keep = valid ? a.keep[ic] : 0u;
@@ -480,6 +551,7 @@ struct pcs_engine {
     double *d_param = nullptr;
     double *h_param = nullptr;  // pinned staging
     void *d_cam_slab = nullptr, *d_pose_slab = nullptr, *d_points = nullptr;
+    void *d_sink = nullptr;  // 64 B: where tail lanes put their residual
     // scratch outputs for the host-buffer entry points
     void *d_resid = nullptr, *d_jac = nullptr;
     int64_t jac_capacity = 0, resid_capacity = 0;
@@ -507,6 +579,7 @@ struct pcs_engine {
     int variant = -1;
     int64_t wgs_per_cu = 0;
     int compact_variant = 1;     // 1 = tile kernel with coalesced stores, 0 = per-lane stores
+    bool rowsplit = false;       // two lanes per detection (ba_eval_rowsplit_kernel)
     double tile_locality = 1.0;  // fraction of 64-detection tiles touching <= 2 distinct (cam, image) pairs
     int64_t tiles_per_wg = 0;  // 0 = derive from wgs_per_cu
     size_t lds_limit = 160 * 1024;
@@ -687,6 +760,7 @@ int pcs_create(pcs_engine **out, int chain, int dtype, int64_t n_cams, int64_t n
     HIPCHK(hipMalloc(&h->d_pose_slab, h->esize * std::max<int64_t>(1, h->n_imgs) * POSE_STRIDE));
     HIPCHK(hipMalloc(&h->d_points, h->esize * padded_points(n_keys)));
     HIPCHK(hipMemset(h->d_points, 0, h->esize * padded_points(n_keys)));
+    HIPCHK(hipMalloc(&h->d_sink, 64));
     *out = h;
     return PCS_OK;
 }
@@ -696,7 +770,7 @@ int pcs_destroy(pcs_engine *h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     void *bufs[] = {h->d_cam, h->d_img, h->d_key, h->d_uv, h->d_param, h->d_cam_slab, h->d_pose_slab, h->d_points,
-                    h->d_resid, h->d_jac, h->d_keep, h->d_row_off, h->d_data, h->d_vin, h->d_vout, h->d_cost, h->d_im_points, h->d_cam_tab};
+                    h->d_resid, h->d_jac, h->d_keep, h->d_row_off, h->d_data, h->d_vin, h->d_vout, h->d_cost, h->d_im_points, h->d_cam_tab, h->d_sink};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (h->h_param) (void)hipHostFree(h->h_param);
@@ -815,6 +889,8 @@ int pcs_set_option(pcs_engine *h, const char *key, int64_t value) {
         if (value < 0 || value > 1000000) return fail(PCS_ERR_ARG, "timing_every must be in [0,1000000]");
         h->timing_every = value;
         h->eval_count = 0;
+    } else if (!strcmp(key, "rowsplit")) {
+        h->rowsplit = value != 0;
     } else if (!strcmp(key, "matfree_lds")) {
         h->matfree_lds = value != 0;
     } else if (!strcmp(key, "compact_variant")) {
@@ -892,6 +968,24 @@ static hipError_t launch_eval_t(int chain, int mode, int variant, const EvalArgs
         case CHAIN_TEMPLATE: return launch_eval_c<CHAIN_TEMPLATE, T>(mode, variant, a, grid, lds, s, ev);
         case CHAIN_SELF: return launch_eval_c<CHAIN_SELF, T>(mode, variant, a, grid, lds, s, ev);
         default: return launch_eval_c<CHAIN_FREE, T>(mode, variant, a, grid, lds, s, ev);
+    }
+}
+
+template <int CHAIN, typename T>
+static hipError_t launch_rowsplit_c(int mode, bool nt, const EvalArgs &a, dim3 grid, size_t lds, hipStream_t s, EvPair ev) {
+#define PCS_RS(MODE_, NT_) hipExtLaunchKernelGGL((ba_eval_rowsplit_kernel<CHAIN, T, MODE_, NT_>), grid, dim3(WG_THREADS), (std::uint32_t)lds, s, ev.start, ev.stop, 0, a)
+    if (mode == MODE_JAC) { if (nt) PCS_RS(MODE_JAC, true); else PCS_RS(MODE_JAC, false); }
+    else { if (nt) PCS_RS(MODE_RESID | MODE_JAC, true); else PCS_RS(MODE_RESID | MODE_JAC, false); }
+#undef PCS_RS
+    return hipGetLastError();
+}
+
+template <typename T>
+static hipError_t launch_rowsplit_t(int chain, int mode, bool nt, const EvalArgs &a, dim3 grid, size_t lds, hipStream_t s, EvPair ev) {
+    switch (chain) {
+        case CHAIN_TEMPLATE: return launch_rowsplit_c<CHAIN_TEMPLATE, T>(mode, nt, a, grid, lds, s, ev);
+        case CHAIN_SELF: return launch_rowsplit_c<CHAIN_SELF, T>(mode, nt, a, grid, lds, s, ev);
+        default: return launch_rowsplit_c<CHAIN_FREE, T>(mode, nt, a, grid, lds, s, ev);
     }
 }
 
@@ -994,7 +1088,7 @@ static int enqueue_eval(pcs_engine *h, const double *d_prm, void *d_resid, void 
     EvalArgs a{};
     a.cam = h->d_cam; a.img = h->d_img; a.key = h->d_key; a.uv = h->d_uv;
     a.cam_slab = h->d_cam_slab; a.pose_slab = h->d_pose_slab; a.points = h->d_points;
-    a.resid = d_resid; a.jac = d_out;
+    a.resid = d_resid; a.jac = d_out; a.sink = h->d_sink;
     a.n = h->n; a.n_cams = (int32_t)h->n_cams; a.n_imgs = (int32_t)h->n_imgs; a.n_keys = (int32_t)h->n_keys;
     a.n_tiles = (h->n + TILE - 1) / TILE;
     if (compact) {
@@ -1018,6 +1112,23 @@ static int enqueue_eval(pcs_engine *h, const double *d_prm, void *d_resid, void 
         }
         if (e != hipSuccess) return fail(PCS_ERR_HIP, "compact kernel launch failed: %s", hipGetErrorString(e));
         if (timed) HIPCHK(hipEventRecord(ev[2], s));
+    } else if (h->rowsplit && (mode & MODE_JAC)) {
+        const bool nt = h->variant < 0 || (h->variant & VAR_NT);
+        a.n_tiles = (h->n + HALF - 1) / HALF;
+        int64_t tpw = h->tiles_per_wg;
+        if (tpw <= 0) {
+            const int64_t wpc = h->wgs_per_cu > 0 ? h->wgs_per_cu : 16;
+            const int64_t target_wgs = (int64_t)h->n_cu * wpc;
+            tpw = (a.n_tiles + target_wgs - 1) / target_wgs;
+            tpw = std::max<int64_t>(WAVES_PER_WG, (tpw + WAVES_PER_WG - 1) / WAVES_PER_WG * WAVES_PER_WG);
+        }
+        a.tiles_per_wg = (int32_t)tpw;
+        const int64_t grid = (a.n_tiles + tpw - 1) / tpw;
+        const size_t lds = h->esize * (size_t)WAVES_PER_WG * HALF * 2 * h->P;
+        const EvPair evp{ev[1], ev[2]};
+        hipError_t e = h->dtype == PCS_F64 ? launch_rowsplit_t<double>(h->chain, mode, nt, a, dim3((unsigned)grid), lds, s, evp)
+                                           : launch_rowsplit_t<float>(h->chain, mode, nt, a, dim3((unsigned)grid), lds, s, evp);
+        if (e != hipSuccess) return fail(PCS_ERR_HIP, "rowsplit kernel launch failed: %s", hipGetErrorString(e));
     } else {
         const bool local = h->tile_locality >= 0.5;
         int variant = h->variant >= 0 ? h->variant : (VAR_TRANSPOSE | VAR_NT | (local ? 0 : VAR_SLAB_LDS));

@@ -367,3 +367,26 @@ def test_slabs_too_large_for_lds_fall_back_to_l2(Engine):
         inv[perm] = np.arange(rig.n_det)
         assert np.array_equal(j.reshape(rig.n_det, 42)[inv], outs[0].reshape(rig.n_det, 42))
         e.close()
+
+
+@pytest.mark.parametrize("chain", CHAINS)
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_rowsplit_kernel_matches(Engine, chain, dtype):
+    """Two-lanes-per-detection variant (option 'rowsplit'): same values as the lane-per-detection kernel."""
+    rig = synthetic.config_rig(1)
+    ps, ref_r, ref_j = oracle_eval(rig, chain)
+    for n in (rig.n_det, 1000, 95, 33, 32, 31, 1):
+        det = rig.detections[:n].copy()
+        det[-1, :3] = [rig.n_cams - 1, rig.n_imgs - 1, rig.n_keys - 1]
+        e = make_engine(Engine, rig, chain, dtype=dtype, det=det)
+        r0, j0 = e.eval(ps)
+        e.set_option("rowsplit", 1)
+        for wpc in (0, 1):
+            e.set_option("wgs_per_cu", wpc)
+            r1, j1 = e.eval(ps)
+            _, j2 = e.eval(ps, want_resid=False)
+            if dtype == "f64":
+                assert np.array_equal(j1, j0) and np.array_equal(r1, r0) and np.array_equal(j2, j0), n
+            else:
+                assert H.jac_rel_err(j1, j0) <= 2 * H.F32_JAC_RTOL and np.max(np.abs(r1 - r0)) <= 1e-3
+        e.close()
