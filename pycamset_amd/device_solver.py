@@ -114,15 +114,20 @@ class DeviceLMResult:
 
 
 def lm_solve(handler, x0, *, max_iter: int = 50, ftol: float = 1e-8, xtol: float = 1e-8, gtol: float = 1e-8,
-             cg_tol: float = 1e-3, cg_max_iter: int = 200, lam0: float = 1e-3, reduce_fn=None, verbose: int = 0) -> DeviceLMResult:
+             cg_tol: float = 1e-3, cg_max_iter: int = 200, lam0: float = 1e-3, reduce_fn=None, verbose: int = 0,
+             operator: JacobianOperator | None = None) -> DeviceLMResult:
     """Levenberg-Marquardt (Marquardt scaling D = diag(J^T J), damped normal equations solved by
     Jacobi-PCG on matrix-free J^T J products) for a pycamset_amd handler.  Every quantity that
-    depends on the detections is computed by the HIP engine; the host only does n_free-vector algebra."""
+    depends on the detections is computed by the HIP engine; the host only does n_free-vector algebra.
+    ``operator`` replaces the engine-backed JacobianOperator (used by the CPU tests of this driver)."""
     op_fun = handler.op_fun
-    dd = handler._flat_detections()
-    eng = op_fun._engine_for(dd)
-    op_fun._bind_template(eng, handler._template_arg())
-    op = JacobianOperator(eng, handler._jac_mask(), reduce_fn=reduce_fn)
+    if operator is not None:
+        op = operator
+    else:
+        dd = handler._flat_detections()
+        eng = op_fun._engine_for(dd)
+        op_fun._bind_template(eng, handler._template_arg())
+        op = JacobianOperator(eng, handler._jac_mask(), reduce_fn=reduce_fn)
 
     def param_str(x):
         return op_fun.build_param_list(*handler.get_bundle_adjustment_inputs(x))
