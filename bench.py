@@ -130,6 +130,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-allgather-probe", action="store_true")
+    ap.add_argument("--stream-to-host", action="store_true",
+                    help="config-5 mode: every step also copies the Jacobian to page-locked host memory on a side "
+                         "stream (double buffered); the step rate is then PCIe-bound and reported as such")
     ap.add_argument("--host-path", action="store_true",
                     help="also time the host-buffer boundary (pcs_eval: H2D params + kernels + D2H of residual and Jacobian); "
                          "reported under 'host_boundary', never in 'value'")
@@ -205,7 +208,30 @@ def main():
     use_gather_in_step = args.collective == "allgather" and world > 1
     out_r, out_j = (pad_r, pad_j) if use_gather_in_step else (d_r, d_j)
 
+    host_ring = None
+    if args.stream_to_host:
+        # two device buffers + two pinned host buffers: the copy of step i overlaps the kernel of step i+1
+        copy_stream = torch.cuda.Stream(dev)
+        dev_bufs = [d_j, torch.empty_like(d_j)]
+        host_ring = [torch.empty(d_j.shape, dtype=tdt, pin_memory=True) for _ in range(2)]
+        ev_done = [torch.cuda.Event() for _ in range(2)]   # kernel finished writing dev_bufs[b]
+        ev_free = [torch.cuda.Event() for _ in range(2)]   # copy out of dev_bufs[b] finished
+        for e_ in ev_free:
+            e_.record(copy_stream)
+        step_no = [0]
+
     def step():
+        if host_ring is not None:
+            b = step_no[0] & 1
+            step_no[0] += 1
+            torch.cuda.current_stream(dev).wait_event(ev_free[b])
+            eng.eval_device_resident(d_p.data_ptr(), out_r.data_ptr(), dev_bufs[b].data_ptr(), stream)
+            ev_done[b].record(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(copy_stream):
+                copy_stream.wait_event(ev_done[b])
+                host_ring[b].copy_(dev_bufs[b], non_blocking=True)
+                ev_free[b].record(copy_stream)
+            return
         eng.eval_device_resident(d_p.data_ptr(), out_r.data_ptr(), out_j.data_ptr(), stream)
         if use_gather_in_step:
             gather()
@@ -284,6 +310,7 @@ def main():
                 "rows_per_step": 2.0 * n_total,
                 "row_len_P": P,
                 "collective_in_step": args.collective if world > 1 else "none",
+                "jacobian_streamed_to_host": bool(args.stream_to_host),
                 "parallelism": f"obs-shard x{world}",
             },
             "roofline": {
@@ -302,6 +329,11 @@ def main():
                 "frac_of_measured_copy_peak_6290": achieved / 6290.0,
             },
         }
+        if args.stream_to_host:
+            jb = d_j.numel() * d_j.element_size()
+            line["host_stream"] = {"bytes_per_step_per_gpu": jb, "d2h_GBps_per_gpu": jb * args.steps / elapsed / 1e9,
+                                   "note": "PCIe-bound: the Jacobian of every step is copied to page-locked host memory "
+                                           "(double buffered, overlapped with the next kernel)"}
         if allgather_info:
             line["allgather"] = allgather_info
         if args.host_path:
