@@ -374,18 +374,27 @@ __global__ __launch_bounds__(WG_THREADS) void ba_compact_kernel(const EvalArgs a
 // Coalesced fixed-parameter compaction: tile-per-wave like ba_eval_kernel.  The kept entries of a
 // tile form one contiguous range of the CSR data array ([row_off[first], row_off[last] + 2*cnt));
 // every lane packs its two rows into the wave-private LDS region at its offset inside that range
-// (two passes of 32 detections), then the wave streams the range out at consecutive addresses
-// (8-byte units: a row offset need not be 16-byte aligned).
+// (two passes of 32 detections), then the wave streams the range out at consecutive addresses.
+//  * The LDS image is shifted by the misalignment of the range's first global element, so that
+//    16-byte LDS units coincide with 16-byte-aligned global units: full units go out as 16-byte
+//    non-temporal stores, only the ragged first / last unit of a pass uses scalar stores.
+//  * Packing is branch-free: entry j goes to slot popcount(keep & ((1 << j) - 1)) of its row, or to a
+//    per-lane dummy slot when the column is fixed or the lane belongs to the other pass (conditional
+//    blocks around the 2P stores would keep the whole Jacobian live in registers, see ba_eval_kernel).
 template <int CHAIN, typename T, int MODE>
 __global__ __launch_bounds__(WG_THREADS) void ba_compact_tile_kernel(const EvalArgs a) {
     constexpr int P = chain_P(CHAIN);
     constexpr int P2 = 2 * P;
     constexpr bool JAC = (MODE & MODE_JAC) != 0;
+    constexpr int VS = 16 / sizeof(T);
+    constexpr int WAVE_LDS = HALF * P2 + VS + 64;  // packed range + alignment shift + one dummy slot per lane
     using V2 = typename Vec2<T>::type;
+    using V16 = __attribute__((ext_vector_type(VS))) T;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
-    T *tr = reinterpret_cast<T *>(smem_raw) + wave * (HALF * P2);
+    T *tr = reinterpret_cast<T *>(smem_raw) + wave * ((WAVE_LDS + VS - 1) / VS * VS);
+    T *dummy = tr + HALF * P2 + VS + lane;
     const T *cam_slab = static_cast<const T *>(a.cam_slab);
     const T *pose_slab = static_cast<const T *>(a.pose_slab);
     const T *points = static_cast<const T *>(a.points);
@@ -411,9 +420,10 @@ __global__ __launch_bounds__(WG_THREADS) void ba_compact_tile_kernel(const EvalA
             __builtin_nontemporal_store(r, valid ? reinterpret_cast<V2 *>(resid) + i : static_cast<V2 *>(a.sink));
         }
         if constexpr (JAC) {
-            const uint32_t keep = valid ? a.keep[ic] : 0u;
+            const uint32_t keep_raw = a.keep[ic];
+            const uint32_t keep = valid ? keep_raw : 0u;
             const int cnt = __popc(keep);
-            const int64_t off = a.row_off[ic] + (valid ? 0 : 2 * (int64_t)__popc(a.keep[ic]));  // tail lanes: end of data
+            const int64_t off = a.row_off[ic] + (valid ? 0 : 2 * (int64_t)__popc(keep_raw));  // tail lanes: end of data
             const int64_t off0 = __shfl(off, 0);                  // first entry of the tile
             const int lo = (int)(off - off0);                     // this detection's offset inside the tile range
             const int mid = __shfl(lo, HALF);                     // pass boundary
@@ -421,25 +431,34 @@ __global__ __launch_bounds__(WG_THREADS) void ba_compact_tile_kernel(const EvalA
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int s0 = h ? mid : 0;
-                const int s1 = h ? end : mid;
-                if ((lane >> 5) == h) {
-                    T *ru = tr + (lo - s0);
-                    T *rv = ru + cnt;
-                    int o = 0;
+                const int len = (h ? end : mid) - s0;
+                T *g0 = data + off0 + s0;                                              // first global element of the pass
+                const int mis = (int)((reinterpret_cast<uintptr_t>(g0) / sizeof(T)) & (VS - 1));
+                const bool mine = (lane >> 5) == h;
+                T *ru = tr + mis + (lo - s0);
+                T *rv = ru + cnt;
 #pragma unroll
-                    for (int j = 0; j < P; ++j) {
-                        if (keep & (1u << j)) {
-                            ru[o] = J[j];
-                            rv[o] = J[P + j];
-                            ++o;
-                        }
-                    }
+                for (int j = 0; j < P; ++j) {
+                    const bool on = mine && ((keep >> j) & 1u);
+                    const int pos = __popc(keep & ((1u << j) - 1u));
+                    *(on ? ru + pos : dummy) = J[j];
+                    *(on ? rv + pos : dummy) = J[P + j];
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                T *dst = data + off0 + s0;
-                for (int e = lane; e < s1 - s0; e += 64) __builtin_nontemporal_store(tr[e], dst + e);
+                T *gal = g0 - mis;                                                     // 16-byte aligned
+                const int n_units = (mis + len + VS - 1) / VS;
+                for (int q = lane; q < n_units; q += 64) {
+                    const int e0 = q * VS;
+                    if (e0 >= mis && e0 + VS <= mis + len) {
+                        __builtin_nontemporal_store(reinterpret_cast<const V16 *>(tr)[q], reinterpret_cast<V16 *>(gal + e0));
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < VS; ++t)
+                            if (e0 + t >= mis && e0 + t < mis + len) gal[e0 + t] = tr[e0 + t];
+                    }
+                }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1106,7 +1125,9 @@ static int enqueue_eval(pcs_engine *h, const double *d_prm, void *d_resid, void 
             tpw = std::max<int64_t>(WAVES_PER_WG, (tpw + WAVES_PER_WG - 1) / WAVES_PER_WG * WAVES_PER_WG);
             a.tiles_per_wg = (int32_t)tpw;
             const int64_t grid = (a.n_tiles + tpw - 1) / tpw;
-            const size_t lds = (mode & MODE_JAC) ? h->esize * (size_t)WAVES_PER_WG * HALF * 2 * h->P : 0;
+            const size_t vs = 16 / h->esize;
+            const size_t wave_lds = ((size_t)HALF * 2 * h->P + vs + 64 + vs - 1) / vs * vs;  // scalars, as in the kernel
+            const size_t lds = (mode & MODE_JAC) ? h->esize * (size_t)WAVES_PER_WG * wave_lds : 0;
             e = h->dtype == PCS_F64 ? launch_compact_tile_t<double>(h->chain, mode, a, dim3((unsigned)grid), lds, s)
                                     : launch_compact_tile_t<float>(h->chain, mode, a, dim3((unsigned)grid), lds, s);
         }
