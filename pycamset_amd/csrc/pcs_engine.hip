@@ -375,9 +375,11 @@ __global__ __launch_bounds__(WG_THREADS) void ba_compact_kernel(const EvalArgs a
 // tile form one contiguous range of the CSR data array ([row_off[first], row_off[last] + 2*cnt));
 // every lane packs its two rows into the wave-private LDS region at its offset inside that range
 // (two passes of 32 detections), then the wave streams the range out at consecutive addresses.
-//  * The LDS image is shifted by the misalignment of the range's first global element, so that
-//    16-byte LDS units coincide with 16-byte-aligned global units: full units go out as 16-byte
-//    non-temporal stores, only the ragged first / last unit of a pass uses scalar stores.
+//  * The LDS image is shifted by the offset of the range's first global element inside its 128-byte
+//    line, so that the 1 KiB window of every store instruction starts on a line boundary: each
+//    instruction writes 8 whole lines (a window that straddles lines leaves one line in eight written
+//    by two different non-temporal instructions, which cost 20 us at N = 1e6); only the ragged first /
+//    last unit of a pass uses scalar stores.
 //  * Packing is branch-free: entry j goes to slot popcount(keep & ((1 << j) - 1)) of its row, or to a
 //    per-lane dummy slot when the column is fixed or the lane belongs to the other pass (conditional
 //    blocks around the 2P stores would keep the whole Jacobian live in registers, see ba_eval_kernel).
@@ -387,14 +389,15 @@ __global__ __launch_bounds__(WG_THREADS) void ba_compact_tile_kernel(const EvalA
     constexpr int P2 = 2 * P;
     constexpr bool JAC = (MODE & MODE_JAC) != 0;
     constexpr int VS = 16 / sizeof(T);
-    constexpr int WAVE_LDS = HALF * P2 + VS + 64;  // packed range + alignment shift + one dummy slot per lane
+    constexpr int LINE = 128 / sizeof(T);            // scalars per 128-byte line
+    constexpr int WAVE_LDS = HALF * P2 + LINE + 64;  // packed range + alignment shift + one dummy slot per lane
     using V2 = typename Vec2<T>::type;
     using V16 = __attribute__((ext_vector_type(VS))) T;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
     T *tr = reinterpret_cast<T *>(smem_raw) + wave * ((WAVE_LDS + VS - 1) / VS * VS);
-    T *dummy = tr + HALF * P2 + VS + lane;
+    T *dummy = tr + HALF * P2 + LINE + lane;
     const T *cam_slab = static_cast<const T *>(a.cam_slab);
     const T *pose_slab = static_cast<const T *>(a.pose_slab);
     const T *points = static_cast<const T *>(a.points);
@@ -433,7 +436,7 @@ __global__ __launch_bounds__(WG_THREADS) void ba_compact_tile_kernel(const EvalA
                 const int s0 = h ? mid : 0;
                 const int len = (h ? end : mid) - s0;
                 T *g0 = data + off0 + s0;                                              // first global element of the pass
-                const int mis = (int)((reinterpret_cast<uintptr_t>(g0) / sizeof(T)) & (VS - 1));
+                const int mis = (int)((reinterpret_cast<uintptr_t>(g0) / sizeof(T)) & (LINE - 1));
                 const bool mine = (lane >> 5) == h;
                 T *ru = tr + mis + (lo - s0);
                 T *rv = ru + cnt;
@@ -447,7 +450,7 @@ __global__ __launch_bounds__(WG_THREADS) void ba_compact_tile_kernel(const EvalA
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                T *gal = g0 - mis;                                                     // 16-byte aligned
+                T *gal = g0 - mis;                                                     // 128-byte aligned
                 const int n_units = (mis + len + VS - 1) / VS;
                 for (int q = lane; q < n_units; q += 64) {
                     const int e0 = q * VS;
@@ -1126,7 +1129,7 @@ static int enqueue_eval(pcs_engine *h, const double *d_prm, void *d_resid, void 
             a.tiles_per_wg = (int32_t)tpw;
             const int64_t grid = (a.n_tiles + tpw - 1) / tpw;
             const size_t vs = 16 / h->esize;
-            const size_t wave_lds = ((size_t)HALF * 2 * h->P + vs + 64 + vs - 1) / vs * vs;  // scalars, as in the kernel
+            const size_t wave_lds = ((size_t)HALF * 2 * h->P + 128 / h->esize + 64 + vs - 1) / vs * vs;  // scalars, as in the kernel
             const size_t lds = (mode & MODE_JAC) ? h->esize * (size_t)WAVES_PER_WG * wave_lds : 0;
             e = h->dtype == PCS_F64 ? launch_compact_tile_t<double>(h->chain, mode, a, dim3((unsigned)grid), lds, s)
                                     : launch_compact_tile_t<float>(h->chain, mode, a, dim3((unsigned)grid), lds, s);
