@@ -1,8 +1,13 @@
-"""Caller of the path: pyCamSet optimisation/optimisation_handling.py:24-117, kept in Python.
+"""The caller of the path, kept in Python like the reference
+(pyCamSet optimisation/optimisation_handling.py:24-117).
 
-``run_bundle_adjustment`` hands the handler's closures to ``scipy.optimize.least_squares`` with the
-same keyword arguments as the reference (oh:88-98).  The reference then rebuilds a CameraSet
-(oh:109); that data model is outside the path, so the full parameter slabs are returned instead.
+``make_optimisation_function`` returns the handler's two closures plus the start vector;
+``run_bundle_adjustment`` feeds them to ``scipy.optimize.least_squares`` with the reference's
+keyword arguments (jac = the CSR closure, ``x_scale='jac'``, ``max_nfev`` and ``verbose`` from the
+handler's options, oh:88-98).  The reference finishes by rebuilding a ``CameraSet`` (oh:109); that
+data model is outside the accelerated path, so the full parameter slabs at the solution are
+returned instead.  ``solver='device'`` swaps scipy for ``device_solver.lm_solve`` (the Jacobian never
+leaves the GPU).
 """
 from __future__ import annotations
 
@@ -12,37 +17,44 @@ import time
 import numpy as np
 from scipy.optimize import least_squares
 
-
-def make_optimisation_function(param_handler, threads: int = 1):  # oh:24-49
-    init_params = param_handler.get_initial_params()
-    bundle_loss_fun = param_handler.make_loss_fun(threads)
-    bundle_loss_jac = param_handler.make_loss_jac(threads) if param_handler.can_make_jac() else None
-    return bundle_loss_fun, bundle_loss_jac, init_params
+log = logging.getLogger(__name__)
 
 
-def run_bundle_adjustment(param_handler, threads: int = 1):  # oh:52-117
-    loss_fn, bundle_jac, init_params = make_optimisation_function(param_handler, threads)
-    init_err = loss_fn(init_params)
-    init_euclid = np.mean(np.linalg.norm(np.reshape(init_err, (-1, 2)), axis=1))
-    logging.info(f"found {len(init_params):.2e} parameters")
-    logging.info(f"found {len(init_err):.2e} control points")
-    logging.info(f"Initial Euclidean error: {init_euclid:.2f} px")
-    if (init_euclid > 150) or np.isnan(init_euclid):
-        logging.critical("Found worryingly high/NaN initial error: check that the initial parametisation is sensible")
-    start = time.time()
-    optimisation = least_squares(
-        loss_fn,
-        init_params,
-        verbose=param_handler.problem_opts["verbosity"],
-        jac=bundle_jac if bundle_jac is not None else "2-point",
-        max_nfev=param_handler.problem_opts["max_nfev"],
-        x_scale="jac",
-    )
-    end = time.time()
-    final_euclid = np.mean(np.linalg.norm(np.reshape(optimisation.fun, (-1, 2)), axis=1))
-    logging.info(f"Final Euclidean error: {final_euclid:.2f} px")
-    logging.info(f"Optimisation took {end - start: .2f} seconds.")
-    if final_euclid > 5:
-        logging.critical("Remaining error is very large: please check the output results")
-    slabs = tuple(np.array(a) for a in param_handler.get_bundle_adjustment_inputs(optimisation.x))
-    return optimisation, slabs
+def mean_reprojection_error(residuals: np.ndarray) -> float:
+    """Mean Euclidean pixel error of a flat residual vector [u0, v0, u1, v1, ...] (the figure the
+    reference logs before and after the solve, oh:66-70, oh:101-103)."""
+    uv = np.asarray(residuals, dtype=np.float64).reshape(-1, 2)
+    return float(np.hypot(uv[:, 0], uv[:, 1]).mean())
+
+
+def make_optimisation_function(param_handler, threads: int = 1):
+    """(loss_fn, jac_fn | None, x0) — oh:24-49."""
+    x0 = param_handler.get_initial_params()
+    loss_fn = param_handler.make_loss_fun(threads)
+    jac_fn = param_handler.make_loss_jac(threads) if param_handler.can_make_jac() else None
+    return loss_fn, jac_fn, x0
+
+
+def run_bundle_adjustment(param_handler, threads: int = 1, solver: str = "scipy"):
+    """Solve the handler's problem; returns (result, parameter slabs at the solution) — oh:52-117."""
+    loss_fn, jac_fn, x0 = make_optimisation_function(param_handler, threads)
+    opts = param_handler.problem_opts
+    start_error = mean_reprojection_error(loss_fn(x0))
+    log.info("%d parameters, %d residuals, start error %.2f px", len(x0), 2 * param_handler._flat_detections().shape[0], start_error)
+    if not np.isfinite(start_error) or start_error > 150:  # the reference's sanity threshold (oh:80-83)
+        log.critical("start error is very high or not finite: check the initial parameters")
+    tic = time.perf_counter()
+    if solver == "device":
+        from .device_solver import lm_solve
+
+        result = lm_solve(param_handler, x0, max_iter=opts["max_nfev"])
+        end_error = mean_reprojection_error(loss_fn(result.x))
+    else:
+        result = least_squares(loss_fn, x0, jac=jac_fn if jac_fn is not None else "2-point", x_scale="jac",
+                               max_nfev=opts["max_nfev"], verbose=opts["verbosity"])
+        end_error = mean_reprojection_error(result.fun)
+    log.info("solved in %.2f s, final error %.2f px", time.perf_counter() - tic, end_error)
+    if end_error > 5:  # oh:105-107
+        log.critical("remaining error is very large: check the result")
+    slabs = tuple(np.array(a) for a in param_handler.get_bundle_adjustment_inputs(result.x))
+    return result, slabs

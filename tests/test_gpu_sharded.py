@@ -1,0 +1,114 @@
+"""Two ranks sharing the one GPU of the test box (gloo for the control plane; RCCL needs one GPU per
+rank): the real engine evaluates each rank's shard; gathered blocks and all-reduced normal-equation
+products must equal the single-process results, and the sharded device LM must land on the same cost."""
+import os
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+REPO = Path(__file__).resolve().parent.parent
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+class _Camset:
+    def __init__(self, n):
+        self.names = [f"cam_{i}" for i in range(n)]
+
+    def get_names(self):
+        return list(self.names)
+
+    def get_n_cams(self):
+        return len(self.names)
+
+
+class _Target:
+    def __init__(self, pts):
+        self.point_data = np.asarray(pts)[None]
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, str(REPO))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pycamset_amd import handlers, sharding, synthetic
+        from pycamset_amd.detections import TargetDetection
+        from pycamset_amd.device_solver import JacobianOperator, lm_solve
+        from pycamset_amd.engine import Engine
+
+        rig = synthetic.make_rig("ring-8-small", 8, 12, synthetic.charuco_points(9, 8.0), seed=21, visibility=0.8)
+        det = rig.detections
+        counts = (rig.n_cams, rig.n_imgs, rig.n_keys)
+        ps = np.concatenate([rig.intr.ravel(), rig.extr.ravel(), rig.poses.ravel()])
+
+        # (1) sharded evaluation + gather (blocks moved to the host for gloo)
+        local = sharding.make_engine_eval("template", det, counts, rig.points, rank=rank, world=world)
+
+        def local_cpu(p, want_resid=True, want_jac=True):
+            r, j = local(p, want_resid, want_jac)
+            torch.cuda.synchronize()
+            return (r.cpu() if r is not None else None), (j.cpu() if j is not None else None)
+
+        ev = sharding.ShardedEvaluator(det.shape[0], 21, local_cpu)
+        r, j = ev.eval_gathered(ps)
+        full = Engine("template", *counts)
+        full.set_detections_table(det)
+        full.set_template(rig.points)
+        r0, j0 = full.eval(ps)
+        assert np.array_equal(r.numpy(), r0) and np.array_equal(j.numpy(), j0)
+
+        # (2) all-reduced matrix-free products on unpadded shards == single-process products
+        per = sharding.shard_rows(det.shape[0], world)
+        mine = det[rank * per:(rank + 1) * per]
+        eng = Engine("template", *counts)
+        eng.set_detections_table(mine)
+        eng.set_template(rig.points)
+        mask = np.ones(ps.shape[0], bool)
+        mask[15 * rig.n_cams: 15 * rig.n_cams + 6] = False
+        op = JacobianOperator(eng, mask, reduce_fn=sharding.allreduce_sum_fn())
+        ref = JacobianOperator(full, mask)
+        op.linearize(ps)
+        ref.linearize(ps)
+        v = np.random.default_rng(0).standard_normal(op.n_free)
+        for a, b in ((op.jtjv(v), ref.jtjv(v)), (op.diag(), ref.diag()), (op.grad()[0], ref.grad()[0])):
+            assert np.max(np.abs(a - b)) <= 1e-10 * np.max(np.abs(b))
+
+        # (3) sharded device LM: every rank holds a handler over its shard with the GLOBAL layout
+        names = [f"cam_{i}" for i in range(rig.n_cams)]
+
+        def handler(rows):
+            return handlers.TemplateBundleHandler(_Camset(rig.n_cams), _Target(rig.points),
+                                                  TargetDetection(names, rows, max_ims=rig.n_imgs),
+                                                  fixed_params={"cam_0": {"ext": rig.extr_true[0].copy()}},
+                                                  options={"verbosity": 0}, counts=counts)
+
+        h_shard, h_full = handler(mine), handler(det)
+        bp = h_full.bundlePrimitive
+        x0 = np.concatenate([rig.intr[bp.intr_unfixed].ravel(), rig.extr[bp.extr_unfixed].ravel(), rig.poses[bp.poses_unfixed].ravel()])
+        res = lm_solve(h_shard, x0.copy(), max_iter=20, reduce_fn=sharding.allreduce_sum_fn())
+        one = lm_solve(h_full, x0.copy(), max_iter=20)
+        assert abs(res.cost - one.cost) <= 1e-5 * one.cost and res.cost < 0.01 * res.history[0]
+        gathered = [None] * world
+        dist.all_gather_object(gathered, res.x)
+        assert all(np.array_equal(gathered[0], g) for g in gathered)      # every rank walked the same path
+        Path(out_dir, f"ok{rank}").write_text("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(world))
