@@ -65,6 +65,7 @@ struct EvalArgs {
     int64_t n;
     int32_t n_cams, n_imgs, n_keys;
     int32_t tiles_per_wg;
+    int32_t xcd_remap;      // 1: workgroups that share an XCD (blockIdx % 8) take one contiguous eighth of the tiles
     int64_t n_tiles;
     // compaction (ba_compact_kernel only)
     void *sink;              // 64 B scratch: tail lanes store their (unused) residual here, so the store needs no branch
@@ -165,7 +166,15 @@ __global__ __launch_bounds__(WG_THREADS) void ba_eval_kernel(const EvalArgs a) {
     const int lane = threadIdx.x & 63;
     T *tr = smem + lds_used + wave * (HALF * P2);  // wave-private transpose region (TRANSPOSE only)
 
-    const int64_t tile0 = (int64_t)blockIdx.x * a.tiles_per_wg;
+    // Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 labels the XCD group).  With
+    // xcd_remap each group walks one contiguous eighth of the table (bijective remap, any grid size);
+    // this is a locality experiment only — the stream has no inter-workgroup reuse beyond the slabs.
+    int64_t wg = blockIdx.x;
+    if (a.xcd_remap) {
+        const int64_t nwg = gridDim.x, q = nwg / 8, r = nwg % 8, x = wg % 8;
+        wg = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + wg / 8;
+    }
+    const int64_t tile0 = wg * a.tiles_per_wg;
     const int64_t tile1 = min(tile0 + (int64_t)a.tiles_per_wg, a.n_tiles);
     const V2 *uv = static_cast<const V2 *>(a.uv);
     T *resid = static_cast<T *>(a.resid);
@@ -602,6 +611,7 @@ struct pcs_engine {
     int64_t wgs_per_cu = 0;
     int compact_variant = 1;     // 1 = tile kernel with coalesced stores, 0 = per-lane stores
     bool rowsplit = false;       // two lanes per detection (ba_eval_rowsplit_kernel)
+    bool xcd_remap = false;      // contiguous eighth of the table per XCD group (experiment; no measured effect)
     double tile_locality = 1.0;  // fraction of 64-detection tiles touching <= 2 distinct (cam, image) pairs
     int64_t tiles_per_wg = 0;  // 0 = derive from wgs_per_cu
     size_t lds_limit = 160 * 1024;
@@ -911,6 +921,8 @@ int pcs_set_option(pcs_engine *h, const char *key, int64_t value) {
         if (value < 0 || value > 1000000) return fail(PCS_ERR_ARG, "timing_every must be in [0,1000000]");
         h->timing_every = value;
         h->eval_count = 0;
+    } else if (!strcmp(key, "xcd_remap")) {
+        h->xcd_remap = value != 0;
     } else if (!strcmp(key, "rowsplit")) {
         h->rowsplit = value != 0;
     } else if (!strcmp(key, "matfree_lds")) {
@@ -1111,6 +1123,7 @@ static int enqueue_eval(pcs_engine *h, const double *d_prm, void *d_resid, void 
     a.cam = h->d_cam; a.img = h->d_img; a.key = h->d_key; a.uv = h->d_uv;
     a.cam_slab = h->d_cam_slab; a.pose_slab = h->d_pose_slab; a.points = h->d_points;
     a.resid = d_resid; a.jac = d_out; a.sink = h->d_sink;
+    a.xcd_remap = h->xcd_remap ? 1 : 0;
     a.n = h->n; a.n_cams = (int32_t)h->n_cams; a.n_imgs = (int32_t)h->n_imgs; a.n_keys = (int32_t)h->n_keys;
     a.n_tiles = (h->n + TILE - 1) / TILE;
     if (compact) {

@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--shuffle", action="store_true", help="random detection order (worst case for slab locality)")
     ap.add_argument("--mode", default="both", choices=["both", "jac", "resid"])
     ap.add_argument("--tag", default="")
+    ap.add_argument("--xcd", default="0", help="comma list of 0/1: XCD-contiguous tile remap")
     ap.add_argument("--rowsplit", default="0", help="comma list of 0/1: also sweep the row-split kernel")
     a = ap.parse_args()
     rig = synthetic.config_rig(a.config)
@@ -47,11 +48,11 @@ def main():
     d_p = torch.from_numpy(ps).cuda()
     pr = d_r.data_ptr() if a.mode in ("both", "resid") else None
     pj = d_j.data_ptr() if a.mode in ("both", "jac") else None
-    combos = [(int(v), int(w), int(rs)) for rs in a.rowsplit.split(",") for v in a.variants.split(",") for w in a.wgs.split(",")]
+    combos = [(int(v), int(w), int(rs), int(x)) for x in a.xcd.split(",") for rs in a.rowsplit.split(",") for v in a.variants.split(",") for w in a.wgs.split(",")]
     times = {c: [] for c in combos}
     for rnd in range(a.rounds + 1):
         for c in combos:
-            e.set_option("variant", c[0]); e.set_option("wgs_per_cu", c[1]); e.set_option("rowsplit", c[2])
+            e.set_option("variant", c[0]); e.set_option("wgs_per_cu", c[1]); e.set_option("rowsplit", c[2]); e.set_option("xcd_remap", c[3])
             for _ in range(3):
                 e.eval_device_resident(d_p.data_ptr(), pr, pj)
             e.synchronize()
@@ -63,8 +64,8 @@ def main():
     for c in combos:
         med, mn = float(np.median(times[c])), float(np.min(times[c]))
         gbs = N * bpd / (med * 1e-3) / 1e9
-        print(f"rowsplit {c[2]} variant {c[0]} wgs/cu {c[1]:3d}: median {med*1e3:8.1f} us  min {mn*1e3:8.1f} us  {gbs:7.1f} GB/s  {gbs/80:.1f}% of 8 TB/s")
-        out[f"rs{c[2]}_v{c[0]}_w{c[1]}"] = {"median_us": med * 1e3, "min_us": mn * 1e3, "GBps": gbs}
+        print(f"xcd {c[3]} rowsplit {c[2]} variant {c[0]} wgs/cu {c[1]:3d}: median {med*1e3:8.1f} us  min {mn*1e3:8.1f} us  {gbs:7.1f} GB/s  {gbs/80:.1f}% of 8 TB/s")
+        out[f"x{c[3]}_rs{c[2]}_v{c[0]}_w{c[1]}"] = {"median_us": med * 1e3, "min_us": mn * 1e3, "GBps": gbs}
     Path("gpurun_out").mkdir(exist_ok=True)
     json.dump(out, open(f"gpurun_out/sweep_{a.config}_{a.chain}_{a.dtype}{'_shuf' if a.shuffle else ''}_{a.mode}{a.tag}.json", "w"), indent=1)
 
