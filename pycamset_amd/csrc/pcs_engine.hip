@@ -4,15 +4,8 @@
 // The path is an HBM-write-bound stream (380 B/detection for the FP64 template chain, of which
 // 352 B are stores); there is no dense contraction, so no MFMA.  See DESIGN.md.
 //
-// Kernels
-//   slab_prep_kernel   K0: one thread per camera / pose -> R, t, dR/dr slabs (ba_device.hpp);
-//                      also narrows / copies the 3-D points of chains SELF / FREE.
-//   ba_eval_kernel     K1-K4: fused residual + dense 2xP Jacobian block per detection.
-//                      One lane owns one detection of a 64-detection tile; slabs + points are
-//                      staged in LDS (or read through L1/L2 when they do not fit); the
-//                      Jacobian tile is transposed through LDS so that every store instruction
-//                      writes 1 KiB of consecutive addresses.
-//   ba_compact_kernel  same maths, writes only unfixed columns at static CSR offsets.
+// Kernels: ba_kernels.hpp (evaluation, compaction, legacy cost), ba_matfree.hpp (J products without J),
+// ba_triangulate.hpp; device maths: ba_device.hpp.  This file: launch plumbing + the C ABI.
 #include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
 
@@ -26,513 +19,9 @@
 
 #include "../../include/pcs_hip.h"
 #include "ba_device.hpp"
+#include "ba_kernels.hpp"
 #include "ba_matfree.hpp"
 #include "ba_triangulate.hpp"
-
-namespace pcs {
-
-// ---------------------------------------------------------------------------------------------
-// small helpers
-// ---------------------------------------------------------------------------------------------
-// clang ext vectors (the nontemporal builtins reject HIP's double2 / float2 structs)
-template <typename T> struct Vec2 { using type = __attribute__((ext_vector_type(2))) T; };
-
-// widest naturally aligned chunk the Jacobian row of one detection allows
-//   double: row = 2P*8 B, always a multiple of 16 -> 16-byte chunks (2 scalars)
-//   float : row = 2P*4 B, multiple of 8 only (P = 21)   ->  8-byte chunks (2 scalars)
-template <typename T> using Chunk = typename Vec2<T>::type;
-
-constexpr int MODE_RESID = 1;
-constexpr int MODE_JAC = 2;
-
-constexpr int VAR_SLAB_LDS = 1;   // stage slabs + points in LDS
-constexpr int VAR_TRANSPOSE = 2;  // transpose the Jacobian tile through LDS, coalesced stores
-constexpr int VAR_NT = 4;         // non-temporal output stores
-
-constexpr int WG_THREADS = 256;
-constexpr int WAVES_PER_WG = WG_THREADS / 64;
-constexpr int TILE = 64;       // detections per wave tile
-constexpr int HALF = 32;       // detections per transpose pass
-
-struct EvalArgs {
-    const int32_t *cam, *img, *key;
-    const void *uv;         // N x 2 scalars
-    const void *cam_slab;   // n_cams x CAM_STRIDE
-    const void *pose_slab;  // n_imgs x POSE_STRIDE
-    const void *points;     // n_keys x 3 (padded)
-    void *resid;            // N x 2
-    void *jac;              // 2N x P
-    int64_t n;
-    int32_t n_cams, n_imgs, n_keys;
-    int32_t tiles_per_wg;
-    int32_t xcd_remap;      // 1: workgroups that share an XCD (blockIdx % 8) take one contiguous eighth of the tiles
-    int64_t n_tiles;
-    // compaction (ba_compact_kernel only)
-    void *sink;              // 64 B scratch: tail lanes store their (unused) residual here, so the store needs no branch
-    const uint32_t *keep;    // per detection: bit j set = local column j is free
-    const int64_t *row_off;  // per detection: offset of its u row in the CSR data array
-};
-
-template <typename T, bool NT>
-__device__ __forceinline__ void store_out(T *p, T v) {
-    if constexpr (NT) __builtin_nontemporal_store(v, p); else *p = v;
-}
-
-// ---------------------------------------------------------------------------------------------
-// K0  slab preparation
-// ---------------------------------------------------------------------------------------------
-// param_str layout: afb make_param_struct (abstract_function_blocks.py:777-820), see pcs_hip.h.
-template <typename T>
-__global__ void slab_prep_kernel(const double *__restrict__ prm, T *__restrict__ cam_slab, T *__restrict__ pose_slab,
-                                 T *__restrict__ points, int n_cams, int n_imgs, int n_keys, int64_t extr_off,
-                                 int64_t pose_off, int64_t point_off, int has_pose, int copy_points) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < n_cams + (has_pose ? n_imgs : 0)) {
-        const bool is_cam = e < n_cams;
-        const double *p6 = is_cam ? prm + extr_off + 6 * (int64_t)e : prm + pose_off + 6 * (int64_t)(e - n_cams);
-        double R[9], dR[27];
-        rodrigues_and_jac(p6[0], p6[1], p6[2], R, dR);
-        if (is_cam) {
-            T *o = cam_slab + (int64_t)e * CAM_STRIDE;
-#pragma unroll
-            for (int j = 0; j < 9; ++j) o[j] = (T)prm[9 * (int64_t)e + j];
-#pragma unroll
-            for (int j = 0; j < 9; ++j) o[CAM_R + j] = (T)R[j];
-#pragma unroll
-            for (int j = 0; j < 3; ++j) o[CAM_T + j] = (T)p6[3 + j];
-#pragma unroll
-            for (int j = 0; j < 27; ++j) o[CAM_DR + j] = (T)dR[j];
-        } else {
-            T *o = pose_slab + (int64_t)(e - n_cams) * POSE_STRIDE;
-#pragma unroll
-            for (int j = 0; j < 9; ++j) o[POSE_R + j] = (T)R[j];
-#pragma unroll
-            for (int j = 0; j < 3; ++j) o[POSE_T + j] = (T)p6[3 + j];
-#pragma unroll
-            for (int j = 0; j < 27; ++j) o[POSE_DR + j] = (T)dR[j];
-            o[39] = T(0);
-        }
-    }
-    if (copy_points) {
-        const int total = n_keys * 3;
-        for (int j = e; j < total; j += gridDim.x * blockDim.x) points[j] = (T)prm[point_off + j];
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// K1-K4  fused residual + Jacobian
-// ---------------------------------------------------------------------------------------------
-template <int CHAIN, typename T, int MODE, int VARIANT>
-__global__ __launch_bounds__(WG_THREADS) void ba_eval_kernel(const EvalArgs a) {
-    constexpr int P = chain_P(CHAIN);
-    constexpr int P2 = 2 * P;
-    constexpr bool SLAB_LDS = (VARIANT & VAR_SLAB_LDS) != 0;
-    constexpr bool TRANSPOSE = (VARIANT & VAR_TRANSPOSE) != 0;
-    constexpr bool NT = (VARIANT & VAR_NT) != 0;
-    constexpr bool JAC = (MODE & MODE_JAC) != 0;
-    constexpr bool RES = (MODE & MODE_RESID) != 0;
-    using V2 = typename Vec2<T>::type;
-
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    T *smem = reinterpret_cast<T *>(smem_raw);
-
-    const T *cam_slab = static_cast<const T *>(a.cam_slab);
-    const T *pose_slab = static_cast<const T *>(a.pose_slab);
-    const T *points = static_cast<const T *>(a.points);
-    int lds_used = 0;  // scalars
-    if constexpr (SLAB_LDS) {
-        const int n_cam_sc = a.n_cams * CAM_STRIDE;
-        const int n_pose_sc = (CHAIN != CHAIN_FREE) ? a.n_imgs * POSE_STRIDE : 0;
-        const int n_pt_sc = (a.n_keys * 3 + 3) & ~3;  // device buffer is padded to a multiple of 4 scalars
-        // 16-byte cooperative copies (all three regions are multiples of 16 bytes)
-        constexpr int VS = 16 / sizeof(T);
-        using V16 = __attribute__((ext_vector_type(VS))) T;
-        const V16 *g0 = reinterpret_cast<const V16 *>(cam_slab);
-        V16 *l0 = reinterpret_cast<V16 *>(smem);
-        for (int i = threadIdx.x; i < n_cam_sc / VS; i += WG_THREADS) l0[i] = g0[i];
-        const V16 *g1 = reinterpret_cast<const V16 *>(pose_slab);
-        V16 *l1 = reinterpret_cast<V16 *>(smem + n_cam_sc);
-        for (int i = threadIdx.x; i < n_pose_sc / VS; i += WG_THREADS) l1[i] = g1[i];
-        const V16 *g2 = reinterpret_cast<const V16 *>(points);
-        V16 *l2 = reinterpret_cast<V16 *>(smem + n_cam_sc + n_pose_sc);
-        for (int i = threadIdx.x; i < n_pt_sc / VS; i += WG_THREADS) l2[i] = g2[i];
-        cam_slab = smem;
-        pose_slab = smem + n_cam_sc;
-        points = smem + n_cam_sc + n_pose_sc;
-        lds_used = n_cam_sc + n_pose_sc + n_pt_sc;
-        __syncthreads();
-    }
-    const int wave = threadIdx.x >> 6;
-    const int lane = threadIdx.x & 63;
-    T *tr = smem + lds_used + wave * (HALF * P2);  // wave-private transpose region (TRANSPOSE only)
-
-    // Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 labels the XCD group).  With
-    // xcd_remap each group walks one contiguous eighth of the table (bijective remap, any grid size);
-    // this is a locality experiment only — the stream has no inter-workgroup reuse beyond the slabs.
-    int64_t wg = blockIdx.x;
-    if (a.xcd_remap) {
-        const int64_t nwg = gridDim.x, q = nwg / 8, r = nwg % 8, x = wg % 8;
-        wg = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + wg / 8;
-    }
-    const int64_t tile0 = wg * a.tiles_per_wg;
-    const int64_t tile1 = min(tile0 + (int64_t)a.tiles_per_wg, a.n_tiles);
-    const V2 *uv = static_cast<const V2 *>(a.uv);
-    T *resid = static_cast<T *>(a.resid);
-    T *jac = static_cast<T *>(a.jac);
-    const int64_t total_jac = a.n * (int64_t)P2;
-
-    for (int64_t tile = tile0 + wave; tile < tile1; tile += WAVES_PER_WG) {
-        const int64_t i = tile * TILE + lane;
-        const bool valid = i < a.n;
-        const int64_t ic = valid ? i : a.n - 1;  // tail lanes recompute the last detection, store nothing
-        const int c = a.cam[ic], im = a.img[ic], k = a.key[ic];
-        const V2 m = uv[ic];
-        const T *cs = cam_slab + c * CAM_STRIDE;
-        const T *ps = pose_slab + im * POSE_STRIDE;
-        const T X0 = points[3 * k], X1 = points[3 * k + 1], X2 = points[3 * k + 2];
-        T u, v;
-        T J[P2];
-        eval_detection<CHAIN, T, JAC>(cs, ps, X0, X1, X2, u, v, J);
-        if constexpr (RES) {
-            // Branch-free: a conditional block here splits the basic block and makes hipcc keep the whole
-            // slab + Jacobian live across it (226 VGPRs instead of 150); tail lanes write to a sink.
-            V2 r;
-            r.x = u - m.x;   // afb:384  losses = projected - measured
-            r.y = v - m.y;
-            V2 *rp = valid ? reinterpret_cast<V2 *>(resid) + i : static_cast<V2 *>(a.sink);
-            if constexpr (NT) __builtin_nontemporal_store(r, rp);
-            else *rp = r;
-        }
-        if constexpr (JAC) {
-            if constexpr (!TRANSPOSE) {
-                if (valid) {
-                    V2 *row = reinterpret_cast<V2 *>(jac + i * P2);
-#pragma unroll
-                    for (int j = 0; j < P; ++j) {
-                        V2 w;
-                        w.x = J[2 * j];
-                        w.y = J[2 * j + 1];
-                        if constexpr (NT) __builtin_nontemporal_store(w, row + j); else row[j] = w;
-                    }
-                }
-            } else {
-                // Two passes of 32 detections: the active half writes its 2P values row-major into
-                // the wave-private LDS region, then all 64 lanes stream the region out in 16-byte
-                // units at consecutive addresses.  Same-wave LDS ops execute in order; the
-                // wavefront-scope fences only stop the compiler from reordering across them.
-                constexpr int VS = 16 / sizeof(T);  // scalars per 16-byte unit
-                using V16 = __attribute__((ext_vector_type(VS))) T;
-                constexpr int UNITS = HALF * P2 / VS;
-                static_assert((HALF * P2) % VS == 0, "half tile must be a whole number of 16-byte units");
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    if ((lane >> 5) == h) {
-                        V2 *dst = reinterpret_cast<V2 *>(tr + (lane & 31) * P2);
-#pragma unroll
-                        for (int j = 0; j < P; ++j) {
-                            V2 w;
-                            w.x = J[2 * j];
-                            w.y = J[2 * j + 1];
-                            dst[j] = w;
-                        }
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    const int64_t base = (tile * TILE + h * HALF) * (int64_t)P2;  // scalar offset, multiple of VS
-#pragma unroll
-                    for (int q0 = 0; q0 < UNITS; q0 += 64) {
-                        const int q = q0 + lane;
-                        if (q < UNITS) {
-                            const int64_t e = base + (int64_t)q * VS;
-                            if (e + VS <= total_jac) {
-                                const V16 w = reinterpret_cast<const V16 *>(tr)[q];
-                                if constexpr (NT) __builtin_nontemporal_store(w, reinterpret_cast<V16 *>(jac + e));
-                                else *reinterpret_cast<V16 *>(jac + e) = w;
-                            } else {
-                                for (int s = 0; s < VS; ++s)
-                                    if (e + s < total_jac) jac[e + s] = tr[q * VS + s];
-                            }
-                        }
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                }
-            }
-        }
-    }
-}
-
-// Row-split variant of the fused kernel (option "rowsplit"): a wave tile is 32 detections and lanes
-// l / l+32 compute the u / v row of the same detection (eval_detection_row).  Half the Jacobian
-// registers per lane -> 3 waves per SIMD instead of 2, and the transposed store needs one LDS pass
-// instead of two.  Costs ~50 % more VALU work (the shared part of the chain is evaluated by both
-// lanes), which this HBM-bound kernel has to spare.  Slabs are read through L1/L2.
-template <int CHAIN, typename T, int MODE, bool NT>
-__global__ __launch_bounds__(WG_THREADS, 3) void ba_eval_rowsplit_kernel(const EvalArgs a) {
-    constexpr int P = chain_P(CHAIN);
-    constexpr int P2 = 2 * P;
-    constexpr bool RES = (MODE & MODE_RESID) != 0;
-    using V2 = typename Vec2<T>::type;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int wave = threadIdx.x >> 6;
-    const int lane = threadIdx.x & 63;
-    const int d = lane & 31;
-    const bool second = lane >= 32;
-    T *tr = reinterpret_cast<T *>(smem_raw) + wave * (HALF * P2);
-    const T *cam_slab = static_cast<const T *>(a.cam_slab);
-    const T *pose_slab = static_cast<const T *>(a.pose_slab);
-    const T *points = static_cast<const T *>(a.points);
-    const V2 *uv = static_cast<const V2 *>(a.uv);
-    T *resid = static_cast<T *>(a.resid);
-    T *jac = static_cast<T *>(a.jac);
-    const int64_t total_jac = a.n * (int64_t)P2;
-    const int64_t tile0 = (int64_t)blockIdx.x * a.tiles_per_wg;   // tiles of HALF = 32 detections here
-    const int64_t tile1 = min(tile0 + (int64_t)a.tiles_per_wg, a.n_tiles);
-    for (int64_t tile = tile0 + wave; tile < tile1; tile += WAVES_PER_WG) {
-        const int64_t i = tile * HALF + d;
-        const bool valid = i < a.n;
-        const int64_t ic = valid ? i : a.n - 1;
-        const int c = a.cam[ic], im = a.img[ic], k = a.key[ic];
-        const V2 m = uv[ic];
-        T proj;
-        T Jr[P];
-        eval_detection_row<CHAIN, T>(cam_slab + c * CAM_STRIDE, pose_slab + im * POSE_STRIDE, points[3 * k], points[3 * k + 1],
-                                     points[3 * k + 2], second, proj, Jr);
-        if constexpr (RES) {  // branch-free (see ba_eval_kernel)
-            T *rp = valid ? resid + 2 * i + (second ? 1 : 0) : static_cast<T *>(a.sink) + (second ? 1 : 0);
-            store_out<T, NT>(rp, proj - (second ? m.y : m.x));
-        }
-        T *dst = tr + d * P2 + (second ? P : 0);
-#pragma unroll
-        for (int j = 0; j < P; ++j) dst[j] = Jr[j];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        constexpr int VS = 16 / sizeof(T);
-        using V16 = __attribute__((ext_vector_type(VS))) T;
-        constexpr int UNITS = HALF * P2 / VS;
-        const int64_t base = tile * HALF * (int64_t)P2;
-#pragma unroll
-        for (int q0 = 0; q0 < UNITS; q0 += 64) {
-            const int q = q0 + lane;
-            if (q < UNITS) {
-                const int64_t e = base + (int64_t)q * VS;
-                if (e + VS <= total_jac) {
-                    const V16 w = reinterpret_cast<const V16 *>(tr)[q];
-                    if constexpr (NT) __builtin_nontemporal_store(w, reinterpret_cast<V16 *>(jac + e));
-                    else *reinterpret_cast<V16 *>(jac + e) = w;
-                } else {
-                    for (int s = 0; s < VS; ++s)
-                        if (e + s < total_jac) jac[e + s] = tr[q * VS + s];
-                }
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
-}
-
-// Fixed-parameter compaction (replaces `data[:n_elements][good_mask]`, afb:627-651): every lane
-// writes the kept entries of its two rows at the static CSR offsets.  Reads slabs through L1/L2.
-template <int CHAIN, typename T, int MODE>
-__global__ __launch_bounds__(WG_THREADS) void ba_compact_kernel(const EvalArgs a) {
-    constexpr int P = chain_P(CHAIN);
-    constexpr int P2 = 2 * P;
-    using V2 = typename Vec2<T>::type;
-    const T *cam_slab = static_cast<const T *>(a.cam_slab);
-    const T *pose_slab = static_cast<const T *>(a.pose_slab);
-    const T *points = static_cast<const T *>(a.points);
-    const V2 *uv = static_cast<const V2 *>(a.uv);
-    T *resid = static_cast<T *>(a.resid);
-    T *data = static_cast<T *>(a.jac);
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += stride) {
-        const int c = a.cam[i], im = a.img[i], k = a.key[i];
-        const V2 m = uv[i];
-        T u, v;
-        T J[P2];
-        eval_detection<CHAIN, T, (MODE & MODE_JAC) != 0>(cam_slab + c * CAM_STRIDE, pose_slab + im * POSE_STRIDE, points[3 * k],
-                                                          points[3 * k + 1], points[3 * k + 2], u, v, J);
-        if constexpr ((MODE & MODE_RESID) != 0) {
-            V2 r;
-            r.x = u - m.x;
-            r.y = v - m.y;
-            reinterpret_cast<V2 *>(resid)[i] = r;
-        }
-        if constexpr ((MODE & MODE_JAC) != 0) {
-            const uint32_t keep = a.keep[i];
-            const int cnt = __popc(keep);
-            T *ru = data + a.row_off[i];
-            T *rv = ru + cnt;
-            int o = 0;
-#pragma unroll
-            for (int j = 0; j < P; ++j) {
-                if (keep & (1u << j)) {
-                    ru[o] = J[j];
-                    rv[o] = J[P + j];
-                    ++o;
-                }
-            }
-        }
-    }
-}
-
-// Coalesced fixed-parameter compaction: tile-per-wave like ba_eval_kernel.  The kept entries of a
-// tile form one contiguous range of the CSR data array ([row_off[first], row_off[last] + 2*cnt));
-// every lane packs its two rows into the wave-private LDS region at its offset inside that range
-// (two passes of 32 detections), then the wave streams the range out at consecutive addresses.
-//  * The LDS image is shifted by the offset of the range's first global element inside its 128-byte
-//    line, so that the 1 KiB window of every store instruction starts on a line boundary: each
-//    instruction writes 8 whole lines (a window that straddles lines leaves one line in eight written
-//    by two different non-temporal instructions, which cost 20 us at N = 1e6); only the ragged first /
-//    last unit of a pass uses scalar stores.
-//  * Packing is branch-free: entry j goes to slot popcount(keep & ((1 << j) - 1)) of its row, or to a
-//    per-lane dummy slot when the column is fixed or the lane belongs to the other pass (conditional
-//    blocks around the 2P stores would keep the whole Jacobian live in registers, see ba_eval_kernel).
-template <int CHAIN, typename T, int MODE>
-__global__ __launch_bounds__(WG_THREADS) void ba_compact_tile_kernel(const EvalArgs a) {
-    constexpr int P = chain_P(CHAIN);
-    constexpr int P2 = 2 * P;
-    constexpr bool JAC = (MODE & MODE_JAC) != 0;
-    constexpr int VS = 16 / sizeof(T);
-    constexpr int LINE = 128 / sizeof(T);            // scalars per 128-byte line
-    constexpr int WAVE_LDS = HALF * P2 + LINE + 64;  // packed range + alignment shift + one dummy slot per lane
-    using V2 = typename Vec2<T>::type;
-    using V16 = __attribute__((ext_vector_type(VS))) T;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int wave = threadIdx.x >> 6;
-    const int lane = threadIdx.x & 63;
-    T *tr = reinterpret_cast<T *>(smem_raw) + wave * ((WAVE_LDS + VS - 1) / VS * VS);
-    T *dummy = tr + HALF * P2 + LINE + lane;
-    const T *cam_slab = static_cast<const T *>(a.cam_slab);
-    const T *pose_slab = static_cast<const T *>(a.pose_slab);
-    const T *points = static_cast<const T *>(a.points);
-    const V2 *uv = static_cast<const V2 *>(a.uv);
-    T *resid = static_cast<T *>(a.resid);
-    T *data = static_cast<T *>(a.jac);
-    const int64_t tile0 = (int64_t)blockIdx.x * a.tiles_per_wg;
-    const int64_t tile1 = min(tile0 + (int64_t)a.tiles_per_wg, a.n_tiles);
-    for (int64_t tile = tile0 + wave; tile < tile1; tile += WAVES_PER_WG) {
-        const int64_t i = tile * TILE + lane;
-        const bool valid = i < a.n;
-        const int64_t ic = valid ? i : a.n - 1;
-        const int c = a.cam[ic], im = a.img[ic], k = a.key[ic];
-        const V2 m = uv[ic];
-        T u, v;
-        T J[P2];
-        eval_detection<CHAIN, T, JAC>(cam_slab + c * CAM_STRIDE, pose_slab + im * POSE_STRIDE, points[3 * k], points[3 * k + 1],
-                                      points[3 * k + 2], u, v, J);
-        if constexpr ((MODE & MODE_RESID) != 0) {  // branch-free (see ba_eval_kernel)
-            V2 r;
-            r.x = u - m.x;
-            r.y = v - m.y;
-            __builtin_nontemporal_store(r, valid ? reinterpret_cast<V2 *>(resid) + i : static_cast<V2 *>(a.sink));
-        }
-        if constexpr (JAC) {
-            const uint32_t keep_raw = a.keep[ic];
-            const uint32_t keep = valid ? keep_raw : 0u;
-            const int cnt = __popc(keep);
-            const int64_t off = a.row_off[ic] + (valid ? 0 : 2 * (int64_t)__popc(keep_raw));  // tail lanes: end of data
-            const int64_t off0 = __shfl(off, 0);                  // first entry of the tile
-            const int lo = (int)(off - off0);                     // this detection's offset inside the tile range
-            const int mid = __shfl(lo, HALF);                     // pass boundary
-            const int end = __shfl(lo + 2 * cnt, TILE - 1);       // tile range length
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int s0 = h ? mid : 0;
-                const int len = (h ? end : mid) - s0;
-                T *g0 = data + off0 + s0;                                              // first global element of the pass
-                const int mis = (int)((reinterpret_cast<uintptr_t>(g0) / sizeof(T)) & (LINE - 1));
-                const bool mine = (lane >> 5) == h;
-                T *ru = tr + mis + (lo - s0);
-                T *rv = ru + cnt;
-#pragma unroll
-                for (int j = 0; j < P; ++j) {
-                    const bool on = mine && ((keep >> j) & 1u);
-                    const int pos = __popc(keep & ((1u << j) - 1u));
-                    *(on ? ru + pos : dummy) = J[j];
-                    *(on ? rv + pos : dummy) = J[P + j];
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                T *gal = g0 - mis;                                                     // 128-byte aligned
-                const int n_units = (mis + len + VS - 1) / VS;
-                for (int q = lane; q < n_units; q += 64) {
-                    const int e0 = q * VS;
-                    if (e0 >= mis && e0 + VS <= mis + len) {
-                        __builtin_nontemporal_store(reinterpret_cast<const V16 *>(tr)[q], reinterpret_cast<V16 *>(gal + e0));
-                    } else {
-#pragma unroll
-                        for (int t = 0; t < VS; ++t)
-                            if (e0 + t >= mis && e0 + t < mis + len) gal[e0 + t] = tr[e0 + t];
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            }
-        }
-    }
-}
-
-// Legacy residual-only cost (compiled_helpers.py:518-549, used by the initial pose
-// selection template_handler.py:535-592): pre-multiplied 3x4 projection matrices and pre-transformed
-// points im_points[image, key].  cam_tab row (24 scalars): P row-major 12 | fx cx fy cy | k0 k1 p0 p1 k2 | pad.
-constexpr int LEGACY_STRIDE = 24;
-template <typename T>
-__global__ __launch_bounds__(256) void legacy_cost_kernel(const int32_t *__restrict__ cam, const int32_t *__restrict__ img,
-                                                          const int32_t *__restrict__ key, const void *__restrict__ uv_,
-                                                          const T *__restrict__ im_points, const T *__restrict__ cam_tab,
-                                                          T *__restrict__ errors, int64_t n, int64_t n_keys) {
-    using V2 = typename Vec2<T>::type;
-    const V2 *uv = static_cast<const V2 *>(uv_);
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const T *ct = cam_tab + (int64_t)cam[i] * LEGACY_STRIDE;
-        const T *X = im_points + 3 * ((int64_t)img[i] * n_keys + key[i]);
-        const T X0 = X[0], X1 = X[1], X2 = X[2];
-        const V2 m = uv[i];
-        T p0 = ct[0] * X0 + ct[1] * X1 + ct[2] * X2 + ct[3];        // ch:538  P [X;1]
-        T p1 = ct[4] * X0 + ct[5] * X1 + ct[6] * X2 + ct[7];
-        const T p2 = ct[8] * X0 + ct[9] * X1 + ct[10] * X2 + ct[11];
-        p0 = p0 / p2;                                               // ch:539
-        p1 = p1 / p2;
-        const T fx = ct[12], cx = ct[13], fy = ct[14], cy = ct[15];
-        const T k0 = ct[16], k1 = ct[17], q0 = ct[18], q1 = ct[19], k2 = ct[20];
-        const T x = (p0 - cx) / fx, y = (p1 - cy) / fy;             // ch:455
-        const T r2 = x * x + y * y;
-        const T kup = T(1) + k0 * r2 + k1 * (r2 * r2) + k2 * (r2 * r2 * r2);
-        const T xD = x * kup + T(2) * q0 * x * y + q1 * (r2 + T(2) * x * x);
-        const T yD = y * kup + q0 * (r2 + T(2) * y * y) + T(2) * q1 * x * y;
-        V2 e;
-        e.x = (xD * fx + cx) - m.x;                                  // ch:541-542
-        e.y = (yD * fy + cy) - m.y;
-        __builtin_nontemporal_store(e, reinterpret_cast<V2 *>(errors) + i);
-    }
-}
-
-// Streaming probes used to measure the box's achievable HBM rate for THIS access shape
-// (16 B per lane, 1 KiB per wave-instruction): kind 0 plain fill, 1 non-temporal fill, 2 plain copy,
-// 3 non-temporal copy.  Reported next to the 8 TB/s spec figure in DESIGN.md.
-template <int KIND>
-__global__ __launch_bounds__(256) void membench_kernel(const double2 *__restrict__ src, double2 *__restrict__ dst, int64_t n16) {
-    using V = __attribute__((ext_vector_type(2))) double;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    V *d = reinterpret_cast<V *>(dst);
-    const V *s = reinterpret_cast<const V *>(src);
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) {
-        V v;
-        if constexpr (KIND >= 2) v = (KIND == 3) ? __builtin_nontemporal_load(s + i) : s[i];
-        else { v.x = (double)i; v.y = 1.0; }
-        if constexpr (KIND == 1 || KIND == 3) __builtin_nontemporal_store(v, d + i); else d[i] = v;
-    }
-}
-
-}  // namespace pcs
 
 // ---------------------------------------------------------------------------------------------
 // host side
@@ -777,22 +266,32 @@ int pcs_create(pcs_engine **out, int chain, int dtype, int64_t n_cams, int64_t n
     h->n_params = chain == PCS_CHAIN_TEMPLATE ? 15 * n_cams + 6 * n_imgs
                   : chain == PCS_CHAIN_SELF   ? 15 * n_cams + 6 * n_imgs + 3 * n_keys
                                               : 15 * n_cams + 3 * n_keys;
+#define CREATE_CHK(expr)                                                                           \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) {                                                                    \
+            int _rc = fail(PCS_ERR_HIP, "%s failed: %s (pcs_create)", #expr, hipGetErrorString(_e)); \
+            pcs_destroy(h); /* releases whatever was allocated so far */                           \
+            return _rc;                                                                            \
+        }                                                                                          \
+    } while (0)
     hipDeviceProp_t prop;
-    HIPCHK(hipGetDeviceProperties(&prop, device));
+    CREATE_CHK(hipGetDeviceProperties(&prop, device));
     h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     h->lds_limit = prop.maxSharedMemoryPerMultiProcessor > 0 ? prop.maxSharedMemoryPerMultiProcessor
                    : prop.sharedMemPerBlock > 0            ? prop.sharedMemPerBlock
                                                            : 64 * 1024;
-    HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    CREATE_CHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     h->ev.assign(3, nullptr);
-    for (auto &e : h->ev) HIPCHK(hipEventCreate(&e));
-    HIPCHK(hipMalloc(&h->d_param, sizeof(double) * h->n_params));
-    HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&h->h_param), sizeof(double) * h->n_params, hipHostMallocDefault));
-    HIPCHK(hipMalloc(&h->d_cam_slab, h->esize * n_cams * CAM_STRIDE));
-    HIPCHK(hipMalloc(&h->d_pose_slab, h->esize * std::max<int64_t>(1, h->n_imgs) * POSE_STRIDE));
-    HIPCHK(hipMalloc(&h->d_points, h->esize * padded_points(n_keys)));
-    HIPCHK(hipMemset(h->d_points, 0, h->esize * padded_points(n_keys)));
-    HIPCHK(hipMalloc(&h->d_sink, 64));
+    for (auto &e : h->ev) CREATE_CHK(hipEventCreate(&e));
+    CREATE_CHK(hipMalloc(&h->d_param, sizeof(double) * h->n_params));
+    CREATE_CHK(hipHostMalloc(reinterpret_cast<void **>(&h->h_param), sizeof(double) * h->n_params, hipHostMallocDefault));
+    CREATE_CHK(hipMalloc(&h->d_cam_slab, h->esize * n_cams * CAM_STRIDE));
+    CREATE_CHK(hipMalloc(&h->d_pose_slab, h->esize * std::max<int64_t>(1, h->n_imgs) * POSE_STRIDE));
+    CREATE_CHK(hipMalloc(&h->d_points, h->esize * padded_points(n_keys)));
+    CREATE_CHK(hipMemset(h->d_points, 0, h->esize * padded_points(n_keys)));
+    CREATE_CHK(hipMalloc(&h->d_sink, 64));
+#undef CREATE_CHK
     *out = h;
     return PCS_OK;
 }

@@ -390,3 +390,45 @@ def test_rowsplit_kernel_matches(Engine, chain, dtype):
             else:
                 assert H.jac_rel_err(j1, j0) <= 2 * H.F32_JAC_RTOL and np.max(np.abs(r1 - r0)) <= 1e-3
         e.close()
+
+
+def test_randomised_shapes_orders_and_masks(Engine):
+    """40 seeded random problems: odd counts (1 camera, 1 image, keys not a multiple of 4), random row
+    order, random kernel variant / geometry, random fixed-parameter masks — HIP vs oracle."""
+    rng = np.random.default_rng(2024)
+    for trial in range(40):
+        chain = CHAINS[trial % 3]
+        n_cams, n_imgs, n_keys = int(rng.integers(1, 6)), int(rng.integers(1, 8)), int(rng.integers(1, 40))
+        rig = synthetic.tiny_rig(seed=trial, n_cams=n_cams, n_imgs=n_imgs, n_keys=n_keys, visibility=float(rng.uniform(0.4, 1.0)))
+        det = rig.detections
+        if trial % 2:
+            det = det[rng.permutation(det.shape[0])]
+        if trial % 5 == 0:   # repeat rows: N is then not tied to the rig's size
+            det = np.concatenate([det] * int(rng.integers(2, 9)))
+        ps = orc.build_param_list(*H.chain_slabs(rig, chain))
+        tm = rig.points if chain == "template" else None
+        counts = (rig.n_cams, rig.n_imgs, rig.n_keys)
+        ref_j, ref_r = orc.full_jac_dense(chain, det, ps, tm, with_resid=True, counts=counts)
+        e = make_engine(Engine, rig, chain, det=det)
+        e.set_option("variant", int(rng.integers(-1, 8)))
+        e.set_option("wgs_per_cu", int(rng.integers(0, 20)))
+        e.set_option("rowsplit", int(rng.integers(0, 2)))
+        e.set_option("xcd_remap", int(rng.integers(0, 2)))
+        r, j = e.eval(ps)
+        H.assert_resid_close(r, ref_r, det[:, 3:])
+        H.assert_jac_close(j, ref_j)
+        mask = rng.random(ps.shape[0]) > rng.uniform(0, 0.9)
+        cols = e.block_param_inds()
+        keep = np.repeat(mask[cols], 2, axis=0)
+        assert e.set_unfixed(mask) == int(keep.sum())
+        _, data = e.eval_compact(ps)
+        assert np.array_equal(data, j[keep]), trial
+        # matrix-free products against the dense block rows
+        v = rng.standard_normal(ps.shape[0])
+        e.linearize(ps)
+        jv = np.einsum("nrp,np->nr", j.reshape(-1, 2, e.P), v[cols]).reshape(-1)
+        assert np.max(np.abs(e.jv(v) - jv)) <= 1e-10 * max(1.0, np.max(np.abs(jv)))
+        jtjv = np.zeros(ps.shape[0])
+        np.add.at(jtjv, np.repeat(cols, 2, axis=0).reshape(-1), (j * jv[:, None]).reshape(-1))
+        assert np.max(np.abs(e.jtjv(v) - jtjv)) <= 1e-10 * max(1.0, np.max(np.abs(jtjv)))
+        e.close()
