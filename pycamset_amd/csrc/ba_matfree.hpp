@@ -14,12 +14,14 @@
 // OP_JTU / out of OP_JV) — the n_params-sized vectors stay in L1/L2.
 //
 // Accumulation (three levels): a tile of 64 detections in the reference's cam -> image -> key order
-// shares its camera and pose, so the 15 camera columns and 6 pose columns are first summed across
-// the wave (6 xor-shuffle steps); the wave sums (and the per-lane contributions of non-uniform tiles
-// and of the 3 point columns) are added into a workgroup-private n_params accumulator in LDS
-// (ds_add_f64); at the end each workgroup flushes its non-zero accumulators with one global f64
-// atomic each.  Going straight to global atomics costs 480 us at N = 1e6 (488 tiles per camera all
-// hit the same 15 addresses, which serialise at the memory side); through LDS it is compute-bound.
+// shares its camera and pose, so the 15 camera columns and 6 pose columns are first summed over the
+// tile: every lane parks its contributions in a wave-private LDS panel (column-major, stride 65), then
+// 63 lanes each add up a third of one column (22 ds_read_b64, no shuffles).  The partial sums (and
+// the per-lane contributions of non-uniform tiles and of the 3 point columns) are added into a
+// workgroup-private n_params accumulator in LDS (ds_add_f64); at the end each workgroup flushes its
+// non-zero accumulators with one global f64 atomic each.  Going straight to global atomics costs
+// 480 us at N = 1e6 (488 tiles per camera all hit the same 15 addresses, which serialise at the memory
+// side); wave xor-shuffle sums + LDS accumulators 73-93 us; the LDS panel form is the current one.
 // Parameter strings too large for LDS (> 64 KiB) fall back to direct global atomics.
 // Atomic order makes the last bits of the sums run-to-run dependent (documented; the tests compare
 // with a tolerance).
@@ -35,6 +37,10 @@ constexpr int OP_JTU = 1;
 constexpr int OP_JTJV = 2;
 constexpr int OP_DIAG = 3;
 constexpr int OP_GRAD = 4;
+
+constexpr int RED_COLS = 21;               // camera (15) + pose (6) columns summed per tile
+constexpr int RED_STRIDE = 65;             // odd stride: the column sums read conflict-free
+constexpr int RED_PANEL = RED_COLS * RED_STRIDE;  // doubles per wave
 
 struct MatfreeArgs {
     const int32_t *cam, *img, *key;
@@ -151,9 +157,49 @@ __global__ __launch_bounds__(256) void ba_matfree_kernel(const MatfreeArgs a) {
             else g[j] = (double)J[j] * w0 + (double)J[P + j] * w1;
         }
         if constexpr (LDS_ACC) {
-            accumulate_group<9>(g, c, 0, 9, valid, lane, lds_acc);
-            accumulate_group<6>(g + 9, c, a.extr_off, 6, valid, lane, lds_acc);
-            if constexpr (CHAIN != CHAIN_FREE) accumulate_group<6>(g + 15, im, a.pose_off, 6, valid, lane, lds_acc);
+            // tile sums through the wave-private LDS panel (see the header)
+            double *red = lds_acc + ((a.n_params + 1) & ~1) + wave * RED_PANEL;
+            const int c0 = __builtin_amdgcn_readfirstlane(c);
+            const int im0 = __builtin_amdgcn_readfirstlane(im);
+            const bool cam_uni = __all(!valid || c == c0);
+            const bool img_uni = (CHAIN != CHAIN_FREE) && __all(!valid || im == im0);
+            if (cam_uni) {
+#pragma unroll
+                for (int j = 0; j < 15; ++j) red[j * RED_STRIDE + lane] = valid ? g[j] : 0.0;
+            } else if (valid) {
+#pragma unroll
+                for (int j = 0; j < 9; ++j) unsafeAtomicAdd(lds_acc + cI + j, g[j]);
+#pragma unroll
+                for (int j = 0; j < 6; ++j) unsafeAtomicAdd(lds_acc + cE + j, g[9 + j]);
+            }
+            if constexpr (CHAIN != CHAIN_FREE) {
+                if (img_uni) {
+#pragma unroll
+                    for (int j = 15; j < 21; ++j) red[j * RED_STRIDE + lane] = valid ? g[j] : 0.0;
+                } else if (valid) {
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) unsafeAtomicAdd(lds_acc + cP + j, g[15 + j]);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            {
+                const int col = lane % RED_COLS, grp = lane / RED_COLS;  // lane 63: grp 3 -> idle
+                const bool is_cam = col < 15;
+                if (grp < 3 && (is_cam ? cam_uni : img_uni)) {
+                    const int r0 = grp * 22, r1 = min(64, r0 + 22);
+                    double sum = 0.0;
+                    for (int r = r0; r < r1; ++r) sum += red[col * RED_STRIDE + r];
+                    const int64_t dst = col < 9 ? 9 * (int64_t)c0 + col
+                                      : is_cam  ? a.extr_off + 6 * (int64_t)c0 + (col - 9)
+                                                : a.pose_off + 6 * (int64_t)im0 + (col - 15);
+                    unsafeAtomicAdd(lds_acc + dst, sum);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             if constexpr (CHAIN != CHAIN_TEMPLATE) {
                 constexpr int o = (CHAIN == CHAIN_SELF) ? 21 : 15;
                 if (valid) {

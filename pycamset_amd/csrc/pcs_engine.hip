@@ -578,6 +578,12 @@ static int launch_slab_prep(pcs_engine *h, const double *d_prm, hipStream_t s, h
 
 template <int CHAIN, typename T, bool LDS_ACC>
 static hipError_t launch_matfree_c(int op, const MatfreeArgs &a, dim3 grid, size_t lds, hipStream_t s) {
+    if (lds > 48 * 1024) {  // opt in to more than the default dynamic-LDS cap
+        const void *fns[] = {(const void *)ba_matfree_kernel<CHAIN, T, OP_JTU, LDS_ACC>, (const void *)ba_matfree_kernel<CHAIN, T, OP_JTJV, LDS_ACC>,
+                             (const void *)ba_matfree_kernel<CHAIN, T, OP_DIAG, LDS_ACC>, (const void *)ba_matfree_kernel<CHAIN, T, OP_GRAD, LDS_ACC>};
+        hipError_t e = hipFuncSetAttribute(fns[op - 1], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
     switch (op) {
         case OP_JV: hipLaunchKernelGGL((ba_matfree_kernel<CHAIN, T, OP_JV, false>), grid, dim3(256), 0, s, a); break;
         case OP_JTU: hipLaunchKernelGGL((ba_matfree_kernel<CHAIN, T, OP_JTU, LDS_ACC>), grid, dim3(256), lds, s, a); break;
@@ -979,9 +985,11 @@ int pcs_matfree(pcs_engine *h, int op, const double *in, double *out, double *co
     a.n = h->n; a.n_tiles = (h->n + TILE - 1) / TILE;
     a.extr_off = h->extr_off; a.pose_off = h->pose_off; a.point_off = h->point_off;
     a.n_params = (int32_t)h->n_params;
-    // workgroup-private LDS accumulators when the parameter string fits 64 KiB (default dynamic-LDS cap)
-    const bool lds_acc = h->matfree_lds && op != OP_JV && sizeof(double) * (size_t)h->n_params <= 64 * 1024;
-    const size_t lds = lds_acc ? sizeof(double) * (size_t)h->n_params : 0;
+    // workgroup-private LDS accumulators (+ one reduction panel per wave) when they fit
+    const size_t acc_bytes = sizeof(double) * (size_t)((h->n_params + 1) & ~(int64_t)1);
+    const size_t lds_need = acc_bytes + sizeof(double) * (size_t)WAVES_PER_WG * RED_PANEL;
+    const bool lds_acc = h->matfree_lds && op != OP_JV && lds_need <= 150 * 1024;
+    const size_t lds = lds_acc ? lds_need : 0;
     const int64_t wpc = h->wgs_per_cu > 0 ? h->wgs_per_cu : (op == OP_JV ? 8 : 2);
     const int64_t target_wgs = (int64_t)h->n_cu * wpc;
     int64_t tpw = (a.n_tiles + target_wgs - 1) / target_wgs;
