@@ -28,8 +28,10 @@ _libs: dict[str, ctypes.CDLL] = {}
 
 
 def build(force: bool = False) -> None:
-    """Compile oracle/ba_oracle.c (gcc) if the shared objects are missing."""
-    if force or not (_HERE / "libba_oracle.so").exists() or not (_HERE / "libba_oracle_fast.so").exists():
+    """Compile oracle/ba_oracle.c (gcc) when the shared objects are missing or older than the source."""
+    src = (_HERE / "ba_oracle.c").stat().st_mtime
+    libs = [_HERE / "libba_oracle.so", _HERE / "libba_oracle_fast.so"]
+    if force or any(not p.exists() or p.stat().st_mtime < src for p in libs):
         subprocess.run(["make", "-C", str(_HERE)] + (["-B"] if force else []), check=True, capture_output=True)
 
 
