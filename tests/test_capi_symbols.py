@@ -60,3 +60,23 @@ def test_product_package_never_imports_the_oracle():
         assert "oracle" not in re.sub(r'""".*?"""', "", src, flags=re.S).replace("no CPU fallback", ""), p
     for p in (REPO / "pycamset_amd" / "csrc").iterdir():
         assert "ba_oracle" not in p.read_text(), p
+
+
+def test_header_is_valid_c99_and_the_c_demo_links():
+    """The boundary is a C ABI: the header must compile as plain C, and a C program must link against
+    libpcs_hip.so without any C++ / torch symbol."""
+    import subprocess
+    inc = REPO / "include"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", str(inc / "pcs_hip.h")], check=True)
+    out = REPO / "examples" / "_c_api_demo"
+    try:
+        subprocess.run(["gcc", "-std=c99", "-Wall", f"-I{inc}", str(REPO / "examples" / "c_api_demo.c"), "-o", str(out),
+                        f"-L{REPO / 'pycamset_amd'}", "-lpcs_hip", f"-Wl,-rpath,{REPO / 'pycamset_amd'}", "-Wl,-rpath,/opt/rocm/lib",
+                        "-Wl,-rpath-link,/opt/rocm/lib"], check=True)
+        lib = _capi.lib()
+        if lib.pcs_device_count() == 0:   # CPU box: the program must fail cleanly with the no-device error
+            res = subprocess.run([str(out)], capture_output=True, text=True)
+            assert res.returncode == 1 and "no HIP device" in res.stderr
+    finally:
+        if out.exists():
+            out.unlink()

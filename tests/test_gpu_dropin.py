@@ -236,3 +236,39 @@ def test_legacy_cost_kernel(golden_dir):
     assert np.max(np.abs(r.reshape(-1) - err)) <= 1e-9
     assert 0 < k_ms < 5
     eng.close()
+
+
+def test_plain_c_program_through_the_c_abi(tmp_path):
+    """examples/c_api_demo.c: a C99 program linked only against libpcs_hip.so must reproduce the
+    Python-side numbers (same library, no Python in the loop)."""
+    import re
+    import subprocess
+    from pathlib import Path
+    from pycamset_amd.engine import Engine
+    repo = Path(__file__).resolve().parent.parent
+    exe = tmp_path / "c_api_demo"
+    subprocess.run(["gcc", "-std=c99", f"-I{repo / 'include'}", str(repo / "examples" / "c_api_demo.c"), "-o", str(exe),
+                    f"-L{repo / 'pycamset_amd'}", "-lpcs_hip", f"-Wl,-rpath,{repo / 'pycamset_amd'}", "-Wl,-rpath,/opt/rocm/lib",
+                    "-Wl,-rpath-link,/opt/rocm/lib"], check=True)
+    res = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    assert "n_params 42, row length 21" in res.stdout and "CSR nnz (all parameters free) 336" in res.stdout
+    vals = [float(x) for x in re.findall(r"detection 0: residual \(([-\d.]+), ([-\d.]+)\), du/dfx ([-\d.]+), dv/dfy ([-\d.]+)", res.stdout)[0]]
+    # same toy problem through the Python binding
+    C, I, K, N = 2, 2, 4, 8
+    det = np.array([[n // 4, (n // 2) % 2, n % 4, 500.0 + 3.0 * n, 480.0 - 2.0 * n] for n in range(N)], dtype=np.float64)
+    tmpl = np.array([-0.01, -0.01, 0, 0.01, -0.01, 0, 0.01, 0.01, 0, -0.01, 0.01, 0.002]).reshape(4, 3)
+    prm = np.zeros(15 * C + 6 * I)
+    for c in range(C):
+        prm[9 * c: 9 * c + 9] = [1000, 500, 1000, 500, 0.01, 0.001, 1e-4, -1e-4, 1e-5]
+        prm[9 * C + 6 * c: 9 * C + 6 * c + 6] = [0.0, 0.3 * c, 0.0, 0.0, 0.0, 0.2]
+    prm[15 * C + 6: 15 * C + 12] = [0.01 * (j + 1) for j in range(6)]
+    e = Engine("template", C, I, K)
+    e.set_detections_table(det)
+    e.set_template(tmpl)
+    r, j = e.eval(prm)
+    ref = [r[0, 0], r[0, 1], j[0, 0], j[1, 2]]
+    assert np.allclose(vals, ref, rtol=0, atol=2e-6)      # the demo prints 6 decimals
+    ro = orc.full_loss("template", det, prm, tmpl)
+    assert np.max(np.abs(r - ro)) <= 1e-9
+    e.close()
