@@ -6,7 +6,7 @@
 //     M = [ P_i | 0 .. -x_i .. 0 ]   (3n x (4+n)),  x_i = (u_i, v_i, 1) undistorted pixels
 // and returns the right singular vector of the smallest singular value (LAPACK SVD), X[:3] / X[3].
 //
-// Here one lane owns one point and never forms M.  The lambda columns of M have disjoint supports, so
+// Here a group of G lanes owns one point and never forms M.  The lambda columns of M have disjoint supports, so
 // a 3x3 Householder reflector per view (Q_i x_i = alpha_i e_1) triangularises them exactly:
 //     Q^T M = [ R  E ]   R: n x 4 (first rows of Q_i P_i),  E = diag(-alpha_i)
 //             [ C  0 ]   C: 2n x 4 (other two rows)
@@ -80,41 +80,82 @@ __device__ __forceinline__ void givens_insert(double (&R)[4][4], double (&row)[4
     }
 }
 
-// one thread = one point; observations of point j are rows [start[j], start[j+1])
+// G lanes per point (64 / G points per wave): lane g of a group handles views g, g+G, ...
+// G = 1 is the plain lane-per-point form; it is latency-bound (97 k points = 1 500 waves, each walking
+// ~10 views serially through every pass).  G = 16 has the shortest critical path but executes the 4x4
+// solves once per 4 points instead of once per 64, and ends up issue-bound at the same time.  The
+// default is in between (profiles/r01/tri_legacy_bench.log).  Every lane folds its views into a private
+// 4x4 factor; the G factors are merged pairwise (xor-shuffle tree: the partner's rows are folded in
+// with Givens rotations = QR of stacked triangular factors, still backward stable); the 4-vector and
+// norm sums of the inverse iteration are group reductions.  Pass 1 caches each view's Householder row
+// r_i and alpha_i (scratch, 48 B per observation) so the later passes do no sqrt / divide per view.
+template <int G>
+__device__ __forceinline__ double group_sum(double x) {
+#pragma unroll
+    for (int off = G / 2; off > 0; off >>= 1) x += __shfl_xor(x, off, G);
+    return x;
+}
+
+template <int G>
 __global__ __launch_bounds__(256) void triangulate_kernel(const int32_t *__restrict__ cam, const double2 *__restrict__ uv,
                                                           const int64_t *__restrict__ start, const double *__restrict__ cam_tab,
-                                                          double2 *__restrict__ scr_uv, double *__restrict__ scr_l,
+                                                          double4 *__restrict__ scr_r, double2 *__restrict__ scr_al,
                                                           double *__restrict__ pts, int64_t n_pts) {
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n_pts) return;
-    const int64_t s0 = start[j], s1 = start[j + 1];
+    const int64_t gid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+    const int g = threadIdx.x & (G - 1);
+    const bool live = gid < n_pts;  // whole groups are live or dead; dead groups still take part in the shuffles
+    const int64_t j = live ? gid : n_pts - 1;
+    const int64_t s0 = start[j], s1 = live ? start[j + 1] : s0;
     double R[4][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-    for (int64_t q = s0; q < s1; ++q) {  // pass 1: undistort once, fold the C rows into R_C
+    for (int64_t q = s0 + g; q < s1; q += G) {  // pass 1: undistort, Householder rows, fold the C rows into R
         const double *ct = cam_tab + (int64_t)cam[q] * TRI_CAM_STRIDE;
         const double2 m = uv[q];
         double uu, vv, alpha, r[4], c0[4], c1[4];
         undistort5(m.x, m.y, ct, uu, vv);
-        scr_uv[q] = make_double2(uu, vv);
-        scr_l[q] = 0.0;
         view_rows(ct, uu, vv, alpha, r, c0, c1);
+        scr_r[q] = make_double4(r[0], r[1], r[2], r[3]);
+        scr_al[q] = make_double2(-1.0 / alpha, 0.0);  // (1 / E_i, lambda component)
         givens_insert(R, c0);
         givens_insert(R, c1);
     }
+    if constexpr (G > 1) {
+        // merge the G private factors: after step `off` every lane holds the factor of its 2*off-lane block
+#pragma unroll
+        for (int off = 1; off < G; off <<= 1) {
+            double Rp[4][4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) Rp[a][b] = (b >= a) ? __shfl_xor(R[a][b], off, G) : 0.0;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                double row[4] = {Rp[a][0], Rp[a][1], Rp[a][2], Rp[a][3]};
+                givens_insert(R, row);
+            }
+        }
+        // the two partners of a step fold in opposite orders; all lanes adopt lane 0's copy
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = a; b < 4; ++b) R[a][b] = __shfl(R[a][b], 0, G);
+    }
     double zX[4] = {0.5, 0.5, 0.5, 0.5};
-    double scale = 1.0;  // z_lambda = scale * scr_l
+    double scale = 1.0;  // z_lambda = scale * stored component
     double X0 = 0, X1 = 0, X2 = 0;
+    bool done = false;
     for (int it = 0; it < 10; ++it) {
         // forward solve  [E 0; R^T R_C^T] y = z
         double acc[4] = {0, 0, 0, 0};
-        for (int64_t q = s0; q < s1; ++q) {
-            const double *P = cam_tab + (int64_t)cam[q] * TRI_CAM_STRIDE;
-            const double2 x = scr_uv[q];
-            double alpha, r[4], c0[4], c1[4];
-            view_rows(P, x.x, x.y, alpha, r, c0, c1);
-            const double yl = (scr_l[q] * scale) / (-alpha);
-            scr_l[q] = yl;
+        for (int64_t q = s0 + g; q < s1; q += G) {
+            const double4 r = scr_r[q];
+            double2 al = scr_al[q];
+            const double yl = (al.y * scale) * al.x;
+            if (!done) scr_al[q] = make_double2(al.x, yl);
+            acc[0] += r.x * yl; acc[1] += r.y * yl; acc[2] += r.z * yl; acc[3] += r.w * yl;
+        }
+        if constexpr (G > 1) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) acc[k] += r[k] * yl;
+            for (int k = 0; k < 4; ++k) acc[k] = group_sum<G>(acc[k]);
         }
         double y[4], w[4];
         y[0] = (zX[0] - acc[0]) / R[0][0];
@@ -126,28 +167,33 @@ __global__ __launch_bounds__(256) void triangulate_kernel(const int32_t *__restr
         w[2] = (y[2] - R[2][3] * w[3]) / R[2][2];
         w[1] = (y[1] - R[1][2] * w[2] - R[1][3] * w[3]) / R[1][1];
         w[0] = (y[0] - R[0][1] * w[1] - R[0][2] * w[2] - R[0][3] * w[3]) / R[0][0];
-        double nrm2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2] + w[3] * w[3];
-        for (int64_t q = s0; q < s1; ++q) {
-            const double *P = cam_tab + (int64_t)cam[q] * TRI_CAM_STRIDE;
-            const double2 x = scr_uv[q];
-            double alpha, r[4], c0[4], c1[4];
-            view_rows(P, x.x, x.y, alpha, r, c0, c1);
-            const double wl = (scr_l[q] - (r[0] * w[0] + r[1] * w[1] + r[2] * w[2] + r[3] * w[3])) / (-alpha);
-            scr_l[q] = wl;
-            nrm2 += wl * wl;
+        double part = 0.0;
+        for (int64_t q = s0 + g; q < s1; q += G) {
+            const double4 r = scr_r[q];
+            const double2 al = scr_al[q];
+            const double wl = (al.y - (r.x * w[0] + r.y * w[1] + r.z * w[2] + r.w * w[3])) * al.x;
+            if (!done) scr_al[q] = make_double2(al.x, wl);
+            part += wl * wl;
         }
-        scale = 1.0 / sqrt(nrm2);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) zX[k] = w[k] * scale;
+        if constexpr (G > 1) part = group_sum<G>(part);
+        const double nrm2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2] + w[3] * w[3] + part;
         const double n0 = w[0] / w[3], n1 = w[1] / w[3], n2 = w[2] / w[3];
         const double change = fmax(fabs(n0 - X0), fmax(fabs(n1 - X1), fabs(n2 - X2)));
         const double size = fmax(fabs(n0), fmax(fabs(n1), fabs(n2)));
-        X0 = n0; X1 = n1; X2 = n2;
-        if (it > 0 && !(change > 1e-14 * size)) break;  // also leaves on NaN
+        if (!done) {  // a converged group is frozen: its result must not depend on its wave neighbours
+            scale = 1.0 / sqrt(nrm2);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) zX[k] = w[k] * scale;
+            X0 = n0; X1 = n1; X2 = n2;
+            done = it > 0 && !(change > 1e-14 * size);  // also leaves on NaN
+        }
+        if (__all(done || !live)) break;  // the shuffles are wave-wide: leave together
     }
-    pts[3 * j + 0] = X0;
-    pts[3 * j + 1] = X1;
-    pts[3 * j + 2] = X2;
+    if (live && g == 0) {
+        pts[3 * j + 0] = X0;
+        pts[3 * j + 1] = X1;
+        pts[3 * j + 2] = X2;
+    }
 }
 
 }  // namespace pcs

@@ -13,6 +13,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -154,8 +155,8 @@ int pcs_triangulate(int device, int64_t n_obs, const int32_t *cam, const double 
     } while (0)
     TRICHK(hipMalloc(&d_cam, sizeof(int32_t) * std::max<int64_t>(1, n_obs)));
     TRICHK(hipMalloc(&d_uv, sizeof(double) * 2 * std::max<int64_t>(1, n_obs)));
-    TRICHK(hipMalloc(&d_scr, sizeof(double) * 2 * std::max<int64_t>(1, n_obs)));
-    TRICHK(hipMalloc(&d_scl, sizeof(double) * std::max<int64_t>(1, n_obs)));
+    TRICHK(hipMalloc(&d_scr, sizeof(double) * 4 * std::max<int64_t>(1, n_obs)));  // Householder row r_i per observation
+    TRICHK(hipMalloc(&d_scl, sizeof(double) * 2 * std::max<int64_t>(1, n_obs)));  // (1 / E_i, lambda_i)
     TRICHK(hipMalloc(&d_tab, sizeof(double) * tab.size()));
     TRICHK(hipMalloc(&d_pts, sizeof(double) * 3 * n_pts));
     TRICHK(hipMalloc(&d_start, sizeof(int64_t) * (n_pts + 1)));
@@ -167,9 +168,19 @@ int pcs_triangulate(int device, int64_t n_obs, const int32_t *cam, const double 
     }
     TRICHK(hipMemcpy(d_tab, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice));
     TRICHK(hipMemcpy(d_start, start_inds, sizeof(int64_t) * (n_pts + 1), hipMemcpyHostToDevice));
-    const dim3 grid((unsigned)((n_pts + 255) / 256));
-    hipExtLaunchKernelGGL(triangulate_kernel, grid, dim3(256), 0, nullptr, e0, e1, 0, (const int32_t *)d_cam, (const double2 *)d_uv,
-                          (const int64_t *)d_start, (const double *)d_tab, (double2 *)d_scr, d_scl, d_pts, n_pts);
+    // lanes per point: PCS_TRI_LANES in {1, 2, 4, 8, 16} (A/B switch; default from profiles/r01/tri_legacy_bench.log)
+    const char *lanes_env = getenv("PCS_TRI_LANES");
+    const int lanes = lanes_env ? atoi(lanes_env) : 4;
+    const dim3 grid((unsigned)((n_pts * (lanes == 1 || lanes == 2 || lanes == 8 || lanes == 16 ? lanes : 4) + 255) / 256));
+#define PCS_TRI_LAUNCH(G_)                                                                                                   \
+    hipExtLaunchKernelGGL(triangulate_kernel<G_>, grid, dim3(256), 0, nullptr, e0, e1, 0, (const int32_t *)d_cam, (const double2 *)d_uv, \
+                          (const int64_t *)d_start, (const double *)d_tab, (double4 *)d_scr, (double2 *)d_scl, d_pts, n_pts)
+    if (lanes == 1) PCS_TRI_LAUNCH(1);
+    else if (lanes == 2) PCS_TRI_LAUNCH(2);
+    else if (lanes == 8) PCS_TRI_LAUNCH(8);
+    else if (lanes == 16) PCS_TRI_LAUNCH(16);
+    else PCS_TRI_LAUNCH(4);
+#undef PCS_TRI_LAUNCH
     TRICHK(hipGetLastError());
     TRICHK(hipMemcpy(pts, d_pts, sizeof(double) * 3 * n_pts, hipMemcpyDeviceToHost));
     if (kernel_ms) {
