@@ -63,6 +63,17 @@ struct EvalArgs {
     const int64_t *row_off;  // per detection: offset of its u row in the CSR data array
 };
 
+// broadcast lane `src`'s value to the whole wave through scalar registers (v_readlane_b32)
+__device__ __forceinline__ float readlane_scalar(float v, int src) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
+}
+__device__ __forceinline__ double readlane_scalar(double v, int src) {
+    const uint64_t b = __builtin_bit_cast(uint64_t, v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, src);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), src);
+    return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+}
+
 template <typename T, bool NT>
 __device__ __forceinline__ void store_out(T *p, T v) {
     if constexpr (NT) __builtin_nontemporal_store(v, p); else *p = v;
@@ -182,7 +193,31 @@ __global__ __launch_bounds__(WG_THREADS) void ba_eval_kernel(const EvalArgs a) {
         const T X0 = points[3 * k], X1 = points[3 * k + 1], X2 = points[3 * k + 2];
         T u, v;
         T J[P2];
-        eval_detection<CHAIN, T, JAC>(cs, ps, X0, X1, X2, u, v, J);
+        if constexpr (!JAC && !SLAB_LDS) {
+            // Residual only: 44 B of traffic per detection, so the ~17 wide slab loads of a tile set the
+            // pace (13.6 us at N = 1e6).  When the tile shares its camera and image (the reference's table
+            // order), 33 lanes fetch the 21 + 12 slab scalars with ONE coalesced load and v_readlane
+            // broadcasts them into scalar registers (10.4 us); other tiles take the per-lane loads.
+            // (The same idea for the fused kernel — staging a tile's slabs in a wave-private LDS strip —
+            // was measured and dropped: the second code path costs 12-36 VGPRs and the HBM-bound kernel
+            // gains nothing, profiles/r01/sweeps.md.)
+            const int c0 = __builtin_amdgcn_readfirstlane(c), im0 = __builtin_amdgcn_readfirstlane(im);
+            if (__all(c == c0 && im == im0)) {
+                constexpr int NC = 21, NP = (CHAIN != CHAIN_FREE) ? 12 : 0;
+                const T *src = lane < NC ? cam_slab + c0 * CAM_STRIDE + lane : pose_slab + im0 * POSE_STRIDE + (lane - NC);
+                const T val = lane < NC + NP ? *src : T(0);
+                T cs_s[NC], ps_s[12];
+#pragma unroll
+                for (int j = 0; j < NC; ++j) cs_s[j] = readlane_scalar(val, j);
+#pragma unroll
+                for (int j = 0; j < NP; ++j) ps_s[j] = readlane_scalar(val, NC + j);
+                eval_detection<CHAIN, T, false>(cs_s, ps_s, X0, X1, X2, u, v, J);
+            } else {
+                eval_detection<CHAIN, T, false>(cs, ps, X0, X1, X2, u, v, J);
+            }
+        } else {
+            eval_detection<CHAIN, T, JAC>(cs, ps, X0, X1, X2, u, v, J);
+        }
         if constexpr (RES) {
             // Branch-free: a conditional block here splits the basic block and makes hipcc keep the whole
             // slab + Jacobian live across it (226 VGPRs instead of 150); tail lanes write to a sink.
