@@ -282,7 +282,10 @@ class SelfBundleHandler(TemplateBundleHandler):  # sbh:109-260
     """Self-calibration: the 3-D target points are free too (chain S), 7-DoF gauge fixed."""
 
     def __init__(self, camset, target, detection, fixed_params=None, options=None, missing_poses=None,
-                 *, dtype: str = "f64", device: int = 0, pinned_ring: int = 0, counts=None):
+                 *, dtype: str = "f64", device: int = 0, pinned_ring: int = 0, counts=None, visible_feature_mask=None):
+        """``visible_feature_mask`` (keyword-only extension): which features are seen by ANY rank.  The
+        reference derives it from the handler's own detections (sbh:160-169); a rank that holds only a
+        shard must be given the global mask, or the ranks would fix different features."""
         super().__init__(camset, target, detection, fixed_params, options, missing_poses, dtype=dtype, device=device,
                          pinned_ring=pinned_ring, counts=counts)
         self.flat_point_data = np.copy(self.point_data.reshape((-1)))
@@ -294,7 +297,12 @@ class SelfBundleHandler(TemplateBundleHandler):  # sbh:109-260
         self.feat_unfixed[3 * i2] = False
         n_points = int(np.prod(self.point_data.shape[:2]))  # sbh:161
         dd = self._flat_detections()[:, 2]
-        self.visible_feature_mask = np.isin(np.arange(n_points), dd)  # sbh:166
+        if visible_feature_mask is not None:
+            self.visible_feature_mask = np.asarray(visible_feature_mask, dtype=bool)
+            if self.visible_feature_mask.shape[0] != n_points:
+                raise ValueError("visible_feature_mask must have one entry per target point")
+        else:
+            self.visible_feature_mask = np.isin(np.arange(n_points), dd)  # sbh:166
         for idf, vf in enumerate(self.visible_feature_mask):  # sbh:167-169
             if not vf:
                 self.feat_unfixed[3 * idf : 3 * idf + 3] = False

@@ -103,6 +103,24 @@ def _worker(rank, world, port, out_dir):
         gathered = [None] * world
         dist.all_gather_object(gathered, res.x)
         assert all(np.array_equal(gathered[0], g) for g in gathered)      # every rank walked the same path
+
+        # (4) self-calibration sharded: the global feature-visibility mask keeps the x layout identical
+        vis = np.isin(np.arange(rig.n_keys), det[:, 2])
+
+        def self_handler(rows):
+            return handlers.SelfBundleHandler(_Camset(rig.n_cams), _Target(rig.points),
+                                              TargetDetection(names, rows, max_ims=rig.n_imgs),
+                                              fixed_params={"cam_0": {"ext": rig.extr_true[0].copy()}},
+                                              options={"verbosity": 0}, counts=counts, visible_feature_mask=vis)
+
+        s_shard, s_full = self_handler(mine), self_handler(det)
+        assert np.array_equal(s_shard._jac_mask(), s_full._jac_mask())
+        bs = s_full.bundlePrimitive
+        xs = np.concatenate([rig.intr[bs.intr_unfixed].ravel(), rig.extr[bs.extr_unfixed].ravel(),
+                             rig.poses[bs.poses_unfixed].ravel(), rig.points.ravel()[bs.bdpt_unfixed]])
+        rs = lm_solve(s_shard, xs.copy(), max_iter=15, reduce_fn=sharding.allreduce_sum_fn())
+        r1 = lm_solve(s_full, xs.copy(), max_iter=15)
+        assert abs(rs.cost - r1.cost) <= 1e-5 * r1.cost and rs.cost < 0.01 * rs.history[0]
         Path(out_dir, f"ok{rank}").write_text("ok")
     finally:
         dist.destroy_process_group()
