@@ -90,9 +90,9 @@ def cpu_baseline(rig, chain, param_str, budget_s: float):
         orc.full_jac_dense(chain, det, param_str, tm, threads=threads, fast=True, with_resid=True, counts=counts)
         passes += 1
         el = time.perf_counter() - t0
-        if el >= budget_s or passes >= 200:
+        if el >= 0.6 * budget_s or passes >= 200:
             break
-    return {
+    out = {
         "value": 2.0 * n_sample * passes / el,
         "unit": "rows/s",
         "cores": threads,
@@ -101,6 +101,21 @@ def cpu_baseline(rig, chain, param_str, budget_s: float):
         "sample": f"{passes} full residual+Jacobian passes over the first {n_sample} detections of the same rig "
                   f"({el:.1f} s, oracle/libba_oracle_fast.so, OpenMP static schedule)",
     }
+    # the reference's own default thread count, min(max(1, cpu_count() - 2), 20) (camera_calibrator.py:57-58)
+    ref_threads = min(max(1, threads - 2), 20)
+    t0, p2 = time.perf_counter(), 0
+    while time.perf_counter() - t0 < min(3.0, budget_s / 4):
+        orc.full_jac_dense(chain, det, param_str, tm, threads=ref_threads, fast=True, with_resid=True, counts=counts)
+        p2 += 1
+    out["reference_default_threads"] = {"threads": ref_threads, "value": 2.0 * n_sample * p2 / (time.perf_counter() - t0)}
+    # NumPy-vectorised twin, 1 core, on a 2e5-detection slice (readability cross-check)
+    from oracle import ba_oracle_np as onp
+
+    n_np = min(n_sample, 200_000)
+    t0 = time.perf_counter()
+    onp.evaluate(chain, det[:n_np], param_str, tm, counts=counts)
+    out["numpy_vectorised_1core"] = {"value": 2.0 * n_np / (time.perf_counter() - t0), "detections": n_np}
+    return out
 
 
 def pmc_traffic(workload_key: str):

@@ -135,3 +135,23 @@ def test_triangulation_oracle_against_reference(golden_dir):
     d = d[np.lexsort((d[:, 0], d[:, 2], d[:, 1]))]
     rec, start = group_reconstructable(d)
     assert np.array_equal(rec, g["data"]) and np.array_equal(start, g["start_inds"])
+
+
+@pytest.mark.parametrize("chain", ["template", "self", "free"])
+def test_numpy_vectorised_twin_against_reference_and_c_oracle(golden_dir, chain, unit):
+    """oracle/ba_oracle_np.py: an independently written vectorised restatement; must agree with the
+    reference goldens and with the C oracle."""
+    from oracle import ba_oracle_np as onp
+    for r, R, dR in zip(unit["rvecs"], unit["rodrigues"], unit["rodrigues_jac"]):
+        assert_close(onp.rodrigues(r[None])[0].ravel(), R)
+        assert_close(onp.rodrigues_jac(r[None])[0].ravel(), dR)
+    for tag, t in (("tiny", "t1"), ("medium", "t4")):
+        g = np.load(golden_dir / f"block_{chain}_{tag}.npz")
+        tm = g["points"] if chain == "template" else None
+        r, j = onp.evaluate(chain, g["detections"], g["param_str"], tm)
+        P = orc.CHAIN_P[chain]
+        ref = g[f"data_all_{t}"].reshape(-1, P)
+        assert np.max(np.abs(r - g[f"resid_{t}"])) <= 1e-10      # pixels: a residual is a difference of ~500 px numbers
+        assert_close(j, ref, rtol=2e-11, rows=np.max(np.abs(ref), axis=1, keepdims=True))
+        jc = orc.full_jac_dense(chain, g["detections"], g["param_str"], tm)
+        assert_close(j, jc, rtol=2e-11, rows=np.max(np.abs(jc), axis=1, keepdims=True))
