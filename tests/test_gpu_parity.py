@@ -432,3 +432,52 @@ def test_randomised_shapes_orders_and_masks(Engine):
         np.add.at(jtjv, np.repeat(cols, 2, axis=0).reshape(-1), (j * jv[:, None]).reshape(-1))
         assert np.max(np.abs(e.jtjv(v) - jtjv)) <= 1e-10 * max(1.0, np.max(np.abs(jtjv)))
         e.close()
+
+
+@pytest.mark.parametrize("chain", CHAINS)
+def test_extreme_inputs_propagate_like_ieee_python(Engine, chain):
+    """Points behind / on the camera plane, huge distortion, NaN and inf parameters: the kernel must
+    produce non-finite values exactly where the CPU oracle does (no clamping, no trap) and agree
+    within tolerance everywhere else."""
+    rig = synthetic.tiny_rig(seed=9, n_cams=3, n_imgs=4, n_keys=12, visibility=1.0)
+    rng = np.random.default_rng(9)
+    cases = []
+    a = synthetic.SyntheticRig("behind", rig.detections, rig.intr.copy(), rig.extr.copy(), rig.poses.copy(), rig.points.copy())
+    a.extr[1, 3:] = [0, 0, -0.2]                       # camera 1 looks away: z < 0
+    cases.append(a)
+    b = synthetic.SyntheticRig("distorted", rig.detections, rig.intr.copy(), rig.extr.copy(), rig.poses.copy(), rig.points.copy())
+    b.intr[:, 4:] = rng.normal(0, 50.0, (rig.n_cams, 5))   # absurd distortion
+    cases.append(b)
+    c = synthetic.SyntheticRig("nan", rig.detections, rig.intr.copy(), rig.extr.copy(), rig.poses.copy(), rig.points.copy())
+    c.intr[0, 5] = np.nan                              # k1 of camera 0
+    c.extr[2, 4] = np.nan                              # t_y of camera 2
+    c.poses[2, 1] = np.inf                             # rotation of image 2
+    # (non-finite or zero FOCAL LENGTHS are the one documented difference: the reference multiplies by fx
+    #  and divides by it again, fbi:32-35, so fx = 0 / NaN poisons both residual rows there; DESIGN.md 2)
+    cases.append(c)
+    d = synthetic.SyntheticRig("onplane", rig.detections, rig.intr.copy(), np.zeros_like(rig.extr), np.zeros_like(rig.poses), rig.points.copy())
+    d.points[:, 2] = 0.0                               # every point on every camera plane: z = 0
+    cases.append(d)
+    for case in cases:
+        ps = orc.build_param_list(*H.chain_slabs(case, chain))
+        tm = case.points if chain == "template" else None
+        with np.errstate(all="ignore"):
+            ref_j, ref_r = orc.full_jac_dense(chain, case.detections, ps, tm, with_resid=True,
+                                              counts=(case.n_cams, case.n_imgs, case.n_keys))
+        e = make_engine(Engine, case, chain)
+        r, j = e.eval(ps)
+        e.close()
+        assert np.array_equal(np.isnan(r), np.isnan(ref_r)), case.name
+        fin = np.isfinite(ref_r) & np.isfinite(r)
+        assert np.array_equal(np.isfinite(r), np.isfinite(ref_r)) or case.name in ("onplane", "nan"), case.name
+        if fin.any():
+            scale = np.maximum(np.abs(ref_r[fin]), 1e-3 * np.max(np.abs(case.detections[:, 3:])))
+            assert np.max(np.abs(r[fin] - ref_r[fin]) / scale) <= 1e-9, case.name
+        finj = np.isfinite(ref_j) & np.isfinite(j)
+        rows_ok = np.all(np.isfinite(ref_j), axis=1) & np.all(np.isfinite(j), axis=1)
+        if rows_ok.any():
+            H.assert_jac_close(j[rows_ok], ref_j[rows_ok], rtol=1e-9)
+        # a row that is finite in the reference must be finite here and vice versa, except at z = 0 / NaN
+        # inputs where inf - inf and 0 * inf orderings legitimately differ between the two formulations
+        if case.name in ("behind", "distorted"):
+            assert np.array_equal(np.isfinite(j), np.isfinite(ref_j)), case.name
