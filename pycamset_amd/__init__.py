@@ -6,7 +6,7 @@ first use and there is no CPU fallback.
 """
 from .detections import TargetDetection  # noqa: F401
 
-__all__ = ["TargetDetection", "Engine", "handlers", "function_blocks", "synthetic"]
+__all__ = ["TargetDetection", "Engine", "handlers", "function_blocks", "compiled_helpers", "device_solver", "sharding", "synthetic"]
 __version__ = "0.1.0"
 
 
@@ -14,7 +14,8 @@ def __getattr__(name):
     if name == "Engine":
         from .engine import Engine
         return Engine
-    if name in ("handlers", "function_blocks", "synthetic", "engine", "optimisation_handling", "sharding"):
+    if name in ("handlers", "function_blocks", "synthetic", "engine", "optimisation_handling", "sharding", "device_solver",
+                "compiled_helpers", "detections"):
         import importlib
         return importlib.import_module(f".{name}", __name__)
     raise AttributeError(name)
