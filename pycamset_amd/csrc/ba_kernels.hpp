@@ -44,6 +44,16 @@ constexpr int WAVES_PER_WG = WG_THREADS / 64;
 constexpr int TILE = 64;       // detections per wave tile
 constexpr int HALF = 32;       // detections per transpose pass
 
+// Row stride (scalars) of the wave-private LDS image the fused kernel transposes through.  Each lane
+// writes its own 2P-scalar row with 16-byte (f64) / 8-byte (f32) stores, so the stride decides the bank
+// pattern: 2P = 42 (template) is conflict-free as it is, but 2P = 48 (self) puts lanes l and l+2 on the
+// same banks (96 dwords = 32 mod 64: 8-way conflict) and 2P = 36 (free) lanes l and l+8.  A stride of
+// 2 mod 4 scalars (f64) spreads 16 lanes over all 64 banks; f32 keeps strides that are a multiple of
+// the 16-byte read unit.
+constexpr int lds_row_stride(int p2, int esize) {
+    return esize == 8 ? (p2 % 4 == 0 ? p2 + 2 : p2) : (p2 % 16 == 0 ? p2 + 4 : p2);
+}
+
 struct EvalArgs {
     const int32_t *cam, *img, *key;
     const void *uv;         // N x 2 scalars
@@ -165,7 +175,8 @@ __global__ __launch_bounds__(WG_THREADS) void ba_eval_kernel(const EvalArgs a) {
     }
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
-    T *tr = smem + lds_used + wave * (HALF * P2);  // wave-private transpose region (TRANSPOSE only)
+    constexpr int LROW = lds_row_stride(P2, (int)sizeof(T));
+    T *tr = smem + lds_used + wave * (HALF * LROW);  // wave-private transpose region (TRANSPOSE only)
 
     // Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 labels the XCD group).  With
     // xcd_remap each group walks one contiguous eighth of the table (bijective remap, any grid size);
@@ -252,7 +263,7 @@ __global__ __launch_bounds__(WG_THREADS) void ba_eval_kernel(const EvalArgs a) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     if ((lane >> 5) == h) {
-                        V2 *dst = reinterpret_cast<V2 *>(tr + (lane & 31) * P2);
+                        V2 *dst = reinterpret_cast<V2 *>(tr + (lane & 31) * LROW);
 #pragma unroll
                         for (int j = 0; j < P; ++j) {
                             V2 w;
@@ -265,18 +276,29 @@ __global__ __launch_bounds__(WG_THREADS) void ba_eval_kernel(const EvalArgs a) {
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     const int64_t base = (tile * TILE + h * HALF) * (int64_t)P2;  // scalar offset, multiple of VS
+                    // The padded-row index maths is tile-invariant; left alone, hipcc hoists all of it out of
+                    // the tile loop and the kernel grows from 164 to 244 VGPRs.  An opaque copy of the lane
+                    // id keeps it inside (148 VGPRs for the self chain).
+                    int lane_v = lane;
+                    if constexpr (LROW != P2) asm volatile("" : "+v"(lane_v));
 #pragma unroll
                     for (int q0 = 0; q0 < UNITS; q0 += 64) {
-                        const int q = q0 + lane;
+                        const int q = q0 + lane_v;
                         if (q < UNITS) {
                             const int64_t e = base + (int64_t)q * VS;
+                            int lq = q;  // unit index inside the (possibly padded) LDS image
+                            if constexpr (LROW != P2) {
+                                static_assert(P2 % VS == 0 && LROW % VS == 0, "padded rows must hold whole 16-byte units");
+                                const int row = q / (P2 / VS);
+                                lq = row * (LROW / VS) + (q - row * (P2 / VS));
+                            }
                             if (e + VS <= total_jac) {
-                                const V16 w = reinterpret_cast<const V16 *>(tr)[q];
+                                const V16 w = reinterpret_cast<const V16 *>(tr)[lq];
                                 if constexpr (NT) __builtin_nontemporal_store(w, reinterpret_cast<V16 *>(jac + e));
                                 else *reinterpret_cast<V16 *>(jac + e) = w;
                             } else {
                                 for (int s = 0; s < VS; ++s)
-                                    if (e + s < total_jac) jac[e + s] = tr[q * VS + s];
+                                    if (e + s < total_jac) jac[e + s] = tr[lq * VS + s];
                             }
                         }
                     }

@@ -206,6 +206,7 @@ int pcs_host_free(void *p) {
 
 int pcs_membench(int device, int kind, int64_t bytes, int iters, int blocks_per_cu, float *mean_ms) {
     if (kind < 0 || kind > 3 || bytes < 4096 || iters < 1 || !mean_ms) return fail(PCS_ERR_ARG, "pcs_membench: bad arguments");
+    if (device < 0 || device >= pcs_device_count()) return fail(PCS_ERR_NODEVICE, "pcs_membench: device %d not available", device);
     HIPCHK(hipSetDevice(device));
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device));
@@ -327,14 +328,18 @@ int64_t pcs_n_params(const pcs_engine *h) { return h ? h->n_params : -1; }
 int pcs_row_len(const pcs_engine *h) { return h ? h->P : -1; }
 int64_t pcs_n_detections(const pcs_engine *h) { return h ? h->n : -1; }
 
-static int upload_detections(pcs_engine *h, const double *uv, int64_t n) {
-    // range check: an out-of-range index would be an out-of-bounds slab read on the device
+static int upload_detections(pcs_engine *h, std::vector<int32_t> &cam, std::vector<int32_t> &img, std::vector<int32_t> &key,
+                             const double *uv, int64_t n) {
+    // range check: an out-of-range index would be an out-of-bounds slab read on the device.  The
+    // engine's own tables are only replaced once the new ones are known to be good.
     for (int64_t i = 0; i < n; ++i) {
-        const int32_t c = h->h_cam[i], im = h->h_img[i], k = h->h_key[i];
+        const int32_t c = cam[i], im = img[i], k = key[i];
         if (c < 0 || c >= h->n_cams || k < 0 || k >= h->n_keys || (h->chain != PCS_CHAIN_FREE && (im < 0 || im >= h->n_imgs)))
             return fail(PCS_ERR_RANGE, "detection %lld = (cam %d, im %d, key %d) outside (%lld, %lld, %lld)", (long long)i, c, im, k,
                         (long long)h->n_cams, (long long)h->n_imgs, (long long)h->n_keys);
     }
+    h->h_cam.swap(cam); h->h_img.swap(img); h->h_key.swap(key);
+    h->n = 0;  // stays 0 (= "no detections set") if an allocation or copy below fails
     {   // slab-read locality of the table, per 64-detection tile (drives the automatic variant choice)
         int64_t tiles = 0, good = 0;
         for (int64_t t0 = 0; t0 < n; t0 += TILE, ++tiles) {
@@ -359,7 +364,6 @@ static int upload_detections(pcs_engine *h, const double *uv, int64_t n) {
     }
     h->jac_capacity = h->resid_capacity = h->data_capacity = 0;
     h->nnz = -1;
-    h->n = n;
     if (n == 0) return PCS_OK;
     HIPCHK(hipMalloc(&h->d_cam, sizeof(int32_t) * n));
     HIPCHK(hipMalloc(&h->d_img, sizeof(int32_t) * n));
@@ -375,30 +379,33 @@ static int upload_detections(pcs_engine *h, const double *uv, int64_t n) {
         for (int64_t i = 0; i < 2 * n; ++i) f[i] = (float)uv[i];
         HIPCHK(hipMemcpy(h->d_uv, f.data(), sizeof(float) * 2 * n, hipMemcpyHostToDevice));
     }
+    h->n = n;
     return PCS_OK;
 }
 
 int pcs_set_detections_table(pcs_engine *h, const double *det5, int64_t n) {
     if (!h || (!det5 && n > 0) || n < 0) return fail(PCS_ERR_ARG, "pcs_set_detections_table: bad arguments");
-    h->h_cam.resize(n); h->h_img.resize(n); h->h_key.resize(n);
+    std::vector<int32_t> cam(n), img(n), key(n);
     std::vector<double> uv(2 * n);
     for (int64_t i = 0; i < n; ++i) {
-        h->h_cam[i] = (int32_t)det5[5 * i + 0];  // int() cast like afb:214 / afb:375
-        h->h_img[i] = (int32_t)det5[5 * i + 1];
-        h->h_key[i] = (int32_t)det5[5 * i + 2];
+        for (int j = 0; j < 3; ++j)  // NaN / huge values have no int32 image: refuse instead of casting
+            if (!(det5[5 * i + j] > -1.0 && det5[5 * i + j] < 2147483648.0))
+                return fail(PCS_ERR_RANGE, "detection %lld: index column %d = %g is not an index", (long long)i, j, det5[5 * i + j]);
+        cam[i] = (int32_t)det5[5 * i + 0];  // int() cast like afb:214 / afb:375
+        img[i] = (int32_t)det5[5 * i + 1];
+        key[i] = (int32_t)det5[5 * i + 2];
         uv[2 * i] = det5[5 * i + 3];
         uv[2 * i + 1] = det5[5 * i + 4];
     }
-    return upload_detections(h, uv.data(), n);
+    return upload_detections(h, cam, img, key, uv.data(), n);
 }
 
 int pcs_set_detections(pcs_engine *h, const int32_t *cam, const int32_t *img, const int32_t *key, const double *uv, int64_t n) {
     if (!h || n < 0 || (n > 0 && (!cam || !key || !uv || (!img && h->chain != PCS_CHAIN_FREE))))
         return fail(PCS_ERR_ARG, "pcs_set_detections: bad arguments");
-    h->h_cam.assign(cam, cam + n);
-    if (img) h->h_img.assign(img, img + n); else h->h_img.assign(n, 0);
-    h->h_key.assign(key, key + n);
-    return upload_detections(h, uv, n);
+    std::vector<int32_t> c(cam, cam + n), k(key, key + n), im;
+    if (img) im.assign(img, img + n); else im.assign(n, 0);
+    return upload_detections(h, c, im, k, uv, n);
 }
 
 int pcs_set_template(pcs_engine *h, const double *points) {
@@ -688,7 +695,7 @@ static int enqueue_eval(pcs_engine *h, const double *d_prm, void *d_resid, void 
         if (!(mode & MODE_JAC)) variant &= ~VAR_TRANSPOSE;
         // LDS budget: slabs + points (+ 4 wave-private transpose regions)
         const size_t slab_bytes = h->esize * (size_t)(h->n_cams * CAM_STRIDE + h->n_imgs * POSE_STRIDE + padded_points(h->n_keys));
-        const size_t tr_bytes = (variant & VAR_TRANSPOSE) ? h->esize * (size_t)WAVES_PER_WG * HALF * 2 * h->P : 0;
+        const size_t tr_bytes = (variant & VAR_TRANSPOSE) ? h->esize * (size_t)WAVES_PER_WG * HALF * lds_row_stride(2 * h->P, (int)h->esize) : 0;
         if ((variant & VAR_SLAB_LDS) && slab_bytes + tr_bytes > h->lds_limit) variant &= ~VAR_SLAB_LDS;  // read slabs through L1/L2
         const size_t lds = ((variant & VAR_SLAB_LDS) ? slab_bytes : 0) + tr_bytes;
         int64_t tpw = h->tiles_per_wg;

@@ -149,6 +149,18 @@ def test_error_paths(Engine):
     bad[0, 2] = -1
     with pytest.raises(_capi.PcsError):
         e.set_detections_table(bad)
+    bad[0, 2] = np.nan                          # not an index at all
+    with pytest.raises(_capi.PcsError) as ex:
+        e.set_detections_table(bad)
+    assert ex.value.code == _capi.PCS_ERR_RANGE
+    # a refused table leaves the previous one in place, host-side index tables included
+    e.set_template(rig.points)
+    r, j = e.eval(ps)
+    _, ref_r, ref_j = oracle_eval(rig, "template")
+    H.assert_resid_close(r, ref_r, rig.detections[:, 3:])
+    H.assert_jac_close(j, ref_j)
+    ind, ptr = e.csr_structure(None)
+    assert ptr[-1] == 2 * rig.detections.shape[0] * e.P and ind.max() < e.n_params
     with pytest.raises(ValueError):
         e.eval(ps[:-1])
     with pytest.raises(_capi.PcsError):

@@ -26,13 +26,15 @@ def main():
     ap.add_argument("--variants", default="6,7")
     ap.add_argument("--wgs", default="1,2,4,8,16")
     ap.add_argument("--rounds", type=int, default=7)
+    ap.add_argument("--n-imgs", type=int, default=None, help="override the number of poses (changes the slab size, N stays ~ the same per pose)")
+    ap.add_argument("--scale", type=float, default=1.0, help="visibility scale of the rig")
     ap.add_argument("--shuffle", action="store_true", help="random detection order (worst case for slab locality)")
     ap.add_argument("--mode", default="both", choices=["both", "jac", "resid"])
     ap.add_argument("--tag", default="")
     ap.add_argument("--xcd", default="0", help="comma list of 0/1: XCD-contiguous tile remap")
     ap.add_argument("--rowsplit", default="0", help="comma list of 0/1: also sweep the row-split kernel")
     a = ap.parse_args()
-    rig = synthetic.config_rig(a.config)
+    rig = synthetic.config_rig(a.config, n_imgs=a.n_imgs, scale=a.scale)
     det = rig.detections
     if a.shuffle:
         det = det[np.random.default_rng(0).permutation(det.shape[0])]
@@ -60,7 +62,8 @@ def main():
                 times[c].append(e.last_kernel_ms()[1])
     bpd = BPD[(a.chain, a.dtype)] if a.mode == "both" else (44 if a.mode == "resid" else BPD[(a.chain, a.dtype)] - 16)
     out = {}
-    print(f"# config {a.config} chain {a.chain} {a.dtype} N={N} shuffle={a.shuffle} mode={a.mode}")
+    slab_kb = (rig.n_cams * 48 + (0 if a.chain == "free" else rig.n_imgs * 40) + 3 * rig.n_keys) * (8 if a.dtype == "f64" else 4) / 1024
+    print(f"# config {a.config} chain {a.chain} {a.dtype} N={N} imgs={rig.n_imgs} slabs={slab_kb:.0f} KiB shuffle={a.shuffle} mode={a.mode}")
     for c in combos:
         med, mn = float(np.median(times[c])), float(np.min(times[c]))
         gbs = N * bpd / (med * 1e-3) / 1e9
