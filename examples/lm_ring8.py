@@ -62,6 +62,16 @@ def main(config=2, max_nfev=15, device_only=False):
     print(f"(b) device LM (matrix-free J)    : {t_dev:7.2f} s  nfev {dev.nfev:3d}  cost {dev.cost:.6e}  error {e2:.4f} px"
           f"  ({dev.n_jtjv} J^T J v products, status: {dev.message})")
 
+    t0 = time.perf_counter()
+    ch = lm_solve(h, x0.copy(), max_iter=max_nfev, linear_solver="cholesky")
+    t_ch = time.perf_counter() - t0
+    e3 = np.mean(np.linalg.norm(loss_fn(ch.x).reshape(-1, 2), axis=1))
+    print(f"(c) device LM (block-reduced J^T J + Cholesky): {t_ch:7.2f} s  nfev {ch.nfev:3d}  cost {ch.cost:.6e}  error {e3:.4f} px"
+          f"  ({ch.n_jtjv} factorisations, status: {ch.message})")
+    t0 = time.perf_counter()
+    ch = lm_solve(h, x0.copy(), max_iter=max_nfev, linear_solver="cholesky")
+    print(f"    second run (rocSOLVER warmed up): {time.perf_counter() - t0:7.2f} s")
+
 
 if __name__ == "__main__":
     main(int(sys.argv[1]) if len(sys.argv) > 1 else 2, device_only="--device-only" in sys.argv)

@@ -100,7 +100,9 @@ int pcs_eval(pcs_engine *h, const double *param_str, double *resid, double *jac)
 
 /*
  * Same evaluation, asynchronous, outputs left in device memory (engine dtype), launched on
- * `stream` (a hipStream_t passed as void*, NULL = the engine's own stream).
+ * `stream` (a hipStream_t passed as void*, NULL = the engine's own non-blocking stream; to queue on the
+ * process's default (NULL) stream pass hipStreamLegacy, i.e. (hipStream_t)1 — work on the engine stream is
+ * NOT ordered against the default stream).
  *   d_resid : device pointer, N*2 elements, or NULL
  *   d_jac   : device pointer, 2N*P elements, or NULL
  * param_str is a host pointer (copied through a pinned staging buffer); use
@@ -144,6 +146,17 @@ int pcs_eval_compact_device(pcs_engine *h, const double *param_str, void *d_resi
  */
 int pcs_linearize(pcs_engine *h, const double *param_str);
 int pcs_matfree(pcs_engine *h, int op, const double *in, double *out, double *cost);
+
+/* Block-reduced normal equations at param_str (what a Levenberg-Marquardt step needs
+ * from the Jacobian that optimisation_handling.py:88-98 hands to scipy), built in one pass without
+ * writing J:  H = J^T J  (n_params x n_params row-major, FULL parameter-string space, only the UPPER
+ * triangle incl. the diagonal is written, the rest is zero),  g = J^T r  (n_params),  cost = r^T r.
+ * float64 whatever the engine dtype.  The sums use f64 atomics: the last bits depend on arrival order.
+ *   pcs_normal_equations         host buffers (engine-owned device scratch, blocking)
+ *   pcs_normal_equations_device  device buffers of the caller, queued on `stream` (NULL = engine stream);
+ *                                the call zeroes them first.  Observation shards: all-reduce H, g, cost. */
+int pcs_normal_equations(pcs_engine *h, const double *param_str, double *H, double *g, double *cost);
+int pcs_normal_equations_device(pcs_engine *h, const double *param_str, double *d_H, double *d_g, double *d_cost, void *stream);
 
 /*
  * Legacy residual-only cost.

@@ -44,6 +44,8 @@ SYMBOLS = {
     "pcs_legacy_cost": (c_int, [_P, POINTER(c_double), POINTER(c_double), POINTER(c_double), POINTER(c_double), POINTER(c_double)]),
     "pcs_linearize": (c_int, [_P, POINTER(c_double)]),
     "pcs_matfree": (c_int, [_P, c_int, POINTER(c_double), POINTER(c_double), POINTER(c_double)]),
+    "pcs_normal_equations": (c_int, [_P, POINTER(c_double), POINTER(c_double), POINTER(c_double), POINTER(c_double)]),
+    "pcs_normal_equations_device": (c_int, [_P, POINTER(c_double), c_void_p, c_void_p, c_void_p, c_void_p]),
     "pcs_synchronize": (c_int, [_P, _P]),
     "pcs_last_kernel_ms": (c_int, [_P, POINTER(c_float), POINTER(c_float)]),
     "pcs_kernel_ms_mean": (c_int, [_P, POINTER(c_int64), POINTER(c_float), POINTER(c_float)]),

@@ -22,6 +22,7 @@
 #include "ba_device.hpp"
 #include "ba_kernels.hpp"
 #include "ba_matfree.hpp"
+#include "ba_normal.hpp"
 #include "ba_triangulate.hpp"
 
 // ---------------------------------------------------------------------------------------------
@@ -85,10 +86,14 @@ struct pcs_engine {
     // matrix-free operators (f2)
     double *d_vin = nullptr, *d_vout = nullptr, *d_cost = nullptr;
     int64_t vin_capacity = 0, vout_capacity = 0;
+    // normal equations (f2): scratch of the host-buffer entry point
+    double *d_H = nullptr;
+    int64_t H_capacity = 0;
     // legacy cost (f3)
     void *d_im_points = nullptr, *d_cam_tab = nullptr;
     int64_t im_points_capacity = 0;
     bool linearized = false;
+    int normal_debug = 0;
     bool matfree_lds = true;  // accumulate J^T products in workgroup-private LDS before the global atomics
     // launch geometry
     int n_cu = 256;
@@ -313,7 +318,7 @@ int pcs_destroy(pcs_engine *h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     void *bufs[] = {h->d_cam, h->d_img, h->d_key, h->d_uv, h->d_param, h->d_cam_slab, h->d_pose_slab, h->d_points,
-                    h->d_resid, h->d_jac, h->d_keep, h->d_row_off, h->d_data, h->d_vin, h->d_vout, h->d_cost, h->d_im_points, h->d_cam_tab, h->d_sink};
+                    h->d_resid, h->d_jac, h->d_keep, h->d_row_off, h->d_data, h->d_vin, h->d_vout, h->d_cost, h->d_im_points, h->d_cam_tab, h->d_sink, h->d_H};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (h->h_param) (void)hipHostFree(h->h_param);
@@ -444,6 +449,8 @@ int pcs_set_option(pcs_engine *h, const char *key, int64_t value) {
         h->rowsplit = value != 0;
     } else if (!strcmp(key, "matfree_lds")) {
         h->matfree_lds = value != 0;
+    } else if (!strcmp(key, "normal_debug")) {
+        h->normal_debug = (int)value;
     } else if (!strcmp(key, "compact_variant")) {
         if (value < 0 || value > 1) return fail(PCS_ERR_ARG, "compact_variant must be 0 or 1");
         h->compact_variant = (int)value;
@@ -626,6 +633,54 @@ static hipError_t launch_matfree_t(int chain, int op, bool lds_acc, const Matfre
         case CHAIN_SELF: return launch_matfree_c<CHAIN_SELF, T, false>(op, a, grid, 0, s);
         default: return launch_matfree_c<CHAIN_FREE, T, false>(op, a, grid, 0, s);
     }
+}
+
+template <typename T>
+static hipError_t launch_normal_t(int chain, const NormalArgs &a, dim3 grid, size_t lds, hipStream_t s) {
+    switch (chain) {
+        case CHAIN_TEMPLATE: hipLaunchKernelGGL((ba_normal_kernel<CHAIN_TEMPLATE, T>), grid, dim3(256), lds, s, a); break;
+        case CHAIN_SELF: hipLaunchKernelGGL((ba_normal_kernel<CHAIN_SELF, T>), grid, dim3(256), lds, s, a); break;
+        default: hipLaunchKernelGGL((ba_normal_kernel<CHAIN_FREE, T>), grid, dim3(256), lds, s, a); break;
+    }
+    return hipGetLastError();
+}
+
+// slab_prep + ba_normal_kernel on `s`; d_prm holds the parameter string; outputs are zeroed here.
+static int enqueue_normal(pcs_engine *h, const double *d_prm, double *d_H, double *d_g, double *d_cost, hipStream_t s) {
+    if (h->n <= 0) return fail(PCS_ERR_STATE, "no detections set");
+    if (h->chain == PCS_CHAIN_TEMPLATE && !h->have_template) return fail(PCS_ERR_STATE, "template points not set");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipMemsetAsync(d_H, 0, sizeof(double) * h->n_params * h->n_params, s));
+    HIPCHK(hipMemsetAsync(d_g, 0, sizeof(double) * h->n_params, s));
+    HIPCHK(hipMemsetAsync(d_cost, 0, sizeof(double), s));
+    int rc = launch_slab_prep(h, d_prm, s);
+    if (rc) return rc;
+    NormalArgs a{};
+    a.cam = h->d_cam; a.img = h->d_img; a.key = h->d_key; a.uv = h->d_uv;
+    a.cam_slab = h->d_cam_slab; a.pose_slab = h->d_pose_slab; a.points = h->d_points;
+    a.H = d_H; a.g = d_g; a.cost = d_cost;
+    a.n = h->n; a.n_tiles = (h->n + TILE - 1) / TILE;
+    a.extr_off = h->extr_off; a.pose_off = h->pose_off; a.point_off = h->point_off;
+    a.n_params = h->n_params;
+    // every wave walks a contiguous range of tiles, so its register accumulators survive across tiles
+    const int64_t wpc = h->wgs_per_cu > 0 ? h->wgs_per_cu : 3;
+    const int64_t target_waves = (int64_t)h->n_cu * wpc * WAVES_PER_WG;
+    const int64_t tpw = std::max<int64_t>(1, (a.n_tiles + target_waves - 1) / target_waves);
+    a.tiles_per_wave = (int32_t)tpw;
+    a.debug = h->normal_debug;
+    const int64_t waves = (a.n_tiles + tpw - 1) / tpw;
+    const dim3 grid((unsigned)((waves + WAVES_PER_WG - 1) / WAVES_PER_WG));
+    const size_t lds = sizeof(double) * (size_t)WAVES_PER_WG * (NORMAL_HALF * normal_row(h->chain) + NORMAL_TAIL);
+    hipEvent_t *ev = h->ev.data() + 3 * (h->ev_count % h->ev_ring);
+    HIPCHK(hipEventRecord(ev[0], s));
+    HIPCHK(hipEventRecord(ev[1], s));
+    hipError_t e = h->dtype == PCS_F64 ? launch_normal_t<double>(h->chain, a, grid, lds, s) : launch_normal_t<float>(h->chain, a, grid, lds, s);
+    if (e != hipSuccess) return fail(PCS_ERR_HIP, "normal-equations kernel launch failed: %s", hipGetErrorString(e));
+    HIPCHK(hipEventRecord(ev[2], s));
+    ++h->ev_count;
+    h->events_valid = true;
+    h->last_stream = s;
+    return PCS_OK;
 }
 
 // Queue slab_prep + the evaluation kernel on `s`.  d_prm must already hold the parameter string.
@@ -1027,6 +1082,37 @@ int pcs_matfree(pcs_engine *h, int op, const double *in, double *out, double *co
     HIPCHK(hipMemcpyAsync(out, h->d_vout, sizeof(double) * n_out, hipMemcpyDeviceToHost, s));
     if (op == OP_GRAD && cost) HIPCHK(hipMemcpyAsync(cost, h->d_cost, sizeof(double), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
+    return PCS_OK;
+}
+
+int pcs_normal_equations_device(pcs_engine *h, const double *param_str, double *d_H, double *d_g, double *d_cost, void *stream) {
+    if (!h || !param_str || !d_H || !d_g || !d_cost) return fail(PCS_ERR_ARG, "pcs_normal_equations_device: bad arguments");
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    HIPCHK(hipSetDevice(h->device));
+    int rc = stage_params(h, param_str, s);
+    if (rc) return rc;
+    return enqueue_normal(h, h->d_param, d_H, d_g, d_cost, s);
+}
+
+int pcs_normal_equations(pcs_engine *h, const double *param_str, double *H, double *g, double *cost) {
+    if (!h || !param_str || !H || !g || !cost) return fail(PCS_ERR_ARG, "pcs_normal_equations: bad arguments");
+    if (h->n <= 0) return fail(PCS_ERR_STATE, "no detections set");
+    HIPCHK(hipSetDevice(h->device));
+    const int64_t need = h->n_params * h->n_params + h->n_params + 1;  // H | g | cost in one scratch buffer
+    if (h->H_capacity < need) {
+        if (h->d_H) HIPCHK(hipFree(h->d_H));
+        h->d_H = nullptr;
+        h->H_capacity = 0;
+        HIPCHK(hipMalloc(&h->d_H, sizeof(double) * need));
+        h->H_capacity = need;
+    }
+    double *d_g = h->d_H + h->n_params * h->n_params, *d_cost = d_g + h->n_params;
+    int rc = pcs_normal_equations_device(h, param_str, h->d_H, d_g, d_cost, nullptr);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(H, h->d_H, sizeof(double) * h->n_params * h->n_params, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(g, d_g, sizeof(double) * h->n_params, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(cost, d_cost, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
     return PCS_OK;
 }
 

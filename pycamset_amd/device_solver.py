@@ -9,6 +9,12 @@ all-reduce J^T J v, diag(J^T J) and J^T r (a few KB).
 
     op  = JacobianOperator(engine, unfixed_mask)          # products in the FREE parameter space
     res = lm_solve(handler, x0)                           # drop-in for run_bundle_adjustment's solve
+    res = lm_solve(handler, x0, linear_solver="cholesky") # block-reduced J^T J per step + dense Cholesky
+
+Two ways to get the LM step from the GPU: ``"pcg"`` — Jacobi-preconditioned CG on matrix-free
+J^T (J v) products (~150 passes over the detections per step, parameter-sized traffic only); and
+``"cholesky"`` — one pass of csrc/ba_normal.hpp builds H = J^T J, g = J^T r and the cost, and the damped
+system is factorised (rocSOLVER through torch on the GPU; the sharded form all-reduces H, g, cost).
 
 ``as_linear_operator()`` exposes J as a scipy LinearOperator (matvec / rmatvec) for callers that
 want scipy's own solvers without materialising J.
@@ -99,6 +105,70 @@ def pcg(apply_a, b, m_inv, tol: float, max_iter: int):
     return x, it
 
 
+class NormalEquations:
+    """H = J^T J, g = J^T r and sum r^2 restricted to the free parameters, built by one pass of the
+    block-reduced kernel (csrc/ba_normal.hpp) and kept on the GPU as torch tensors.
+
+    ``reduce_fn`` (optional, sharded detections) sums a float64 vector across ranks; it receives the packed
+    [H_ff, g_f, cost] — the "all-reduce of the small result instead of an all-gather of J" of SURVEY 8 f2.
+    A callable with attribute ``on_device = True`` is handed the CUDA tensor itself (RCCL), otherwise a
+    NumPy copy."""
+
+    def __init__(self, engine, unfixed=None, reduce_fn=None):
+        import torch
+
+        self.torch = torch
+        self.eng = engine
+        mask = np.ones(engine.n_params, dtype=bool) if unfixed is None else np.asarray(unfixed, dtype=bool)
+        if mask.shape[0] != engine.n_params:
+            raise ValueError("mask must have one entry per parameter")
+        self.free = np.flatnonzero(mask)
+        self.n_free = self.free.shape[0]
+        self.reduce_fn = reduce_fn
+        dev = torch.device("cuda", engine.device)
+        n = engine.n_params
+        self._H = torch.empty((n, n), dtype=torch.float64, device=dev)
+        self._g = torch.empty(n, dtype=torch.float64, device=dev)
+        self._c = torch.empty(1, dtype=torch.float64, device=dev)
+        self._idx = torch.from_numpy(self.free).to(dev)
+        self._all_free = self.n_free == n
+
+    def build(self, param_str):
+        """-> (H_ff (n_free, n_free) symmetric CUDA tensor, g_f CUDA tensor, sum r^2 float)."""
+        torch = self.torch
+        with torch.cuda.device(self._H.device):
+            stream = torch.cuda.current_stream().cuda_stream
+            self.eng.normal_equations_device(param_str, self._H.data_ptr(), self._g.data_ptr(), self._c.data_ptr(), stream)
+            U = self._H if self._all_free else self._H[self._idx][:, self._idx]
+            g = self._g if self._all_free else self._g[self._idx]
+            if self.reduce_fn is not None:
+                packed = torch.cat([U.reshape(-1), g, self._c])
+                if getattr(self.reduce_fn, "on_device", False):
+                    packed = self.reduce_fn(packed)
+                else:
+                    packed = torch.from_numpy(self.reduce_fn(packed.cpu().numpy())).to(U.device)
+                m = self.n_free
+                U, g, c = packed[: m * m].view(m, m), packed[m * m: m * m + m], packed[-1:]
+            else:
+                c = self._c
+            Hs = torch.triu(U) + torch.triu(U, 1).T   # the kernel writes the upper triangle only
+            return Hs, g.clone(), float(c.item())
+
+    def solve(self, Hs, g, lam, d):
+        """delta of (H + lam diag(d)) delta = -g; None if the damped matrix is not positive definite."""
+        return cholesky_step(Hs, g, lam, d)
+
+
+def cholesky_step(Hs, g, lam, d):
+    """Damped normal equations by Cholesky on torch tensors (rocSOLVER on a CUDA tensor)."""
+    import torch
+
+    L, info = torch.linalg.cholesky_ex(Hs + torch.diag(lam * d))
+    if int(info.item()) != 0:
+        return None
+    return torch.cholesky_solve(-g.unsqueeze(1), L).squeeze(1)
+
+
 @dataclass
 class DeviceLMResult:
     x: np.ndarray
@@ -107,70 +177,124 @@ class DeviceLMResult:
     optimality: float
     nit: int
     nfev: int
-    n_jtjv: int
+    n_jtjv: int                 # matrix-free J^T J v products ("pcg") / factorisations ("cholesky")
     status: int
     message: str
     history: list = field(default_factory=list)
 
 
+class _PcgStep:
+    """LM linear algebra from matrix-free products (JacobianOperator)."""
+
+    def __init__(self, op, cg_tol, cg_max_iter):
+        self.op, self.cg_tol, self.cg_max_iter = op, cg_tol, cg_max_iter
+
+    def evaluate(self, ps, need_scale=True):
+        self.op.linearize(ps)
+        g, sumsq = self.op.grad()
+        return {"ps": ps, "g": g, "sumsq": sumsq, "d": None}
+
+    def scale(self, st):
+        if st["d"] is None:
+            st["d"] = np.maximum(self.op.diag(), 1e-300)   # refers to the current linearisation = st
+        return st["d"]
+
+    def restore(self, st):
+        self.op.linearize(st["ps"])   # the slabs hold a rejected trial point
+
+    def solve(self, st, lam):
+        dd = self.scale(st)
+        delta, k = pcg(lambda v: self.op.jtjv(v) + lam * dd * v, -st["g"], 1.0 / ((1.0 + lam) * dd), self.cg_tol, self.cg_max_iter)
+        return delta, k, 0.5 * float(-(st["g"] @ delta) + lam * (delta @ (dd * delta)))
+
+
+class _CholeskyStep:
+    """LM linear algebra from the block-reduced normal equations (NormalEquations)."""
+
+    def __init__(self, ne):
+        self.ne = ne
+
+    def evaluate(self, ps, need_scale=True):
+        Hs, g, sumsq = self.ne.build(ps)
+        return {"ps": ps, "H": Hs, "g_dev": g, "g": g.cpu().numpy(), "sumsq": sumsq, "d": None}
+
+    def scale(self, st):
+        if st["d"] is None:
+            import torch
+
+            st["d"] = torch.clamp(torch.diagonal(st["H"]).clone(), min=1e-300)
+        return st["d"]
+
+    def restore(self, st):
+        pass   # the state carries H: nothing refers to the engine's slabs
+
+    def solve(self, st, lam):
+        dd = self.scale(st)
+        delta = self.ne.solve(st["H"], st["g_dev"], lam, dd)
+        if delta is None:
+            return None, 1, 0.0
+        pred = 0.5 * float((-(st["g_dev"] @ delta) + lam * (delta @ (dd * delta))).item())
+        return delta.cpu().numpy(), 1, pred
+
+
 def lm_solve(handler, x0, *, max_iter: int = 50, ftol: float = 1e-8, xtol: float = 1e-8, gtol: float = 1e-8,
              cg_tol: float = 1e-3, cg_max_iter: int = 200, lam0: float = 1e-3, reduce_fn=None, verbose: int = 0,
-             operator: JacobianOperator | None = None) -> DeviceLMResult:
-    """Levenberg-Marquardt (Marquardt scaling D = diag(J^T J), damped normal equations solved by
-    Jacobi-PCG on matrix-free J^T J products) for a pycamset_amd handler.  Every quantity that
-    depends on the detections is computed by the HIP engine; the host only does n_free-vector algebra.
-    ``operator`` replaces the engine-backed JacobianOperator (used by the CPU tests of this driver)."""
+             operator=None, linear_solver: str = "pcg") -> DeviceLMResult:
+    """Levenberg-Marquardt (Marquardt scaling D = diag(J^T J)) for a pycamset_amd handler.  The damped
+    normal equations are solved by Jacobi-PCG on matrix-free J^T J products (``linear_solver='pcg'``) or
+    by a Cholesky factorisation of the block-reduced J^T J (``'cholesky'``).  Every quantity that depends
+    on the detections is computed by the HIP engine.  ``operator`` replaces the engine-backed
+    JacobianOperator / NormalEquations (used by the CPU tests of this driver)."""
+    if linear_solver not in ("pcg", "cholesky"):
+        raise ValueError("linear_solver must be 'pcg' or 'cholesky'")
     op_fun = handler.op_fun
-    if operator is not None:
-        op = operator
-    else:
+    if operator is None:
         dd = handler._flat_detections()
         eng = op_fun._engine_for(dd)
         op_fun._bind_template(eng, handler._template_arg())
-        op = JacobianOperator(eng, handler._jac_mask(), reduce_fn=reduce_fn)
+        operator = (JacobianOperator if linear_solver == "pcg" else NormalEquations)(eng, handler._jac_mask(), reduce_fn=reduce_fn)
+    step = _PcgStep(operator, cg_tol, cg_max_iter) if linear_solver == "pcg" else _CholeskyStep(operator)
 
     def param_str(x):
         return op_fun.build_param_list(*handler.get_bundle_adjustment_inputs(x))
 
     x = np.array(x0, dtype=np.float64)
-    op.linearize(param_str(x))
-    g, sumsq = op.grad()
-    d = op.diag()
-    nfev, n_jtjv, lam = 1, 0, lam0
-    history = [0.5 * sumsq]
+    st = step.evaluate(param_str(x))
+    nfev, n_lin, lam = 1, 0, lam0
+    history = [0.5 * st["sumsq"]]
     status, message = 0, "maximum number of iterations reached"
     it = 0
     for it in range(1, max_iter + 1):
-        gnorm = float(np.max(np.abs(g)))
-        if gnorm <= gtol:
+        if float(np.max(np.abs(st["g"]))) <= gtol:
             status, message = 1, "gtol reached"
             break
         accepted = False
-        for _ in range(12):  # damping retries
-            dd_ = np.maximum(d, 1e-300)
-            delta, k = pcg(lambda v: op.jtjv(v) + lam * dd_ * v, -g, 1.0 / ((1.0 + lam) * dd_), cg_tol, cg_max_iter)
-            n_jtjv += k
+        for retry in range(12):  # damping retries
+            if retry:
+                step.restore(st)
+            delta, k, pred = step.solve(st, lam)
+            n_lin += k
+            if delta is None:   # damped matrix not positive definite: more damping
+                lam *= 4.0
+                continue
             x_new = x + delta
-            op.linearize(param_str(x_new))
-            g_new, sumsq_new = op.grad()
+            st_new = step.evaluate(param_str(x_new))
             nfev += 1
-            pred = 0.5 * float(-(g @ delta) + lam * (delta @ (dd_ * delta)))
-            actual = 0.5 * (sumsq - sumsq_new)
+            actual = 0.5 * (st["sumsq"] - st_new["sumsq"])
             rho = actual / pred if pred > 0 else -1.0
             if verbose:
-                print(f"  it {it}: lam {lam:.2e} cg {k} cost {0.5 * sumsq:.6e} -> {0.5 * sumsq_new:.6e} rho {rho:.3f}")
-            if np.isfinite(sumsq_new) and actual > 0:
+                print(f"  it {it}: lam {lam:.2e} lin {k} cost {0.5 * st['sumsq']:.6e} -> {0.5 * st_new['sumsq']:.6e} rho {rho:.3f}")
+            if np.isfinite(st_new["sumsq"]) and actual > 0:
                 accepted = True
                 step_norm, x_norm = float(np.linalg.norm(delta)), float(np.linalg.norm(x))
-                rel_drop = actual / (0.5 * sumsq)
-                x, g, sumsq = x_new, g_new, sumsq_new
-                d = op.diag()
+                rel_drop = actual / (0.5 * st["sumsq"])
+                x, st = x_new, st_new
                 lam = max(lam * (1.0 / 3.0 if rho > 0.75 else 1.0 if rho > 0.25 else 2.0), 1e-12)
-                history.append(0.5 * sumsq)
+                history.append(0.5 * st["sumsq"])
                 break
             lam *= 4.0
         if not accepted:
-            op.linearize(param_str(x))  # the slabs hold the rejected trial point
+            step.restore(st)
             status, message = 2, "no further decrease (damping exhausted)"
             break
         if rel_drop <= ftol:
@@ -179,5 +303,5 @@ def lm_solve(handler, x0, *, max_iter: int = 50, ftol: float = 1e-8, xtol: float
         if step_norm <= xtol * (xtol + x_norm):
             status, message = 4, "xtol reached"
             break
-    return DeviceLMResult(x=x, cost=0.5 * sumsq, grad=g, optimality=float(np.max(np.abs(g))), nit=it, nfev=nfev,
-                          n_jtjv=n_jtjv, status=status, message=message, history=history)
+    return DeviceLMResult(x=x, cost=0.5 * st["sumsq"], grad=st["g"], optimality=float(np.max(np.abs(st["g"]))), nit=it, nfev=nfev,
+                          n_jtjv=n_lin, status=status, message=message, history=history)

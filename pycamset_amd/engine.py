@@ -51,6 +51,16 @@ def pinned_empty(shape, dtype=np.float64) -> np.ndarray:
     return np.frombuffer(buf, dtype=dtype, count=n).reshape(shape)
 
 
+def _stream_arg(stream):
+    """HIP stream handle for the C ABI.  ``None`` = the engine's own (non-blocking) stream.  An integer is
+    a ``hipStream_t``; 0 — what ``torch.cuda.current_stream().cuda_stream`` returns for torch's default
+    stream — means the process's default (NULL) stream, which the ABI spells ``hipStreamLegacy`` because a
+    NULL argument already selects the engine stream."""
+    if stream is None:
+        return c_void_p(0)
+    return c_void_p(1 if stream == 0 else stream)
+
+
 class Engine:
     """One chain ('template' | 'self' | 'free') on one device.
 
@@ -212,22 +222,41 @@ class Engine:
         """(J^T r, sum r^2) at the linearisation point."""
         return self._matfree(self.OP_GRAD, None, self.n_params, want_cost=True)
 
+    # -- block-reduced normal equations (J never materialised) --------------------------------------
+    def normal_equations(self, param_str, symmetric: bool = True):
+        """(H = J^T J (n_params, n_params), g = J^T r, cost = r^T r) at ``param_str``, built on the GPU in
+        one pass.  The kernel writes the upper triangle; ``symmetric`` mirrors it on the host."""
+        p = self._check_params(param_str)
+        H = np.empty((self.n_params, self.n_params))
+        g = np.empty(self.n_params)
+        cost = c_double(0.0)
+        check(lib().pcs_normal_equations(self._h, _dp(p), _dp(H), _dp(g), byref(cost)))
+        if symmetric:
+            H = H + np.triu(H, 1).T
+        return H, g, float(cost.value)
+
+    def normal_equations_device(self, param_str, d_H: int, d_g: int, d_cost: int, stream: int | None = None):
+        """Asynchronous; raw device addresses of float64 buffers (n_params^2, n_params, 1), zeroed by the call.
+        Only the upper triangle of H is written."""
+        p = self._check_params(param_str)
+        check(lib().pcs_normal_equations_device(self._h, _dp(p), c_void_p(d_H), c_void_p(d_g), c_void_p(d_cost), _stream_arg(stream)))
+
     # -- evaluation: device buffers -----------------------------------------------------------
     def eval_device(self, param_str, d_resid: int | None, d_jac: int | None, stream: int | None = None):
         """Asynchronous; ``d_resid`` / ``d_jac`` are raw device addresses in the engine dtype."""
         p = self._check_params(param_str)
-        check(lib().pcs_eval_device(self._h, _dp(p), c_void_p(d_resid or 0), c_void_p(d_jac or 0), c_void_p(stream or 0)))
+        check(lib().pcs_eval_device(self._h, _dp(p), c_void_p(d_resid or 0), c_void_p(d_jac or 0), _stream_arg(stream)))
 
     def eval_device_resident(self, d_param_str: int, d_resid: int | None, d_jac: int | None, stream: int | None = None):
         """Parameter string already in HBM (float64, n_params entries)."""
-        check(lib().pcs_eval_device_resident(self._h, c_void_p(d_param_str), c_void_p(d_resid or 0), c_void_p(d_jac or 0), c_void_p(stream or 0)))
+        check(lib().pcs_eval_device_resident(self._h, c_void_p(d_param_str), c_void_p(d_resid or 0), c_void_p(d_jac or 0), _stream_arg(stream)))
 
     def eval_compact_device(self, param_str, d_resid: int | None, d_data: int | None, stream: int | None = None):
         p = self._check_params(param_str)
-        check(lib().pcs_eval_compact_device(self._h, _dp(p), c_void_p(d_resid or 0), c_void_p(d_data or 0), c_void_p(stream or 0)))
+        check(lib().pcs_eval_compact_device(self._h, _dp(p), c_void_p(d_resid or 0), c_void_p(d_data or 0), _stream_arg(stream)))
 
     def synchronize(self, stream: int | None = None):
-        check(lib().pcs_synchronize(self._h, c_void_p(stream or 0)))
+        check(lib().pcs_synchronize(self._h, _stream_arg(stream)))
 
     def last_kernel_ms(self) -> tuple[float, float]:
         """(slab_prep ms, eval kernel ms) of the most recent evaluation, from HIP events on its stream."""

@@ -126,3 +126,17 @@ def allreduce_sum_fn(group=None, device=None):
         return t.cpu().numpy()
 
     return reduce_fn
+
+
+def allreduce_sum_tensor_fn(group=None):
+    """``reduce_fn`` for ``device_solver.NormalEquations`` on the RCCL backend: sums the packed
+    [J^T J, J^T r, cost] CUDA tensor across the ranks in place, without a host copy."""
+    import torch.distributed as dist
+
+    def reduce_fn(t):
+        if dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        return t
+
+    reduce_fn.on_device = True
+    return reduce_fn

@@ -177,6 +177,46 @@ def test_matrix_free_products_match_sparse_products_of_the_oracle_jacobian(chain
         e.close()
 
 
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("chain", ["template", "self", "free"])
+def test_block_reduced_normal_equations_match_the_oracle_jacobian(chain, dtype):
+    """H = J^T J, g = J^T r, cost = r^T r in one pass (no J in memory) against the same products of the
+    oracle's Jacobian.  A Gram matrix obeys |H_ij| <= sqrt(H_ii H_jj), so that is the scale of the
+    tolerance: |dH_ij| <= 1e-10 sqrt(H_ii H_jj) in FP64 (atomics reorder the sums), 2e-3 for FP32 engines."""
+    from pycamset_amd.engine import Engine
+    rig = synthetic.config_rig(1)
+    ps = orc.build_param_list(*H.chain_slabs(rig, chain))
+    tm = rig.points if chain == "template" else None
+    dense, r = orc.full_jac_dense(chain, rig.detections, ps, tm, with_resid=True)
+    idx, ptr, _ = orc.csr_structure(chain, rig.detections, np.ones(ps.shape[0], bool))
+    J = csr_array((dense.reshape(-1), idx, ptr), shape=(2 * rig.n_det, ps.shape[0]))
+    H_ref = (J.T @ J).toarray()
+    g_ref = J.T @ r.reshape(-1)
+    c_ref = float(np.sum(r * r))
+    scale = np.sqrt(np.outer(np.diag(H_ref), np.diag(H_ref)))
+    tol = 1e-10 if dtype == "f64" else 2e-3
+    rng = np.random.default_rng(0)
+    orders = {"sorted": np.arange(rig.n_det), "shuffled": rng.permutation(rig.n_det),
+              # runs of 7 detections: every tile mixes several (cam, image) pairs but keeps some run structure
+              "runs-of-7": np.concatenate([np.arange(s, min(s + 7, rig.n_det)) for s in rng.permutation(np.arange(0, rig.n_det, 7))])}
+    for name, perm in orders.items():
+        e = Engine(chain, rig.n_cams, rig.n_imgs, rig.n_keys, dtype=dtype)
+        e.set_detections_table(rig.detections[perm])
+        if tm is not None:
+            e.set_template(tm)
+        Hu, g, cost = e.normal_equations(ps, symmetric=False)
+        assert np.all(np.tril(Hu, -1) == 0), "only the upper triangle is written"
+        Hs = Hu + np.triu(Hu, 1).T
+        err = np.max(np.abs(Hs - H_ref) / np.where(scale > 0, scale, 1.0))
+        assert err <= tol, (name, err)
+        assert np.all(Hs[H_ref == 0] == 0), "structural zeros stay zero"
+        assert np.max(np.abs(g - g_ref)) <= tol * np.max(np.abs(g_ref)), name
+        assert abs(cost - c_ref) <= tol * c_ref, name
+        H2, g2, c2 = e.normal_equations(ps)           # second call: buffers are re-zeroed
+        assert np.allclose(H2, Hs, rtol=1e-9 if dtype == "f64" else 1e-6, atol=0) and np.allclose(H2, H2.T)
+        e.close()
+
+
 @pytest.mark.parametrize("chain", ["template", "self"])
 def test_device_lm_reaches_the_scipy_solution(chain):
     from pycamset_amd.device_solver import JacobianOperator, lm_solve
@@ -192,13 +232,14 @@ def test_device_lm_reaches_the_scipy_solution(chain):
     x0 = np.concatenate(parts)
     loss_fn, jac_fn = h.make_loss_fun(1), h.make_loss_jac(1)
     ref = least_squares(loss_fn, x0.copy(), jac=jac_fn, x_scale="jac", max_nfev=30, verbose=0)
-    res = lm_solve(h, x0.copy(), max_iter=30)
-    assert res.history == sorted(res.history, reverse=True)           # monotone decrease
-    assert res.cost <= ref.cost * (1 + 1e-3)                           # at least as low as scipy's trf+lsmr
-    assert abs(0.5 * np.sum(loss_fn(res.x) ** 2) - res.cost) <= 1e-9 * res.cost   # device cost == residual kernel
-    e_dev = np.mean(np.linalg.norm(loss_fn(res.x).reshape(-1, 2), axis=1))
     e_ref = np.mean(np.linalg.norm(ref.fun.reshape(-1, 2), axis=1))
-    assert e_dev <= e_ref + 1e-3
+    for linear_solver in ("pcg", "cholesky"):   # matrix-free CG / block-reduced J^T J + Cholesky
+        res = lm_solve(h, x0.copy(), max_iter=30, linear_solver=linear_solver)
+        assert res.history == sorted(res.history, reverse=True), linear_solver        # monotone decrease
+        assert res.cost <= ref.cost * (1 + 1e-3), linear_solver                       # at least as low as scipy's trf+lsmr
+        assert abs(0.5 * np.sum(loss_fn(res.x) ** 2) - res.cost) <= 1e-9 * res.cost   # device cost == residual kernel
+        e_dev = np.mean(np.linalg.norm(loss_fn(res.x).reshape(-1, 2), axis=1))
+        assert e_dev <= e_ref + 1e-3, linear_solver
     # the operator view agrees with the CSR closure
     op = JacobianOperator(h.op_fun.engine, h._jac_mask())
     ps = h.op_fun.build_param_list(*h.get_bundle_adjustment_inputs(res.x))

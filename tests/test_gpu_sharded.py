@@ -103,6 +103,11 @@ def _worker(rank, world, port, out_dir):
         gathered = [None] * world
         dist.all_gather_object(gathered, res.x)
         assert all(np.array_equal(gathered[0], g) for g in gathered)      # every rank walked the same path
+        # the same with the block-reduced normal equations: ranks all-reduce [J^T J, J^T r, cost]
+        chol = lm_solve(h_shard, x0.copy(), max_iter=20, reduce_fn=sharding.allreduce_sum_fn(), linear_solver="cholesky")
+        assert abs(chol.cost - one.cost) <= 1e-5 * one.cost, (chol.cost, one.cost)
+        dist.all_gather_object(gathered, chol.x)
+        assert all(np.array_equal(gathered[0], g) for g in gathered)
 
         # (4) self-calibration sharded: the global feature-visibility mask keeps the x layout identical
         vis = np.isin(np.arange(rig.n_keys), det[:, 2])

@@ -202,3 +202,24 @@ def test_device_lm_driver_logic_on_cpu_operator():
     assert err < 0.6 and res.cost < 0.01 * res.history[0]
     L = op.as_linear_operator()
     assert L.shape == (2 * det.shape[0], x0.shape[0])
+
+    # the same driver with the Cholesky step on explicit normal equations (CPU stand-in for NormalEquations)
+    import torch
+    from pycamset_amd.device_solver import cholesky_step
+
+    class CpuNormal:
+        free = np.flatnonzero(mask)
+
+        def build(self, ps):
+            e = CpuEngine()
+            e.linearize(ps)
+            Jf = e.J[:, self.free]
+            return torch.from_numpy((Jf.T @ Jf).toarray()), torch.from_numpy(Jf.T @ e.r), float(e.r @ e.r)
+
+        solve = staticmethod(cholesky_step)
+
+    res2 = lm_solve(h, x0.copy(), max_iter=25, operator=CpuNormal(), linear_solver="cholesky")
+    assert res2.history == sorted(res2.history, reverse=True)
+    assert abs(res2.cost - res.cost) <= 1e-6 * res.cost and res2.nfev <= res.nfev + 2
+    with pytest.raises(ValueError):
+        lm_solve(h, x0.copy(), operator=op, linear_solver="qr")
