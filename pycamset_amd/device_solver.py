@@ -132,6 +132,8 @@ class NormalEquations:
         self._c = torch.empty(1, dtype=torch.float64, device=dev)
         self._idx = torch.from_numpy(self.free).to(dev)
         self._all_free = self.n_free == n
+        self.schur = trailing_block_structure(engine.chain, engine.n_cams, engine.n_imgs, engine.n_keys, mask)
+        self._perm = self._inv_perm = None
 
     def build(self, param_str):
         """-> (H_ff (n_free, n_free) symmetric CUDA tensor, g_f CUDA tensor, sum r^2 float)."""
@@ -156,7 +158,17 @@ class NormalEquations:
 
     def solve(self, Hs, g, lam, d):
         """delta of (H + lam diag(d)) delta = -g; None if the damped matrix is not positive definite."""
-        return cholesky_step(Hs, g, lam, d)
+        if self.schur is None:
+            return cholesky_step(Hs, g, lam, d)
+        n_lead, block, perm = self.schur
+        if perm is None:
+            return schur_cholesky_step(Hs, g, lam, d, n_lead, block)
+        if self._perm is None:
+            self._perm = self.torch.from_numpy(perm).to(Hs.device)
+            self._inv_perm = self.torch.argsort(self._perm)
+        p = self._perm
+        delta = schur_cholesky_step(Hs[p][:, p], g[p], lam, d[p], n_lead, block)
+        return None if delta is None else delta[self._inv_perm]
 
 
 def cholesky_step(Hs, g, lam, d):
@@ -167,6 +179,66 @@ def cholesky_step(Hs, g, lam, d):
     if int(info.item()) != 0:
         return None
     return torch.cholesky_solve(-g.unsqueeze(1), L).squeeze(1)
+
+
+def schur_cholesky_step(Hs, g, lam, d, n_lead: int, block: int):
+    """The same step through the Schur complement of the trailing parameter group.
+
+    The free parameters are ordered [leading | trailing]; the trailing group (the per-image poses of the
+    template chain, the per-key points of the self / free chains) consists of ``block``-sized sets that
+    never share a detection, so its part of J^T J is block diagonal:  H = [[A, B], [B^T, C]],
+    C = diag(C_1 .. C_m).  Eliminating it leaves a dense system of the leading size only
+    (480 instead of 1 680 unknowns on rig-32):
+        (A_d - B C_d^-1 B^T) x_a = -g_a + B C_d^-1 g_c,      x_c = -C_d^-1 (g_c + B^T x_a)
+    with A_d, C_d the damped blocks.  Returns None when a factorisation fails."""
+    import torch
+
+    n = Hs.shape[0]
+    m = (n - n_lead) // block
+    if m == 0 or n_lead == 0:
+        return cholesky_step(Hs, g, lam, d)
+    A = Hs[:n_lead, :n_lead] + torch.diag(lam * d[:n_lead])
+    B = Hs[:n_lead, n_lead:]                                           # (n_lead, m * block)
+    Ct = Hs[n_lead:, n_lead:].reshape(m, block, m, block)
+    C = Ct.diagonal(dim1=0, dim2=2).permute(2, 0, 1)                  # (m, block, block) diagonal blocks
+    C = C + torch.diag_embed(lam * d[n_lead:].reshape(m, block))
+    Lc, info_c = torch.linalg.cholesky_ex(C)
+    if int(info_c.max().item()) != 0:
+        return None
+    Cinv = torch.cholesky_inverse(Lc)
+    BCinv = torch.einsum("amk,mkl->aml", B.reshape(n_lead, m, block), Cinv).reshape(n_lead, m * block)
+    S = A - BCinv @ B.T
+    rhs = -g[:n_lead] + BCinv @ g[n_lead:]
+    Ls, info_s = torch.linalg.cholesky_ex(S)
+    if int(info_s.item()) != 0:
+        return None
+    xa = torch.cholesky_solve(rhs.unsqueeze(1), Ls).squeeze(1)
+    t = (g[n_lead:] + B.T @ xa).reshape(m, block)
+    xc = -torch.einsum("mkl,ml->mk", Cinv, t).reshape(-1)
+    return torch.cat([xa, xc])
+
+
+def trailing_block_structure(chain: str, n_cams: int, n_imgs: int, n_keys: int, mask):
+    """(n_lead, block, perm) for schur_cholesky_step, or None if there is nothing to eliminate.
+    template: poses (6 per image) trail the cameras; self / free: points (3 per key) trail everything
+    else.  Sets that are only partly free (single point coordinates fixed by the self-calibration gauge,
+    sbh:153-158) are moved to the leading group: ``perm`` is that reordering of the free-parameter vector
+    (None when it is the identity)."""
+    mask = np.asarray(mask, dtype=bool)
+    block = 6 if chain == "template" else 3
+    start = 15 * n_cams if chain in ("template", "free") else 15 * n_cams + 6 * n_imgs
+    sets = mask[start:].reshape(-1, block)
+    whole = sets.all(axis=1)
+    if not whole.any() or not (mask[:start].any() or (sets.any(axis=1) & ~whole).any()):
+        return None
+    free_pos = np.cumsum(mask) - 1                       # full index -> position in the free vector
+    trailing = np.repeat(whole, block)
+    full_idx = np.arange(mask.shape[0])
+    lead_full = np.concatenate([full_idx[:start][mask[:start]], (full_idx[start:])[mask[start:] & ~trailing]])
+    trail_full = (full_idx[start:])[trailing]
+    perm = free_pos[np.concatenate([lead_full, trail_full])]
+    n_lead = lead_full.shape[0]
+    return n_lead, block, (None if np.array_equal(perm, np.arange(perm.shape[0])) else perm)
 
 
 @dataclass

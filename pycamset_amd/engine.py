@@ -74,6 +74,7 @@ class Engine:
         if dtype not in DTYPE_IDS:
             raise ValueError("dtype must be 'f64' or 'f32'")
         self.chain, self.dtype, self.device = chain, dtype, device
+        self.n_cams, self.n_imgs, self.n_keys = int(n_cams), (0 if chain == "free" else int(n_imgs)), int(n_keys)
         self.P = CHAIN_P[chain]
         self._h = c_void_p()
         check(lib().pcs_create(byref(self._h), CHAIN_IDS[chain], DTYPE_IDS[dtype], int(n_cams), int(n_imgs), int(n_keys), int(device)))

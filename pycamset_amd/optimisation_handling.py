@@ -35,8 +35,9 @@ def make_optimisation_function(param_handler, threads: int = 1):
     return loss_fn, jac_fn, x0
 
 
-def run_bundle_adjustment(param_handler, threads: int = 1, solver: str = "scipy"):
-    """Solve the handler's problem; returns (result, parameter slabs at the solution) — oh:52-117."""
+def run_bundle_adjustment(param_handler, threads: int = 1, solver: str = "scipy", linear_solver: str = "cholesky"):
+    """Solve the handler's problem; returns (result, parameter slabs at the solution) — oh:52-117.
+    ``solver='device'`` runs device_solver.lm_solve with ``linear_solver`` in {'cholesky', 'pcg'}."""
     loss_fn, jac_fn, x0 = make_optimisation_function(param_handler, threads)
     opts = param_handler.problem_opts
     start_error = mean_reprojection_error(loss_fn(x0))
@@ -47,7 +48,7 @@ def run_bundle_adjustment(param_handler, threads: int = 1, solver: str = "scipy"
     if solver == "device":
         from .device_solver import lm_solve
 
-        result = lm_solve(param_handler, x0, max_iter=opts["max_nfev"])
+        result = lm_solve(param_handler, x0, max_iter=opts["max_nfev"], linear_solver=linear_solver)
         end_error = mean_reprojection_error(loss_fn(result.x))
     else:
         result = least_squares(loss_fn, x0, jac=jac_fn if jac_fn is not None else "2-point", x_scale="jac",

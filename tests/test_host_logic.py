@@ -218,6 +218,26 @@ def test_device_lm_driver_logic_on_cpu_operator():
 
         solve = staticmethod(cholesky_step)
 
+    # the Schur-complement form of the step equals the dense solve
+    from pycamset_amd.device_solver import schur_cholesky_step, trailing_block_structure
+    n_cams, n_imgs, n_keys = counts
+    st = trailing_block_structure("template", n_cams, n_imgs, n_keys, mask)
+    assert st[:2] == (int(mask[: 15 * n_cams].sum()), 6) and st[2] is None
+    Hs, gs, _ = CpuNormal().build(orc.build_param_list(*h.get_bundle_adjustment_inputs(x0)))
+    dd = torch.diagonal(Hs).clone()
+    for lam in (1e-6, 1e-2, 10.0):
+        a, b = cholesky_step(Hs, gs, lam, dd), schur_cholesky_step(Hs, gs, lam, dd, st[0], st[1])
+        assert float((a - b).abs().max()) <= 1e-9 * float(a.abs().max())
+    # a gauge-style mask that fixes single point coordinates: the partly fixed point joins the leading group
+    m2 = np.ones(15 * 3 + 6 * 4 + 3 * 8, bool)
+    assert trailing_block_structure("self", 3, 4, 8, m2)[:2] == (15 * 3 + 6 * 4, 3)
+    m2[-2] = False                                       # y of the last point fixed
+    n_lead, blk, perm = trailing_block_structure("self", 3, 4, 8, m2)
+    assert (n_lead, blk) == (15 * 3 + 6 * 4 + 2, 3) and sorted(perm) == list(range(m2.sum()))
+    assert list(perm[:69]) == list(range(69)) and list(perm[69:71]) == [90, 91] and list(perm[71:]) == list(range(69, 90))
+    assert trailing_block_structure("free", 3, 0, 8, np.ones(15 * 3 + 24, bool))[:2] == (45, 3)
+    assert trailing_block_structure("template", 3, 4, 8, np.r_[np.ones(45, bool), np.zeros(24, bool)]) is None
+
     res2 = lm_solve(h, x0.copy(), max_iter=25, operator=CpuNormal(), linear_solver="cholesky")
     assert res2.history == sorted(res2.history, reverse=True)
     assert abs(res2.cost - res.cost) <= 1e-6 * res.cost and res2.nfev <= res.nfev + 2
