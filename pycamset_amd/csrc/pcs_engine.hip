@@ -1097,6 +1097,9 @@ int pcs_normal_equations_device(pcs_engine *h, const double *param_str, double *
 int pcs_normal_equations(pcs_engine *h, const double *param_str, double *H, double *g, double *cost) {
     if (!h || !param_str || !H || !g || !cost) return fail(PCS_ERR_ARG, "pcs_normal_equations: bad arguments");
     if (h->n <= 0) return fail(PCS_ERR_STATE, "no detections set");
+    if (h->n_params > 32768)  // 8.6 GB of H: beyond this the matrix-free products (pcs_matfree) are the tool
+        return fail(PCS_ERR_ARG, "pcs_normal_equations: %lld parameters make a dense J^T J of %.1f GB; use pcs_matfree",
+                    (long long)h->n_params, (double)h->n_params * (double)h->n_params * 8e-9);
     HIPCHK(hipSetDevice(h->device));
     const int64_t need = h->n_params * h->n_params + h->n_params + 1;  // H | g | cost in one scratch buffer
     if (h->H_capacity < need) {

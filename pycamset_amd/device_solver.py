@@ -143,16 +143,7 @@ class NormalEquations:
             self.eng.normal_equations_device(param_str, self._H.data_ptr(), self._g.data_ptr(), self._c.data_ptr(), stream)
             U = self._H if self._all_free else self._H[self._idx][:, self._idx]
             g = self._g if self._all_free else self._g[self._idx]
-            if self.reduce_fn is not None:
-                packed = torch.cat([U.reshape(-1), g, self._c])
-                if getattr(self.reduce_fn, "on_device", False):
-                    packed = self.reduce_fn(packed)
-                else:
-                    packed = torch.from_numpy(self.reduce_fn(packed.cpu().numpy())).to(U.device)
-                m = self.n_free
-                U, g, c = packed[: m * m].view(m, m), packed[m * m: m * m + m], packed[-1:]
-            else:
-                c = self._c
+            U, g, c = reduce_normal_equations(U, g, self._c, self.reduce_fn)
             Hs = torch.triu(U) + torch.triu(U, 1).T   # the kernel writes the upper triangle only
             return Hs, g.clone(), float(c.item())
 
@@ -169,6 +160,23 @@ class NormalEquations:
         p = self._perm
         delta = schur_cholesky_step(Hs[p][:, p], g[p], lam, d[p], n_lead, block)
         return None if delta is None else delta[self._inv_perm]
+
+
+def reduce_normal_equations(U, g, c, reduce_fn):
+    """Sum one rank's (J^T J, J^T r, cost) torch tensors over the ranks with ONE collective on the packed
+    buffer.  ``reduce_fn`` with ``on_device = True`` receives the tensor itself (RCCL on a CUDA tensor, see
+    sharding.allreduce_sum_tensor_fn), otherwise a NumPy copy (sharding.allreduce_sum_fn, gloo)."""
+    if reduce_fn is None:
+        return U, g, c
+    import torch
+
+    m = g.shape[0]
+    packed = torch.cat([U.reshape(-1), g, c.reshape(1)])
+    if getattr(reduce_fn, "on_device", False):
+        packed = reduce_fn(packed)
+    else:
+        packed = torch.from_numpy(reduce_fn(packed.cpu().numpy())).to(U.device)
+    return packed[: m * m].view(m, m), packed[m * m: m * m + m], packed[-1:]
 
 
 def cholesky_step(Hs, g, lam, d):

@@ -129,6 +129,24 @@ def _worker_normal_eq(rank, world, port, out_dir):
         for a, b in ((op.jtjv(v), full.jtjv(v)), (op.diag(), full.diag()), (op.grad()[0], full.grad()[0])):
             assert np.max(np.abs(a - b)) <= 1e-12 * np.max(np.abs(b))
         assert abs(op.grad()[1] - full.grad()[1]) <= 1e-12 * full.grad()[1]
+
+        # block-reduced form: every rank's (J^T J, J^T r, cost) packed into ONE all-reduce, both flavours of reduce_fn
+        import torch
+        from pycamset_amd.device_solver import reduce_normal_equations, schur_cholesky_step, cholesky_step, trailing_block_structure
+        free = np.flatnonzero(mask)
+        Jm, Jf = op.eng.J[:, free], full.eng.J[:, free]
+        H_full, g_full, c_full = (Jf.T @ Jf).toarray(), Jf.T @ full.eng.r, float(full.eng.r @ full.eng.r)
+        for fn in (sharding.allreduce_sum_fn(), sharding.allreduce_sum_tensor_fn()):
+            U = torch.from_numpy(np.triu((Jm.T @ Jm).toarray()))         # the kernel writes the upper triangle
+            Ur, gr, cr = reduce_normal_equations(U, torch.from_numpy(Jm.T @ op.eng.r), torch.tensor([float(op.eng.r @ op.eng.r)], dtype=torch.float64), fn)
+            Hs = torch.triu(Ur) + torch.triu(Ur, 1).T
+            assert np.max(np.abs(Hs.numpy() - H_full)) <= 1e-12 * np.max(np.abs(H_full))
+            assert np.max(np.abs(gr.numpy() - g_full)) <= 1e-12 * np.max(np.abs(g_full)) and abs(float(cr) - c_full) <= 1e-12 * c_full
+        n_lead, blk, perm = trailing_block_structure("template", *counts, mask)
+        assert perm is None and blk == 6
+        dd = torch.diagonal(Hs).clone()
+        a, b = cholesky_step(Hs, gr, 1e-3, dd), schur_cholesky_step(Hs, gr, 1e-3, dd, n_lead, blk)
+        assert float((a - b).abs().max()) <= 1e-8 * float(a.abs().max())
         Path(out_dir, f"ok{rank}").write_text("ok")
     finally:
         dist.destroy_process_group()
