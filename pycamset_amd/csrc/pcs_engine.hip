@@ -663,7 +663,9 @@ static int enqueue_normal(pcs_engine *h, const double *d_prm, double *d_H, doubl
     a.extr_off = h->extr_off; a.pose_off = h->pose_off; a.point_off = h->point_off;
     a.n_params = h->n_params;
     // every wave walks a contiguous range of tiles, so its register accumulators survive across tiles
-    const int64_t wpc = h->wgs_per_cu > 0 ? h->wgs_per_cu : 3;
+    // 227 VGPRs -> 2 waves/SIMD = 2 workgroups per CU resident; more workgroups only add a second round
+    // (166 us at 2 per CU, 221 us at 3, profiles/r01/normal_bench.log)
+    const int64_t wpc = h->wgs_per_cu > 0 ? h->wgs_per_cu : 2;
     const int64_t target_waves = (int64_t)h->n_cu * wpc * WAVES_PER_WG;
     const int64_t tpw = std::max<int64_t>(1, (a.n_tiles + target_waves - 1) / target_waves);
     a.tiles_per_wave = (int32_t)tpw;

@@ -134,6 +134,34 @@ def test_least_squares_with_hip_closures_converges_like_the_cpu_path(chain):
     assert np.max(np.abs(loss_fn(x0) - o_loss(x0))) <= 1e-9
 
 
+def test_run_bundle_adjustment_caller_with_both_solvers():
+    """optimisation_handling.run_bundle_adjustment (the reference's caller, oh:52-117) end to end: scipy on the
+    HIP closures and the device solver (block-reduced normal equations + Schur step) reach the same solution
+    and hand back the full parameter slabs."""
+    from pycamset_amd.optimisation_handling import run_bundle_adjustment
+    rig = synthetic.make_rig("ring-6-small", 6, 10, synthetic.charuco_points(9, 8.0), seed=23, visibility=0.85)
+    names = [f"cam_{i}" for i in range(rig.n_cams)]
+
+    def build():
+        h = handlers.TemplateBundleHandler(DuckCamset(rig.n_cams), DuckTarget(rig.points), TargetDetection(names, rig.detections),
+                                           fixed_params={"cam_0": {"ext": rig.extr_true[0].copy()}}, options={"verbosity": 0, "max_nfev": 40})
+        bp = h.bundlePrimitive
+        h.set_initial_params(np.concatenate([rig.intr[bp.intr_unfixed].ravel(), rig.extr[bp.extr_unfixed].ravel(), rig.poses[bp.poses_unfixed].ravel()]))
+        return h
+
+    r_scipy, slabs_scipy = run_bundle_adjustment(build())
+    out = {}
+    for ls in ("cholesky", "pcg"):
+        r_dev, slabs = run_bundle_adjustment(build(), solver="device", linear_solver=ls)
+        out[ls] = r_dev
+        assert r_dev.cost <= r_scipy.cost * (1 + 1e-3), ls
+        assert [a.shape for a in slabs] == [a.shape for a in slabs_scipy]
+        assert np.array_equal(slabs[1][0], rig.extr_true[0])              # the fixed extrinsic is handed back untouched
+    # exact steps (Cholesky) end at least as low as the inexact CG steps, and both sit on the noise floor
+    assert out["cholesky"].cost <= out["pcg"].cost * (1 + 1e-6)
+    assert abs(out["cholesky"].cost - out["pcg"].cost) <= 1e-3 * out["pcg"].cost
+
+
 # ---- SURVEY f2: Jacobian kept on the device -------------------------------------------------------
 @pytest.mark.parametrize("chain", ["template", "self", "free"])
 def test_matrix_free_products_match_sparse_products_of_the_oracle_jacobian(chain):
