@@ -16,8 +16,8 @@
 // (NA = 22, or 16 for the free chain): a small symmetric rank-k update whose NA (NA + 1) / 2 entries are
 // the run's contribution to the camera block, the pose block, the camera-pose block, g and the cost.
 //   * Every lane evaluates one detection (eval_detection, as the fused kernel does) and parks its two
-//     augmented rows in a wave-private LDS image (32 detections per pass, row stride padded to an odd
-//     number of 16-byte slots: conflict-free ds_write_b128).
+//     augmented rows in a wave-private LDS image (64 rows of 23 16-byte slots — an odd stride, so the
+//     ds_write_b128 are conflict-free; 23.6 KB per wave, 2 waves per workgroup, 3 workgroups per CU).
 //   * The upper triangle is cut row by row into chunks (p; q0 .. q0+4), one per lane (60 of 64 lanes for
 //     NA = 22).  A lane accumulates sum_l X[l][p] X[l][q] over the member lanes: per l one
 //     ds_read_b128 for the (u, v) pair of column p and one per q, at immediate offsets — all lanes read
@@ -56,8 +56,11 @@ constexpr int normal_shared_cols(int chain) { return chain == CHAIN_FREE ? 15 : 
 // LDS row of one detection: NA 16-byte slots (J[0][p], J[1][p]), slot NS = (r_u, r_v), padded to an odd
 // number of slots so that the 8-lane groups of ds_write_b128 land on different banks
 constexpr int normal_row(int chain) { return 2 * (normal_shared_cols(chain) + 1) + 2; }  // doubles
-constexpr int NORMAL_HALF = 32;
-constexpr int NORMAL_TAIL = 16;  // doubles after a wave's image: the dummy columns of short chunks read into it
+constexpr int NORMAL_ROWS = 64;  // detections per LDS image (the whole wave tile)
+constexpr int NORMAL_WAVES = 2;  // waves per workgroup: 2 x 23.6 KB of LDS -> 3 workgroups per CU
+constexpr int NORMAL_DEPTH = 4;  // rows of operands in flight in the dot loop
+// doubles after a wave's image: the dummy columns of short chunks and the last DEPTH - 1 prefetches read into it
+constexpr int normal_tail(int chain) { return (NORMAL_DEPTH - 1) * normal_row(chain) + 16; }
 
 // Entry ownership: the upper triangle (p <= q < NA) is cut, row by row, into chunks of up to CH
 // consecutive q; one chunk per lane.  CH is the smallest chunk length that fits 64 lanes.
@@ -72,6 +75,17 @@ constexpr int normal_chunk_len(int na) {
     return ch;
 }
 
+// Lane -> chunk tables from tools/normal_lane_table.py (255 = idle lane).  ds_read_b128 serves a wave in four
+// 16-lane groups over 16 slots of 16 B, so two lanes of a group collide when their slots differ by exactly 16;
+// handing the chunks out in order leaves 4 such pairs for NA = 22 (SQ_LDS_BANK_CONFLICT = 34 % of the LDS
+// cycles); these assignments have none.
+// NA = 22, CH = 5: 60 chunks, 0 slot pairs 16 apart left (sequential order: 4)
+__device__ constexpr unsigned char NORMAL_P_22[64] = {1, 13, 13, 14, 8, 255, 9, 4, 1, 1, 11, 4, 5, 255, 9, 2, 21, 12, 255, 0, 0, 4, 255, 19, 7, 2, 0, 5, 2, 14, 0, 0, 2, 17, 3, 6, 3, 10, 7, 1, 1, 16, 15, 6, 11, 12, 8, 5, 3, 15, 8, 10, 6, 16, 7, 9, 5, 10, 20, 11, 4, 18, 3, 6};
+__device__ constexpr unsigned char NORMAL_Q_22[64] = {11, 18, 13, 19, 8, 255, 14, 4, 21, 1, 11, 14, 20, 255, 9, 7, 21, 12, 255, 0, 20, 19, 255, 19, 7, 17, 5, 5, 2, 14, 15, 10, 12, 17, 8, 11, 18, 20, 17, 6, 16, 21, 20, 16, 21, 17, 18, 10, 13, 15, 13, 15, 21, 16, 12, 19, 15, 10, 20, 16, 9, 18, 3, 6};
+// NA = 16, CH = 3: 51 chunks, 0 slot pairs 16 apart left (sequential order: 0)
+__device__ constexpr unsigned char NORMAL_P_16[64] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 3, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 6, 6, 6, 6, 7, 7, 7, 8, 8, 8, 9, 9, 9, 10, 10, 11, 11, 12, 12, 13, 14, 15, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255};
+__device__ constexpr unsigned char NORMAL_Q_16[64] = {0, 3, 6, 9, 12, 15, 1, 4, 7, 10, 13, 2, 5, 8, 11, 14, 3, 6, 9, 12, 15, 4, 7, 10, 13, 5, 8, 11, 14, 6, 9, 12, 15, 7, 10, 13, 8, 11, 14, 9, 12, 15, 10, 13, 11, 14, 12, 15, 13, 14, 15, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255};
+
 // global column of shared local column p for (cam c, image im)
 template <int CHAIN>
 __device__ __forceinline__ int64_t shared_col(const NormalArgs &a, int p, int c, int im) {
@@ -81,22 +95,22 @@ __device__ __forceinline__ int64_t shared_col(const NormalArgs &a, int p, int c,
 }
 
 template <int CHAIN, typename T>
-__global__ __launch_bounds__(256) void ba_normal_kernel(const NormalArgs a) {
+__global__ __launch_bounds__(64 * NORMAL_WAVES) void ba_normal_kernel(const NormalArgs a) {
     constexpr int P = chain_P(CHAIN);
     constexpr int P2 = 2 * P;
     constexpr int NS = normal_shared_cols(CHAIN);
     constexpr int NA = NS + 1;                 // shared columns + the residual column
-    constexpr int CH = normal_chunk_len(NA);   // 5 (NA = 22: 60 chunks), 3 (NA = 16: 47 chunks)
+    constexpr int CH = normal_chunk_len(NA);   // 5 (NA = 22: 60 chunks), 3 (NA = 16: 51 chunks)
     constexpr int ROW = normal_row(CHAIN);
     static_assert((ROW / 2) % 2 == 1, "row must be an odd number of 16-byte slots");
-    static_assert(2 * CH <= NORMAL_TAIL, "dummy columns must stay inside the tail pad");
+    static_assert(2 * CH <= 16 && NORMAL_ROWS % NORMAL_DEPTH == 0, "dummy columns must stay inside the tail pad");
     using V2 = __attribute__((ext_vector_type(2))) T;
     using D2 = __attribute__((ext_vector_type(2))) double;
 
     extern __shared__ __attribute__((aligned(16))) double lds_rows[];
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
-    double *X = lds_rows + wave * (NORMAL_HALF * ROW + NORMAL_TAIL);
+    double *X = lds_rows + wave * (NORMAL_ROWS * ROW + normal_tail(CHAIN));
 
     const T *cam_slab = static_cast<const T *>(a.cam_slab);
     const T *pose_slab = static_cast<const T *>(a.pose_slab);
@@ -104,20 +118,11 @@ __global__ __launch_bounds__(256) void ba_normal_kernel(const NormalArgs a) {
     const V2 *uv = static_cast<const V2 *>(a.uv);
 
     // this lane's chunk: row ep, columns eq0 .. eq0 + elen - 1
-    int ep = 0, eq0 = 0, elen = 0;
-    {
-        int t = lane;
-        for (int p = 0; p < NA; ++p) {
-            const int nch = (NA - p + CH - 1) / CH;
-            if (t < nch) {
-                ep = p;
-                eq0 = p + t * CH;
-                elen = min(CH, NA - eq0);
-                break;
-            }
-            t -= nch;
-        }
-    }
+    static_assert(NA == 22 || NA == 16, "lane tables exist for NA = 22 and 16");
+    const unsigned char tp = NA == 22 ? NORMAL_P_22[lane] : NORMAL_P_16[lane];
+    const unsigned char tq = NA == 22 ? NORMAL_Q_22[lane] : NORMAL_Q_16[lane];
+    const int ep = tp == 255 ? 0 : tp, eq0 = tp == 255 ? 0 : tq;
+    const int elen = tp == 255 ? 0 : min(CH, NA - eq0);
     const D2 *xa = reinterpret_cast<const D2 *>(X) + ep;
     const D2 *xb = reinterpret_cast<const D2 *>(X) + eq0;
     double acc[CH];
@@ -126,14 +131,20 @@ __global__ __launch_bounds__(256) void ba_normal_kernel(const NormalArgs a) {
     int c_run = -1, i_run = -1;  // wave-uniform: the (cam, image) the accumulators belong to
     double cost_acc = 0.0;
 
-    auto flush = [&]() {
+    // Entries that involve no pose column (camera block, camera part of g, cost) belong to the camera alone:
+    // they stay in registers across image changes and are flushed when the camera changes.  The camera
+    // block of H otherwise receives one atomic per entry per (cam, image) run — ~260 serialised adds on
+    // each of its addresses; this way it is one per wave that touches the camera.
+    auto flush = [&](const bool cam_changed) {
         if (c_run < 0) return;
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
+            const int q = eq0 + j;
+            const bool pose_entry = CHAIN != CHAIN_FREE && (ep >= 15 || (q >= 15 && q < NS));
+            if (!cam_changed && !pose_entry) continue;
             const double s = acc[j];
             acc[j] = 0.0;
             if (j >= elen || s == 0.0 || (a.debug & 2)) continue;
-            const int q = eq0 + j;
             if (q == NS) {
                 if (ep == NS) cost_acc += s;
                 else unsafeAtomicAdd(a.g + shared_col<CHAIN>(a, ep, c_run, i_run), s);
@@ -144,7 +155,7 @@ __global__ __launch_bounds__(256) void ba_normal_kernel(const NormalArgs a) {
         }
     };
 
-    const int64_t wave_id = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t wave_id = (int64_t)blockIdx.x * NORMAL_WAVES + wave;
     const int64_t tile0 = wave_id * a.tiles_per_wave;
     const int64_t tile1 = min(tile0 + (int64_t)a.tiles_per_wave, a.n_tiles);
     for (int64_t tile = tile0; tile < tile1; ++tile) {
@@ -182,41 +193,71 @@ __global__ __launch_bounds__(256) void ba_normal_kernel(const NormalArgs a) {
             }
         }
 
-        const uint64_t valid_mask = __ballot(valid);
-#pragma unroll 1
-        for (int h = 0; h < 2; ++h) {
-            if ((lane >> 5) == h) {
-                D2 *dst = reinterpret_cast<D2 *>(X + (lane & 31) * ROW);
+        // the tile's 64 augmented rows -> LDS; J is dead after this, so the dot loops below have the
+        // registers to keep many ds_read_b128 in flight (with a 32-row image and J alive across two passes
+        // hipcc issued one read at a time: 470 cycles per row instead of ~100)
+        {
+            D2 *dst = reinterpret_cast<D2 *>(X + lane * ROW);
 #pragma unroll
-                for (int p = 0; p < NS; ++p) {
-                    D2 w;
-                    w.x = (double)J[p];
-                    w.y = (double)J[P + p];
-                    dst[p] = w;
-                }
+            for (int p = 0; p < NS; ++p) {
                 D2 w;
-                w.x = r0;
-                w.y = r1;
-                dst[NS] = w;
+                w.x = (double)J[p];
+                w.y = (double)J[P + p];
+                dst[p] = w;
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            uint32_t rem = (uint32_t)(valid_mask >> (32 * h));
-            while (rem) {  // one (cam, image) pair of this half at a time; all conditions are wave-uniform
-                const int leader = __builtin_ctz(rem) + 32 * h;
-                const int c0 = __builtin_amdgcn_readlane(c, leader), i0 = __builtin_amdgcn_readlane(im, leader);
-                const uint32_t member = (uint32_t)(__ballot(valid && c == c0 && im == i0) >> (32 * h)) & rem;
-                if (c0 != c_run || i0 != i_run) {
-                    flush();
-                    c_run = c0;
-                    i_run = i0;
+            D2 w;
+            w.x = r0;
+            w.y = r1;
+            dst[NS] = w;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        uint64_t rem = __ballot(valid);
+        while (rem) {  // one (cam, image) pair of the tile at a time; all conditions are wave-uniform
+            const int leader = __builtin_ctzll(rem);
+            const int c0 = __builtin_amdgcn_readlane(c, leader), i0 = __builtin_amdgcn_readlane(im, leader);
+            const uint64_t member = __ballot(valid && c == c0 && im == i0) & rem;
+            if (c0 != c_run || i0 != i_run) {
+                flush(c0 != c_run);
+                c_run = c0;
+                i_run = i0;
+            }
+            if (a.debug & 1) {
+                acc[0] += 1.0;
+            } else if (member == ~0ull) {
+                // The whole tile is one run (the common case).  Software pipeline: the operands of row
+                // l + DEPTH - 1 are requested before row l is consumed; the compiler barrier keeps hipcc from
+                // sinking the ds_read_b128 back down to their uses (which it does otherwise: one read, one
+                // s_waitcnt 0, three VALU ops — the LDS latency fully exposed).  Rows past the image fall into
+                // the tail pad and are never used.
+                constexpr int DEPTH = NORMAL_DEPTH;
+                D2 pr[DEPTH], qr[DEPTH][CH];
+#pragma unroll
+                for (int s = 0; s < DEPTH - 1; ++s) {
+                    pr[s] = xa[s * (ROW / 2)];
+#pragma unroll
+                    for (int j = 0; j < CH; ++j) qr[s][j] = xb[s * (ROW / 2) + j];
                 }
-                if (a.debug & 1) {
-                    acc[0] += 1.0;
-                } else if (member == 0xffffffffu) {  // the whole half is one run: straight-line code, reads pipelined
-#pragma unroll 8
-                    for (int l = 0; l < NORMAL_HALF; ++l) {
+#pragma unroll 1
+                for (int l0 = 0; l0 < NORMAL_ROWS; l0 += DEPTH) {
+                    const D2 *xa0 = xa + l0 * (ROW / 2), *xb0 = xb + l0 * (ROW / 2);
+#pragma unroll
+                    for (int s = 0; s < DEPTH; ++s) {
+                        constexpr int AHEAD = DEPTH - 1;
+                        const int slot = (s + AHEAD) % DEPTH;
+                        pr[slot] = xa0[(s + AHEAD) * (ROW / 2)];
+#pragma unroll
+                        for (int j = 0; j < CH; ++j) qr[slot][j] = xb0[(s + AHEAD) * (ROW / 2) + j];
+                        asm volatile("" ::: "memory");
+#pragma unroll
+                        for (int j = 0; j < CH; ++j) acc[j] += pr[s].x * qr[s][j].x + pr[s].y * qr[s][j].y;
+                    }
+                }
+            } else {
+#pragma unroll 4
+                for (int l = 0; l < NORMAL_ROWS; ++l) {
+                    if (member & (1ull << l)) {
                         const D2 p2 = xa[l * (ROW / 2)];
 #pragma unroll
                         for (int j = 0; j < CH; ++j) {
@@ -224,27 +265,15 @@ __global__ __launch_bounds__(256) void ba_normal_kernel(const NormalArgs a) {
                             acc[j] += p2.x * q2.x + p2.y * q2.y;
                         }
                     }
-                } else {
-#pragma unroll 4
-                    for (int l = 0; l < NORMAL_HALF; ++l) {
-                        if (member & (1u << l)) {
-                            const D2 p2 = xa[l * (ROW / 2)];
-#pragma unroll
-                            for (int j = 0; j < CH; ++j) {
-                                const D2 q2 = xb[l * (ROW / 2) + j];
-                                acc[j] += p2.x * q2.x + p2.y * q2.y;
-                            }
-                        }
-                    }
                 }
-                rem &= ~member;
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            rem &= ~member;
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    flush();
+    flush(true);
     const double cs = wave_sum(cost_acc);
     if (lane == 0 && cs != 0.0) unsafeAtomicAdd(a.cost, cs);
 }

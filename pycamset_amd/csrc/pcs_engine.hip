@@ -638,9 +638,9 @@ static hipError_t launch_matfree_t(int chain, int op, bool lds_acc, const Matfre
 template <typename T>
 static hipError_t launch_normal_t(int chain, const NormalArgs &a, dim3 grid, size_t lds, hipStream_t s) {
     switch (chain) {
-        case CHAIN_TEMPLATE: hipLaunchKernelGGL((ba_normal_kernel<CHAIN_TEMPLATE, T>), grid, dim3(256), lds, s, a); break;
-        case CHAIN_SELF: hipLaunchKernelGGL((ba_normal_kernel<CHAIN_SELF, T>), grid, dim3(256), lds, s, a); break;
-        default: hipLaunchKernelGGL((ba_normal_kernel<CHAIN_FREE, T>), grid, dim3(256), lds, s, a); break;
+        case CHAIN_TEMPLATE: hipLaunchKernelGGL((ba_normal_kernel<CHAIN_TEMPLATE, T>), grid, dim3(64 * NORMAL_WAVES), lds, s, a); break;
+        case CHAIN_SELF: hipLaunchKernelGGL((ba_normal_kernel<CHAIN_SELF, T>), grid, dim3(64 * NORMAL_WAVES), lds, s, a); break;
+        default: hipLaunchKernelGGL((ba_normal_kernel<CHAIN_FREE, T>), grid, dim3(64 * NORMAL_WAVES), lds, s, a); break;
     }
     return hipGetLastError();
 }
@@ -662,17 +662,16 @@ static int enqueue_normal(pcs_engine *h, const double *d_prm, double *d_H, doubl
     a.n = h->n; a.n_tiles = (h->n + TILE - 1) / TILE;
     a.extr_off = h->extr_off; a.pose_off = h->pose_off; a.point_off = h->point_off;
     a.n_params = h->n_params;
-    // every wave walks a contiguous range of tiles, so its register accumulators survive across tiles
-    // 227 VGPRs -> 2 waves/SIMD = 2 workgroups per CU resident; more workgroups only add a second round
-    // (166 us at 2 per CU, 221 us at 3, profiles/r01/normal_bench.log)
-    const int64_t wpc = h->wgs_per_cu > 0 ? h->wgs_per_cu : 2;
-    const int64_t target_waves = (int64_t)h->n_cu * wpc * WAVES_PER_WG;
+    // every wave walks a contiguous range of tiles, so its register accumulators survive across tiles;
+    // LDS (23.6 KB per wave) allows 3 two-wave workgroups per CU
+    const int64_t wpc = h->wgs_per_cu > 0 ? h->wgs_per_cu : 3;
+    const int64_t target_waves = (int64_t)h->n_cu * wpc * NORMAL_WAVES;
     const int64_t tpw = std::max<int64_t>(1, (a.n_tiles + target_waves - 1) / target_waves);
     a.tiles_per_wave = (int32_t)tpw;
     a.debug = h->normal_debug;
     const int64_t waves = (a.n_tiles + tpw - 1) / tpw;
-    const dim3 grid((unsigned)((waves + WAVES_PER_WG - 1) / WAVES_PER_WG));
-    const size_t lds = sizeof(double) * (size_t)WAVES_PER_WG * (NORMAL_HALF * normal_row(h->chain) + NORMAL_TAIL);
+    const dim3 grid((unsigned)((waves + NORMAL_WAVES - 1) / NORMAL_WAVES));
+    const size_t lds = sizeof(double) * (size_t)NORMAL_WAVES * (NORMAL_ROWS * normal_row(h->chain) + normal_tail(h->chain));
     hipEvent_t *ev = h->ev.data() + 3 * (h->ev_count % h->ev_ring);
     HIPCHK(hipEventRecord(ev[0], s));
     HIPCHK(hipEventRecord(ev[1], s));

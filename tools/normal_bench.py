@@ -9,7 +9,9 @@ from pycamset_amd import synthetic
 from pycamset_amd.engine import Engine
 
 configs = [(3, "template", False), (3, "template", True), (4, "self", False), (4, "free", False)]
-if len(sys.argv) > 1:
+if "--only-default" in sys.argv:
+    configs = [c for c in configs if not c[2]]
+if any(not a.startswith("--") for a in sys.argv[1:]):
     configs = [c for c in configs if c[1] in sys.argv[1:]]
 for cfg, chain, shuffle in configs:
     rig = synthetic.config_rig(cfg)
@@ -27,7 +29,15 @@ for cfg, chain, shuffle in configs:
     gd = torch.empty(n, dtype=torch.float64, device="cuda")
     cd = torch.empty(1, dtype=torch.float64, device="cuda")
     print(f"# {rig.name} chain {chain} N={det.shape[0]} n_params={n} shuffled={shuffle}  H = {n*n*8/1e6:.1f} MB")
-    for wpc in (0, 1, 2, 3, 4, 8):
+    if "--phases" in sys.argv:   # option normal_debug: 1 = skip the dot loops, 2 = skip the flush atomics (results are wrong)
+        for dbg in (3, 1, 2, 0):
+            e.set_option("normal_debug", dbg)
+            ks = []
+            for _ in range(8):
+                e.normal_equations_device(ps, Hd.data_ptr(), gd.data_ptr(), cd.data_ptr()); e.synchronize(); ks.append(e.last_kernel_ms()[1])
+            print(f"normal_debug {dbg}: kernel {np.median(ks[2:])*1e3:8.1f} us")
+        e.set_option("normal_debug", 0)
+    for wpc in ((0,) if "--only-default" in sys.argv else (0, 1, 2, 3, 4, 8)):
         e.set_option("wgs_per_cu", wpc)
         for _ in range(2):
             e.normal_equations_device(ps, Hd.data_ptr(), gd.data_ptr(), cd.data_ptr())
@@ -39,7 +49,7 @@ for cfg, chain, shuffle in configs:
             ks.append(e.last_kernel_ms()[1])
         host = (time.perf_counter() - t0) / 10
         print(f"normal wgs/cu {wpc:2d}: kernel {np.median(ks)*1e3:8.1f} us   call incl. memsets + sync {host*1e6:8.1f} us")
-    if chain == "template" and not shuffle:
+    if chain == "template" and not shuffle and "--only-default" not in sys.argv:
         # what follows in an LM step: symmetrise, damp, Cholesky, solve (rocSOLVER through torch)
         free = torch.ones(n, dtype=torch.bool, device="cuda"); free[15 * rig.n_cams: 15 * rig.n_cams + 6] = False; free[9 * rig.n_cams: 9 * rig.n_cams + 6] = False
         idx = torch.nonzero(free).ravel()
