@@ -3,7 +3,10 @@
 
   (a) scipy.optimize.least_squares driven by the HIP closures — the reference's own call
       (pyCamSet optimisation_handling.py:88-98), Jacobian shipped to the host as CSR every iteration;
-  (b) pycamset_amd.device_solver.lm_solve — the Jacobian never leaves the GPU (matrix-free products).
+  (b) pycamset_amd.device_solver.lm_solve — the Jacobian never leaves the GPU (matrix-free products);
+  (c) the same with block-reduced normal equations and a Schur-complement Cholesky step.
+
+    python examples/lm_ring8.py [config] [--device-only] [--self]     # --self: self-calibration chain
 
 Needs an MI355X.  The CPU oracle is not used here.
 """
@@ -36,14 +39,18 @@ class Target:
         self.point_data = np.asarray(pts)[None]
 
 
-def main(config=2, max_nfev=15, device_only=False):
+def main(config=2, max_nfev=15, device_only=False, self_cal=False):
     rig = synthetic.config_rig(config)
     cs = Camset(rig.n_cams)
-    h = handlers.TemplateBundleHandler(cs, Target(rig.points), TargetDetection(cs.get_names(), rig.detections),
-                                       fixed_params={"cam_0": {"ext": rig.extr_true[0].copy()}},
-                                       options={"verbosity": 0, "max_nfev": max_nfev}, pinned_ring=3)
+    cls = handlers.SelfBundleHandler if self_cal else handlers.TemplateBundleHandler
+    h = cls(cs, Target(rig.points), TargetDetection(cs.get_names(), rig.detections),
+            fixed_params={"cam_0": {"ext": rig.extr_true[0].copy()}},
+            options={"verbosity": 0, "max_nfev": max_nfev}, pinned_ring=3)
     bp = h.bundlePrimitive
-    x0 = np.concatenate([rig.intr[bp.intr_unfixed].ravel(), rig.extr[bp.extr_unfixed].ravel(), rig.poses[bp.poses_unfixed].ravel()])
+    parts = [rig.intr[bp.intr_unfixed].ravel(), rig.extr[bp.extr_unfixed].ravel(), rig.poses[bp.poses_unfixed].ravel()]
+    if self_cal:
+        parts.append(rig.points.ravel()[bp.bdpt_unfixed])
+    x0 = np.concatenate(parts)
     loss_fn, jac_fn = h.make_loss_fun(1), h.make_loss_jac(1)
     e0 = np.mean(np.linalg.norm(loss_fn(x0).reshape(-1, 2), axis=1))
     print(f"{rig.name}: N = {rig.n_det}, free parameters = {x0.size}, initial mean reprojection error {e0:.3f} px")
@@ -74,4 +81,5 @@ def main(config=2, max_nfev=15, device_only=False):
 
 
 if __name__ == "__main__":
-    main(int(sys.argv[1]) if len(sys.argv) > 1 else 2, device_only="--device-only" in sys.argv)
+    nums = [a for a in sys.argv[1:] if not a.startswith("--")]
+    main(int(nums[0]) if nums else 2, device_only="--device-only" in sys.argv, self_cal="--self" in sys.argv)
