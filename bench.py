@@ -145,6 +145,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-allgather-probe", action="store_true")
+    ap.add_argument("--no-normal-probe", action="store_true")
     ap.add_argument("--stream-to-host", action="store_true",
                     help="config-5 mode: every step also copies the Jacobian to page-locked host memory on a side "
                          "stream (double buffered); the step rate is then PCIe-bound and reported as such")
@@ -304,6 +305,42 @@ def main():
         except Exception as exc:  # noqa: BLE001
             allgather_info = {"error": f"{type(exc).__name__}: {exc}"}
 
+    # SURVEY 8 f2 probe (outside the timed region): what a solver needs instead of the gathered J — the
+    # block-reduced normal equations per rank and ONE all-reduce of the packed [J^T J, J^T r, cost]
+    normal_info = None
+    if not args.no_normal_probe and eng.n_params <= 8192:
+        try:
+            npar = eng.n_params
+            packed = torch.empty(npar * npar + npar + 1, dtype=torch.float64, device=dev)
+            pH, pg, pc = packed.data_ptr(), packed.data_ptr() + 8 * npar * npar, packed.data_ptr() + 8 * (npar * npar + npar)
+            eng.set_option("timing_every", 1)
+            for _ in range(2):
+                eng.normal_equations_device(ps, pH, pg, pc, stream)
+            fence()
+            reps, k_ms = 5, []
+            b0 = time.perf_counter()
+            for _ in range(reps):
+                eng.normal_equations_device(ps, pH, pg, pc, stream)
+                torch.cuda.synchronize(dev)
+                k_ms.append(eng.last_kernel_ms()[1])
+            build_ms = (time.perf_counter() - b0) / reps * 1e3
+            normal_info = {"n_params": npar, "kernel_ms": float(np.median(k_ms)), "build_call_ms": build_ms,
+                           "bytes": packed.numel() * 8,
+                           "note": "ba_normal_kernel: H = J^T J (upper triangle), g, cost in one pass; J never written"}
+            if world > 1:
+                for _ in range(2):
+                    dist.all_reduce(packed)
+                fence()
+                a0 = time.perf_counter()
+                for _ in range(reps):
+                    dist.all_reduce(packed)
+                torch.cuda.synchronize(dev)
+                at = torch.tensor([(time.perf_counter() - a0) / reps], dtype=torch.float64, device=dev)
+                dist.all_reduce(at, op=dist.ReduceOp.MAX)
+                normal_info["allreduce_ms"] = float(at.item()) * 1e3
+        except Exception as exc:  # noqa: BLE001
+            normal_info = {"error": f"{type(exc).__name__}: {exc}"}
+
     if rank == 0:
         bpd = BYTES_PER_DET[(chain, dtype)]
         achieved = N * bpd / (eval_ms * 1e-3) / 1e9
@@ -354,6 +391,8 @@ def main():
                                            "(double buffered, overlapped with the next kernel)"}
         if allgather_info:
             line["allgather"] = allgather_info
+        if normal_info:
+            line["normal_equations"] = normal_info
         if args.host_path:
             eng.eval(ps)  # allocate scratch, warm
             reps, h0 = 3, time.perf_counter()
