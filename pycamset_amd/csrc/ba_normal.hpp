@@ -49,7 +49,7 @@ struct NormalArgs {
     int64_t extr_off, pose_off, point_off;
     int64_t n_params;
     int32_t tiles_per_wave;
-    int32_t debug;  // profiling switches: 1 skip the dot loops, 2 skip the flush atomics
+    int32_t debug;  // profiling switches: 1 skip the dot loops, 2 skip the flush atomics, 4 / 8 skip the point-block / shared-point atomics
 };
 
 constexpr int normal_shared_cols(int chain) { return chain == CHAIN_FREE ? 15 : 21; }
@@ -177,12 +177,15 @@ __global__ __launch_bounds__(64 * NORMAL_WAVES) void ba_normal_kernel(const Norm
                 double jp0[3], jp1[3];
 #pragma unroll
                 for (int t = 0; t < 3; ++t) { jp0[t] = (double)J[NS + t]; jp1[t] = (double)J[P + NS + t]; }
+                if (!(a.debug & 4)) {
 #pragma unroll
-                for (int t = 0; t < 3; ++t) {
-                    unsafeAtomicAdd(a.g + gX + t, jp0[t] * r0 + jp1[t] * r1);
+                    for (int t = 0; t < 3; ++t) {
+                        unsafeAtomicAdd(a.g + gX + t, jp0[t] * r0 + jp1[t] * r1);
 #pragma unroll
-                    for (int s = t; s < 3; ++s) unsafeAtomicAdd(a.H + (gX + t) * a.n_params + gX + s, jp0[t] * jp0[s] + jp1[t] * jp1[s]);
+                        for (int s = t; s < 3; ++s) unsafeAtomicAdd(a.H + (gX + t) * a.n_params + gX + s, jp0[t] * jp0[s] + jp1[t] * jp1[s]);
+                    }
                 }
+                if (!(a.debug & 8))
 #pragma unroll
                 for (int p = 0; p < NS; ++p) {
                     double *row = a.H + shared_col<CHAIN>(a, p, c, im) * a.n_params + gX;

@@ -30,7 +30,7 @@ for cfg, chain, shuffle in configs:
     cd = torch.empty(1, dtype=torch.float64, device="cuda")
     print(f"# {rig.name} chain {chain} N={det.shape[0]} n_params={n} shuffled={shuffle}  H = {n*n*8/1e6:.1f} MB")
     if "--phases" in sys.argv:   # option normal_debug: 1 = skip the dot loops, 2 = skip the flush atomics (results are wrong)
-        for dbg in (3, 1, 2, 0):
+        for dbg in ((3, 1, 2, 0) if chain == "template" else (12, 8, 4, 0)):   # 4 = no point-block atomics, 8 = no shared-point atomics
             e.set_option("normal_debug", dbg)
             ks = []
             for _ in range(8):
