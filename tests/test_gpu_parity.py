@@ -493,3 +493,55 @@ def test_extreme_inputs_propagate_like_ieee_python(Engine, chain):
         # inputs where inf - inf and 0 * inf orderings legitimately differ between the two formulations
         if case.name in ("behind", "distorted"):
             assert np.array_equal(np.isfinite(j), np.isfinite(ref_j)), case.name
+
+
+# ---- randomized shapes through every evaluation entry point ------------------------------------------------
+@pytest.mark.parametrize("seed", range(6))
+def test_random_shapes_through_every_entry_point(Engine, seed):
+    """Seeded random rig shapes (1-7 cameras, 1-9 images, 1-40 keys, random visibility, random row order,
+    random fixed-parameter mask): dense evaluation, CSR compaction, matrix-free products and the block-reduced
+    normal equations must all agree with the oracle's Jacobian of the same table."""
+    from scipy.sparse import csr_array
+    rng = np.random.default_rng(1234 + seed)
+    n_cams, n_imgs, n_keys = int(rng.integers(1, 8)), int(rng.integers(1, 10)), int(rng.integers(1, 41))
+    pts = rng.uniform(-0.04, 0.04, (n_keys, 3))
+    rig = synthetic.make_rig(f"rand-{seed}", n_cams, n_imgs, pts, seed=500 + seed, visibility=float(rng.uniform(0.3, 1.0)))
+    det = rig.detections
+    if seed % 2:
+        det = det[rng.permutation(det.shape[0])]
+    n = det.shape[0]
+    for chain in CHAINS:
+        ps, ref_r, ref_j = oracle_eval(rig, chain, det)
+        npar = ps.shape[0]
+        e = make_engine(Engine, rig, chain, det=det)
+        r, j = e.eval(ps)
+        H.assert_resid_close(r, ref_r, det[:, 3:])
+        H.assert_jac_close(j, ref_j)
+        # compaction under a random mask (at least one free parameter)
+        mask = rng.random(npar) < 0.7
+        mask[int(rng.integers(npar))] = True
+        idx, ptr, _ = orc.csr_structure(chain, det, mask)
+        gi, gp = e.csr_structure(mask)
+        assert np.array_equal(gp, ptr) and np.array_equal(gi, idx)
+        e.set_unfixed(mask)
+        _, data = e.eval_compact(ps)
+        full_idx, full_ptr, _ = orc.csr_structure(chain, det, np.ones(npar, bool))
+        keep = mask[full_idx]
+        ref_data = ref_j.reshape(-1)[keep]
+        assert data.shape == ref_data.shape
+        scale = np.maximum(np.abs(ref_data), 1e-6 * np.repeat(np.max(np.abs(ref_j), axis=1), ref_j.shape[1])[keep])
+        assert np.max(np.abs(data - ref_data) / scale) <= H.JAC_RTOL
+        # products and normal equations
+        J = csr_array((ref_j.reshape(-1), full_idx, full_ptr), shape=(2 * n, npar))
+        v = rng.standard_normal(npar)
+        e.linearize(ps)
+        ref = J.T @ (J @ v)
+        assert np.max(np.abs(e.jtjv(v) - ref)) <= 1e-10 * max(np.max(np.abs(ref)), 1e-300)
+        Hm, g, cost = e.normal_equations(ps)
+        H_ref = (J.T @ J).toarray()
+        sc = np.sqrt(np.outer(np.diag(H_ref), np.diag(H_ref)))
+        assert np.max(np.abs(Hm - H_ref) / np.where(sc > 0, sc, 1.0)) <= 1e-10
+        g_ref = J.T @ ref_r.reshape(-1)
+        assert np.max(np.abs(g - g_ref)) <= 1e-10 * max(np.max(np.abs(g_ref)), 1e-300)
+        assert abs(cost - float(np.sum(ref_r ** 2))) <= 1e-10 * float(np.sum(ref_r ** 2))
+        e.close()
