@@ -281,24 +281,51 @@ __global__ __launch_bounds__(WG_THREADS) void ba_eval_kernel(const EvalArgs a) {
                     // id keeps it inside (148 VGPRs for the self chain).
                     int lane_v = lane;
                     if constexpr (LROW != P2) asm volatile("" : "+v"(lane_v));
+                    auto lds_unit = [&](const int q) {  // unit index inside the (possibly padded) LDS image
+                        if constexpr (LROW != P2) {
+                            static_assert(P2 % VS == 0 && LROW % VS == 0, "padded rows must hold whole 16-byte units");
+                            const int row = q / (P2 / VS);
+                            return row * (LROW / VS) + (q - row * (P2 / VS));
+                        } else {
+                            return q;
+                        }
+                    };
+                    if (base + (int64_t)HALF * P2 <= total_jac) {
+                        // whole half tile inside the array (every tile but the last): no per-unit range checks, and
+                        // the LDS read of unit u + 1 is issued before unit u is stored (left alone hipcc pairs every
+                        // ds_read_b128 with an s_waitcnt 0 right before its store)
+                        constexpr int NU = (UNITS + 63) / 64;
+                        V16 w[2];
+                        w[0] = reinterpret_cast<const V16 *>(tr)[lds_unit(lane_v)];
 #pragma unroll
-                    for (int q0 = 0; q0 < UNITS; q0 += 64) {
-                        const int q = q0 + lane_v;
-                        if (q < UNITS) {
-                            const int64_t e = base + (int64_t)q * VS;
-                            int lq = q;  // unit index inside the (possibly padded) LDS image
-                            if constexpr (LROW != P2) {
-                                static_assert(P2 % VS == 0 && LROW % VS == 0, "padded rows must hold whole 16-byte units");
-                                const int row = q / (P2 / VS);
-                                lq = row * (LROW / VS) + (q - row * (P2 / VS));
+                        for (int u = 0; u < NU; ++u) {
+                            const int qn = (u + 1) * 64 + lane_v;
+                            if (u + 1 < NU) {
+                                if ((u + 2) * 64 <= UNITS || qn < UNITS) w[(u + 1) & 1] = reinterpret_cast<const V16 *>(tr)[lds_unit(qn)];
                             }
-                            if (e + VS <= total_jac) {
-                                const V16 w = reinterpret_cast<const V16 *>(tr)[lq];
-                                if constexpr (NT) __builtin_nontemporal_store(w, reinterpret_cast<V16 *>(jac + e));
-                                else *reinterpret_cast<V16 *>(jac + e) = w;
-                            } else {
-                                for (int s = 0; s < VS; ++s)
-                                    if (e + s < total_jac) jac[e + s] = tr[lq * VS + s];
+                            asm volatile("" ::: "memory");
+                            const int q = u * 64 + lane_v;
+                            if ((u + 1) * 64 <= UNITS || q < UNITS) {
+                                V16 *dst = reinterpret_cast<V16 *>(jac + base + (int64_t)q * VS);
+                                if constexpr (NT) __builtin_nontemporal_store(w[u & 1], dst);
+                                else *dst = w[u & 1];
+                            }
+                        }
+                    } else {
+#pragma unroll
+                        for (int q0 = 0; q0 < UNITS; q0 += 64) {
+                            const int q = q0 + lane_v;
+                            if (q < UNITS) {
+                                const int64_t e = base + (int64_t)q * VS;
+                                const int lq = lds_unit(q);
+                                if (e + VS <= total_jac) {
+                                    const V16 w = reinterpret_cast<const V16 *>(tr)[lq];
+                                    if constexpr (NT) __builtin_nontemporal_store(w, reinterpret_cast<V16 *>(jac + e));
+                                    else *reinterpret_cast<V16 *>(jac + e) = w;
+                                } else {
+                                    for (int s = 0; s < VS; ++s)
+                                        if (e + s < total_jac) jac[e + s] = tr[lq * VS + s];
+                                }
                             }
                         }
                     }
