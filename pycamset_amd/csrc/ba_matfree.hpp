@@ -188,9 +188,17 @@ __global__ __launch_bounds__(256) void ba_matfree_kernel(const MatfreeArgs a) {
                 const int col = lane % RED_COLS, grp = lane / RED_COLS;  // lane 63: grp 3 -> idle
                 const bool is_cam = col < 15;
                 if (grp < 3 && (is_cam ? cam_uni : img_uni)) {
-                    const int r0 = grp * 22, r1 = min(64, r0 + 22);
+                    // 22 independent reads first, then the adds: as a plain loop hipcc emits read - wait - add
+                    // per row (22 exposed LDS latencies per tile).  Rows past 63 (third group) are clamped and masked.
+                    const int r0 = grp * 22;
+                    const double *colp = red + col * RED_STRIDE;
+                    double vals[22];
+#pragma unroll
+                    for (int t = 0; t < 22; ++t) vals[t] = colp[min(r0 + t, 63)];
+                    asm volatile("" ::: "memory");
                     double sum = 0.0;
-                    for (int r = r0; r < r1; ++r) sum += red[col * RED_STRIDE + r];
+#pragma unroll
+                    for (int t = 0; t < 22; ++t) sum += (r0 + t < 64) ? vals[t] : 0.0;
                     const int64_t dst = col < 9 ? 9 * (int64_t)c0 + col
                                       : is_cam  ? a.extr_off + 6 * (int64_t)c0 + (col - 9)
                                                 : a.pose_off + 6 * (int64_t)im0 + (col - 15);
