@@ -63,7 +63,7 @@ def main(config=2, max_nfev=15, device_only=False, self_cal=False):
         print(f"(a) least_squares + HIP closures : {t_scipy:7.2f} s  nfev {res.nfev:3d}  cost {res.cost:.6e}  error {e1:.4f} px")
 
     t0 = time.perf_counter()
-    dev = lm_solve(h, x0.copy(), max_iter=max_nfev)
+    dev = lm_solve(h, x0.copy(), max_iter=max_nfev, linear_solver="pcg")
     t_dev = time.perf_counter() - t0
     e2 = np.mean(np.linalg.norm(loss_fn(dev.x).reshape(-1, 2), axis=1))
     print(f"(b) device LM (matrix-free J)    : {t_dev:7.2f} s  nfev {dev.nfev:3d}  cost {dev.cost:.6e}  error {e2:.4f} px"

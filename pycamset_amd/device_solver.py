@@ -105,6 +105,9 @@ def pcg(apply_a, b, m_inv, tol: float, max_iter: int):
     return x, it
 
 
+DENSE_LIMIT = 8192   # parameters up to which lm_solve(linear_solver="auto") forms the dense J^T J
+
+
 class NormalEquations:
     """H = J^T J, g = J^T r and sum r^2 restricted to the free parameters, built by one pass of the
     block-reduced kernel (csrc/ba_normal.hpp) and kept on the GPU as torch tensors.
@@ -319,20 +322,24 @@ class _CholeskyStep:
 
 def lm_solve(handler, x0, *, max_iter: int = 50, ftol: float = 1e-8, xtol: float = 1e-8, gtol: float = 1e-8,
              cg_tol: float = 1e-3, cg_max_iter: int = 200, lam0: float = 1e-3, reduce_fn=None, verbose: int = 0,
-             operator=None, linear_solver: str = "pcg") -> DeviceLMResult:
+             operator=None, linear_solver: str = "auto") -> DeviceLMResult:
     """Levenberg-Marquardt (Marquardt scaling D = diag(J^T J)) for a pycamset_amd handler.  The damped
     normal equations are solved by Jacobi-PCG on matrix-free J^T J products (``linear_solver='pcg'``) or
     by a Cholesky factorisation of the block-reduced J^T J (``'cholesky'``).  Every quantity that depends
     on the detections is computed by the HIP engine.  ``operator`` replaces the engine-backed
     JacobianOperator / NormalEquations (used by the CPU tests of this driver)."""
-    if linear_solver not in ("pcg", "cholesky"):
-        raise ValueError("linear_solver must be 'pcg' or 'cholesky'")
+    if linear_solver not in ("auto", "pcg", "cholesky"):
+        raise ValueError("linear_solver must be 'auto', 'pcg' or 'cholesky'")
     op_fun = handler.op_fun
     if operator is None:
         dd = handler._flat_detections()
         eng = op_fun._engine_for(dd)
         op_fun._bind_template(eng, handler._template_arg())
+        if linear_solver == "auto":   # a dense J^T J up to 8 192 parameters (0.5 GB); beyond that matrix-free CG
+            linear_solver = "cholesky" if eng.n_params <= DENSE_LIMIT else "pcg"
         operator = (JacobianOperator if linear_solver == "pcg" else NormalEquations)(eng, handler._jac_mask(), reduce_fn=reduce_fn)
+    elif linear_solver == "auto":
+        linear_solver = "cholesky" if hasattr(operator, "build") else "pcg"
     step = _PcgStep(operator, cg_tol, cg_max_iter) if linear_solver == "pcg" else _CholeskyStep(operator)
 
     def param_str(x):

@@ -35,9 +35,9 @@ def make_optimisation_function(param_handler, threads: int = 1):
     return loss_fn, jac_fn, x0
 
 
-def run_bundle_adjustment(param_handler, threads: int = 1, solver: str = "scipy", linear_solver: str = "cholesky"):
+def run_bundle_adjustment(param_handler, threads: int = 1, solver: str = "scipy", linear_solver: str = "auto"):
     """Solve the handler's problem; returns (result, parameter slabs at the solution) — oh:52-117.
-    ``solver='device'`` runs device_solver.lm_solve with ``linear_solver`` in {'cholesky', 'pcg'}."""
+    ``solver='device'`` runs device_solver.lm_solve with ``linear_solver`` in {'auto', 'cholesky', 'pcg'}."""
     loss_fn, jac_fn, x0 = make_optimisation_function(param_handler, threads)
     opts = param_handler.problem_opts
     start_error = mean_reprojection_error(loss_fn(x0))
