@@ -26,7 +26,8 @@
 //   * Accumulators live in registers across tiles for as long as (cam, image) does not change; on a
 //     change (and at the end) they are added to H / g / cost with one global f64 atomic each.  A tile
 //     that mixes several (cam, image) pairs is processed pair by pair (wave-uniform member masks), so any
-//     table order gives the same result; shuffled tables simply flush more often.
+//     table order gives the same result.  For a scattered table (every detection its own run: 18 ms on rig-32)
+//     the host hands over a (cam, image)-sorted visiting order instead — the sums do not depend on it.
 //   * The 3 point columns (self / free chains) differ per lane, so their rows of H (point-point,
 //     shared-point) and of g are added per detection with global atomics.
 // Atomic order makes the last bits run-to-run dependent (documented; tests compare with a tolerance).
@@ -41,6 +42,8 @@ namespace pcs {
 struct NormalArgs {
     const int32_t *cam, *img, *key;
     const void *uv;
+    const int32_t *order;  // optional: visit the detections in this order (a (cam, image)-sorted permutation of a
+                           // scattered table; H, g and the cost do not depend on the row order), or NULL
     const void *cam_slab, *pose_slab, *points;
     double *H;      // n_params x n_params, zeroed by the host; upper triangle written
     double *g;      // n_params, zeroed by the host
@@ -161,7 +164,8 @@ __global__ __launch_bounds__(64 * NORMAL_WAVES) void ba_normal_kernel(const Norm
     for (int64_t tile = tile0; tile < tile1; ++tile) {
         const int64_t i = tile * 64 + lane;
         const bool valid = i < a.n;
-        const int64_t ic = valid ? i : a.n - 1;
+        const int64_t is = valid ? i : a.n - 1;
+        const int64_t ic = a.order ? a.order[is] : is;
         const int c = a.cam[ic], im = (CHAIN != CHAIN_FREE) ? a.img[ic] : 0, k = a.key[ic];
         const V2 m = uv[ic];
         T u, v;

@@ -66,6 +66,7 @@ struct pcs_engine {
     hipStream_t last_stream = nullptr;
     // static inputs
     int32_t *d_cam = nullptr, *d_img = nullptr, *d_key = nullptr;
+    int32_t *d_order = nullptr;  // (cam, image)-sorted visiting order of a scattered table (normal equations), or NULL
     void *d_uv = nullptr;
     std::vector<int32_t> h_cam, h_img, h_key;
     bool have_template = false;
@@ -317,7 +318,7 @@ int pcs_destroy(pcs_engine *h) {
     if (!h) return PCS_OK;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
-    void *bufs[] = {h->d_cam, h->d_img, h->d_key, h->d_uv, h->d_param, h->d_cam_slab, h->d_pose_slab, h->d_points,
+    void *bufs[] = {h->d_cam, h->d_img, h->d_key, h->d_order, h->d_uv, h->d_param, h->d_cam_slab, h->d_pose_slab, h->d_points,
                     h->d_resid, h->d_jac, h->d_keep, h->d_row_off, h->d_data, h->d_vin, h->d_vout, h->d_cost, h->d_im_points, h->d_cam_tab, h->d_sink, h->d_H};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
@@ -362,7 +363,7 @@ static int upload_detections(pcs_engine *h, std::vector<int32_t> &cam, std::vect
     }
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(h->stream));
-    for (void **b : {(void **)&h->d_cam, (void **)&h->d_img, (void **)&h->d_key, &h->d_uv, &h->d_resid, &h->d_jac,
+    for (void **b : {(void **)&h->d_cam, (void **)&h->d_img, (void **)&h->d_key, (void **)&h->d_order, &h->d_uv, &h->d_resid, &h->d_jac,
                      (void **)&h->d_keep, (void **)&h->d_row_off, &h->d_data}) {
         if (*b) HIPCHK(hipFree(*b));
         *b = nullptr;
@@ -383,6 +384,17 @@ static int upload_detections(pcs_engine *h, std::vector<int32_t> &cam, std::vect
         std::vector<float> f(2 * n);
         for (int64_t i = 0; i < 2 * n; ++i) f[i] = (float)uv[i];
         HIPCHK(hipMemcpy(h->d_uv, f.data(), sizeof(float) * 2 * n, hipMemcpyHostToDevice));
+    }
+    if (h->tile_locality < 0.5 && n <= INT32_MAX) {
+        // scattered table: a (cam, image)-sorted visiting order for the kernels whose result does not depend on
+        // the row order (ba_normal_kernel keeps its accumulators per (cam, image) run)
+        std::vector<int32_t> order(n);
+        for (int64_t i = 0; i < n; ++i) order[i] = (int32_t)i;
+        std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) {
+            return h->h_cam[x] != h->h_cam[y] ? h->h_cam[x] < h->h_cam[y] : h->h_img[x] < h->h_img[y];
+        });
+        HIPCHK(hipMalloc(&h->d_order, sizeof(int32_t) * n));
+        HIPCHK(hipMemcpy(h->d_order, order.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice));
     }
     h->n = n;
     return PCS_OK;
@@ -657,6 +669,7 @@ static int enqueue_normal(pcs_engine *h, const double *d_prm, double *d_H, doubl
     if (rc) return rc;
     NormalArgs a{};
     a.cam = h->d_cam; a.img = h->d_img; a.key = h->d_key; a.uv = h->d_uv;
+    a.order = h->d_order;
     a.cam_slab = h->d_cam_slab; a.pose_slab = h->d_pose_slab; a.points = h->d_points;
     a.H = d_H; a.g = d_g; a.cost = d_cost;
     a.n = h->n; a.n_tiles = (h->n + TILE - 1) / TILE;
