@@ -545,3 +545,58 @@ def test_random_shapes_through_every_entry_point(Engine, seed):
         assert np.max(np.abs(g - g_ref)) <= 1e-10 * max(np.max(np.abs(g_ref)), 1e-300)
         assert abs(cost - float(np.sum(ref_r ** 2))) <= 1e-10 * float(np.sum(ref_r ** 2))
         e.close()
+
+
+def test_engine_lifecycle_releases_device_memory(Engine):
+    """Create / use / destroy engines repeatedly (every scratch buffer exercised: dense + compact outputs,
+    matrix-free vectors, normal equations, legacy cost tables, the sorted visiting order of a scattered table);
+    the device memory in use must return to where it started, and two live engines must not disturb each other."""
+    import torch
+    rig = synthetic.config_rig(1)
+    shuffled = rig.detections[np.random.default_rng(0).permutation(rig.n_det)]
+    ps_t, ref_r, ref_j = oracle_eval(rig, "template")
+
+    def exercise(det):
+        e = make_engine(Engine, rig, "template", det=det)
+        e.eval(ps_t)
+        mask = np.ones(e.n_params, bool)
+        mask[:9] = False
+        e.set_unfixed(mask)
+        e.eval_compact(ps_t, want_resid=True)
+        e.linearize(ps_t)
+        e.jtjv(np.ones(e.n_params))
+        e.normal_equations(ps_t)
+        return e
+
+    torch.cuda.synchronize()
+    exercise(rig.detections).close()          # first use: one-off allocations of the runtime itself
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for it in range(20):
+        exercise(shuffled if it % 2 else rig.detections).close()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 8 << 20, f"{(free0 - free1) / 2**20:.1f} MiB not returned after 20 create/destroy cycles"
+    # two engines alive at once, different chains, interleaved calls
+    a = make_engine(Engine, rig, "template")
+    b = make_engine(Engine, rig, "self")
+    ps_s, ref_rs, ref_js = oracle_eval(rig, "self")
+    for _ in range(3):
+        ra, ja = a.eval(ps_t)
+        rb, jb = b.eval(ps_s)
+        H.assert_jac_close(ja, ref_j)
+        H.assert_jac_close(jb, ref_js)
+    # a table of another size on a live engine: capacities are re-derived
+    half = rig.detections[: rig.n_det // 2].copy()
+    half[-1, :3] = [rig.n_cams - 1, rig.n_imgs - 1, rig.n_keys - 1]
+    a.set_detections_table(half)
+    a.set_template(rig.points)
+    _, r_half, j_half = oracle_eval(rig, "template", half)
+    r2, j2 = a.eval(ps_t)
+    H.assert_resid_close(r2, r_half, half[:, 3:])
+    H.assert_jac_close(j2, j_half)
+    a.set_detections_table(rig.detections)
+    r3, j3 = a.eval(ps_t)
+    H.assert_jac_close(j3, ref_j)
+    a.close()
+    b.close()
