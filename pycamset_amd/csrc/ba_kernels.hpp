@@ -592,12 +592,31 @@ __global__ __launch_bounds__(256) void legacy_cost_kernel(const int32_t *__restr
 // Streaming probes used to measure the box's achievable HBM rate for THIS access shape
 // (16 B per lane, 1 KiB per wave-instruction): kind 0 plain fill, 1 non-temporal fill, 2 plain copy,
 // 3 non-temporal copy.  Reported next to the 8 TB/s spec figure in DESIGN.md.
+// kind 4: non-temporal fill in the fused kernel's shape — every wave owns whole 10 752-byte chunks (a half tile
+// of the template chain: 672 units of 16 B, 10.5 store instructions) far apart from the other waves' chunks.
 template <int KIND>
 __global__ __launch_bounds__(256) void membench_kernel(const double2 *__restrict__ src, double2 *__restrict__ dst, int64_t n16) {
     using V = __attribute__((ext_vector_type(2))) double;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     V *d = reinterpret_cast<V *>(dst);
     const V *s = reinterpret_cast<const V *>(src);
+    if constexpr (KIND == 4) {
+        constexpr int CHUNK = 672;
+        const int lane = threadIdx.x & 63;
+        const int64_t n_chunks = n16 / CHUNK, waves = stride / 64;
+        for (int64_t c = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / 64; c < n_chunks; c += waves) {
+            V *o = d + c * CHUNK;
+#pragma unroll
+            for (int u = 0; u < 11; ++u) {
+                const int q = u * 64 + lane;
+                V v;
+                v.x = (double)c;
+                v.y = (double)q;
+                if (q < CHUNK) __builtin_nontemporal_store(v, o + q);
+            }
+        }
+        return;
+    }
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) {
         V v;
         if constexpr (KIND >= 2) v = (KIND == 3) ? __builtin_nontemporal_load(s + i) : s[i];

@@ -211,14 +211,14 @@ int pcs_host_free(void *p) {
 }
 
 int pcs_membench(int device, int kind, int64_t bytes, int iters, int blocks_per_cu, float *mean_ms) {
-    if (kind < 0 || kind > 3 || bytes < 4096 || iters < 1 || !mean_ms) return fail(PCS_ERR_ARG, "pcs_membench: bad arguments");
+    if (kind < 0 || kind > 4 || bytes < 4096 || iters < 1 || !mean_ms) return fail(PCS_ERR_ARG, "pcs_membench: bad arguments");
     if (device < 0 || device >= pcs_device_count()) return fail(PCS_ERR_NODEVICE, "pcs_membench: device %d not available", device);
     HIPCHK(hipSetDevice(device));
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device));
     void *src = nullptr, *dst = nullptr;
     HIPCHK(hipMalloc(&dst, bytes));
-    if (kind >= 2) {
+    if (kind == 2 || kind == 3) {
         HIPCHK(hipMalloc(&src, bytes));
         HIPCHK(hipMemset(src, 1, bytes));
     }
@@ -232,7 +232,8 @@ int pcs_membench(int device, int kind, int64_t bytes, int iters, int blocks_per_
             case 0: hipLaunchKernelGGL(membench_kernel<0>, grid, dim3(256), 0, nullptr, (const double2 *)src, (double2 *)dst, n16); break;
             case 1: hipLaunchKernelGGL(membench_kernel<1>, grid, dim3(256), 0, nullptr, (const double2 *)src, (double2 *)dst, n16); break;
             case 2: hipLaunchKernelGGL(membench_kernel<2>, grid, dim3(256), 0, nullptr, (const double2 *)src, (double2 *)dst, n16); break;
-            default: hipLaunchKernelGGL(membench_kernel<3>, grid, dim3(256), 0, nullptr, (const double2 *)src, (double2 *)dst, n16); break;
+            case 3: hipLaunchKernelGGL(membench_kernel<3>, grid, dim3(256), 0, nullptr, (const double2 *)src, (double2 *)dst, n16); break;
+            default: hipLaunchKernelGGL(membench_kernel<4>, grid, dim3(256), 0, nullptr, (const double2 *)src, (double2 *)dst, n16); break;
         }
     };
     for (int i = 0; i < 3; ++i) launch();

@@ -7,14 +7,17 @@ from pycamset_amd import _capi
 
 lib = _capi.lib()
 res = {}
-for kind, name in ((0, "fill"), (1, "fill_nt"), (2, "copy"), (3, "copy_nt")):
+kinds = ((0, "fill"), (1, "fill_nt"), (2, "copy"), (3, "copy_nt"), (4, "fill_nt_chunks"))
+if len(sys.argv) > 1:
+    kinds = [k for k in kinds if k[1] in sys.argv[1:]]
+for kind, name in kinds:
     for mb in (352, 1024, 4096):
-        for bpc in (4, 8, 16):
+        for bpc in ((4, 8, 16) if kind != 4 else (4, 8, 12, 16, 32, 64)):
             ms = ctypes.c_float()
             _capi.check(lib.pcs_membench(0, kind, mb * 1000 * 1000, 20, bpc, ctypes.byref(ms)))
-            moved = mb * 1e6 * (2 if kind >= 2 else 1)
+            moved = mb * 1e6 * (2 if kind in (2, 3) else 1)
             gbs = moved / (ms.value * 1e-3) / 1e9
             res[f"{name}_{mb}MB_bpc{bpc}"] = gbs
-            print(f"{name:8s} {mb:5d} MB  blocks/CU {bpc:2d}: {ms.value*1e3:8.1f} us  {gbs:7.1f} GB/s")
+            print(f"{name:14s} {mb:5d} MB  blocks/CU {bpc:2d}: {ms.value*1e3:8.1f} us  {gbs:7.1f} GB/s")
 Path("gpurun_out").mkdir(exist_ok=True)
 json.dump(res, open("gpurun_out/membench.json", "w"), indent=1)
