@@ -382,6 +382,10 @@ def main():
                 "timed_every": every,
                 "algorithmic_bytes_per_detection": bpd,
                 "frac_of_measured_copy_peak_6290": achieved / 6290.0,
+                # written bytes only, against a bare non-temporal fill of the same chunk shape on the same part
+                # (pcs_membench kind 4: 5.5-5.6 TB/s, profiles/r01/sweeps.md) — the write stream is the bound
+                "written_GBps": N * (bpd - (28 if dtype == "f64" else 20)) / (eval_ms * 1e-3) / 1e9,
+                "frac_of_measured_nt_fill_5600": N * (bpd - (28 if dtype == "f64" else 20)) / (eval_ms * 1e-3) / 1e9 / 5600.0,
             },
         }
         if args.stream_to_host:
