@@ -204,7 +204,8 @@ int pcs_host_alloc(void **out, int64_t bytes);
 int pcs_host_free(void *p);
 /* Streaming probe of the device's achievable HBM rate with this engine's access shape (16 B per lane):
  * kind 0 fill, 1 non-temporal fill, 2 copy, 3 non-temporal copy, 4 non-temporal fill in the fused kernel's
- * shape (every wave writes whole 10 752-byte chunks); `bytes` per launch (per buffer).
+ * shape (every wave writes whole 10 752-byte chunks), 5..8 the same with 21 KiB / 1 KiB / 64 KiB / 256 KiB chunks;
+ * `bytes` per launch (per buffer).
  * Measurement aid for DESIGN.md / bench.py --membench; not on the evaluation path. */
 int pcs_membench(int device, int kind, int64_t bytes, int iters, int blocks_per_cu, float *mean_ms);
 /* Engine-owned device scratch for outputs (engine dtype); valid until the next set_detections. */

@@ -600,19 +600,19 @@ __global__ __launch_bounds__(256) void membench_kernel(const double2 *__restrict
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     V *d = reinterpret_cast<V *>(dst);
     const V *s = reinterpret_cast<const V *>(src);
-    if constexpr (KIND == 4) {
-        constexpr int CHUNK = 672;
+    if constexpr (KIND >= 4) {
+        // chunk sizes (16-byte units) of kinds 4..8: the half tile, the whole tile, 1 KiB, 64 KiB, 256 KiB
+        constexpr int CHUNK = KIND == 4 ? 672 : KIND == 5 ? 1344 : KIND == 6 ? 64 : KIND == 7 ? 4096 : 16384;
         const int lane = threadIdx.x & 63;
         const int64_t n_chunks = n16 / CHUNK, waves = stride / 64;
         for (int64_t c = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / 64; c < n_chunks; c += waves) {
             V *o = d + c * CHUNK;
-#pragma unroll
-            for (int u = 0; u < 11; ++u) {
-                const int q = u * 64 + lane;
+#pragma unroll 4
+            for (int q = lane; q < CHUNK; q += 64) {
                 V v;
                 v.x = (double)c;
                 v.y = (double)q;
-                if (q < CHUNK) __builtin_nontemporal_store(v, o + q);
+                __builtin_nontemporal_store(v, o + q);
             }
         }
         return;

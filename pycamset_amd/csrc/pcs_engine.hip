@@ -211,7 +211,7 @@ int pcs_host_free(void *p) {
 }
 
 int pcs_membench(int device, int kind, int64_t bytes, int iters, int blocks_per_cu, float *mean_ms) {
-    if (kind < 0 || kind > 4 || bytes < 4096 || iters < 1 || !mean_ms) return fail(PCS_ERR_ARG, "pcs_membench: bad arguments");
+    if (kind < 0 || kind > 8 || bytes < 4096 || iters < 1 || !mean_ms) return fail(PCS_ERR_ARG, "pcs_membench: bad arguments");
     if (device < 0 || device >= pcs_device_count()) return fail(PCS_ERR_NODEVICE, "pcs_membench: device %d not available", device);
     HIPCHK(hipSetDevice(device));
     hipDeviceProp_t prop;
@@ -233,7 +233,11 @@ int pcs_membench(int device, int kind, int64_t bytes, int iters, int blocks_per_
             case 1: hipLaunchKernelGGL(membench_kernel<1>, grid, dim3(256), 0, nullptr, (const double2 *)src, (double2 *)dst, n16); break;
             case 2: hipLaunchKernelGGL(membench_kernel<2>, grid, dim3(256), 0, nullptr, (const double2 *)src, (double2 *)dst, n16); break;
             case 3: hipLaunchKernelGGL(membench_kernel<3>, grid, dim3(256), 0, nullptr, (const double2 *)src, (double2 *)dst, n16); break;
-            default: hipLaunchKernelGGL(membench_kernel<4>, grid, dim3(256), 0, nullptr, (const double2 *)src, (double2 *)dst, n16); break;
+            case 4: hipLaunchKernelGGL(membench_kernel<4>, grid, dim3(256), 0, nullptr, (const double2 *)src, (double2 *)dst, n16); break;
+            case 5: hipLaunchKernelGGL(membench_kernel<5>, grid, dim3(256), 0, nullptr, (const double2 *)src, (double2 *)dst, n16); break;
+            case 6: hipLaunchKernelGGL(membench_kernel<6>, grid, dim3(256), 0, nullptr, (const double2 *)src, (double2 *)dst, n16); break;
+            case 7: hipLaunchKernelGGL(membench_kernel<7>, grid, dim3(256), 0, nullptr, (const double2 *)src, (double2 *)dst, n16); break;
+            default: hipLaunchKernelGGL(membench_kernel<8>, grid, dim3(256), 0, nullptr, (const double2 *)src, (double2 *)dst, n16); break;
         }
     };
     for (int i = 0; i < 3; ++i) launch();
