@@ -1,6 +1,8 @@
 """Host logic of the drop-in boundary (no GPU): free-vector <-> slab scatter, fixed-parameter masks,
 key flattening, synthetic rig layout.  The handler goldens come from the reference's own handlers
 (tests/golden/make_golden.py); the arithmetic here is done by the CPU oracle."""
+from pathlib import Path
+
 import numpy as np
 import pytest
 
@@ -243,3 +245,33 @@ def test_device_lm_driver_logic_on_cpu_operator():
     assert abs(res2.cost - res.cost) <= 1e-6 * res.cost and res2.nfev <= res.nfev + 2
     with pytest.raises(ValueError):
         lm_solve(h, x0.copy(), operator=op, linear_solver="qr")
+
+
+def test_normal_kernel_lane_tables_are_a_conflict_free_partition():
+    """csrc/ba_normal.hpp hard-codes which chunk of the J^T J triangle every lane owns (tools/normal_lane_table.py).
+    The tables must cover every entry (p <= q < NA) exactly once and keep slots 16 apart out of the same
+    ds_read_b128 lane group (idle lanes read slot 0)."""
+    import importlib.util
+    import re
+    root = Path(__file__).resolve().parent.parent
+    spec = importlib.util.spec_from_file_location("normal_lane_table", root / "tools" / "normal_lane_table.py")
+    tool = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tool)
+    src = (root / "pycamset_amd" / "csrc" / "ba_normal.hpp").read_text()
+    for na, ch in ((22, 5), (16, 3)):
+        tabs = {}
+        for name in ("P", "Q"):
+            m = re.search(rf"NORMAL_{name}_{na}\[64\] = \{{([^}}]*)\}}", src)
+            tabs[name] = [int(v) for v in m.group(1).split(",")]
+            assert len(tabs[name]) == 64
+        assign = [None if p == 255 else (p, q) for p, q in zip(tabs["P"], tabs["Q"])]
+        assert all((a is None) == (q == 255) for a, q in zip(assign, tabs["Q"]))
+        covered = []
+        for a in assign:
+            if a is not None:
+                p, q0 = a
+                assert 0 <= p <= q0 < na
+                covered += [(p, q) for q in range(q0, min(q0 + ch, na))]
+        assert sorted(covered) == [(p, q) for p in range(na) for q in range(p, na)], "every entry exactly once"
+        assert tool.conflicts(assign) == 0
+        assert sorted(a for a in assign if a is not None) == sorted(tool.chunks(na, ch))
