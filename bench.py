@@ -34,7 +34,9 @@ if str(REPO) not in sys.path:
     sys.path.insert(0, str(REPO))
 
 BYTES_PER_DET = {("template", "f64"): 380, ("self", "f64"): 428, ("free", "f64"): 332,
-                 ("template", "f32"): 196, ("self", "f32"): 220, ("free", "f32"): 172}
+                 ("template", "f32"): 196, ("self", "f32"): 220, ("free", "f32"): 172,
+                 # mixed (FP64 arithmetic and measurements, FP32 outputs): 28 B in like f64, outputs like f32
+                 ("template", "mixed"): 204, ("self", "mixed"): 228, ("free", "mixed"): 180}
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 CONFIG_CHAIN = {1: "template", 2: "template", 3: "template", 4: "self", 5: "template"}
 CONFIG_DTYPE = {1: "f64", 2: "f64", 3: "f64", 4: "f64", 5: "f32"}
@@ -384,8 +386,8 @@ def main():
                 "frac_of_measured_copy_peak_6290": achieved / 6290.0,
                 # written bytes only, against a bare non-temporal fill of the same chunk shape on the same part
                 # (pcs_membench kind 4: 5.5-5.6 TB/s, profiles/r01/sweeps.md) — the write stream is the bound
-                "written_GBps": N * (bpd - (28 if dtype == "f64" else 20)) / (eval_ms * 1e-3) / 1e9,
-                "frac_of_measured_nt_fill_5600": N * (bpd - (28 if dtype == "f64" else 20)) / (eval_ms * 1e-3) / 1e9 / 5600.0,
+                "written_GBps": N * (bpd - (20 if dtype == "f32" else 28)) / (eval_ms * 1e-3) / 1e9,
+                "frac_of_measured_nt_fill_5600": N * (bpd - (20 if dtype == "f32" else 28)) / (eval_ms * 1e-3) / 1e9 / 5600.0,
             },
         }
         if args.stream_to_host:

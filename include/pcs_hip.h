@@ -44,7 +44,10 @@ typedef enum {
     PCS_CHAIN_FREE = 2      /* projection + extrinsic3D + free_point                fph:143  P = 18 */
 } pcs_chain;
 
-typedef enum { PCS_F64 = 0, PCS_F32 = 1 } pcs_dtype;
+/* PCS_MIXED: FP64 arithmetic on FP64 slabs and measurements, residual / Jacobian written as FP32 — the bytes of
+ * PCS_F32 with the accuracy of one final rounding (the all-float engine loses ~5e-3 relative to cancellation in
+ * the chain rule).  Device outputs of the *_device entry points are float for PCS_F32 and PCS_MIXED. */
+typedef enum { PCS_F64 = 0, PCS_F32 = 1, PCS_MIXED = 2 } pcs_dtype;
 
 /* Library / build identification. */
 int pcs_version(void);

@@ -17,7 +17,7 @@ LIB_PATH = PKG_DIR / "libpcs_hip.so"
 PCS_OK, PCS_ERR_ARG, PCS_ERR_HIP, PCS_ERR_STATE, PCS_ERR_NODEVICE, PCS_ERR_RANGE = 0, -1, -2, -3, -4, -5
 CHAIN_IDS = {"template": 0, "self": 1, "free": 2}
 CHAIN_P = {"template": 21, "self": 24, "free": 18}
-DTYPE_IDS = {"f64": 0, "f32": 1}
+DTYPE_IDS = {"f64": 0, "f32": 1, "mixed": 2}   # mixed: FP64 arithmetic, FP32 residual / Jacobian bytes
 
 # every symbol include/pcs_hip.h declares: name -> (restype, argtypes)
 _P = c_void_p

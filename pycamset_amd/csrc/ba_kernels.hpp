@@ -133,7 +133,9 @@ __global__ void slab_prep_kernel(const double *__restrict__ prm, T *__restrict__
 // ---------------------------------------------------------------------------------------------
 // K1-K4  fused residual + Jacobian
 // ---------------------------------------------------------------------------------------------
-template <int CHAIN, typename T, int MODE, int VARIANT>
+// T = arithmetic / slab / measurement type, TO = type of the residual and Jacobian written out (TO = float with
+// T = double is the "mixed" engine: FP32 bytes, FP64 arithmetic).
+template <int CHAIN, typename T, int MODE, int VARIANT, typename TO = T>
 __global__ __launch_bounds__(WG_THREADS) void ba_eval_kernel(const EvalArgs a) {
     constexpr int P = chain_P(CHAIN);
     constexpr int P2 = 2 * P;
@@ -143,6 +145,7 @@ __global__ __launch_bounds__(WG_THREADS) void ba_eval_kernel(const EvalArgs a) {
     constexpr bool JAC = (MODE & MODE_JAC) != 0;
     constexpr bool RES = (MODE & MODE_RESID) != 0;
     using V2 = typename Vec2<T>::type;
+    using O2 = typename Vec2<TO>::type;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T *smem = reinterpret_cast<T *>(smem_raw);
@@ -175,8 +178,8 @@ __global__ __launch_bounds__(WG_THREADS) void ba_eval_kernel(const EvalArgs a) {
     }
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
-    constexpr int LROW = lds_row_stride(P2, (int)sizeof(T));
-    T *tr = smem + lds_used + wave * (HALF * LROW);  // wave-private transpose region (TRANSPOSE only)
+    constexpr int LROW = lds_row_stride(P2, (int)sizeof(TO));
+    TO *tr = reinterpret_cast<TO *>(smem + lds_used) + wave * (HALF * LROW);  // wave-private transpose region (TRANSPOSE only)
 
     // Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 labels the XCD group).  With
     // xcd_remap each group walks one contiguous eighth of the table (bijective remap, any grid size);
@@ -189,8 +192,8 @@ __global__ __launch_bounds__(WG_THREADS) void ba_eval_kernel(const EvalArgs a) {
     const int64_t tile0 = wg * a.tiles_per_wg;
     const int64_t tile1 = min(tile0 + (int64_t)a.tiles_per_wg, a.n_tiles);
     const V2 *uv = static_cast<const V2 *>(a.uv);
-    T *resid = static_cast<T *>(a.resid);
-    T *jac = static_cast<T *>(a.jac);
+    TO *resid = static_cast<TO *>(a.resid);
+    TO *jac = static_cast<TO *>(a.jac);
     const int64_t total_jac = a.n * (int64_t)P2;
 
     for (int64_t tile = tile0 + wave; tile < tile1; tile += WAVES_PER_WG) {
@@ -232,22 +235,22 @@ __global__ __launch_bounds__(WG_THREADS) void ba_eval_kernel(const EvalArgs a) {
         if constexpr (RES) {
             // Branch-free: a conditional block here splits the basic block and makes hipcc keep the whole
             // slab + Jacobian live across it (226 VGPRs instead of 150); tail lanes write to a sink.
-            V2 r;
-            r.x = u - m.x;   // afb:384  losses = projected - measured
-            r.y = v - m.y;
-            V2 *rp = valid ? reinterpret_cast<V2 *>(resid) + i : static_cast<V2 *>(a.sink);
+            O2 r;
+            r.x = (TO)(u - m.x);   // afb:384  losses = projected - measured
+            r.y = (TO)(v - m.y);
+            O2 *rp = valid ? reinterpret_cast<O2 *>(resid) + i : static_cast<O2 *>(a.sink);
             if constexpr (NT) __builtin_nontemporal_store(r, rp);
             else *rp = r;
         }
         if constexpr (JAC) {
             if constexpr (!TRANSPOSE) {
                 if (valid) {
-                    V2 *row = reinterpret_cast<V2 *>(jac + i * P2);
+                    O2 *row = reinterpret_cast<O2 *>(jac + i * P2);
 #pragma unroll
                     for (int j = 0; j < P; ++j) {
-                        V2 w;
-                        w.x = J[2 * j];
-                        w.y = J[2 * j + 1];
+                        O2 w;
+                        w.x = (TO)J[2 * j];
+                        w.y = (TO)J[2 * j + 1];
                         if constexpr (NT) __builtin_nontemporal_store(w, row + j); else row[j] = w;
                     }
                 }
@@ -256,19 +259,19 @@ __global__ __launch_bounds__(WG_THREADS) void ba_eval_kernel(const EvalArgs a) {
                 // the wave-private LDS region, then all 64 lanes stream the region out in 16-byte
                 // units at consecutive addresses.  Same-wave LDS ops execute in order; the
                 // wavefront-scope fences only stop the compiler from reordering across them.
-                constexpr int VS = 16 / sizeof(T);  // scalars per 16-byte unit
-                using V16 = __attribute__((ext_vector_type(VS))) T;
+                constexpr int VS = 16 / sizeof(TO);  // scalars per 16-byte unit
+                using V16 = __attribute__((ext_vector_type(VS))) TO;
                 constexpr int UNITS = HALF * P2 / VS;
                 static_assert((HALF * P2) % VS == 0, "half tile must be a whole number of 16-byte units");
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     if ((lane >> 5) == h) {
-                        V2 *dst = reinterpret_cast<V2 *>(tr + (lane & 31) * LROW);
+                        O2 *dst = reinterpret_cast<O2 *>(tr + (lane & 31) * LROW);
 #pragma unroll
                         for (int j = 0; j < P; ++j) {
-                            V2 w;
-                            w.x = J[2 * j];
-                            w.y = J[2 * j + 1];
+                            O2 w;
+                            w.x = (TO)J[2 * j];
+                            w.y = (TO)J[2 * j + 1];
                             dst[j] = w;
                         }
                     }
@@ -466,27 +469,28 @@ __global__ __launch_bounds__(WG_THREADS) void ba_compact_kernel(const EvalArgs a
 //  * Packing is branch-free: entry j goes to slot popcount(keep & ((1 << j) - 1)) of its row, or to a
 //    per-lane dummy slot when the column is fixed or the lane belongs to the other pass (conditional
 //    blocks around the 2P stores would keep the whole Jacobian live in registers, see ba_eval_kernel).
-template <int CHAIN, typename T, int MODE>
+template <int CHAIN, typename T, int MODE, typename TO = T>
 __global__ __launch_bounds__(WG_THREADS) void ba_compact_tile_kernel(const EvalArgs a) {
     constexpr int P = chain_P(CHAIN);
     constexpr int P2 = 2 * P;
     constexpr bool JAC = (MODE & MODE_JAC) != 0;
-    constexpr int VS = 16 / sizeof(T);
-    constexpr int LINE = 128 / sizeof(T);            // scalars per 128-byte line
+    constexpr int VS = 16 / sizeof(TO);
+    constexpr int LINE = 128 / sizeof(TO);           // scalars per 128-byte line
     constexpr int WAVE_LDS = HALF * P2 + LINE + 64;  // packed range + alignment shift + one dummy slot per lane
     using V2 = typename Vec2<T>::type;
-    using V16 = __attribute__((ext_vector_type(VS))) T;
+    using O2 = typename Vec2<TO>::type;
+    using V16 = __attribute__((ext_vector_type(VS))) TO;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
-    T *tr = reinterpret_cast<T *>(smem_raw) + wave * ((WAVE_LDS + VS - 1) / VS * VS);
-    T *dummy = tr + HALF * P2 + LINE + lane;
+    TO *tr = reinterpret_cast<TO *>(smem_raw) + wave * ((WAVE_LDS + VS - 1) / VS * VS);
+    TO *dummy = tr + HALF * P2 + LINE + lane;
     const T *cam_slab = static_cast<const T *>(a.cam_slab);
     const T *pose_slab = static_cast<const T *>(a.pose_slab);
     const T *points = static_cast<const T *>(a.points);
     const V2 *uv = static_cast<const V2 *>(a.uv);
-    T *resid = static_cast<T *>(a.resid);
-    T *data = static_cast<T *>(a.jac);
+    TO *resid = static_cast<TO *>(a.resid);
+    TO *data = static_cast<TO *>(a.jac);
     const int64_t tile0 = (int64_t)blockIdx.x * a.tiles_per_wg;
     const int64_t tile1 = min(tile0 + (int64_t)a.tiles_per_wg, a.n_tiles);
     for (int64_t tile = tile0 + wave; tile < tile1; tile += WAVES_PER_WG) {
@@ -500,10 +504,10 @@ __global__ __launch_bounds__(WG_THREADS) void ba_compact_tile_kernel(const EvalA
         eval_detection<CHAIN, T, JAC>(cam_slab + c * CAM_STRIDE, pose_slab + im * POSE_STRIDE, points[3 * k], points[3 * k + 1],
                                       points[3 * k + 2], u, v, J);
         if constexpr ((MODE & MODE_RESID) != 0) {  // branch-free (see ba_eval_kernel)
-            V2 r;
-            r.x = u - m.x;
-            r.y = v - m.y;
-            __builtin_nontemporal_store(r, valid ? reinterpret_cast<V2 *>(resid) + i : static_cast<V2 *>(a.sink));
+            O2 r;
+            r.x = (TO)(u - m.x);
+            r.y = (TO)(v - m.y);
+            __builtin_nontemporal_store(r, valid ? reinterpret_cast<O2 *>(resid) + i : static_cast<O2 *>(a.sink));
         }
         if constexpr (JAC) {
             const uint32_t keep_raw = a.keep[ic];
@@ -518,22 +522,22 @@ __global__ __launch_bounds__(WG_THREADS) void ba_compact_tile_kernel(const EvalA
             for (int h = 0; h < 2; ++h) {
                 const int s0 = h ? mid : 0;
                 const int len = (h ? end : mid) - s0;
-                T *g0 = data + off0 + s0;                                              // first global element of the pass
-                const int mis = (int)((reinterpret_cast<uintptr_t>(g0) / sizeof(T)) & (LINE - 1));
+                TO *g0 = data + off0 + s0;                                             // first global element of the pass
+                const int mis = (int)((reinterpret_cast<uintptr_t>(g0) / sizeof(TO)) & (LINE - 1));
                 const bool mine = (lane >> 5) == h;
-                T *ru = tr + mis + (lo - s0);
-                T *rv = ru + cnt;
+                TO *ru = tr + mis + (lo - s0);
+                TO *rv = ru + cnt;
 #pragma unroll
                 for (int j = 0; j < P; ++j) {
                     const bool on = mine && ((keep >> j) & 1u);
                     const int pos = __popc(keep & ((1u << j) - 1u));
-                    *(on ? ru + pos : dummy) = J[j];
-                    *(on ? rv + pos : dummy) = J[P + j];
+                    *(on ? ru + pos : dummy) = (TO)J[j];
+                    *(on ? rv + pos : dummy) = (TO)J[P + j];
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                T *gal = g0 - mis;                                                     // 128-byte aligned
+                TO *gal = g0 - mis;                                                    // 128-byte aligned
                 const int n_units = (mis + len + VS - 1) / VS;
                 for (int q = lane; q < n_units; q += 64) {
                     const int e0 = q * VS;

@@ -52,7 +52,8 @@ struct pcs_engine {
     int chain = 0, dtype = 0, device = 0, P = 0;
     int64_t n_cams = 0, n_imgs = 0, n_keys = 0, n_params = 0, n = 0;
     int64_t extr_off = 0, pose_off = 0, point_off = 0;
-    size_t esize = 8;
+    size_t esize = 8;   // bytes of the arithmetic / slab / measurement type
+    size_t osize = 8;   // bytes of the residual / Jacobian type written out (4 for PCS_F32 and PCS_MIXED)
     hipStream_t stream = nullptr;
     std::vector<hipEvent_t> ev;  // ring of (start, after slab_prep, after eval) triples
     int64_t ev_ring = 1;         // triples in the ring
@@ -265,7 +266,7 @@ int pcs_create(pcs_engine **out, int chain, int dtype, int64_t n_cams, int64_t n
     if (!out) return fail(PCS_ERR_ARG, "pcs_create: out is NULL");
     *out = nullptr;
     if (chain < 0 || chain > 2) return fail(PCS_ERR_ARG, "pcs_create: chain %d not in {0,1,2}", chain);
-    if (dtype != PCS_F64 && dtype != PCS_F32) return fail(PCS_ERR_ARG, "pcs_create: dtype %d not in {0,1}", dtype);
+    if (dtype != PCS_F64 && dtype != PCS_F32 && dtype != PCS_MIXED) return fail(PCS_ERR_ARG, "pcs_create: dtype %d not in {0,1,2}", dtype);
     if (n_cams <= 0 || n_keys <= 0 || (chain != PCS_CHAIN_FREE && n_imgs <= 0))
         return fail(PCS_ERR_ARG, "pcs_create: counts must be positive (cams %lld imgs %lld keys %lld)", (long long)n_cams,
                     (long long)n_imgs, (long long)n_keys);
@@ -279,7 +280,8 @@ int pcs_create(pcs_engine **out, int chain, int dtype, int64_t n_cams, int64_t n
     h->dtype = dtype;
     h->device = device;
     h->P = chain_P(chain);
-    h->esize = dtype == PCS_F64 ? 8 : 4;
+    h->esize = dtype == PCS_F32 ? 4 : 8;
+    h->osize = dtype == PCS_F64 ? 8 : 4;
     h->n_cams = n_cams;
     h->n_imgs = chain == PCS_CHAIN_FREE ? 0 : n_imgs;
     h->n_keys = n_keys;
@@ -383,7 +385,7 @@ static int upload_detections(pcs_engine *h, std::vector<int32_t> &cam, std::vect
     HIPCHK(hipMemcpy(h->d_cam, h->h_cam.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->d_img, h->h_img.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->d_key, h->h_key.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice));
-    if (h->dtype == PCS_F64) {
+    if (h->esize == 8) {
         HIPCHK(hipMemcpy(h->d_uv, uv, sizeof(double) * 2 * n, hipMemcpyHostToDevice));
     } else {
         std::vector<float> f(2 * n);
@@ -436,7 +438,7 @@ int pcs_set_template(pcs_engine *h, const double *points) {
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(h->stream));
     const int64_t cnt = 3 * h->n_keys;
-    if (h->dtype == PCS_F64) {
+    if (h->esize == 8) {
         HIPCHK(hipMemcpy(h->d_points, points, sizeof(double) * cnt, hipMemcpyHostToDevice));
     } else {
         std::vector<float> f(cnt);
@@ -499,9 +501,9 @@ int pcs_set_option(pcs_engine *h, const char *key, int64_t value) {
 // dispatch itself, without the extra barrier packets that hipEventRecord would put between kernels.
 struct EvPair { hipEvent_t start, stop; };
 
-template <int CHAIN, typename T, int MODE, int VARIANT>
+template <int CHAIN, typename T, int MODE, int VARIANT, typename TO>
 static hipError_t launch_eval_v(const EvalArgs &a, dim3 grid, size_t lds, hipStream_t s, EvPair ev) {
-    auto kern = ba_eval_kernel<CHAIN, T, MODE, VARIANT>;
+    auto kern = ba_eval_kernel<CHAIN, T, MODE, VARIANT, TO>;
     static size_t configured[64] = {0};  // per device: largest dynamic-LDS size already enabled for this kernel
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -514,35 +516,35 @@ static hipError_t launch_eval_v(const EvalArgs &a, dim3 grid, size_t lds, hipStr
     return hipGetLastError();
 }
 
-template <int CHAIN, typename T, int MODE>
+template <int CHAIN, typename T, int MODE, typename TO>
 static hipError_t launch_eval_m(int variant, const EvalArgs &a, dim3 grid, size_t lds, hipStream_t s, EvPair ev) {
     switch (variant) {
-        case 0: return launch_eval_v<CHAIN, T, MODE, 0>(a, grid, lds, s, ev);
-        case 1: return launch_eval_v<CHAIN, T, MODE, 1>(a, grid, lds, s, ev);
-        case 2: return launch_eval_v<CHAIN, T, MODE, 2>(a, grid, lds, s, ev);
-        case 3: return launch_eval_v<CHAIN, T, MODE, 3>(a, grid, lds, s, ev);
-        case 4: return launch_eval_v<CHAIN, T, MODE, 4>(a, grid, lds, s, ev);
-        case 5: return launch_eval_v<CHAIN, T, MODE, 5>(a, grid, lds, s, ev);
-        case 6: return launch_eval_v<CHAIN, T, MODE, 6>(a, grid, lds, s, ev);
-        default: return launch_eval_v<CHAIN, T, MODE, 7>(a, grid, lds, s, ev);
+        case 0: return launch_eval_v<CHAIN, T, MODE, 0, TO>(a, grid, lds, s, ev);
+        case 1: return launch_eval_v<CHAIN, T, MODE, 1, TO>(a, grid, lds, s, ev);
+        case 2: return launch_eval_v<CHAIN, T, MODE, 2, TO>(a, grid, lds, s, ev);
+        case 3: return launch_eval_v<CHAIN, T, MODE, 3, TO>(a, grid, lds, s, ev);
+        case 4: return launch_eval_v<CHAIN, T, MODE, 4, TO>(a, grid, lds, s, ev);
+        case 5: return launch_eval_v<CHAIN, T, MODE, 5, TO>(a, grid, lds, s, ev);
+        case 6: return launch_eval_v<CHAIN, T, MODE, 6, TO>(a, grid, lds, s, ev);
+        default: return launch_eval_v<CHAIN, T, MODE, 7, TO>(a, grid, lds, s, ev);
     }
 }
 
-template <int CHAIN, typename T>
+template <int CHAIN, typename T, typename TO>
 static hipError_t launch_eval_c(int mode, int variant, const EvalArgs &a, dim3 grid, size_t lds, hipStream_t s, EvPair ev) {
     switch (mode) {
-        case MODE_RESID: return launch_eval_m<CHAIN, T, MODE_RESID>(variant & ~VAR_TRANSPOSE, a, grid, lds, s, ev);
-        case MODE_JAC: return launch_eval_m<CHAIN, T, MODE_JAC>(variant, a, grid, lds, s, ev);
-        default: return launch_eval_m<CHAIN, T, MODE_RESID | MODE_JAC>(variant, a, grid, lds, s, ev);
+        case MODE_RESID: return launch_eval_m<CHAIN, T, MODE_RESID, TO>(variant & ~VAR_TRANSPOSE, a, grid, lds, s, ev);
+        case MODE_JAC: return launch_eval_m<CHAIN, T, MODE_JAC, TO>(variant, a, grid, lds, s, ev);
+        default: return launch_eval_m<CHAIN, T, MODE_RESID | MODE_JAC, TO>(variant, a, grid, lds, s, ev);
     }
 }
 
-template <typename T>
+template <typename T, typename TO = T>
 static hipError_t launch_eval_t(int chain, int mode, int variant, const EvalArgs &a, dim3 grid, size_t lds, hipStream_t s, EvPair ev) {
     switch (chain) {
-        case CHAIN_TEMPLATE: return launch_eval_c<CHAIN_TEMPLATE, T>(mode, variant, a, grid, lds, s, ev);
-        case CHAIN_SELF: return launch_eval_c<CHAIN_SELF, T>(mode, variant, a, grid, lds, s, ev);
-        default: return launch_eval_c<CHAIN_FREE, T>(mode, variant, a, grid, lds, s, ev);
+        case CHAIN_TEMPLATE: return launch_eval_c<CHAIN_TEMPLATE, T, TO>(mode, variant, a, grid, lds, s, ev);
+        case CHAIN_SELF: return launch_eval_c<CHAIN_SELF, T, TO>(mode, variant, a, grid, lds, s, ev);
+        default: return launch_eval_c<CHAIN_FREE, T, TO>(mode, variant, a, grid, lds, s, ev);
     }
 }
 
@@ -564,20 +566,20 @@ static hipError_t launch_rowsplit_t(int chain, int mode, bool nt, const EvalArgs
     }
 }
 
-template <int CHAIN, typename T>
+template <int CHAIN, typename T, typename TO>
 static hipError_t launch_compact_tile_c(int mode, const EvalArgs &a, dim3 grid, size_t lds, hipStream_t s) {
-    if (mode == MODE_RESID) hipLaunchKernelGGL((ba_compact_tile_kernel<CHAIN, T, MODE_RESID>), grid, dim3(WG_THREADS), lds, s, a);
-    else if (mode == MODE_JAC) hipLaunchKernelGGL((ba_compact_tile_kernel<CHAIN, T, MODE_JAC>), grid, dim3(WG_THREADS), lds, s, a);
-    else hipLaunchKernelGGL((ba_compact_tile_kernel<CHAIN, T, MODE_RESID | MODE_JAC>), grid, dim3(WG_THREADS), lds, s, a);
+    if (mode == MODE_RESID) hipLaunchKernelGGL((ba_compact_tile_kernel<CHAIN, T, MODE_RESID, TO>), grid, dim3(WG_THREADS), lds, s, a);
+    else if (mode == MODE_JAC) hipLaunchKernelGGL((ba_compact_tile_kernel<CHAIN, T, MODE_JAC, TO>), grid, dim3(WG_THREADS), lds, s, a);
+    else hipLaunchKernelGGL((ba_compact_tile_kernel<CHAIN, T, MODE_RESID | MODE_JAC, TO>), grid, dim3(WG_THREADS), lds, s, a);
     return hipGetLastError();
 }
 
-template <typename T>
+template <typename T, typename TO = T>
 static hipError_t launch_compact_tile_t(int chain, int mode, const EvalArgs &a, dim3 grid, size_t lds, hipStream_t s) {
     switch (chain) {
-        case CHAIN_TEMPLATE: return launch_compact_tile_c<CHAIN_TEMPLATE, T>(mode, a, grid, lds, s);
-        case CHAIN_SELF: return launch_compact_tile_c<CHAIN_SELF, T>(mode, a, grid, lds, s);
-        default: return launch_compact_tile_c<CHAIN_FREE, T>(mode, a, grid, lds, s);
+        case CHAIN_TEMPLATE: return launch_compact_tile_c<CHAIN_TEMPLATE, T, TO>(mode, a, grid, lds, s);
+        case CHAIN_SELF: return launch_compact_tile_c<CHAIN_SELF, T, TO>(mode, a, grid, lds, s);
+        default: return launch_compact_tile_c<CHAIN_FREE, T, TO>(mode, a, grid, lds, s);
     }
 }
 
@@ -605,7 +607,7 @@ static int launch_slab_prep(pcs_engine *h, const double *d_prm, hipStream_t s, h
     int64_t threads = ents;
     if (copy_points) threads = std::max<int64_t>(threads, std::min<int64_t>(3 * h->n_keys, 1 << 16));
     const dim3 grid((unsigned)((threads + 127) / 128));
-    if (h->dtype == PCS_F64)
+    if (h->esize == 8)
         hipExtLaunchKernelGGL(slab_prep_kernel<double>, grid, dim3(128), 0, s, start, nullptr, 0, d_prm, (double *)h->d_cam_slab,
                               (double *)h->d_pose_slab, (double *)h->d_points, (int)h->n_cams, (int)h->n_imgs, (int)h->n_keys,
                               h->extr_off, h->pose_off, h->point_off, has_pose, copy_points);
@@ -693,7 +695,7 @@ static int enqueue_normal(pcs_engine *h, const double *d_prm, double *d_H, doubl
     hipEvent_t *ev = h->ev.data() + 3 * (h->ev_count % h->ev_ring);
     HIPCHK(hipEventRecord(ev[0], s));
     HIPCHK(hipEventRecord(ev[1], s));
-    hipError_t e = h->dtype == PCS_F64 ? launch_normal_t<double>(h->chain, a, grid, lds, s) : launch_normal_t<float>(h->chain, a, grid, lds, s);
+    hipError_t e = h->esize == 8 ? launch_normal_t<double>(h->chain, a, grid, lds, s) : launch_normal_t<float>(h->chain, a, grid, lds, s);
     if (e != hipSuccess) return fail(PCS_ERR_HIP, "normal-equations kernel launch failed: %s", hipGetErrorString(e));
     HIPCHK(hipEventRecord(ev[2], s));
     ++h->ev_count;
@@ -727,9 +729,9 @@ static int enqueue_eval(pcs_engine *h, const double *d_prm, void *d_resid, void 
         a.keep = h->d_keep; a.row_off = h->d_row_off;
         if (timed) HIPCHK(hipEventRecord(ev[1], s));
         hipError_t e;
-        if (h->compact_variant == 0) {  // per-lane stores (first version, kept for A/B)
+        if (h->compact_variant == 0 && h->dtype != PCS_MIXED) {  // per-lane stores (first version, kept for A/B)
             const int64_t blocks = std::min<int64_t>((h->n + WG_THREADS - 1) / WG_THREADS, (int64_t)h->n_cu * 8);
-            e = h->dtype == PCS_F64 ? launch_compact_t<double>(h->chain, mode, a, dim3((unsigned)blocks), s)
+            e = h->esize == 8 ? launch_compact_t<double>(h->chain, mode, a, dim3((unsigned)blocks), s)
                                     : launch_compact_t<float>(h->chain, mode, a, dim3((unsigned)blocks), s);
         } else {
             const int64_t wpc = h->wgs_per_cu > 0 ? h->wgs_per_cu : 16;
@@ -738,15 +740,16 @@ static int enqueue_eval(pcs_engine *h, const double *d_prm, void *d_resid, void 
             tpw = std::max<int64_t>(WAVES_PER_WG, (tpw + WAVES_PER_WG - 1) / WAVES_PER_WG * WAVES_PER_WG);
             a.tiles_per_wg = (int32_t)tpw;
             const int64_t grid = (a.n_tiles + tpw - 1) / tpw;
-            const size_t vs = 16 / h->esize;
-            const size_t wave_lds = ((size_t)HALF * 2 * h->P + 128 / h->esize + 64 + vs - 1) / vs * vs;  // scalars, as in the kernel
-            const size_t lds = (mode & MODE_JAC) ? h->esize * (size_t)WAVES_PER_WG * wave_lds : 0;
-            e = h->dtype == PCS_F64 ? launch_compact_tile_t<double>(h->chain, mode, a, dim3((unsigned)grid), lds, s)
-                                    : launch_compact_tile_t<float>(h->chain, mode, a, dim3((unsigned)grid), lds, s);
+            const size_t vs = 16 / h->osize;
+            const size_t wave_lds = ((size_t)HALF * 2 * h->P + 128 / h->osize + 64 + vs - 1) / vs * vs;  // scalars, as in the kernel
+            const size_t lds = (mode & MODE_JAC) ? h->osize * (size_t)WAVES_PER_WG * wave_lds : 0;
+            e = h->dtype == PCS_F64     ? launch_compact_tile_t<double>(h->chain, mode, a, dim3((unsigned)grid), lds, s)
+                : h->dtype == PCS_F32 ? launch_compact_tile_t<float>(h->chain, mode, a, dim3((unsigned)grid), lds, s)
+                                      : launch_compact_tile_t<double, float>(h->chain, mode, a, dim3((unsigned)grid), lds, s);
         }
         if (e != hipSuccess) return fail(PCS_ERR_HIP, "compact kernel launch failed: %s", hipGetErrorString(e));
         if (timed) HIPCHK(hipEventRecord(ev[2], s));
-    } else if (h->rowsplit && (mode & MODE_JAC)) {
+    } else if (h->rowsplit && (mode & MODE_JAC) && h->dtype != PCS_MIXED) {
         const bool nt = h->variant < 0 || (h->variant & VAR_NT);
         a.n_tiles = (h->n + HALF - 1) / HALF;
         int64_t tpw = h->tiles_per_wg;
@@ -760,7 +763,7 @@ static int enqueue_eval(pcs_engine *h, const double *d_prm, void *d_resid, void 
         const int64_t grid = (a.n_tiles + tpw - 1) / tpw;
         const size_t lds = h->esize * (size_t)WAVES_PER_WG * HALF * 2 * h->P;
         const EvPair evp{ev[1], ev[2]};
-        hipError_t e = h->dtype == PCS_F64 ? launch_rowsplit_t<double>(h->chain, mode, nt, a, dim3((unsigned)grid), lds, s, evp)
+        hipError_t e = h->esize == 8 ? launch_rowsplit_t<double>(h->chain, mode, nt, a, dim3((unsigned)grid), lds, s, evp)
                                            : launch_rowsplit_t<float>(h->chain, mode, nt, a, dim3((unsigned)grid), lds, s, evp);
         if (e != hipSuccess) return fail(PCS_ERR_HIP, "rowsplit kernel launch failed: %s", hipGetErrorString(e));
     } else {
@@ -769,7 +772,7 @@ static int enqueue_eval(pcs_engine *h, const double *d_prm, void *d_resid, void 
         if (!(mode & MODE_JAC)) variant &= ~VAR_TRANSPOSE;
         // LDS budget: slabs + points (+ 4 wave-private transpose regions)
         const size_t slab_bytes = h->esize * (size_t)(h->n_cams * CAM_STRIDE + h->n_imgs * POSE_STRIDE + padded_points(h->n_keys));
-        const size_t tr_bytes = (variant & VAR_TRANSPOSE) ? h->esize * (size_t)WAVES_PER_WG * HALF * lds_row_stride(2 * h->P, (int)h->esize) : 0;
+        const size_t tr_bytes = (variant & VAR_TRANSPOSE) ? h->osize * (size_t)WAVES_PER_WG * HALF * lds_row_stride(2 * h->P, (int)h->osize) : 0;
         if ((variant & VAR_SLAB_LDS) && slab_bytes + tr_bytes > h->lds_limit) variant &= ~VAR_SLAB_LDS;  // read slabs through L1/L2
         const size_t lds = ((variant & VAR_SLAB_LDS) ? slab_bytes : 0) + tr_bytes;
         int64_t tpw = h->tiles_per_wg;
@@ -782,8 +785,9 @@ static int enqueue_eval(pcs_engine *h, const double *d_prm, void *d_resid, void 
         a.tiles_per_wg = (int32_t)tpw;
         const int64_t grid = (a.n_tiles + tpw - 1) / tpw;
         const EvPair evp{ev[1], ev[2]};  // start / stop of the evaluation kernel itself
-        hipError_t e = h->dtype == PCS_F64 ? launch_eval_t<double>(h->chain, mode, variant, a, dim3((unsigned)grid), lds, s, evp)
-                                           : launch_eval_t<float>(h->chain, mode, variant, a, dim3((unsigned)grid), lds, s, evp);
+        hipError_t e = h->dtype == PCS_F64   ? launch_eval_t<double>(h->chain, mode, variant, a, dim3((unsigned)grid), lds, s, evp)
+                       : h->dtype == PCS_F32 ? launch_eval_t<float>(h->chain, mode, variant, a, dim3((unsigned)grid), lds, s, evp)
+                                             : launch_eval_t<double, float>(h->chain, mode, variant, a, dim3((unsigned)grid), lds, s, evp);
         if (e != hipSuccess) return fail(PCS_ERR_HIP, "eval kernel launch failed: %s", hipGetErrorString(e));
     }
     if (timed) {
@@ -806,24 +810,25 @@ static int ensure_scratch(pcs_engine *h, bool want_resid, bool want_jac, bool wa
     HIPCHK(hipSetDevice(h->device));
     if (want_resid && h->resid_capacity < 2 * h->n) {
         if (h->d_resid) HIPCHK(hipFree(h->d_resid));
-        HIPCHK(hipMalloc(&h->d_resid, h->esize * 2 * h->n));
+        HIPCHK(hipMalloc(&h->d_resid, sizeof(double) * 2 * h->n));  // doubles: the legacy cost of a mixed engine writes f64
         h->resid_capacity = 2 * h->n;
     }
     if (want_jac && h->jac_capacity < 2 * h->n * h->P) {
         if (h->d_jac) HIPCHK(hipFree(h->d_jac));
-        HIPCHK(hipMalloc(&h->d_jac, h->esize * 2 * h->n * h->P));
+        HIPCHK(hipMalloc(&h->d_jac, h->osize * 2 * h->n * h->P));
         h->jac_capacity = 2 * h->n * h->P;
     }
     if (want_data && h->data_capacity < std::max<int64_t>(1, h->nnz)) {
         if (h->d_data) HIPCHK(hipFree(h->d_data));
-        HIPCHK(hipMalloc(&h->d_data, h->esize * std::max<int64_t>(1, h->nnz)));
+        HIPCHK(hipMalloc(&h->d_data, h->osize * std::max<int64_t>(1, h->nnz)));
         h->data_capacity = std::max<int64_t>(1, h->nnz);
     }
     return PCS_OK;
 }
 
-static int download(pcs_engine *h, double *dst, const void *d_src, int64_t count, hipStream_t s) {
-    if (h->dtype == PCS_F64) {
+// device -> host as float64; `elem` = element size on the device (default: the engine's output type)
+static int download(pcs_engine *h, double *dst, const void *d_src, int64_t count, hipStream_t s, size_t elem = 0) {
+    if ((elem ? elem : h->osize) == 8) {
         HIPCHK(hipMemcpyAsync(dst, d_src, sizeof(double) * count, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
     } else {
@@ -1008,7 +1013,7 @@ int pcs_legacy_cost(pcs_engine *h, const double *im_points, const double *proj, 
         for (int j = 0; j < 5; ++j) t[16 + j] = dists[5 * c + j];
     }
     HIPCHK(hipStreamSynchronize(s));
-    if (h->dtype == PCS_F64) {
+    if (h->esize == 8) {
         HIPCHK(hipMemcpyAsync(h->d_im_points, im_points, sizeof(double) * n_pts, hipMemcpyHostToDevice, s));
         HIPCHK(hipMemcpyAsync(h->d_cam_tab, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice, s));
         HIPCHK(hipStreamSynchronize(s));
@@ -1023,7 +1028,7 @@ int pcs_legacy_cost(pcs_engine *h, const double *im_points, const double *proj, 
     const dim3 grid((unsigned)std::min<int64_t>((h->n + 255) / 256, (int64_t)h->n_cu * 16));
     hipEvent_t *ev = h->ev.data() + 3 * (h->ev_count % h->ev_ring);
     HIPCHK(hipEventRecord(ev[0], s));  // keeps (ev0, ev1) a valid pair for pcs_last_kernel_ms
-    if (h->dtype == PCS_F64)
+    if (h->esize == 8)
         hipExtLaunchKernelGGL(legacy_cost_kernel<double>, grid, dim3(256), 0, s, ev[1], ev[2], 0, h->d_cam, h->d_img, h->d_key, h->d_uv,
                               (const double *)h->d_im_points, (const double *)h->d_cam_tab, (double *)h->d_resid, h->n, h->n_keys);
     else
@@ -1033,7 +1038,7 @@ int pcs_legacy_cost(pcs_engine *h, const double *im_points, const double *proj, 
     ++h->ev_count;
     h->events_valid = true;
     h->last_stream = s;
-    return download(h, errors, h->d_resid, 2 * h->n, s);
+    return download(h, errors, h->d_resid, 2 * h->n, s, h->esize);
 }
 
 int pcs_linearize(pcs_engine *h, const double *param_str) {
@@ -1091,7 +1096,7 @@ int pcs_matfree(pcs_engine *h, int op, const double *in, double *out, double *co
     hipEvent_t *ev = h->ev.data() + 3 * (h->ev_count % h->ev_ring);
     HIPCHK(hipEventRecord(ev[0], s));
     HIPCHK(hipEventRecord(ev[1], s));
-    hipError_t e = h->dtype == PCS_F64 ? launch_matfree_t<double>(h->chain, op, lds_acc, a, grid, lds, s)
+    hipError_t e = h->esize == 8 ? launch_matfree_t<double>(h->chain, op, lds_acc, a, grid, lds, s)
                                        : launch_matfree_t<float>(h->chain, op, lds_acc, a, grid, lds, s);
     if (e != hipSuccess) return fail(PCS_ERR_HIP, "matfree kernel launch failed: %s", hipGetErrorString(e));
     HIPCHK(hipEventRecord(ev[2], s));

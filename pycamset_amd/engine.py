@@ -72,7 +72,7 @@ class Engine:
         if chain not in CHAIN_IDS:
             raise ValueError(f"chain must be one of {sorted(CHAIN_IDS)}")
         if dtype not in DTYPE_IDS:
-            raise ValueError("dtype must be 'f64' or 'f32'")
+            raise ValueError("dtype must be 'f64', 'f32' or 'mixed'")
         self.chain, self.dtype, self.device = chain, dtype, device
         self.n_cams, self.n_imgs, self.n_keys = int(n_cams), (0 if chain == "free" else int(n_imgs)), int(n_keys)
         self.P = CHAIN_P[chain]
@@ -83,7 +83,7 @@ class Engine:
         self.nnz = None
         self.mask_key = None
         self._rings = {}
-        self.np_dtype = np.float64 if dtype == "f64" else np.float32
+        self.np_dtype = np.float64 if dtype == "f64" else np.float32   # element type of the DEVICE outputs
 
     # -- lifetime -----------------------------------------------------------------------------
     def close(self):

@@ -11,6 +11,9 @@ RES_RTOL = 1e-10
 # FP32 engine (config 5): single-precision arithmetic on ~1e3 px projections, cancelling chain-rule sums
 F32_JAC_RTOL = 5e-3
 F32_RES_ATOL = 2e-3  # pixels
+# mixed engine: FP64 arithmetic, one rounding to FP32 at the store (2^-24 = 6e-8 relative per value)
+MIXED_JAC_RTOL = 1.2e-7
+MIXED_RES_RTOL = 1.2e-7
 
 
 def chain_slabs(rig, chain):

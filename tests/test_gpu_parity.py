@@ -111,6 +111,42 @@ def test_fp32_engine(Engine, chain):
     e.close()
 
 
+@pytest.mark.parametrize("chain", CHAINS)
+def test_mixed_engine_has_fp32_bytes_and_fp64_accuracy(Engine, chain):
+    """dtype='mixed': FP64 arithmetic on FP64 slabs and measurements, residual / Jacobian stored as FP32.  Every
+    value must be the correctly rounded float of the FP64 result up to the FP64 kernel's own 1e-10 — i.e. within
+    1.2e-7 relative, against 5e-3 for the all-float engine — on the host path, in the device buffers (float32)
+    and through the compaction kernel."""
+    import torch
+    rig = synthetic.config_rig(1)
+    ps, ref_r, ref_j = oracle_eval(rig, chain)
+    e = make_engine(Engine, rig, chain, dtype="mixed")
+    assert e.np_dtype == np.float32
+    rows = np.max(np.abs(ref_j), axis=1, keepdims=True)
+    for variant in (0, 3, 6, 7):
+        e.set_option("variant", variant)
+        r, j = e.eval(ps)
+        assert np.array_equal(j, j.astype(np.float32)), "values are float32-representable"
+        assert H.jac_rel_err(j, ref_j) <= H.MIXED_JAC_RTOL
+        assert np.max(np.abs(r - ref_r) / np.maximum(np.abs(ref_r), 1e-3)) <= H.MIXED_RES_RTOL
+    e.set_option("variant", -1)
+    d_r = torch.zeros((rig.n_det, 2), dtype=torch.float32, device="cuda")
+    d_j = torch.zeros((2 * rig.n_det, e.P), dtype=torch.float32, device="cuda")
+    e.eval_device(ps, d_r.data_ptr(), d_j.data_ptr())
+    e.synchronize()
+    assert np.array_equal(d_j.cpu().numpy().astype(np.float64), j) and np.array_equal(d_r.cpu().numpy().astype(np.float64), r)
+    mask = np.random.default_rng(2).random(ps.shape[0]) > 0.3
+    _, _, m = orc.csr_structure(chain, rig.detections, mask)
+    e.set_unfixed(mask)
+    r2, data = e.eval_compact(ps, want_resid=True)
+    assert np.array_equal(data, j[m]) and np.array_equal(r2, r)
+    # products that never leave the GPU are plain FP64 on a mixed engine
+    e.linearize(ps)
+    g, cost = e.grad()
+    assert abs(cost - float(np.sum(ref_r ** 2))) <= 1e-10 * float(np.sum(ref_r ** 2))
+    e.close()
+
+
 # ---- ragged / edge inputs ----------------------------------------------------------------------
 @pytest.mark.parametrize("n", [1, 2, 31, 32, 33, 63, 64, 65, 127, 129, 255, 257, 1000])
 def test_ragged_sizes(Engine, n):

@@ -10,7 +10,8 @@ import torch
 from pycamset_amd import synthetic
 from pycamset_amd.engine import Engine
 
-BPD = {("template", "f64"): 380, ("self", "f64"): 428, ("free", "f64"): 332, ("template", "f32"): 196, ("self", "f32"): 220, ("free", "f32"): 172}
+BPD = {("template", "f64"): 380, ("self", "f64"): 428, ("free", "f64"): 332, ("template", "f32"): 196, ("self", "f32"): 220, ("free", "f32"): 172,
+       ("template", "mixed"): 204, ("self", "mixed"): 228, ("free", "mixed"): 180}
 
 
 def slabs(rig, chain):
@@ -44,7 +45,7 @@ def main():
     e.set_detections_table(det)
     if a.chain == "template":
         e.set_template(rig.points)
-    tdt = torch.float64 if a.dtype == "f64" else torch.float32
+    tdt = torch.float64 if a.dtype == "f64" else torch.float32   # device outputs of f32 and mixed engines are float
     d_r = torch.empty(N * 2, dtype=tdt, device="cuda")
     d_j = torch.empty(N * 2 * e.P, dtype=tdt, device="cuda")
     d_p = torch.from_numpy(ps).cuda()
