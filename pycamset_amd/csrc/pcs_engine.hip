@@ -776,8 +776,13 @@ static int enqueue_eval(pcs_engine *h, const double *d_prm, void *d_resid, void 
         if ((variant & VAR_SLAB_LDS) && slab_bytes + tr_bytes > h->lds_limit) variant &= ~VAR_SLAB_LDS;  // read slabs through L1/L2
         const size_t lds = ((variant & VAR_SLAB_LDS) ? slab_bytes : 0) + tr_bytes;
         int64_t tpw = h->tiles_per_wg;
-        if (tpw <= 0) {
-            const int64_t wpc = h->wgs_per_cu > 0 ? h->wgs_per_cu : ((variant & VAR_SLAB_LDS) ? 2 : 16);
+        if (tpw <= 0 && h->wgs_per_cu <= 0 && !(variant & VAR_SLAB_LDS)) {
+            // slabs through L1/L2: one tile per wave, as many workgroups as that takes.  Up to 1e6 detections this
+            // is what 16 workgroups per CU give anyway; at 1e7 it beats 10 tiles per wave by 17 % (FP32: 275 us
+            // against 330 us, profiles/r01/sweeps.md)
+            tpw = WAVES_PER_WG;
+        } else if (tpw <= 0) {
+            const int64_t wpc = h->wgs_per_cu > 0 ? h->wgs_per_cu : 2;  // LDS-staged slabs: few long-lived workgroups
             const int64_t target_wgs = (int64_t)h->n_cu * wpc;
             tpw = (a.n_tiles + target_wgs - 1) / target_wgs;
             tpw = std::max<int64_t>(WAVES_PER_WG, (tpw + WAVES_PER_WG - 1) / WAVES_PER_WG * WAVES_PER_WG);
