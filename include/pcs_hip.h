@@ -182,7 +182,8 @@ int pcs_last_kernel_ms(pcs_engine *h, float *slab_prep_ms, float *eval_ms);
  * roofline figure: live HIP-event timing of every launch of the timed region. */
 int pcs_kernel_ms_mean(pcs_engine *h, int64_t *count, float *slab_prep_ms, float *eval_ms);
 /* Tuning knobs ("variant", "wgs_per_cu", "tiles_per_wg", "event_ring", "timing_every",
- * "compact_variant", "matfree_lds", "rowsplit", "xcd_remap"; "normal_debug" is a profiling switch of
+ * "compact_variant", "matfree_lds", "rowsplit", "xcd_remap"; "normal_point_pass" = 0 selects the per-detection
+ * atomics for the point columns of pcs_normal_equations instead of the key-sorted passes; "normal_debug" is a profiling switch of
  * pcs_normal_equations that skips parts of the kernel — results are wrong while it is non-zero); see DESIGN.md.
  * Unknown keys -> PCS_ERR_ARG. */
 int pcs_set_option(pcs_engine *h, const char *key, int64_t value);

@@ -52,6 +52,7 @@ struct NormalArgs {
     int64_t extr_off, pose_off, point_off;
     int64_t n_params;
     int32_t tiles_per_wave;
+    int32_t skip_points;  // 1: the point columns are left to ba_normal_point_kernel
     int32_t debug;  // profiling switches: 1 skip the dot loops, 2 skip the flush atomics, 4 / 8 skip the point-block / shared-point atomics
 };
 
@@ -175,8 +176,10 @@ __global__ __launch_bounds__(64 * NORMAL_WAVES) void ba_normal_kernel(const Norm
         const double r0 = (double)(u - m.x), r1 = (double)(v - m.y);
 
         if constexpr (CHAIN != CHAIN_TEMPLATE) {
-            // point columns: per-detection rows of H and g (upper triangle: shared columns come first)
-            if (valid) {
+            // point columns: per-detection rows of H and g (upper triangle: shared columns come first).  Fallback
+            // only — 54-72 global atomics per detection (2.1-2.7 ms at N = 1e6); the engine normally runs
+            // ba_normal_point_kernel over key-sorted visiting orders instead.
+            if (valid && !a.skip_points) {
                 const int64_t gX = a.point_off + 3 * (int64_t)k;
                 double jp0[3], jp1[3];
 #pragma unroll
@@ -283,6 +286,112 @@ __global__ __launch_bounds__(64 * NORMAL_WAVES) void ba_normal_kernel(const Norm
     flush(true);
     const double cs = wave_sum(cost_acc);
     if (lane == 0 && cs != 0.0) unsafeAtomicAdd(a.cost, cs);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Point columns of the self / free chains, pass by pass over key-sorted visiting orders.
+//
+// A detection's point block couples its key k to its camera (15 columns) and — self chain — to its image (6
+// columns).  Summed per detection that is 54-72 global f64 atomics each.  Visiting the detections sorted by
+// (cam, key) makes the contributions to one camera-point block E[c,k] (and to D[k], g[k]) a contiguous run of
+// lanes (one per image that sees the key, ~64 on rig-32); sorted by (image, key) the same holds for the pose-point
+// block F[i,k] (~10 cameras).  Each pass re-evaluates the detection (38 us of arithmetic at N = 1e6), forms its
+// products, sums them over the run with a segmented shuffle reduction (6 steps, lanes only add a neighbour that
+// carries the same key — runs are contiguous, so that is exact) and the first lane of every run adds the sums
+// to H / g with one atomic per entry.
+//   WHICH 0: order by (cam, key):    E[c,k] 15 x 3, D[k] 3 x 3 upper, g[k]                      (54 sums)
+//   WHICH 1: order by (image, key):  F[i,k] 6 x 3   (self chain only)                          (18 sums)
+template <int CHAIN, typename T, int WHICH>
+__global__ __launch_bounds__(256) void ba_normal_point_kernel(const NormalArgs a) {
+    static_assert(CHAIN != CHAIN_TEMPLATE && (WHICH == 0 || CHAIN == CHAIN_SELF), "no such pass");
+    constexpr int P = chain_P(CHAIN);
+    constexpr int P2 = 2 * P;
+    constexpr int NS = normal_shared_cols(CHAIN);
+    constexpr int NV = WHICH == 0 ? 45 + 6 + 3 : 18;
+    using V2 = __attribute__((ext_vector_type(2))) T;
+    const int lane = threadIdx.x & 63;
+    const T *cam_slab = static_cast<const T *>(a.cam_slab);
+    const T *pose_slab = static_cast<const T *>(a.pose_slab);
+    const T *points = static_cast<const T *>(a.points);
+    const V2 *uv = static_cast<const V2 *>(a.uv);
+    const int64_t n_waves = (int64_t)gridDim.x * 4, wave_id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    for (int64_t tile = wave_id; tile < a.n_tiles; tile += n_waves) {
+        const int64_t i = tile * 64 + lane;
+        const bool valid = i < a.n;
+        const int64_t ic = a.order[valid ? i : a.n - 1];
+        const int c = a.cam[ic], im = (CHAIN != CHAIN_FREE) ? a.img[ic] : 0, k = a.key[ic];
+        const V2 m = uv[ic];
+        T u, v;
+        T J[P2];
+        eval_detection<CHAIN, T, true>(cam_slab + c * CAM_STRIDE, pose_slab + im * POSE_STRIDE, points[3 * k], points[3 * k + 1],
+                                       points[3 * k + 2], u, v, J);
+        double jp0[3], jp1[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) { jp0[t] = (double)J[NS + t]; jp1[t] = (double)J[P + NS + t]; }
+        double s[NV];
+        if constexpr (WHICH == 0) {
+            const double r0 = (double)(u - m.x), r1 = (double)(v - m.y);
+#pragma unroll
+            for (int p = 0; p < 15; ++p)
+#pragma unroll
+                for (int t = 0; t < 3; ++t) s[3 * p + t] = (double)J[p] * jp0[t] + (double)J[P + p] * jp1[t];
+            int e = 45;
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int q = t; q < 3; ++q) s[e++] = jp0[t] * jp0[q] + jp1[t] * jp1[q];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) s[51 + t] = jp0[t] * r0 + jp1[t] * r1;
+        } else {
+#pragma unroll
+            for (int p = 0; p < 6; ++p)
+#pragma unroll
+                for (int t = 0; t < 3; ++t) s[3 * p + t] = (double)J[15 + p] * jp0[t] + (double)J[P + 15 + p] * jp1[t];
+        }
+        // run key; invalid lanes get one that matches nothing and contribute zeros
+        const int ka = valid ? (WHICH == 0 ? c : im) : -1 - lane, kb = valid ? k : -1;
+        if (!valid) {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) s[j] = 0.0;
+        }
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int na = __shfl_down(ka, off), nb = __shfl_down(kb, off);
+            const bool same = lane + off < 64 && na == ka && nb == kb;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const double t = __shfl_down(s[j], off);
+                s[j] += same ? t : 0.0;
+            }
+        }
+        const int pa = __shfl_up(ka, 1), pb = __shfl_up(kb, 1);
+        const bool leader = valid && (lane == 0 || pa != ka || pb != kb);
+        if (leader) {
+            const int64_t gX = a.point_off + 3 * (int64_t)k;
+            if constexpr (WHICH == 0) {
+#pragma unroll
+                for (int p = 0; p < 15; ++p) {
+                    double *row = a.H + shared_col<CHAIN>(a, p, c, im) * a.n_params + gX;
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) unsafeAtomicAdd(row + t, s[3 * p + t]);
+                }
+                int e = 45;
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+#pragma unroll
+                    for (int q = t; q < 3; ++q) unsafeAtomicAdd(a.H + (gX + t) * a.n_params + gX + q, s[e++]);
+#pragma unroll
+                for (int t = 0; t < 3; ++t) unsafeAtomicAdd(a.g + gX + t, s[51 + t]);
+            } else {
+#pragma unroll
+                for (int p = 0; p < 6; ++p) {
+                    double *row = a.H + shared_col<CHAIN>(a, 15 + p, c, im) * a.n_params + gX;
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) unsafeAtomicAdd(row + t, s[3 * p + t]);
+                }
+            }
+        }
+    }
 }
 
 }  // namespace pcs

@@ -68,6 +68,9 @@ struct pcs_engine {
     // static inputs
     int32_t *d_cam = nullptr, *d_img = nullptr, *d_key = nullptr;
     int32_t *d_order = nullptr;  // (cam, image)-sorted visiting order of a scattered table (normal equations), or NULL
+    int32_t *d_order_ck = nullptr, *d_order_ik = nullptr;  // (cam, key) / (image, key) orders for the point passes
+    bool point_orders_tried = false;
+    bool normal_point_pass = true;
     void *d_uv = nullptr;
     std::vector<int32_t> h_cam, h_img, h_key;
     bool have_template = false;
@@ -325,7 +328,7 @@ int pcs_destroy(pcs_engine *h) {
     if (!h) return PCS_OK;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
-    void *bufs[] = {h->d_cam, h->d_img, h->d_key, h->d_order, h->d_uv, h->d_param, h->d_cam_slab, h->d_pose_slab, h->d_points,
+    void *bufs[] = {h->d_cam, h->d_img, h->d_key, h->d_order, h->d_order_ck, h->d_order_ik, h->d_uv, h->d_param, h->d_cam_slab, h->d_pose_slab, h->d_points,
                     h->d_resid, h->d_jac, h->d_keep, h->d_row_off, h->d_data, h->d_vin, h->d_vout, h->d_cost, h->d_im_points, h->d_cam_tab, h->d_sink, h->d_H};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
@@ -370,7 +373,9 @@ static int upload_detections(pcs_engine *h, std::vector<int32_t> &cam, std::vect
     }
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(h->stream));
-    for (void **b : {(void **)&h->d_cam, (void **)&h->d_img, (void **)&h->d_key, (void **)&h->d_order, &h->d_uv, &h->d_resid, &h->d_jac,
+    h->point_orders_tried = false;
+    for (void **b : {(void **)&h->d_cam, (void **)&h->d_img, (void **)&h->d_key, (void **)&h->d_order, (void **)&h->d_order_ck,
+                     (void **)&h->d_order_ik, &h->d_uv, &h->d_resid, &h->d_jac,
                      (void **)&h->d_keep, (void **)&h->d_row_off, &h->d_data}) {
         if (*b) HIPCHK(hipFree(*b));
         *b = nullptr;
@@ -470,6 +475,8 @@ int pcs_set_option(pcs_engine *h, const char *key, int64_t value) {
         h->matfree_lds = value != 0;
     } else if (!strcmp(key, "normal_debug")) {
         h->normal_debug = (int)value;
+    } else if (!strcmp(key, "normal_point_pass")) {
+        h->normal_point_pass = value != 0;
     } else if (!strcmp(key, "compact_variant")) {
         if (value < 0 || value > 1) return fail(PCS_ERR_ARG, "compact_variant must be 0 or 1");
         h->compact_variant = (int)value;
@@ -664,11 +671,45 @@ static hipError_t launch_normal_t(int chain, const NormalArgs &a, dim3 grid, siz
     return hipGetLastError();
 }
 
+template <typename T>
+static hipError_t launch_normal_point_t(int chain, int which, const NormalArgs &a, dim3 grid, hipStream_t s) {
+    if (chain == CHAIN_SELF && which == 0) hipLaunchKernelGGL((ba_normal_point_kernel<CHAIN_SELF, T, 0>), grid, dim3(256), 0, s, a);
+    else if (chain == CHAIN_SELF) hipLaunchKernelGGL((ba_normal_point_kernel<CHAIN_SELF, T, 1>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((ba_normal_point_kernel<CHAIN_FREE, T, 0>), grid, dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// (cam, key)- and (image, key)-sorted visiting orders for ba_normal_point_kernel: built on the host at the first
+// normal-equations call of a self / free engine (two stable sorts, ~0.1 s at 1e6 detections)
+static int ensure_point_orders(pcs_engine *h) {
+    if (h->point_orders_tried || h->chain == PCS_CHAIN_TEMPLATE) return PCS_OK;
+    h->point_orders_tried = true;
+    const int64_t n = h->n;
+    if (n <= 0 || n > INT32_MAX) return PCS_OK;
+    std::vector<int32_t> order(n);
+    for (int pass = 0; pass < (h->chain == PCS_CHAIN_SELF ? 2 : 1); ++pass) {
+        const std::vector<int32_t> &major = pass == 0 ? h->h_cam : h->h_img;
+        for (int64_t i = 0; i < n; ++i) order[i] = (int32_t)i;
+        std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) {
+            return major[x] != major[y] ? major[x] < major[y] : h->h_key[x] < h->h_key[y];
+        });
+        int32_t **dst = pass == 0 ? &h->d_order_ck : &h->d_order_ik;
+        HIPCHK(hipMalloc(dst, sizeof(int32_t) * n));
+        HIPCHK(hipMemcpy(*dst, order.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice));
+    }
+    return PCS_OK;
+}
+
 // slab_prep + ba_normal_kernel on `s`; d_prm holds the parameter string; outputs are zeroed here.
 static int enqueue_normal(pcs_engine *h, const double *d_prm, double *d_H, double *d_g, double *d_cost, hipStream_t s) {
     if (h->n <= 0) return fail(PCS_ERR_STATE, "no detections set");
     if (h->chain == PCS_CHAIN_TEMPLATE && !h->have_template) return fail(PCS_ERR_STATE, "template points not set");
     HIPCHK(hipSetDevice(h->device));
+    if (h->normal_point_pass) {
+        int rc0 = ensure_point_orders(h);
+        if (rc0) return rc0;
+    }
+    const bool point_pass = h->normal_point_pass && h->d_order_ck && (h->chain != PCS_CHAIN_SELF || h->d_order_ik);
     HIPCHK(hipMemsetAsync(d_H, 0, sizeof(double) * h->n_params * h->n_params, s));
     HIPCHK(hipMemsetAsync(d_g, 0, sizeof(double) * h->n_params, s));
     HIPCHK(hipMemsetAsync(d_cost, 0, sizeof(double), s));
@@ -688,6 +729,7 @@ static int enqueue_normal(pcs_engine *h, const double *d_prm, double *d_H, doubl
     const int64_t target_waves = (int64_t)h->n_cu * wpc * NORMAL_WAVES;
     const int64_t tpw = std::max<int64_t>(1, (a.n_tiles + target_waves - 1) / target_waves);
     a.tiles_per_wave = (int32_t)tpw;
+    a.skip_points = point_pass ? 1 : 0;
     a.debug = h->normal_debug;
     const int64_t waves = (a.n_tiles + tpw - 1) / tpw;
     const dim3 grid((unsigned)((waves + NORMAL_WAVES - 1) / NORMAL_WAVES));
@@ -697,6 +739,14 @@ static int enqueue_normal(pcs_engine *h, const double *d_prm, double *d_H, doubl
     HIPCHK(hipEventRecord(ev[1], s));
     hipError_t e = h->esize == 8 ? launch_normal_t<double>(h->chain, a, grid, lds, s) : launch_normal_t<float>(h->chain, a, grid, lds, s);
     if (e != hipSuccess) return fail(PCS_ERR_HIP, "normal-equations kernel launch failed: %s", hipGetErrorString(e));
+    if (point_pass) {  // point columns: one pass per coupling over its key-sorted order (ba_normal.hpp)
+        const dim3 pgrid((unsigned)std::min<int64_t>((a.n_tiles + 3) / 4, (int64_t)h->n_cu * 8));
+        for (int which = 0; which < (h->chain == PCS_CHAIN_SELF ? 2 : 1); ++which) {
+            a.order = which == 0 ? h->d_order_ck : h->d_order_ik;
+            e = h->esize == 8 ? launch_normal_point_t<double>(h->chain, which, a, pgrid, s) : launch_normal_point_t<float>(h->chain, which, a, pgrid, s);
+            if (e != hipSuccess) return fail(PCS_ERR_HIP, "normal-equations point kernel launch failed: %s", hipGetErrorString(e));
+        }
+    }
     HIPCHK(hipEventRecord(ev[2], s));
     ++h->ev_count;
     h->events_valid = true;

@@ -242,6 +242,11 @@ def test_block_reduced_normal_equations_match_the_oracle_jacobian(chain, dtype):
         assert abs(cost - c_ref) <= tol * c_ref, name
         H2, g2, c2 = e.normal_equations(ps)           # second call: buffers are re-zeroed
         assert np.allclose(H2, Hs, rtol=1e-9 if dtype == "f64" else 1e-6, atol=0) and np.allclose(H2, H2.T)
+        if chain != "template":   # the fallback for the point columns (per-detection atomics) gives the same matrix
+            e.set_option("normal_point_pass", 0)
+            H3, g3, c3 = e.normal_equations(ps)
+            assert np.max(np.abs(H3 - H_ref) / np.where(scale > 0, scale, 1.0)) <= tol, name
+            assert np.max(np.abs(g3 - g_ref)) <= tol * np.max(np.abs(g_ref)), name
         e.close()
 
 

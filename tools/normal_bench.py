@@ -37,6 +37,13 @@ for cfg, chain, shuffle in configs:
                 e.normal_equations_device(ps, Hd.data_ptr(), gd.data_ptr(), cd.data_ptr()); e.synchronize(); ks.append(e.last_kernel_ms()[1])
             print(f"normal_debug {dbg}: kernel {np.median(ks[2:])*1e3:8.1f} us")
         e.set_option("normal_debug", 0)
+    if chain != "template":
+        for pp in (0, 1):   # per-detection point atomics against the key-sorted point passes
+            e.set_option("normal_point_pass", pp)
+            ks = []
+            for _ in range(8):
+                e.normal_equations_device(ps, Hd.data_ptr(), gd.data_ptr(), cd.data_ptr()); e.synchronize(); ks.append(e.last_kernel_ms()[1])
+            print(f"normal_point_pass {pp}: kernels {np.median(ks[2:])*1e3:8.1f} us")
     for wpc in ((0,) if "--only-default" in sys.argv else (0, 1, 2, 3, 4, 8)):
         e.set_option("wgs_per_cu", wpc)
         for _ in range(2):
