@@ -328,7 +328,7 @@ def main():
             build_ms = (time.perf_counter() - b0) / reps * 1e3
             normal_info = {"n_params": npar, "kernel_ms": float(np.median(k_ms)), "build_call_ms": build_ms,
                            "bytes": packed.numel() * 8,
-                           "note": "ba_normal_kernel: H = J^T J (upper triangle), g, cost in one pass; J never written"}
+                           "note": "ba_normal_kernel (+ point passes for the self / free chains): H = J^T J (upper triangle), g, cost; J never written"}
             if world > 1:
                 for _ in range(2):
                     dist.all_reduce(packed)
