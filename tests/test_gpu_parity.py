@@ -636,3 +636,29 @@ def test_engine_lifecycle_releases_device_memory(Engine):
     H.assert_jac_close(j3, ref_j)
     a.close()
     b.close()
+
+
+def test_scattered_table_whose_slabs_exceed_lds_falls_back_to_l2(Engine):
+    """128 cameras x 500 images: 216 KB of FP64 slabs, more than the 160 KiB of LDS.  A shuffled table asks for
+    LDS-staged slabs (tile locality < 0.5); the launch must fall back to reading them through L1/L2 and still
+    match the oracle (dense, compaction, normal equations through the sorted visiting order)."""
+    from scipy.sparse import csr_array
+    rig = synthetic.config_rig(5, scale=0.002)        # ~6e4 detections, full-size slabs
+    assert rig.n_cams == 128 and rig.n_imgs == 500 and 2e4 < rig.n_det < 2e5
+    det = rig.detections[np.random.default_rng(3).permutation(rig.n_det)][:30000].copy()
+    det[-1, :3] = [rig.n_cams - 1, rig.n_imgs - 1, rig.n_keys - 1]
+    ps, ref_r, ref_j = oracle_eval(rig, "template", det)
+    e = make_engine(Engine, rig, "template", det=det)
+    for variant in (-1, 7, 3):                       # automatic choice and explicit requests for LDS slabs
+        e.set_option("variant", variant)
+        r, j = e.eval(ps)
+        H.assert_resid_close(r, ref_r, det[:, 3:])
+        H.assert_jac_close(j, ref_j)
+    e.set_option("variant", -1)
+    idx, ptr, _ = orc.csr_structure("template", det, np.ones(ps.shape[0], bool))
+    J = csr_array((ref_j.reshape(-1), idx, ptr), shape=(2 * det.shape[0], ps.shape[0]))
+    Hm, g, cost = e.normal_equations(ps)
+    H_ref = (J.T @ J).toarray()
+    sc = np.sqrt(np.outer(np.diag(H_ref), np.diag(H_ref)))
+    assert np.max(np.abs(Hm - H_ref) / np.where(sc > 0, sc, 1.0)) <= 1e-10
+    e.close()
