@@ -662,3 +662,50 @@ def test_scattered_table_whose_slabs_exceed_lds_falls_back_to_l2(Engine):
     sc = np.sqrt(np.outer(np.diag(H_ref), np.diag(H_ref)))
     assert np.max(np.abs(Hm - H_ref) / np.where(sc > 0, sc, 1.0)) <= 1e-10
     e.close()
+
+
+def test_soa_upload_engine_buffers_and_timing_options(Engine):
+    """The entry points the other tests do not touch: pcs_set_detections (separate index / measurement arrays),
+    pcs_device_buffers (engine-owned output scratch), the HIP-event ring behind pcs_kernel_ms_mean and the
+    timing_every option."""
+    import torch
+    rig = synthetic.config_rig(1)
+    det = rig.detections
+    ps, ref_r, ref_j = oracle_eval(rig, "template")
+    e = Engine("template", rig.n_cams, rig.n_imgs, rig.n_keys)
+    e.set_detections(det[:, 0].astype(np.int32), det[:, 1].astype(np.int32), det[:, 2].astype(np.int32), det[:, 3:])
+    e.set_template(rig.points)
+    r, j = e.eval(ps)
+    H.assert_resid_close(r, ref_r, det[:, 3:])
+    H.assert_jac_close(j, ref_j)
+    with pytest.raises(ValueError):
+        e.set_detections(det[:, 0].astype(np.int32), det[:5, 1].astype(np.int32), det[:, 2].astype(np.int32), det[:, 3:])
+    # engine-owned device scratch: the pointers pcs_eval itself writes to
+    d_r, d_j = e.device_buffers()
+    assert d_r and d_j
+    e.eval_device(ps * (1 + 1e-4), d_r, d_j)      # overwrite with another point ...
+    e.synchronize()
+    r2, j2 = e.eval(ps)                           # ... and the host path still returns the right one
+    assert np.array_equal(r2, r) and np.array_equal(j2, j)
+    # event ring: the last R timed evaluations are averaged; timing_every = k times every k-th evaluation only
+    e.set_option("event_ring", 4)
+    e.set_option("timing_every", 1)
+    for _ in range(6):
+        e.eval_device(ps, d_r, d_j)
+    e.synchronize()
+    cnt, prep_ms, eval_ms = e.kernel_ms_mean()
+    assert cnt == 4 and 0 < eval_ms < 5 and 0 < prep_ms < 5
+    e.set_option("event_ring", 8)
+    e.set_option("timing_every", 3)
+    for _ in range(7):                            # evaluations 0, 3, 6 are timed
+        e.eval_device(ps, d_r, d_j)
+    e.synchronize()
+    cnt, _, eval_ms2 = e.kernel_ms_mean()
+    assert cnt == 3 and 0 < eval_ms2 < 5
+    e.set_option("timing_every", 0)               # never: the ring keeps what it has
+    e.eval_device(ps, d_r, d_j)
+    e.synchronize()
+    assert e.kernel_ms_mean()[0] == 3
+    with pytest.raises(_capi.PcsError):
+        e.set_option("event_ring", 0)
+    e.close()
