@@ -1,7 +1,7 @@
 // ba_normal.hpp — block-reduced normal equations ("block-reduced J^T J / J^T r, then
 // all-reduce of the small result instead of all-gather of J").
 //
-// One pass over the detections builds, without ever writing J:
+// Built on the GPU without ever writing J:
 //     H    = J^T J   upper triangle of the n_params x n_params matrix (row-major, full parameter-string space)
 //     g    = J^T r   n_params
 //     cost = r^T r
@@ -28,8 +28,12 @@
 //     that mixes several (cam, image) pairs is processed pair by pair (wave-uniform member masks), so any
 //     table order gives the same result.  For a scattered table (every detection its own run: 18 ms on rig-32)
 //     the host hands over a (cam, image)-sorted visiting order instead — the sums do not depend on it.
-//   * The 3 point columns (self / free chains) differ per lane, so their rows of H (point-point,
-//     shared-point) and of g are added per detection with global atomics.
+//   * The 3 point columns (self / free chains) differ per lane; their rows of H (point-point, shared-point) and
+//     of g come from ba_normal_point_kernel (end of this file: separate passes over key-sorted visiting
+//     orders), or — fallback — from per-detection global atomics in this kernel.
+//   * The read loop is software-pipelined by hand (NORMAL_DEPTH rows of operands in flight) and the lane ->
+//     chunk assignment comes from a table that keeps LDS slots 16 apart out of the same read group.
+// One pass / one kernel for the template chain; up to three kernels for the self chain.
 // Atomic order makes the last bits run-to-run dependent (documented; tests compare with a tolerance).
 #pragma once
 #include <hip/hip_runtime.h>
