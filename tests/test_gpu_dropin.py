@@ -134,6 +134,32 @@ def test_least_squares_with_hip_closures_converges_like_the_cpu_path(chain):
     assert np.max(np.abs(loss_fn(x0) - o_loss(x0))) <= 1e-9
 
 
+def test_handler_closures_with_the_mixed_engine():
+    """dtype='mixed' through the handler surface: the closures return float64 arrays whose values are the FP64
+    results rounded once to FP32 (1.2e-7), the CSR structure is unchanged, and the device solver — which never reads
+    the FP32 stream — reaches the FP64 solution."""
+    from pycamset_amd.device_solver import lm_solve
+    rig = synthetic.make_rig("ring-5-small", 5, 8, synthetic.charuco_points(7, 8.0), seed=29, visibility=0.9)
+    names = [f"cam_{i}" for i in range(rig.n_cams)]
+
+    def build(dtype):
+        return handlers.TemplateBundleHandler(DuckCamset(rig.n_cams), DuckTarget(rig.points), TargetDetection(names, rig.detections),
+                                              fixed_params={"cam_0": {"ext": rig.extr_true[0].copy()}}, options={"verbosity": 0}, dtype=dtype)
+
+    h64, hmx = build("f64"), build("mixed")
+    bp = h64.bundlePrimitive
+    x0 = np.concatenate([rig.intr[bp.intr_unfixed].ravel(), rig.extr[bp.extr_unfixed].ravel(), rig.poses[bp.poses_unfixed].ravel()])
+    r64, rmx = h64.make_loss_fun(1)(x0), hmx.make_loss_fun(1)(x0)
+    J64, Jmx = h64.make_loss_jac(1)(x0), hmx.make_loss_jac(1)(x0)
+    assert rmx.dtype == np.float64 and Jmx.data.dtype == np.float64
+    assert np.array_equal(J64.indices, Jmx.indices) and np.array_equal(J64.indptr, Jmx.indptr)
+    assert np.max(np.abs(rmx - r64) / np.maximum(np.abs(r64), 1e-3)) <= 1.2e-7
+    rowmax = np.repeat(np.abs(J64).max(axis=1).toarray().ravel(), np.diff(J64.indptr))
+    assert np.max(np.abs(Jmx.data - J64.data) / np.maximum(np.abs(J64.data), 1e-6 * rowmax)) <= 1.2e-7
+    a, b = lm_solve(h64, x0.copy(), max_iter=25), lm_solve(hmx, x0.copy(), max_iter=25)
+    assert abs(a.cost - b.cost) <= 1e-9 * a.cost
+
+
 def test_run_bundle_adjustment_caller_with_both_solvers():
     """optimisation_handling.run_bundle_adjustment (the reference's caller, oh:52-117) end to end: scipy on the
     HIP closures and the device solver (block-reduced normal equations + Schur step) reach the same solution
