@@ -80,9 +80,10 @@ def counts_from_detections(det: np.ndarray) -> tuple[int, int, int]:
     return int(det[:, 0].max()) + 1, int(det[:, 1].max()) + 1, int(det[:, 2].max()) + 1
 
 
-def param_struct(chain: str, det: np.ndarray):
-    """(starts, n_params, total) of the unique parameter groups in block order (afb:804-820)."""
-    C, I, K = counts_from_detections(det)
+def param_struct(chain: str, det: np.ndarray, counts=None):
+    """(starts, n_params, total) of the unique parameter groups in block order (afb:804-820).
+    ``counts`` = (n_cams, n_imgs, n_keys) replaces the reference's max-index+1 rule (afb:793-795)."""
+    C, I, K = counts if counts is not None else counts_from_detections(det)
     groups = {"template": [(9, C), (6, C), (6, I)],
               "self": [(9, C), (6, C), (6, I), (3, K)],
               "free": [(9, C), (6, C), (3, K)]}[chain]
@@ -93,9 +94,9 @@ def param_struct(chain: str, det: np.ndarray):
     return np.array(starts), np.array([g[0] for g in groups]), total
 
 
-def block_param_inds(chain: str, det: np.ndarray) -> np.ndarray:
+def block_param_inds(chain: str, det: np.ndarray, counts=None) -> np.ndarray:
     """Per-detection global column of every local parameter, (N, P) (afb:211-217, unthreaded)."""
-    starts, npar, _ = param_struct(chain, det)
+    starts, npar, _ = param_struct(chain, det, counts)
     key_col = {"template": [0, 0, 1], "self": [0, 0, 1, 2], "free": [0, 0, 2]}[chain]
     cols = []
     for s, n, kc in zip(starts, npar, key_col):
@@ -104,9 +105,9 @@ def block_param_inds(chain: str, det: np.ndarray) -> np.ndarray:
     return np.concatenate(cols, axis=1)
 
 
-def csr_structure(chain: str, det: np.ndarray, unfixed: np.ndarray):
+def csr_structure(chain: str, det: np.ndarray, unfixed: np.ndarray, counts=None):
     """make_jac_CSR_columns_row_pointers (afb:465-489): static indices / indptr."""
-    c = np.repeat(block_param_inds(chain, det), 2, axis=0)
+    c = np.repeat(block_param_inds(chain, det, counts), 2, axis=0)
     unfixed = np.asarray(unfixed, dtype=bool)
     conversion = np.concatenate([[0], np.cumsum(unfixed)])
     mask = unfixed[c]

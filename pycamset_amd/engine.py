@@ -123,6 +123,8 @@ class Engine:
 
     def set_template(self, points: np.ndarray):
         points = _f64c(points).reshape(-1, 3)
+        if points.shape[0] < self.n_keys:
+            raise ValueError(f"template has {points.shape[0]} points, the engine indexes {self.n_keys} keys")
         check(lib().pcs_set_template(self._h, _dp(points)))
 
     def set_option(self, key: str, value: int):

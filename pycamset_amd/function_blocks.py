@@ -105,14 +105,23 @@ def _counts(detections: np.ndarray) -> tuple[int, int, int]:
 class optimisation_function:  # afb:111-685
     """A chain of function blocks evaluated by the MI355X engine."""
 
-    def __init__(self, function_blocks, *, dtype: str = "f64", device: int = 0, pinned_ring: int = 0, counts=None) -> None:
+    DEFAULT_PINNED_RING = 2
+
+    def __init__(self, function_blocks, *, dtype: str = "f64", device: int = 0, pinned_ring: int | None = None, counts=None) -> None:
         """``pinned_ring`` = R > 0 returns the Jacobian ``data`` array from a ring of R page-locked
-        host buffers (PCIe-rate device -> host copy, wrapped by ``csr_array`` without a copy); an
-        array handed out stays valid for R further Jacobian calls.  0 = a fresh NumPy array per
-        call, exactly like the reference (afb:561)."""
-        self.pinned_ring = int(pinned_ring)
-        # (n_cams, n_imgs, n_keys) override of the max-index+1 rule (afb:793-795): a rank that holds
-        # only a shard of the detections must still lay out the GLOBAL parameter string.
+        host buffers (PCIe-rate device -> host copy, wrapped by ``csr_array`` without a copy); the array
+        handed out by one Jacobian call is overwritten by the R-th call after it.  The default (None) is
+        R = 2: scipy's ``least_squares`` drops the previous Jacobian before it asks for the next one
+        (optimisation_handling.py:88-98 -> scipy trf / lm), so the current and the previous one are always
+        intact, and a 335 MB Jacobian arrives in ~10 ms instead of ~34 ms (pageable memory).
+        0 = a fresh pageable NumPy array per call, exactly like the reference (afb:561) — for callers that
+        keep Jacobians of older parameter vectors around."""
+        self.pinned_ring = self.DEFAULT_PINNED_RING if pinned_ring is None else int(pinned_ring)
+        # (n_cams, n_imgs, n_keys): slab sizes of the parameter string.  None = the reference's own rule, max
+        # index + 1 of the detection table (afb:793-795).  The handlers pass their slab sizes (a trailing camera /
+        # image / key without detections must still have its place in the string), a rank that holds only a
+        # shard of the detections passes the GLOBAL sizes.  Counts smaller than what the table needs are raised
+        # to max index + 1.
         self.counts = None if counts is None else tuple(int(c) for c in counts)
         self.function_blocks = list(function_blocks)
         self.n_blocks = len(self.function_blocks)
@@ -122,7 +131,6 @@ class optimisation_function:  # afb:111-685
         self.param_line_length = int(self.n_params.sum())  # P
         self._engine: Engine | None = None
         self._engine_key = None
-        self._template_key = None
 
     @property
     def chain(self) -> str:
@@ -144,10 +152,12 @@ class optimisation_function:  # afb:111-685
             raise ValueError("detections must be the flattened (N, 5) table [cam, im, key, u, v]")
         key = (det.shape, hash(det.tobytes()))
         if self._engine is None or key != self._engine_key:
-            C, I, K = self.counts if self.counts is not None else _counts(det)
+            C, I, K = _counts(det)
+            if self.counts is not None:
+                C, I, K = (max(a, b) for a, b in zip(self.counts, (C, I, K)))
             eng = Engine(self.chain, C, I, K, dtype=self.dtype, device=self.device)
             eng.set_detections_table(det)
-            self._engine, self._engine_key, self._template_key = eng, key, None
+            self._engine, self._engine_key = eng, key
         return self._engine
 
     def _bind_template(self, eng: Engine, template) -> None:
@@ -157,9 +167,19 @@ class optimisation_function:  # afb:111-685
             raise ValueError("the template chain needs the template points (target.point_data.reshape(-1, 3))")
         t = np.ascontiguousarray(template, dtype=np.float64).reshape(-1, 3)
         key = hash(t.tobytes())
-        if key != self._template_key:
+        if key != getattr(eng, "_bound_template_key", None):   # per engine: closures built on different tables own different engines
             eng.set_template(t)
-            self._template_key = key
+            eng._bound_template_key = key
+
+    @staticmethod
+    def _leading(param, eng: Engine) -> np.ndarray:
+        """The generated reference functions gather ``inp_params[block_param_inds]`` (afb:363, afb:570): entries of
+        the parameter string beyond the last indexed one are never read.  A string LONGER than the engine's layout is
+        therefore cut to its leading ``n_params`` entries — with ``counts=None`` (layout from max index + 1 of the
+        detections, afb:793-795) that is bit for bit what the reference evaluates, including its mis-offset groups
+        when a trailing camera / image has no detection (SURVEY 8a quirk ii).  A shorter string is an error."""
+        p = np.asarray(param, dtype=np.float64).reshape(-1)
+        return p[: eng.n_params] if p.shape[0] > eng.n_params else p
 
     # -- reference API -------------------------------------------------------------------------
     def can_make_jac(self) -> bool:  # afb:683-684
@@ -175,7 +195,7 @@ class optimisation_function:  # afb:111-685
 
         def loss_fn(param, template=None):
             self._bind_template(eng, template)
-            r, _ = eng.eval(param, want_resid=True, want_jac=False)
+            r, _ = eng.eval(self._leading(param, eng), want_resid=True, want_jac=False)
             return r
 
         return loss_fn
@@ -185,9 +205,11 @@ class optimisation_function:  # afb:111-685
         if unfixed_params is None:
             unfixed = np.ones(eng.n_params, dtype=bool)
         else:
-            unfixed = np.asarray(unfixed_params, dtype=bool)
+            # A mask longer than the string (a handler whose slabs have trailing entries no detection indexes) is
+            # cut like the string itself, see _leading(): `conversion` (afb:482) only ever looks up indexed columns.
+            unfixed = np.asarray(unfixed_params, dtype=bool)[: eng.n_params]
             if unfixed.shape[0] != eng.n_params:
-                raise ValueError(f"unfixed_params has {unfixed.shape[0]} entries, expected {eng.n_params}")
+                raise ValueError(f"unfixed_params has {unfixed.shape[0]} entries, expected at least {eng.n_params}")
         indices, indptr = eng.csr_structure(unfixed)  # static, built once (afb:619)
         all_free = bool(np.all(unfixed))
         mask_key = hash(unfixed.tobytes())
@@ -197,11 +219,11 @@ class optimisation_function:  # afb:111-685
         def jac_fn(param, template=None):
             self._bind_template(eng, template)
             if all_free:  # afb:633-642
-                _, j = eng.eval(param, want_resid=False, want_jac=True, pinned_ring=self.pinned_ring)
+                _, j = eng.eval(self._leading(param, eng), want_resid=False, want_jac=True, pinned_ring=self.pinned_ring)
                 return j.reshape(-1), indices, indptr
             if eng.mask_key != mask_key:  # another closure re-bound the engine's mask
                 eng.set_unfixed(unfixed)
-            _, data = eng.eval_compact(param, pinned_ring=self.pinned_ring)  # afb:644-651, masked on the device
+            _, data = eng.eval_compact(self._leading(param, eng), pinned_ring=self.pinned_ring)  # afb:644-651, masked on the device
             return data, indices, indptr
 
         return jac_fn
@@ -210,7 +232,8 @@ class optimisation_function:  # afb:111-685
         return self._engine_for(detections).block_param_inds()
 
     def make_jac_CSR_columns_row_pointers(self, detections, threads, unfixed_params):  # afb:465-489
-        return self._engine_for(detections).csr_structure(np.asarray(unfixed_params, dtype=bool))
+        eng = self._engine_for(detections)
+        return eng.csr_structure(np.asarray(unfixed_params, dtype=bool)[: eng.n_params])
 
     @property
     def engine(self) -> Engine | None:

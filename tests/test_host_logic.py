@@ -71,6 +71,129 @@ def test_handler_host_logic_against_reference_goldens(golden_dir, chain, tag, fi
     assert_close(dense[m], g["data"], rows=rows[m])
 
 
+class DuckTargetND:
+    """Ccube-shaped target: point_data (6, 81, 3) (target_Ccube.py:227-244)."""
+
+    def __init__(self, points, keydims):
+        self.point_data = np.array(points, dtype=np.float64).reshape(tuple(int(k) for k in keydims) + (3,))
+
+
+# round-2 fixtures (tests/golden/make_golden.py round2_vectors): name -> (chain, options)
+R2_CASES = {
+    "handler_template_ccube": ("template", {"fixed_pose": 3}),
+    "handler_self_ccube": ("self", {"fixed_pose": 3}),
+    "handler_template_fixedpose_none": ("template", {"fixed_pose": None}),
+    "quirk_template_last_image_unobserved": ("template", {}),
+    "quirk_self_last_key_unobserved": ("self", {}),
+    "quirk_self_last_image_unobserved": ("self", {}),
+    "quirk_template_last_cam_unobserved": ("template", {}),
+}
+R2_SAME_AS_REFERENCE = [n for n in R2_CASES if n not in ("quirk_self_last_image_unobserved", "quirk_template_last_cam_unobserved")]
+
+
+def make_handler_r2(g, name, **kw):
+    """Rebuild the handler of a round-2 fixture from the inputs stored beside the reference's outputs."""
+    chain, options = R2_CASES[name]
+    n_cams = int(g["n_cams"])
+    names = [f"cam_{i}" for i in range(n_cams)]
+    fixed = {}
+    for c in range(n_cams):
+        if not g["intr_unfixed"][c]:
+            fixed.setdefault(names[c], {})["int"] = g["intr_slab"][c].copy()
+        if not g["extr_unfixed"][c]:
+            fixed.setdefault(names[c], {})["ext"] = g["extr_slab"][c].copy()
+    det = TargetDetection(names, g["detections"], max_ims=int(g["max_ims"]))
+    keydims = tuple(int(k) for k in g["keydims"])
+    target = DuckTargetND(g["points"], keydims)
+    opts = {"verbosity": 0}
+    opts.update(options)
+    return HANDLERS[chain](DuckCamset(n_cams), target, det, fixed_params=fixed or None, options=opts, **kw), chain
+
+
+def test_return_flattened_keys_against_the_reference(golden_dir):
+    """TargetDetection.return_flattened_keys (target_detections.py:333-351), fixtures made by the
+    reference on 2-, 3- and 1-dimensional key tables."""
+    g = np.load(golden_dir / "flatten_keys.npz")
+    for tag in ("ccube", "three_dim", "one_dim"):
+        td = TargetDetection(["cam_0", "cam_1", "cam_2"], g[f"{tag}_in"], max_ims=7)
+        flat = td.return_flattened_keys(tuple(g[f"{tag}_dims"]))
+        assert np.array_equal(flat.get_data(), g[f"{tag}_out"]), tag       # integer-valued keys: bit-exact
+        assert flat.max_ims == int(g[f"{tag}_max_ims"]) == 7
+    # the flattened key indexes point_data.reshape(-1, 3) (th:160-163)
+    dims = tuple(g["ccube_dims"])
+    pts = np.arange(int(np.prod(dims)) * 3, dtype=np.float64).reshape(dims + (3,))
+    a, b = g["ccube_in"], g["ccube_out"]
+    assert np.array_equal(pts.reshape(-1, 3)[b[:, 2].astype(int)], pts[a[:, 2].astype(int), a[:, 3].astype(int)])
+
+
+@pytest.mark.parametrize("name", R2_SAME_AS_REFERENCE)
+def test_ccube_shaped_and_edge_handlers_against_reference_goldens(golden_dir, name):
+    """Handler host logic (masks, x -> slabs, CSR structure) on Ccube-shaped targets (6, 81, 3) with multi-dimensional
+    keys, fixed_pose = 3 / None, a camera with 'int' AND 'ext' fixed, and trailing unobserved images / keys.
+    Values go through the CPU oracle."""
+    g = np.load(golden_dir / f"{name}.npz")
+    h, chain = make_handler_r2(g, name)
+    bp = h.bundlePrimitive
+    assert np.array_equal(bp.intr_unfixed, g["intr_unfixed"]) and np.array_equal(bp.extr_unfixed, g["extr_unfixed"])
+    assert np.array_equal(bp.poses_unfixed, g["poses_unfixed"])
+    if chain == "self":
+        assert np.array_equal(bp.bdpt_unfixed, g["bdpt_unfixed"])
+        assert np.array_equal(h.visible_feature_mask, g["visible_feature_mask"])
+    if name == "handler_template_fixedpose_none":
+        assert not bp.poses_unfixed.any()          # a None index fixes every pose (th:134-137)
+    x = g["x"]
+    slabs = h.get_bundle_adjustment_inputs(x.copy())
+    assert np.array_equal(slabs[0], g["intr_slab"]) and np.array_equal(slabs[1], g["extr_slab"]) and np.array_equal(slabs[2], g["poses_slab"])
+    param_str = h.op_fun.build_param_list(*slabs)
+    mask = h._jac_mask()
+    assert int(mask.sum()) == x.shape[0] == g["shape"][1]
+    det = h._flat_detections()
+    assert det.shape[1] == 5
+    counts = h.op_fun.counts
+    assert counts == (bp.intr.shape[0], bp.poses.shape[0], int(np.prod(g["keydims"])))
+    assert orc.param_struct(chain, det, counts)[2] == param_str.shape[0] == mask.shape[0]
+    idx, ptr, m = orc.csr_structure(chain, det, mask, counts)
+    assert np.array_equal(idx, g["indices"]) and np.array_equal(ptr, g["indptr"])
+    tmpl = h._template_arg()
+    res = orc.full_loss(chain, det, param_str, tmpl, counts=counts).flatten()
+    assert_close(res, g["resid"], rtol=1e-11)
+    dense = orc.full_jac_dense(chain, det, param_str, tmpl, counts=counts)
+    rows = np.broadcast_to(np.max(np.abs(dense), axis=1, keepdims=True), dense.shape)
+    assert_close(dense[m], g["data"], rows=rows[m])
+
+
+@pytest.mark.parametrize("name", ["quirk_self_last_image_unobserved", "quirk_template_last_cam_unobserved"])
+def test_reference_quirk_ii_is_understood_and_not_reproduced(golden_dir, name):
+    """abstract_function_blocks.py:793-795 sizes the parameter groups from max(index) + 1 of the detections while the
+    handlers size their slabs from n_cams / max_ims / point_data (th:124-129).  With a trailing unobserved camera (any
+    chain) or image (self chain) the reference therefore reads later groups at the wrong offset.  (1) The fixture IS
+    what that rule gives: the oracle, laid out with max(index) + 1 and fed the handler's longer string, reproduces it.
+    (2) This package lays the string out from the slab sizes instead and evaluates the slabs the handler built."""
+    g = np.load(golden_dir / f"{name}.npz")
+    h, chain = make_handler_r2(g, name)
+    x = g["x"]
+    param_str = h.op_fun.build_param_list(*h.get_bundle_adjustment_inputs(x.copy()))
+    mask, det, tmpl = h._jac_mask(), h._flat_detections(), h._template_arg()
+    ref_counts = orc.counts_from_detections(det)
+    own_counts = h.op_fun.counts
+    assert ref_counts != own_counts and orc.param_struct(chain, det, own_counts)[2] == param_str.shape[0]
+    # (1) the reference's rule on the handler's string
+    n_ref = orc.param_struct(chain, det, ref_counts)[2]
+    assert n_ref < param_str.shape[0]
+    res = orc.full_loss(chain, det, param_str[:n_ref], tmpl, counts=ref_counts).flatten()
+    assert_close(res, g["resid"], rtol=1e-11)
+    idx, ptr, m = orc.csr_structure(chain, det, mask, ref_counts)     # columns by the detections' rule, mask by the handler's
+    assert np.array_equal(idx, g["indices"]) and np.array_equal(ptr, g["indptr"])
+    dense = orc.full_jac_dense(chain, det, param_str[:n_ref], tmpl, counts=ref_counts)
+    rows = np.broadcast_to(np.max(np.abs(dense), axis=1, keepdims=True), dense.shape)
+    assert_close(dense[m], g["data"], rows=rows[m])
+    # (2) the slab-size layout gives a different (the intended) function: residuals stay at the noise level
+    own = orc.full_loss(chain, det, param_str, tmpl, counts=own_counts).flatten()
+    assert np.median(np.abs(own)) < 20 and np.max(np.abs(own - g["resid"])) > 1.0
+    idx2, ptr2, _ = orc.csr_structure(chain, det, mask, own_counts)
+    assert idx2.max() < x.shape[0] and ptr2[-1] == idx2.shape[0]
+
+
 def test_fill_flat_scatter_and_layout():
     rng = np.random.default_rng(0)
     full = np.zeros((5, 6))
