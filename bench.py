@@ -3,18 +3,27 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A *step* is one LM-step evaluation of the hot path over the whole detection table: slab
-preparation (K0) + the fused residual/Jacobian kernel (K1), with the parameter string and the
-detection table already resident in HBM and the residual / dense Jacobian blocks left in HBM.
+A *step* is one LM-step evaluation of the hot path over the detection table: slab preparation (K0) + the
+fused residual/Jacobian kernel (K1), with the parameter string and the detection table already resident in
+HBM and the residual / dense Jacobian blocks left in HBM.
 
-Workload at N = 1: BASELINE.json configs[2], "rig-32" — 32 cameras, Ccube target (486 keys),
-200 poses, ~1.0e6 detections, template chain, FP64.  For N > 1 (one process
-per GPU, launched by torch.distributed.run, RCCL backend) scaling is *weak*: rank r evaluates an
-independent rig-32 block (same shape, seed + 1000 r) — together a 32N-camera / 200N-pose rig whose
-visibility is block diagonal — with no data-path collective in the timed region (the path
-partitions by observation).  The all-gather of residual + Jacobian blocks that a
-host-side consumer would need is link-bound; it is timed separately and reported under
-"allgather" (never inside `value` unless --collective allgather is given).
+Workload: BASELINE.json configs[2], "rig-32" — 32 cameras, Ccube target (486 keys), 200 poses, ~1.0e6
+detections, template chain, FP64; `--config 4 / 5` select the self-calibration and the
+1e7-detection FP32 rigs.
+
+N > 1 (one process per GPU, launched by torch.distributed.run, RCCL backend): `--scaling strong` (default) —
+every rank evaluates its contiguous ceil(N/G)-row shard of the ONE rig the config names (the reference's
+equal-chunk rule incl. cyclic padding, abstract_function_blocks.py:281-288; `pycamset_amd.sharding.padded_shard`),
+all ranks hold the same parameter string, and the timed region contains no collective: the path partitions by
+observation.  `value` = rows of the whole rig x steps / max-over-ranks time.  Two more step times are
+measured outside that region and reported under "multi_gpu": step + RCCL all-gather of the residual / Jacobian
+blocks (what a host-side consumer of J needs; xGMI-link-bound) and normal-equations build + ONE all-reduce of the
+packed [J^T J, J^T r, cost] (what a device-side LM step needs).  `--scaling weak` gives every rank an independent
+rig of the same shape instead (seed + 1000 r).
+
+Kernel time for the roofline figure: after the wall-clock region, >= 20 extra launches carry HIP start/stop
+events (hipExtLaunchKernelGGL on the launch stream); mean / median / min are reported, the mean is what
+`roofline.achieved` uses.  The timed region itself runs without events, so they cannot perturb `value`.
 
 Rank 0 prints ONE JSON line (schema: task contract + "roofline" + "cpu_baseline").
 """
@@ -40,6 +49,7 @@ BYTES_PER_DET = {("template", "f64"): 380, ("self", "f64"): 428, ("free", "f64")
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 CONFIG_CHAIN = {1: "template", 2: "template", 3: "template", 4: "self", 5: "template"}
 CONFIG_DTYPE = {1: "f64", 2: "f64", 3: "f64", 4: "f64", 5: "f32"}
+KERNEL_SAMPLES = 24     # event-timed launches after the wall-clock region (>= 20)
 
 
 def chain_slabs(rig, chain):
@@ -48,6 +58,57 @@ def chain_slabs(rig, chain):
     if chain == "self":
         return [rig.intr, rig.extr, rig.poses, rig.points]
     return [rig.intr, rig.extr, rig.points]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the per-rank problem (importable without a GPU: tests/test_sharding_gloo.py drives exactly this code)
+# ---------------------------------------------------------------------------------------------------------------
+def rank_problem(config: int, chain: str, rank: int, world: int, scaling: str = "strong", scale: float = 1.0):
+    """What rank `rank` of `world` evaluates.  -> dict(rig, det, n_real, n_total, per, param_str, template)
+    strong: the rank's `padded_shard` of the one config rig (rows beyond the table are cyclic repeats, dropped
+            again by `strip_padding`); weak: an independent rig of the same shape per rank."""
+    from pycamset_amd import sharding, synthetic
+
+    if scaling == "strong":
+        rig = synthetic.config_rig(config, scale=scale)
+        n_total = rig.n_det
+        per = sharding.shard_rows(n_total, world)
+        det = sharding.padded_shard(rig.detections, rank, world)
+        n_real = max(0, min(n_total, (rank + 1) * per) - rank * per)
+    elif scaling == "weak":
+        rig = synthetic.config_rig(config, scale=scale, block=rank)
+        det, n_real, per, n_total = rig.detections, rig.n_det, rig.n_det, None   # n_total: sum over ranks (all-reduced)
+    else:
+        raise ValueError("scaling must be 'strong' or 'weak'")
+    ps = np.concatenate([np.asarray(a, dtype=np.float64).ravel() for a in chain_slabs(rig, chain)])
+    return dict(rig=rig, det=det, n_real=n_real, n_total=n_total, per=per, param_str=ps,
+                template=rig.points if chain == "template" else None)
+
+
+def gather_blocks(dist, local, out=None, via_host: bool = False):
+    """All-gather equal-sized blocks (rows x cols tensors) from every rank into one (world * rows, cols) tensor.
+    RCCL: `all_gather_into_tensor` on the device.  via_host (the gloo rehearsal on one GPU): staged through the host."""
+    import torch
+
+    world = dist.get_world_size()
+    if via_host:
+        loc = local.detach().cpu().contiguous()
+        buf = torch.empty((world * loc.shape[0],) + tuple(loc.shape[1:]), dtype=loc.dtype)
+        dist.all_gather_into_tensor(buf, loc)
+        if out is None:
+            return buf.to(local.device)
+        out.copy_(buf)
+        return out
+    if out is None:
+        out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, local.contiguous())
+    return out
+
+
+def strip_padding(gathered, n_total: int, rows_per_det: int = 1):
+    """Contiguous shards in rank order: the real rows are the leading n_total (x rows_per_det) of the gathered
+    block, everything after them is the cyclic padding of the last rank(s) (afb:385, afb:641)."""
+    return gathered[: n_total * rows_per_det]
 
 
 def usable_cpus() -> int:
@@ -121,14 +182,17 @@ def cpu_baseline(rig, chain, param_str, budget_s: float):
 
 
 def pmc_traffic(workload_key: str):
-    """HBM bytes per launch from the committed rocprofv3 PMC summary of this same command, if any."""
+    """(HBM bytes per launch, where they come from): the committed rocprofv3 PMC summary of this same command —
+    FETCH_SIZE and WRITE_SIZE need passes of their own (MI355X_MICROARCH.md), so they cannot be taken inside this run."""
     f = REPO / "profiles" / "pmc_traffic.json"
     if f.exists():
         try:
-            return json.loads(f.read_text()).get(workload_key, {}).get("hbm_bytes_per_launch")
+            e = json.loads(f.read_text()).get(workload_key)
+            if e:
+                return e.get("hbm_bytes_per_launch"), f"profiles/pmc_traffic.json['{workload_key}'] <- {e.get('source')}"
         except Exception:
-            return None
-    return None
+            pass
+    return None, None
 
 
 def main():
@@ -140,6 +204,8 @@ def main():
     ap.add_argument("--chain", default=None)
     ap.add_argument("--dtype", default=None)
     ap.add_argument("--scale", type=float, default=1.0, help="visibility scale (<1: smaller N, for quick checks)")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="N > 1: 'strong' shards the ONE rig of the config over the ranks (default), 'weak' gives every rank its own rig")
     ap.add_argument("--collective", default="none", choices=["none", "allgather"],
                     help="'allgather' puts the RCCL all-gather of residual+Jacobian blocks inside the timed step")
     ap.add_argument("--variant", type=int, default=None)
@@ -169,13 +235,13 @@ def main():
     import torch
     import torch.distributed as dist
 
-    from pycamset_amd import synthetic
     from pycamset_amd.engine import Engine
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
     # PCS_BENCH_BACKEND=gloo lets the N > 1 code path be rehearsed on a one-GPU box (ranks share the card)
     backend = os.environ.get("PCS_BENCH_BACKEND", "nccl")
+    via_host = backend != "nccl"
     local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -187,12 +253,12 @@ def main():
 
     chain = args.chain or CONFIG_CHAIN[args.config]
     dtype = args.dtype or CONFIG_DTYPE[args.config]
-    rig = synthetic.config_rig(args.config, scale=args.scale, block=rank)
-    N = rig.n_det
-    ps = np.concatenate([np.asarray(a, dtype=np.float64).ravel() for a in chain_slabs(rig, chain)])
+    prob = rank_problem(args.config, chain, rank, world, args.scaling, args.scale)
+    rig, det, ps = prob["rig"], prob["det"], prob["param_str"]
+    N = det.shape[0]            # rows this rank evaluates (incl. cyclic padding of the last shard)
 
     eng = Engine(chain, rig.n_cams, rig.n_imgs, rig.n_keys, dtype=dtype, device=local_rank)
-    eng.set_detections_table(rig.detections)
+    eng.set_detections_table(det)
     if chain == "template":
         eng.set_template(rig.points)
     if args.variant is not None:
@@ -206,25 +272,31 @@ def main():
     d_p = torch.from_numpy(ps).to(dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
 
-    gather = None
-    if world > 1 and backend != "nccl" and args.collective == "none":
-        args.no_allgather_probe = True  # gloo rehearsal: no device all-gather
-    if world > 1 and (args.collective == "allgather" or not args.no_allgather_probe):
-        counts = torch.tensor([N], device=dev)
-        dist.all_reduce(counts, op=dist.ReduceOp.MAX)
-        per = int(counts.item())
-        pad_r = torch.zeros((per, 2), dtype=tdt, device=dev)
-        pad_j = torch.zeros((2 * per, P), dtype=tdt, device=dev)
-        g_r = torch.empty((world * per, 2), dtype=tdt, device=dev)
-        g_j = torch.empty((world * 2 * per, P), dtype=tdt, device=dev)
+    def reduce_scalar(x: float, op):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=op)
+        return float(t.item())
+
+    # equal block sizes for the all-gather (strong: already equal; weak: pad to the largest rank)
+    per = int(reduce_scalar(float(N), dist.ReduceOp.MAX)) if world > 1 else N
+    n_total = prob["n_total"] if prob["n_total"] is not None else int(reduce_scalar(float(prob["n_real"]), dist.ReduceOp.SUM))
+    want_gather = world > 1 and (args.collective == "allgather" or not args.no_allgather_probe)
+    if want_gather:
+        send_r = d_r if per == N else torch.zeros((per, 2), dtype=tdt, device=dev)
+        send_j = d_j if per == N else torch.zeros((2 * per, P), dtype=tdt, device=dev)
+        g_r = torch.empty((world * per, 2), dtype=tdt, device="cpu" if via_host else dev)
+        g_j = torch.empty((world * 2 * per, P), dtype=tdt, device="cpu" if via_host else dev)
 
         def gather():
-            # equal counts per rank (pad like afb:281-288); outputs land in the padded send buffers
-            dist.all_gather_into_tensor(g_r, pad_r)
-            dist.all_gather_into_tensor(g_j, pad_j)
+            if per != N:
+                send_r[:N].copy_(d_r)
+                send_j[: 2 * N].copy_(d_j)
+            gather_blocks(dist, send_r, g_r, via_host)
+            gather_blocks(dist, send_j, g_j, via_host)
 
     use_gather_in_step = args.collective == "allgather" and world > 1
-    out_r, out_j = (pad_r, pad_j) if use_gather_in_step else (d_r, d_j)
 
     host_ring = None
     if args.stream_to_host:
@@ -243,14 +315,14 @@ def main():
             b = step_no[0] & 1
             step_no[0] += 1
             torch.cuda.current_stream(dev).wait_event(ev_free[b])
-            eng.eval_device_resident(d_p.data_ptr(), out_r.data_ptr(), dev_bufs[b].data_ptr(), stream)
+            eng.eval_device_resident(d_p.data_ptr(), d_r.data_ptr(), dev_bufs[b].data_ptr(), stream)
             ev_done[b].record(torch.cuda.current_stream(dev))
             with torch.cuda.stream(copy_stream):
                 copy_stream.wait_event(ev_done[b])
                 host_ring[b].copy_(dev_bufs[b], non_blocking=True)
                 ev_free[b].record(copy_stream)
             return
-        eng.eval_device_resident(d_p.data_ptr(), out_r.data_ptr(), out_j.data_ptr(), stream)
+        eng.eval_device_resident(d_p.data_ptr(), d_r.data_ptr(), d_j.data_ptr(), stream)
         if use_gather_in_step:
             gather()
 
@@ -259,56 +331,60 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    def timed(fn, reps):
+        """max-over-ranks seconds per call of `fn`, bracketed by barrier + synchronize on both sides"""
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        return reduce_scalar(time.perf_counter() - t0, dist.ReduceOp.MAX) / reps
+
+    # ---- the timed region: K steps, no HIP events attached to the launches ---------------------------------------
+    eng.set_option("timing_every", 0)
     for _ in range(args.warmup):
         step()
-    # HIP start/stop events on every 10th launch of the timed region (a timed launch costs ~12 us of
-    # extra dispatch gaps, profiles/r01/step_overhead.log; untimed ones run back to back)
-    every = max(1, min(10, args.steps))
-    eng.set_option("timing_every", every)
-    eng.set_option("event_ring", max(1, -(-args.steps // every)))
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    sec_per_step = timed(step, args.steps)
+    elapsed = sec_per_step * args.steps
+
+    # ---- kernel durations: >= 20 extra launches with start/stop events, outside the wall-clock region ------------
+    eng.set_option("timing_every", 1)
+    eng.set_option("event_ring", KERNEL_SAMPLES)
+    for _ in range(KERNEL_SAMPLES):
+        eng.eval_device_resident(d_p.data_ptr(), d_r.data_ptr(), d_j.data_ptr(), stream)
     torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    n_all = torch.tensor([float(N)], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(n_all, op=dist.ReduceOp.SUM)
-    elapsed = float(t.item())
-    n_total = float(n_all.item())
-    n_ev, prep_ms, eval_ms = eng.kernel_ms_mean()
+    prep_s, eval_s = eng.kernel_ms_samples(KERNEL_SAMPLES)
+    eng.set_option("timing_every", 0)
+    eval_ms, prep_ms = float(np.mean(eval_s)), float(np.mean(prep_s))
 
-    allgather_info = None
-    if gather is not None and not use_gather_in_step:
-        try:  # a probe, after the timed region: its failure must not cost the bench line
-            pad_r[:N].copy_(d_r)
-            pad_j[: 2 * N].copy_(d_j)
-            for _ in range(3):
+    # ---- multi-GPU extras, outside the timed region --------------------------------------------------------------
+    multi = None
+    if world > 1:
+        multi = {"kernel_only_step_ms": sec_per_step * 1e3, "shard_rows_per_gpu": N, "collective_backend": backend}
+    if want_gather and not use_gather_in_step:
+        try:  # a probe: its failure must not cost the bench line
+            def step_gather():
+                eng.eval_device_resident(d_p.data_ptr(), d_r.data_ptr(), d_j.data_ptr(), stream)
                 gather()
-            fence()
-            reps = 10
-            g0 = time.perf_counter()
-            for _ in range(reps):
-                gather()
-            torch.cuda.synchronize(dev)
-            dist.barrier()
-            gt = torch.tensor([(time.perf_counter() - g0) / reps], dtype=torch.float64, device=dev)
-            dist.all_reduce(gt, op=dist.ReduceOp.MAX)
-            sent = (pad_r.numel() + pad_j.numel()) * pad_r.element_size()
-            allgather_info = {"ms": float(gt.item()) * 1e3, "bytes_sent_per_gpu": sent,
-                              "bytes_received_per_gpu": sent * (world - 1),
-                              "recv_GBps_per_gpu": sent * (world - 1) / float(gt.item()) / 1e9,
-                              "note": "RCCL all_gather_into_tensor of residual+Jacobian blocks, timed outside the step"}
+
+            for _ in range(2):
+                step_gather()
+            reps = max(3, min(10, args.steps))
+            t_sg = timed(step_gather, reps)
+            t_g = timed(gather, reps)
+            sent = (2 * per + 2 * per * P) * d_r.element_size()
+            multi["step_plus_allgather_ms"] = t_sg * 1e3
+            multi["allgather"] = {"ms": t_g * 1e3, "bytes_sent_per_gpu": sent, "bytes_received_per_gpu": sent * (world - 1),
+                                  "recv_GBps_per_gpu": sent * (world - 1) / t_g / 1e9,
+                                  "note": ("gloo rehearsal: staged through the host" if via_host else
+                                           "RCCL all_gather_into_tensor of residual + Jacobian blocks (equal counts, afb:281-288 padding)")}
         except Exception as exc:  # noqa: BLE001
-            allgather_info = {"error": f"{type(exc).__name__}: {exc}"}
+            multi["allgather"] = {"error": f"{type(exc).__name__}: {exc}"}
 
-    # SURVEY 8 f2 probe (outside the timed region): what a solver needs instead of the gathered J — the
-    # block-reduced normal equations per rank and ONE all-reduce of the packed [J^T J, J^T r, cost]
+    # SURVEY 8 f2: what a solver needs instead of the gathered J — the block-reduced normal equations per rank and
+    # ONE all-reduce of the packed [J^T J, J^T r, cost]
     normal_info = None
     if not args.no_normal_probe and eng.n_params <= 8192:
         try:
@@ -316,37 +392,48 @@ def main():
             packed = torch.empty(npar * npar + npar + 1, dtype=torch.float64, device=dev)
             pH, pg, pc = packed.data_ptr(), packed.data_ptr() + 8 * npar * npar, packed.data_ptr() + 8 * (npar * npar + npar)
             eng.set_option("timing_every", 1)
+            eng.set_option("event_ring", 8)
             for _ in range(2):
                 eng.normal_equations_device(ps, pH, pg, pc, stream)
-            fence()
-            reps, k_ms = 5, []
-            b0 = time.perf_counter()
-            for _ in range(reps):
+            torch.cuda.synchronize(dev)
+            k_ms = []
+            for _ in range(5):
                 eng.normal_equations_device(ps, pH, pg, pc, stream)
                 torch.cuda.synchronize(dev)
                 k_ms.append(eng.last_kernel_ms()[1])
-            build_ms = (time.perf_counter() - b0) / reps * 1e3
-            normal_info = {"n_params": npar, "kernel_ms": float(np.median(k_ms)), "build_call_ms": build_ms,
+            eng.set_option("timing_every", 0)
+
+            def build():
+                eng.normal_equations_device(ps, pH, pg, pc, stream)
+
+            def build_reduce():
+                build()
+                if via_host:
+                    t = packed.cpu()
+                    dist.all_reduce(t)
+                    packed.copy_(t)
+                else:
+                    dist.all_reduce(packed)
+
+            normal_info = {"n_params": npar, "kernel_ms": float(np.median(k_ms)), "build_call_ms": timed(build, 5) * 1e3,
                            "bytes": packed.numel() * 8,
                            "note": "ba_normal_kernel (+ point passes for the self / free chains): H = J^T J (upper triangle), g, cost; J never written"}
             if world > 1:
                 for _ in range(2):
-                    dist.all_reduce(packed)
-                fence()
-                a0 = time.perf_counter()
-                for _ in range(reps):
-                    dist.all_reduce(packed)
-                torch.cuda.synchronize(dev)
-                at = torch.tensor([(time.perf_counter() - a0) / reps], dtype=torch.float64, device=dev)
-                dist.all_reduce(at, op=dist.ReduceOp.MAX)
-                normal_info["allreduce_ms"] = float(at.item()) * 1e3
+                    build_reduce()
+                multi["step_plus_normal_allreduce_ms"] = timed(build_reduce, 5) * 1e3
         except Exception as exc:  # noqa: BLE001
             normal_info = {"error": f"{type(exc).__name__}: {exc}"}
 
     if rank == 0:
         bpd = BYTES_PER_DET[(chain, dtype)]
         achieved = N * bpd / (eval_ms * 1e-3) / 1e9
-        key = f"{rig.name.split('/')[0]}/{chain}/{dtype}"
+        name = rig.name.split("/")[0]
+        traffic, traffic_source = pmc_traffic(f"{name}/{chain}/{dtype}") if (world == 1 and args.scale == 1.0) else (None, None)
+        in_bytes = 20 if dtype == "f32" else 28
+        shard_txt = (f"{n_total} detections" if world == 1 else
+                     f"{n_total} detections sharded into contiguous blocks of {per} per GPU" if args.scaling == "strong" else
+                     f"{n_total} detections = one independent rig of {N} per GPU")
         line = {
             "metric": "residual+Jacobian rows/sec",
             "value": 2.0 * n_total * args.steps / elapsed,
@@ -356,13 +443,14 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": dtype,
             "data": "synthetic",
             "config": {
-                "workload": f"{rig.name.split('/')[0]} (BASELINE config {args.config}): {rig.n_cams} cams x {rig.n_imgs} poses x "
-                            f"{rig.n_keys} keys, {N} detections per GPU, chain {chain}, slab_prep + fused residual/Jacobian kernel per step",
+                "workload": f"{name} (BASELINE config {args.config}): {rig.n_cams} cams x {rig.n_imgs} poses x {rig.n_keys} keys, "
+                            f"{shard_txt}, chain {chain}, slab_prep + fused residual/Jacobian kernel per step",
+                "detections_total": n_total,
                 "detections_per_gpu": N,
                 "rows_per_step": 2.0 * n_total,
                 "row_len_P": P,
@@ -376,18 +464,22 @@ def main():
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": pmc_traffic(key),
+                "traffic": traffic,
+                "traffic_source": traffic_source,
                 "kernel": "ba_eval_kernel",
                 "kernel_ms": eval_ms,
+                "kernel_ms_median": float(np.median(eval_s)),
+                "kernel_ms_min": float(np.min(eval_s)),
                 "slab_prep_ms": prep_ms,
-                "launches_timed": n_ev,
-                "timed_every": every,
+                "launches_timed": int(eval_s.shape[0]),
+                "timing": "HIP start/stop events of hipExtLaunchKernelGGL on the launch stream, on extra launches after the wall-clock region",
+                "units_per_launch": N,
                 "algorithmic_bytes_per_detection": bpd,
                 "frac_of_measured_copy_peak_6290": achieved / 6290.0,
                 # written bytes only, against a bare non-temporal fill of the same chunk shape on the same part
                 # (pcs_membench kind 4: 5.5-5.6 TB/s, profiles/r01/sweeps.md) — the write stream is the bound
-                "written_GBps": N * (bpd - (20 if dtype == "f32" else 28)) / (eval_ms * 1e-3) / 1e9,
-                "frac_of_measured_nt_fill_5600": N * (bpd - (20 if dtype == "f32" else 28)) / (eval_ms * 1e-3) / 1e9 / 5600.0,
+                "written_GBps": N * (bpd - in_bytes) / (eval_ms * 1e-3) / 1e9,
+                "frac_of_measured_nt_fill_5600": N * (bpd - in_bytes) / (eval_ms * 1e-3) / 1e9 / 5600.0,
             },
         }
         if args.stream_to_host:
@@ -395,8 +487,8 @@ def main():
             line["host_stream"] = {"bytes_per_step_per_gpu": jb, "d2h_GBps_per_gpu": jb * args.steps / elapsed / 1e9,
                                    "note": "PCIe-bound: the Jacobian of every step is copied to page-locked host memory "
                                            "(double buffered, overlapped with the next kernel)"}
-        if allgather_info:
-            line["allgather"] = allgather_info
+        if multi:
+            line["multi_gpu"] = multi
         if normal_info:
             line["normal_equations"] = normal_info
         if args.host_path:

@@ -181,6 +181,10 @@ int pcs_last_kernel_ms(pcs_engine *h, float *slab_prep_ms, float *eval_ms);
  * the last R evaluations; the ring is reset when the option is set).  Used by bench.py for the
  * roofline figure: live HIP-event timing of every launch of the timed region. */
 int pcs_kernel_ms_mean(pcs_engine *h, int64_t *count, float *slab_prep_ms, float *eval_ms);
+/* The individual durations behind pcs_kernel_ms_mean, oldest first: up to `capacity` (slab_prep, eval) pairs are
+ * written, *count = how many.  bench.py takes its median / min / mean from these (the reference's analogue is
+ * the sample list of general_utils.benchmark(), utils/general_utils.py:62-104). */
+int pcs_kernel_ms_samples(pcs_engine *h, int64_t capacity, float *slab_prep_ms, float *eval_ms, int64_t *count);
 /* Tuning knobs ("variant", "wgs_per_cu", "tiles_per_wg", "event_ring", "timing_every",
  * "compact_variant", "matfree_lds", "rowsplit", "xcd_remap"; "normal_point_pass" = 0 selects the per-detection
  * atomics for the point columns of pcs_normal_equations instead of the key-sorted passes; "normal_debug" is a profiling switch of

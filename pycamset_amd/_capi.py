@@ -49,6 +49,7 @@ SYMBOLS = {
     "pcs_synchronize": (c_int, [_P, _P]),
     "pcs_last_kernel_ms": (c_int, [_P, POINTER(c_float), POINTER(c_float)]),
     "pcs_kernel_ms_mean": (c_int, [_P, POINTER(c_int64), POINTER(c_float), POINTER(c_float)]),
+    "pcs_kernel_ms_samples": (c_int, [_P, c_int64, POINTER(c_float), POINTER(c_float), POINTER(c_int64)]),
     "pcs_triangulate": (c_int, [c_int, c_int64, POINTER(c_int32), POINTER(c_double), c_int64, POINTER(c_int64), c_int64,
                                 POINTER(c_double), POINTER(c_double), POINTER(c_double), POINTER(c_double), POINTER(c_float)]),
     "pcs_host_alloc": (c_int, [POINTER(_P), c_int64]),

@@ -1238,4 +1238,19 @@ int pcs_kernel_ms_mean(pcs_engine *h, int64_t *count, float *slab_prep_ms, float
     return PCS_OK;
 }
 
+int pcs_kernel_ms_samples(pcs_engine *h, int64_t capacity, float *slab_prep_ms, float *eval_ms, int64_t *count) {
+    if (!h || capacity < 0 || !count || (capacity > 0 && (!slab_prep_ms || !eval_ms))) return fail(PCS_ERR_ARG, "pcs_kernel_ms_samples: bad arguments");
+    if (!h->events_valid) return fail(PCS_ERR_STATE, "no evaluation has been queued yet");
+    const int64_t have = std::min<int64_t>(h->ev_count, h->ev_ring), n = std::min<int64_t>(have, capacity);
+    const int64_t first = h->ev_count - n;   // the n most recent evaluations, oldest first
+    for (int64_t i = 0; i < n; ++i) {
+        hipEvent_t *ev = h->ev.data() + 3 * ((first + i) % h->ev_ring);
+        HIPCHK(hipEventSynchronize(ev[2]));
+        HIPCHK(hipEventElapsedTime(slab_prep_ms + i, ev[0], ev[1]));
+        HIPCHK(hipEventElapsedTime(eval_ms + i, ev[1], ev[2]));
+    }
+    *count = n;
+    return PCS_OK;
+}
+
 }  // extern "C"

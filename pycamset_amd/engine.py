@@ -274,6 +274,14 @@ class Engine:
         check(lib().pcs_kernel_ms_mean(self._h, byref(n), byref(a), byref(b)))
         return int(n.value), float(a.value), float(b.value)
 
+    def kernel_ms_samples(self, capacity: int = 4096) -> tuple[np.ndarray, np.ndarray]:
+        """(slab_prep ms, eval ms) of each evaluation kept in the event ring, oldest first."""
+        a, b = np.empty(capacity, dtype=np.float32), np.empty(capacity, dtype=np.float32)
+        n = c_int64()
+        fp = POINTER(c_float)
+        check(lib().pcs_kernel_ms_samples(self._h, capacity, a.ctypes.data_as(fp), b.ctypes.data_as(fp), byref(n)))
+        return a[: n.value].astype(np.float64), b[: n.value].astype(np.float64)
+
     def device_buffers(self) -> tuple[int, int]:
         r, j = c_void_p(), c_void_p()
         check(lib().pcs_device_buffers(self._h, byref(r), byref(j)))

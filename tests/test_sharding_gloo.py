@@ -58,6 +58,45 @@ def test_sharded_allgather_matches_single_process(tmp_path, world):
     assert all((tmp_path / f"ok{r}").exists() for r in range(world))
 
 
+def _worker_bench_path(rank, world, port, out_dir):
+    """bench.py's own strong-scaling code path (rank_problem -> per-rank evaluation -> gather_blocks -> strip_padding)
+    with the CPU oracle standing in for the kernel: the gathered blocks equal the single-process output."""
+    sys.path.insert(0, str(REPO))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import bench
+        from oracle import ba_oracle as orc
+
+        prob = bench.rank_problem(1, "template", rank, world, "strong", scale=0.5)     # ccube-plumbing, N ~ 3.5e3
+        rig, shard, ps = prob["rig"], prob["det"], prob["param_str"]
+        n_total, per = prob["n_total"], prob["per"]
+        assert n_total == rig.n_det and shard.shape[0] == per == -(-n_total // world)
+        assert prob["n_real"] == max(0, min(n_total, (rank + 1) * per) - rank * per)
+        counts = (rig.n_cams, rig.n_imgs, rig.n_keys)
+        j, r = orc.full_jac_dense("template", shard, ps, prob["template"], with_resid=True, counts=counts)
+        g_r = bench.strip_padding(bench.gather_blocks(dist, torch.from_numpy(r)), n_total)
+        g_j = bench.strip_padding(bench.gather_blocks(dist, torch.from_numpy(j)), n_total, rows_per_det=2)
+        g_r2 = bench.strip_padding(bench.gather_blocks(dist, torch.from_numpy(r), via_host=True), n_total)
+        ref_j, ref_r = orc.full_jac_dense("template", rig.detections, ps, rig.points, with_resid=True, counts=counts)
+        assert np.array_equal(g_r.numpy(), ref_r) and np.array_equal(g_j.numpy(), ref_j) and np.array_equal(g_r2.numpy(), ref_r)
+        # every rank holds the SAME parameter string and the rows of all ranks add up to the table
+        t = torch.tensor([float(prob["n_real"]), float(np.sum(ps))], dtype=torch.float64)
+        dist.all_reduce(t)
+        assert int(t[0]) == n_total and abs(float(t[1]) - world * float(np.sum(ps))) <= 1e-9 * abs(float(t[1]))
+        w = bench.rank_problem(1, "template", rank, world, "weak", scale=0.5)
+        assert w["n_total"] is None and w["det"].shape[0] == w["n_real"] and (rank == 0 or not np.array_equal(w["det"][:50], rig.detections[:50]))
+        Path(out_dir, f"ok{rank}").write_text("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_bench_strong_scaling_path_gathers_the_single_process_output(tmp_path, world):
+    mp.spawn(_worker_bench_path, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(world))
+
+
 def test_padded_shard_rule():
     from pycamset_amd import sharding
 
