@@ -44,9 +44,14 @@ typedef enum {
     PCS_CHAIN_FREE = 2      /* projection + extrinsic3D + free_point                fph:143  P = 18 */
 } pcs_chain;
 
-/* PCS_MIXED: FP64 arithmetic on FP64 slabs and measurements, residual / Jacobian written as FP32 — the bytes of
- * PCS_F32 with the accuracy of one final rounding (the all-float engine loses ~5e-3 relative to cancellation in
- * the chain rule).  Device outputs of the *_device entry points are float for PCS_F32 and PCS_MIXED. */
+/* Arithmetic and parameter slabs are FP64 for every dtype (the reference's precision, fbi:11); the dtype selects the
+ * BYTES of the streams:  PCS_F64   measurements double, residual / Jacobian double   (380 B per detection, chain T)
+ *                        PCS_F32   measurements float,  residual / Jacobian float    (196 B) — BASELINE config 5
+ *                        PCS_MIXED measurements double, residual / Jacobian float    (204 B)
+ * A float output is the FP64 result rounded once at the store (<= 1.2e-7 relative); PCS_F32 additionally rounds the
+ * measured (u, v) to float on upload (<= 6e-5 px at ~1e3 px).  Round 1's all-float arithmetic (5e-3 relative error
+ * from cancellation in the chain rule) is gone.  Device outputs of the *_device entry points are float for PCS_F32
+ * and PCS_MIXED. */
 typedef enum { PCS_F64 = 0, PCS_F32 = 1, PCS_MIXED = 2 } pcs_dtype;
 
 /* Library / build identification. */
@@ -161,6 +166,13 @@ int pcs_matfree(pcs_engine *h, int op, const double *in, double *out, double *co
 int pcs_normal_equations(pcs_engine *h, const double *param_str, double *H, double *g, double *cost);
 int pcs_normal_equations_device(pcs_engine *h, const double *param_str, double *d_H, double *d_g, double *d_cost, void *stream);
 
+/* Which entry of H / g / cost every accumulator register of the normal-equations kernel stands for (host function, no
+ * GPU needed): out[m][lane][r][2], m < 2 MFMAs, lane < 64, r < 4 registers = the two local column ids (index into
+ * a J row, 30 = the residual column) of D_m[(lane >> 4) + 4 r][lane & 15], or -1, -1 where the register is not owned.
+ * pass 0 = shared (camera + pose + residual), 1 = (cam, key) point pass, 2 = (image, key) point pass.
+ * Diagnostic aid: tests/test_host_logic.py checks that every needed column pair is owned exactly once. */
+int pcs_normal_entry_map(int chain, int pass, int32_t *out);
+
 /*
  * Legacy residual-only cost.
  * Replaces: bundle_adjustment_costfn / numpy_bundle_adjustment_costfn (compiled_helpers.py:518-549),
@@ -186,21 +198,40 @@ int pcs_kernel_ms_mean(pcs_engine *h, int64_t *count, float *slab_prep_ms, float
  * the sample list of general_utils.benchmark(), utils/general_utils.py:62-104). */
 int pcs_kernel_ms_samples(pcs_engine *h, int64_t capacity, float *slab_prep_ms, float *eval_ms, int64_t *count);
 /* Tuning knobs ("variant", "wgs_per_cu", "tiles_per_wg", "event_ring", "timing_every",
- * "compact_variant", "matfree_lds", "rowsplit", "xcd_remap"; "normal_point_pass" = 0 selects the per-detection
- * atomics for the point columns of pcs_normal_equations instead of the key-sorted passes; "normal_debug" is a profiling switch of
- * pcs_normal_equations that skips parts of the kernel — results are wrong while it is non-zero); see DESIGN.md.
+ * "compact_variant", "matfree_lds", "xcd_remap", "waves_per_wg", "pack_indices", "normal_rows"; "normal_debug" is a
+ * profiling switch of pcs_normal_equations that skips the flush atomics — results are wrong while it is non-zero);
+ * see DESIGN.md.
  * Unknown keys -> PCS_ERR_ARG. */
 int pcs_set_option(pcs_engine *h, const char *key, int64_t value);
 /*
- * Batched n-view triangulation; stateless.
+ * Batched n-view triangulation.
  * Replaces: nb_triangulate_full (compiled_helpers.py:609-643) = per point nb_undistort (ch:409-431) +
  *           nb_triangulate_nviews (ch:645-663, smallest right singular vector of the 3n x (4+n) DLT
- *           matrix); front end CameraSet.multi_cam_triangulate (cameras/camera_set.py:343-402).
- *   cam (n_obs) int32, uv (n_obs,2): observations sorted by point; point j owns rows
- *   [start_inds[j], start_inds[j+1]) (start_inds has n_pts+1 entries, like the reference's).
- *   proj (n_cams,3,4), intrinsics (n_cams,3,3), dists (n_cams,5) = [k0,k1,p0,p1,k2].
- *   pts (n_pts,3) out; kernel_ms (optional) = duration of the kernel by HIP events.
+ *           matrix); front end CameraSet.multi_cam_triangulate (cameras/camera_set.py:343-402), which calls it once
+ *           per set of frames with the same cameras.
+ * A pcs_triangulator owns the camera table, device copies of the observations, the kernel's scratch and (optionally)
+ * the output, so repeated calls allocate nothing:
+ *   pcs_tri_set_cameras              proj (n_cams,3,4), intrinsics (n_cams,3,3), dists (n_cams,5) = [k0,k1,p0,p1,k2]
+ *   pcs_tri_set_observations         host arrays, copied: cam (n_obs) int32, uv (n_obs,2) sorted by point; point j owns
+ *                                    rows [start_inds[j], start_inds[j+1]) (n_pts+1 entries, like the reference's);
+ *                                    cameras are range-checked -> PCS_ERR_RANGE
+ *   pcs_tri_set_observations_device  the same arrays already in device memory (caller-owned, not copied, not checked)
+ *   pcs_tri_run                      queue the kernel on `stream` (NULL = the handle's own stream); d_pts = device
+ *                                    buffer (n_pts,3) of the caller, or NULL = handle-owned output
+ *   pcs_tri_points                   copy the handle-owned output to the host (blocking)
+ * pcs_triangulate is the stateless convenience form (temporary handle: allocations and copies on every call).
  */
+typedef struct pcs_triangulator pcs_triangulator;
+int pcs_tri_create(pcs_triangulator **out, int device, int64_t n_cams);
+int pcs_tri_destroy(pcs_triangulator *t);
+int pcs_tri_set_cameras(pcs_triangulator *t, const double *proj, const double *intrinsics, const double *dists);
+int pcs_tri_set_observations(pcs_triangulator *t, int64_t n_obs, const int32_t *cam, const double *uv, int64_t n_pts, const int64_t *start_inds);
+int pcs_tri_set_observations_device(pcs_triangulator *t, int64_t n_obs, const int32_t *d_cam, const double *d_uv, int64_t n_pts,
+                                    const int64_t *d_start_inds);
+int pcs_tri_run(pcs_triangulator *t, double *d_pts, void *stream);
+int pcs_tri_points(pcs_triangulator *t, double *pts);
+int pcs_tri_synchronize(pcs_triangulator *t, void *stream);
+int pcs_tri_last_kernel_ms(pcs_triangulator *t, float *kernel_ms);
 int pcs_triangulate(int device, int64_t n_obs, const int32_t *cam, const double *uv, int64_t n_pts, const int64_t *start_inds,
                     int64_t n_cams, const double *proj, const double *intrinsics, const double *dists, double *pts,
                     float *kernel_ms);

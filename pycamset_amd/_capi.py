@@ -50,8 +50,18 @@ SYMBOLS = {
     "pcs_last_kernel_ms": (c_int, [_P, POINTER(c_float), POINTER(c_float)]),
     "pcs_kernel_ms_mean": (c_int, [_P, POINTER(c_int64), POINTER(c_float), POINTER(c_float)]),
     "pcs_kernel_ms_samples": (c_int, [_P, c_int64, POINTER(c_float), POINTER(c_float), POINTER(c_int64)]),
+    "pcs_normal_entry_map": (c_int, [c_int, c_int, POINTER(c_int32)]),
     "pcs_triangulate": (c_int, [c_int, c_int64, POINTER(c_int32), POINTER(c_double), c_int64, POINTER(c_int64), c_int64,
                                 POINTER(c_double), POINTER(c_double), POINTER(c_double), POINTER(c_double), POINTER(c_float)]),
+    "pcs_tri_create": (c_int, [POINTER(_P), c_int, c_int64]),
+    "pcs_tri_destroy": (c_int, [_P]),
+    "pcs_tri_set_cameras": (c_int, [_P, POINTER(c_double), POINTER(c_double), POINTER(c_double)]),
+    "pcs_tri_set_observations": (c_int, [_P, c_int64, POINTER(c_int32), POINTER(c_double), c_int64, POINTER(c_int64)]),
+    "pcs_tri_set_observations_device": (c_int, [_P, c_int64, _P, _P, c_int64, _P]),
+    "pcs_tri_run": (c_int, [_P, _P, _P]),
+    "pcs_tri_points": (c_int, [_P, POINTER(c_double)]),
+    "pcs_tri_synchronize": (c_int, [_P, _P]),
+    "pcs_tri_last_kernel_ms": (c_int, [_P, POINTER(c_float)]),
     "pcs_host_alloc": (c_int, [POINTER(_P), c_int64]),
     "pcs_host_free": (c_int, [_P]),
     "pcs_membench": (c_int, [c_int, c_int, c_int64, c_int, c_int, POINTER(c_float)]),

@@ -12,6 +12,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstdint>
+
 namespace pcs {
 
 constexpr int CHAIN_TEMPLATE = 0;
@@ -28,6 +30,73 @@ constexpr int CAM_STRIDE = 48;
 constexpr int POSE_STRIDE = 40;
 constexpr int CAM_R = 9, CAM_T = 18, CAM_DR = 21;
 constexpr int POSE_R = 0, POSE_T = 9, POSE_DR = 12;
+
+// The static detection table as every kernel sees it (td:51-55 after return_flattened_keys).
+//   * indices: one packed 32-bit word per detection, cam | image | key bit fields (widths from the engine's counts),
+//     or — when the three fields need more than 32 bits — three int32 arrays.  12 -> 4 bytes per detection: at 1e7
+//     detections the whole table (4 + 16 B) then stays inside the 256 MiB Infinity Cache between LM steps; with
+//     28 B per detection it does not, and reads that go to HBM in the middle of the write stream cost the fused
+//     kernel a third of its rate (profiles/r02/sweeps.md, "input footprint").
+//   * measurements: (u, v) pairs as double (PCS_F64, PCS_MIXED) or float (PCS_F32); arithmetic is always double.
+// All branches on the table's form are wave-uniform.
+struct DetTable {
+    const uint32_t *packed;          // NULL -> use cam / img / key
+    const int32_t *cam, *img, *key;
+    const void *uv;
+    int32_t key_bits, img_bits;      // packed = cam << (img_bits + key_bits) | img << key_bits | key
+    int32_t uv_f32;
+};
+
+// raw index words of detection i (1 word when packed, 3 otherwise) and their decoding: split so that a kernel can
+// request the words of its NEXT tile early and decode them when it gets there
+struct DetWords { uint32_t w0, w1, w2; };
+__device__ __forceinline__ DetWords load_words(const DetTable &t, const int64_t i) {
+    DetWords r;
+    if (t.packed) { r.w0 = t.packed[i]; r.w1 = 0; r.w2 = 0; }
+    else { r.w0 = (uint32_t)t.cam[i]; r.w1 = (uint32_t)t.img[i]; r.w2 = (uint32_t)t.key[i]; }
+    return r;
+}
+__device__ __forceinline__ void decode_words(const DetTable &t, const DetWords &r, int &c, int &im, int &k) {
+    if (t.packed) {
+        k = (int)(r.w0 & ((1u << t.key_bits) - 1u));
+        im = (int)((r.w0 >> t.key_bits) & ((1u << t.img_bits) - 1u));
+        c = (int)(r.w0 >> (t.key_bits + t.img_bits));
+    } else {
+        c = (int)r.w0; im = (int)r.w1; k = (int)r.w2;
+    }
+}
+__device__ __forceinline__ void load_indices(const DetTable &t, const int64_t i, int &c, int &im, int &k) {
+    decode_words(t, load_words(t, i), c, im, k);
+}
+
+using double2v = __attribute__((ext_vector_type(2))) double;
+__device__ __forceinline__ double2v load_uv(const DetTable &t, const int64_t i) {
+    double2v m;
+    if (t.uv_f32) {
+        const __attribute__((ext_vector_type(2))) float f = static_cast<const __attribute__((ext_vector_type(2))) float *>(t.uv)[i];
+        m.x = (double)f.x; m.y = (double)f.y;
+    } else {
+        m = static_cast<const double2v *>(t.uv)[i];
+    }
+    return m;
+}
+
+// broadcast lane `src`'s value to the whole wave through scalar registers (v_readlane_b32)
+__device__ __forceinline__ double readlane_scalar(double v, int src) {
+    const uint64_t b = __builtin_bit_cast(uint64_t, v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, src);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), src);
+    return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+}
+
+// A parameter slab held ACROSS the lanes of a wave (lane j holds element j, fetched with one coalesced load) and
+// read element-wise through v_readlane into scalar registers.  Usable as the slab argument of eval_detection when
+// every lane of the wave refers to the same camera (pose): 1 load instruction instead of 48 (39) per-lane loads of
+// the same address, and no vector registers tied up by slab values.
+struct LaneSlab {
+    double v;
+    __device__ __forceinline__ double operator[](const int j) const { return readlane_scalar(v, j); }
+};
 
 // Rodrigues rotation and its derivative from a rotation vector, in double whatever the slab
 // dtype.  Same formulas and the same theta < 1e-10 branches as ch:205-234 and ch:244-286
@@ -199,92 +268,6 @@ __device__ __forceinline__ void eval_detection(SlabPtrC cs, SlabPtrP ps, const T
                     for (int c = 0; c < 3; ++c)
                         J[i * P + 21 + c] = S[i][0] * ps[POSE_R + 0 * 3 + c] + S[i][1] * ps[POSE_R + 1 * 3 + c] + S[i][2] * ps[POSE_R + 2 * 3 + c];
             }
-        }
-    }
-}
-
-// Row-split form: the same chain for ONE of the two rows (u when !second, v when second) of a
-// detection.  Two lanes share a detection, so a lane carries P instead of 2P Jacobian values (half
-// the registers -> more waves per SIMD).  Both lanes run the same instruction stream; the row only
-// enters through selects, never through a branch.  Values are identical to eval_detection's.
-template <int CHAIN, typename T, typename SlabPtrC, typename SlabPtrP>
-__device__ __forceinline__ void eval_detection_row(SlabPtrC cs, SlabPtrP ps, const T X0, const T X1, const T X2, const bool second,
-                                                   T &proj, T (&Jr)[chain_P(CHAIN)]) {
-    T Xw0, Xw1, Xw2;
-    T Qr[9];
-    if constexpr (CHAIN != CHAIN_FREE) {
-        Xw0 = ps[POSE_R + 0] * X0 + ps[POSE_R + 1] * X1 + ps[POSE_R + 2] * X2 + ps[POSE_T + 0];
-        Xw1 = ps[POSE_R + 3] * X0 + ps[POSE_R + 4] * X1 + ps[POSE_R + 5] * X2 + ps[POSE_T + 1];
-        Xw2 = ps[POSE_R + 6] * X0 + ps[POSE_R + 7] * X1 + ps[POSE_R + 8] * X2 + ps[POSE_T + 2];
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-            for (int c = 0; c < 3; ++c)
-                Qr[c * 3 + a] = ps[POSE_DR + a * 9 + c * 3 + 0] * X0 + ps[POSE_DR + a * 9 + c * 3 + 1] * X1 +
-                                ps[POSE_DR + a * 9 + c * 3 + 2] * X2;
-    } else {
-        Xw0 = X0; Xw1 = X1; Xw2 = X2;
-    }
-    const T e0 = cs[CAM_R + 0], e1 = cs[CAM_R + 1], e2 = cs[CAM_R + 2];
-    const T e3 = cs[CAM_R + 3], e4 = cs[CAM_R + 4], e5 = cs[CAM_R + 5];
-    const T e6 = cs[CAM_R + 6], e7 = cs[CAM_R + 7], e8 = cs[CAM_R + 8];
-    const T x = e0 * Xw0 + e1 * Xw1 + e2 * Xw2 + cs[CAM_T + 0];
-    const T y = e3 * Xw0 + e4 * Xw1 + e5 * Xw2 + cs[CAM_T + 1];
-    const T z = e6 * Xw0 + e7 * Xw1 + e8 * Xw2 + cs[CAM_T + 2];
-    const T fx = cs[0], px = cs[1], fy = cs[2], py = cs[3];
-    const T k0 = cs[4], k1 = cs[5], p0 = cs[6], p1 = cs[7], k2 = cs[8];
-    const T iz = T(1) / z;
-    const T a = x * iz, b = y * iz;
-    const T a2 = a * a, b2 = b * b, ab = a * b;
-    const T r2 = a2 + b2;
-    const T r4 = r2 * r2;
-    const T r6 = r4 * r2;
-    const T kup = T(1) + k0 * r2 + k1 * r4 + k2 * r6;
-    const T xD = a * kup + T(2) * p0 * ab + p1 * (r2 + T(2) * a2);
-    const T yD = b * kup + p0 * (r2 + T(2) * b2) + T(2) * p1 * ab;
-    const T u = xD * fx + px;
-    const T v = yD * fy + py;
-    proj = second ? v : u;
-    const T dk = k0 + T(2) * k1 * r2 + T(3) * k2 * r4;
-    const T ua = fx * (kup + T(2) * a2 * dk + T(2) * p0 * b + T(6) * p1 * a);
-    const T cross = T(2) * (ab * dk + p0 * a + p1 * b);
-    const T ub = fx * cross;
-    const T va = fy * cross;
-    const T vb = fy * (kup + T(2) * b2 * dk + T(6) * p0 * b + T(2) * p1 * a);
-    const T da = second ? va : ua;
-    const T db = second ? vb : ub;
-    const T Ax0 = da * iz, Ax1 = db * iz, Ax2 = -(a * da + b * db) * iz;
-    const T f = second ? fy : fx;
-    const T ar = second ? b : a;
-    Jr[0] = second ? T(0) : xD;
-    Jr[1] = second ? T(0) : T(1);
-    Jr[2] = second ? yD : T(0);
-    Jr[3] = second ? T(1) : T(0);
-    Jr[4] = f * ar * r2;
-    Jr[5] = f * ar * r4;
-    Jr[6] = second ? fy * (r2 + T(2) * b2) : T(2) * fx * ab;
-    Jr[7] = second ? T(2) * fy * ab : fx * (r2 + T(2) * a2);
-    Jr[8] = f * ar * r6;
-#pragma unroll
-    for (int aa = 0; aa < 3; ++aa) {
-        const T er0 = cs[CAM_DR + aa * 9 + 0] * Xw0 + cs[CAM_DR + aa * 9 + 1] * Xw1 + cs[CAM_DR + aa * 9 + 2] * Xw2;
-        const T er1 = cs[CAM_DR + aa * 9 + 3] * Xw0 + cs[CAM_DR + aa * 9 + 4] * Xw1 + cs[CAM_DR + aa * 9 + 5] * Xw2;
-        const T er2 = cs[CAM_DR + aa * 9 + 6] * Xw0 + cs[CAM_DR + aa * 9 + 7] * Xw1 + cs[CAM_DR + aa * 9 + 8] * Xw2;
-        Jr[9 + aa] = Ax0 * er0 + Ax1 * er1 + Ax2 * er2;
-    }
-    Jr[12] = Ax0; Jr[13] = Ax1; Jr[14] = Ax2;
-    const T S0 = Ax0 * e0 + Ax1 * e3 + Ax2 * e6;
-    const T S1 = Ax0 * e1 + Ax1 * e4 + Ax2 * e7;
-    const T S2 = Ax0 * e2 + Ax1 * e5 + Ax2 * e8;
-    if constexpr (CHAIN == CHAIN_FREE) {
-        Jr[15] = S0; Jr[16] = S1; Jr[17] = S2;
-    } else {
-#pragma unroll
-        for (int aa = 0; aa < 3; ++aa) Jr[15 + aa] = S0 * Qr[0 * 3 + aa] + S1 * Qr[1 * 3 + aa] + S2 * Qr[2 * 3 + aa];
-        Jr[18] = S0; Jr[19] = S1; Jr[20] = S2;
-        if constexpr (CHAIN == CHAIN_SELF) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) Jr[21 + c] = S0 * ps[POSE_R + 0 * 3 + c] + S1 * ps[POSE_R + 1 * 3 + c] + S2 * ps[POSE_R + 2 * 3 + c];
         }
     }
 }

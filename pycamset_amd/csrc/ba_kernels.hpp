@@ -1,16 +1,19 @@
 // ba_kernels.hpp — the HIP kernels of the bundle-adjustment engine (gfx950 / CDNA4 only).
 //
 //   slab_prep_kernel         K0: one thread per camera / pose -> R, t, dR/dr slabs (ba_device.hpp);
-//                            also narrows / copies the 3-D points of chains SELF / FREE.
+//                            also copies the 3-D points of chains SELF / FREE out of the parameter string.
 //   ba_eval_kernel           K1-K4: fused residual + dense 2xP Jacobian block per detection.  One lane
 //                            owns one detection of a 64-detection tile; slabs + points are read through
 //                            L1/L2 or staged in LDS; the Jacobian tile is transposed through LDS so that
 //                            every store instruction writes 1 KiB of consecutive addresses.
-//   ba_eval_rowsplit_kernel  two lanes per detection (A/B variant).
 //   ba_compact_kernel / ba_compact_tile_kernel
 //                            same maths, only unfixed columns, in CSR data order.
 //   legacy_cost_kernel       pre-bundle residual-only cost.
 //   membench_kernel          streaming probes for the roofline comparison.
+// Arithmetic and slabs are FP64 in every kernel (the reference's precision, fbi:11); what varies is the type the
+// residual / Jacobian are WRITTEN in (TO: double, or float for PCS_F32 / PCS_MIXED) and the type the measurements
+// are READ in (DetTable::uv_f32).  An all-float arithmetic path existed in round 1 and was removed: the chain rule
+// cancels, and single-precision sums left 5e-3 relative error in Jacobian entries.
 // The launch plumbing and the C ABI are in pcs_engine.hip.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -25,12 +28,7 @@ namespace pcs {
 // small helpers
 // ---------------------------------------------------------------------------------------------
 // clang ext vectors (the nontemporal builtins reject HIP's double2 / float2 structs)
-template <typename T> struct Vec2 { using type = __attribute__((ext_vector_type(2))) T; };
-
-// widest naturally aligned chunk the Jacobian row of one detection allows
-//   double: row = 2P*8 B, always a multiple of 16 -> 16-byte chunks (2 scalars)
-//   float : row = 2P*4 B, multiple of 8 only (P = 21)   ->  8-byte chunks (2 scalars)
-template <typename T> using Chunk = typename Vec2<T>::type;
+template <typename S> struct Vec2 { using type = __attribute__((ext_vector_type(2))) S; };
 
 constexpr int MODE_RESID = 1;
 constexpr int MODE_JAC = 2;
@@ -39,10 +37,12 @@ constexpr int VAR_SLAB_LDS = 1;   // stage slabs + points in LDS
 constexpr int VAR_TRANSPOSE = 2;  // transpose the Jacobian tile through LDS, coalesced stores
 constexpr int VAR_NT = 4;         // non-temporal output stores
 
-constexpr int WG_THREADS = 256;
+constexpr int WG_THREADS = 256;   // largest workgroup; small tables are launched with fewer waves per workgroup
 constexpr int WAVES_PER_WG = WG_THREADS / 64;
 constexpr int TILE = 64;       // detections per wave tile
 constexpr int HALF = 32;       // detections per transpose pass
+
+using T = double;   // arithmetic and slab type of every kernel
 
 // Row stride (scalars) of the wave-private LDS image the fused kernel transposes through.  Each lane
 // writes its own 2P-scalar row with 16-byte (f64) / 8-byte (f32) stores, so the stride decides the bank
@@ -55,8 +55,7 @@ constexpr int lds_row_stride(int p2, int esize) {
 }
 
 struct EvalArgs {
-    const int32_t *cam, *img, *key;
-    const void *uv;         // N x 2 scalars
+    DetTable tab;           // indices + measurements (ba_device.hpp)
     const void *cam_slab;   // n_cams x CAM_STRIDE
     const void *pose_slab;  // n_imgs x POSE_STRIDE
     const void *points;     // n_keys x 3 (padded)
@@ -67,33 +66,16 @@ struct EvalArgs {
     int32_t tiles_per_wg;
     int32_t xcd_remap;      // 1: workgroups that share an XCD (blockIdx % 8) take one contiguous eighth of the tiles
     int64_t n_tiles;
-    // compaction (ba_compact_kernel only)
     void *sink;              // 64 B scratch: tail lanes store their (unused) residual here, so the store needs no branch
+    // compaction (ba_compact_* only)
     const uint32_t *keep;    // per detection: bit j set = local column j is free
     const int64_t *row_off;  // per detection: offset of its u row in the CSR data array
 };
-
-// broadcast lane `src`'s value to the whole wave through scalar registers (v_readlane_b32)
-__device__ __forceinline__ float readlane_scalar(float v, int src) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
-}
-__device__ __forceinline__ double readlane_scalar(double v, int src) {
-    const uint64_t b = __builtin_bit_cast(uint64_t, v);
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, src);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), src);
-    return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
-}
-
-template <typename T, bool NT>
-__device__ __forceinline__ void store_out(T *p, T v) {
-    if constexpr (NT) __builtin_nontemporal_store(v, p); else *p = v;
-}
 
 // ---------------------------------------------------------------------------------------------
 // K0  slab preparation
 // ---------------------------------------------------------------------------------------------
 // param_str layout: afb make_param_struct (abstract_function_blocks.py:777-820), see pcs_hip.h.
-template <typename T>
 __global__ void slab_prep_kernel(const double *__restrict__ prm, T *__restrict__ cam_slab, T *__restrict__ pose_slab,
                                  T *__restrict__ points, int n_cams, int n_imgs, int n_keys, int64_t extr_off,
                                  int64_t pose_off, int64_t point_off, int has_pose, int copy_points) {
@@ -106,36 +88,37 @@ __global__ void slab_prep_kernel(const double *__restrict__ prm, T *__restrict__
         if (is_cam) {
             T *o = cam_slab + (int64_t)e * CAM_STRIDE;
 #pragma unroll
-            for (int j = 0; j < 9; ++j) o[j] = (T)prm[9 * (int64_t)e + j];
+            for (int j = 0; j < 9; ++j) o[j] = prm[9 * (int64_t)e + j];
 #pragma unroll
-            for (int j = 0; j < 9; ++j) o[CAM_R + j] = (T)R[j];
+            for (int j = 0; j < 9; ++j) o[CAM_R + j] = R[j];
 #pragma unroll
-            for (int j = 0; j < 3; ++j) o[CAM_T + j] = (T)p6[3 + j];
+            for (int j = 0; j < 3; ++j) o[CAM_T + j] = p6[3 + j];
 #pragma unroll
-            for (int j = 0; j < 27; ++j) o[CAM_DR + j] = (T)dR[j];
+            for (int j = 0; j < 27; ++j) o[CAM_DR + j] = dR[j];
         } else {
             T *o = pose_slab + (int64_t)(e - n_cams) * POSE_STRIDE;
 #pragma unroll
-            for (int j = 0; j < 9; ++j) o[POSE_R + j] = (T)R[j];
+            for (int j = 0; j < 9; ++j) o[POSE_R + j] = R[j];
 #pragma unroll
-            for (int j = 0; j < 3; ++j) o[POSE_T + j] = (T)p6[3 + j];
+            for (int j = 0; j < 3; ++j) o[POSE_T + j] = p6[3 + j];
 #pragma unroll
-            for (int j = 0; j < 27; ++j) o[POSE_DR + j] = (T)dR[j];
+            for (int j = 0; j < 27; ++j) o[POSE_DR + j] = dR[j];
             o[39] = T(0);
         }
     }
     if (copy_points) {
         const int total = n_keys * 3;
-        for (int j = e; j < total; j += gridDim.x * blockDim.x) points[j] = (T)prm[point_off + j];
+        for (int j = e; j < total; j += gridDim.x * blockDim.x) points[j] = prm[point_off + j];
     }
 }
 
 // ---------------------------------------------------------------------------------------------
 // K1-K4  fused residual + Jacobian
 // ---------------------------------------------------------------------------------------------
-// T = arithmetic / slab / measurement type, TO = type of the residual and Jacobian written out (TO = float with
-// T = double is the "mixed" engine: FP32 bytes, FP64 arithmetic).
-template <int CHAIN, typename T, int MODE, int VARIANT, typename TO = T>
+// TO = type of the residual and Jacobian written out.  The workgroup has blockDim.x / 64 waves (4 for large tables,
+// fewer for small ones so that the grid still covers every CU several times); wave w takes tiles w, w + waves, ...
+// of the workgroup's run of tiles.
+template <int CHAIN, int MODE, int VARIANT, typename TO>
 __global__ __launch_bounds__(WG_THREADS) void ba_eval_kernel(const EvalArgs a) {
     constexpr int P = chain_P(CHAIN);
     constexpr int P2 = 2 * P;
@@ -144,7 +127,6 @@ __global__ __launch_bounds__(WG_THREADS) void ba_eval_kernel(const EvalArgs a) {
     constexpr bool NT = (VARIANT & VAR_NT) != 0;
     constexpr bool JAC = (MODE & MODE_JAC) != 0;
     constexpr bool RES = (MODE & MODE_RESID) != 0;
-    using V2 = typename Vec2<T>::type;
     using O2 = typename Vec2<TO>::type;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -153,6 +135,7 @@ __global__ __launch_bounds__(WG_THREADS) void ba_eval_kernel(const EvalArgs a) {
     const T *cam_slab = static_cast<const T *>(a.cam_slab);
     const T *pose_slab = static_cast<const T *>(a.pose_slab);
     const T *points = static_cast<const T *>(a.points);
+    const int n_threads = blockDim.x;
     int lds_used = 0;  // scalars
     if constexpr (SLAB_LDS) {
         const int n_cam_sc = a.n_cams * CAM_STRIDE;
@@ -163,13 +146,13 @@ __global__ __launch_bounds__(WG_THREADS) void ba_eval_kernel(const EvalArgs a) {
         using V16 = __attribute__((ext_vector_type(VS))) T;
         const V16 *g0 = reinterpret_cast<const V16 *>(cam_slab);
         V16 *l0 = reinterpret_cast<V16 *>(smem);
-        for (int i = threadIdx.x; i < n_cam_sc / VS; i += WG_THREADS) l0[i] = g0[i];
+        for (int i = threadIdx.x; i < n_cam_sc / VS; i += n_threads) l0[i] = g0[i];
         const V16 *g1 = reinterpret_cast<const V16 *>(pose_slab);
         V16 *l1 = reinterpret_cast<V16 *>(smem + n_cam_sc);
-        for (int i = threadIdx.x; i < n_pose_sc / VS; i += WG_THREADS) l1[i] = g1[i];
+        for (int i = threadIdx.x; i < n_pose_sc / VS; i += n_threads) l1[i] = g1[i];
         const V16 *g2 = reinterpret_cast<const V16 *>(points);
         V16 *l2 = reinterpret_cast<V16 *>(smem + n_cam_sc + n_pose_sc);
-        for (int i = threadIdx.x; i < n_pt_sc / VS; i += WG_THREADS) l2[i] = g2[i];
+        for (int i = threadIdx.x; i < n_pt_sc / VS; i += n_threads) l2[i] = g2[i];
         cam_slab = smem;
         pose_slab = smem + n_cam_sc;
         points = smem + n_cam_sc + n_pose_sc;
@@ -177,6 +160,7 @@ __global__ __launch_bounds__(WG_THREADS) void ba_eval_kernel(const EvalArgs a) {
         __syncthreads();
     }
     const int wave = threadIdx.x >> 6;
+    const int n_waves = n_threads >> 6;
     const int lane = threadIdx.x & 63;
     constexpr int LROW = lds_row_stride(P2, (int)sizeof(TO));
     TO *tr = reinterpret_cast<TO *>(smem + lds_used) + wave * (HALF * LROW);  // wave-private transpose region (TRANSPOSE only)
@@ -191,17 +175,17 @@ __global__ __launch_bounds__(WG_THREADS) void ba_eval_kernel(const EvalArgs a) {
     }
     const int64_t tile0 = wg * a.tiles_per_wg;
     const int64_t tile1 = min(tile0 + (int64_t)a.tiles_per_wg, a.n_tiles);
-    const V2 *uv = static_cast<const V2 *>(a.uv);
     TO *resid = static_cast<TO *>(a.resid);
     TO *jac = static_cast<TO *>(a.jac);
     const int64_t total_jac = a.n * (int64_t)P2;
 
-    for (int64_t tile = tile0 + wave; tile < tile1; tile += WAVES_PER_WG) {
+    for (int64_t tile = tile0 + wave; tile < tile1; tile += n_waves) {
         const int64_t i = tile * TILE + lane;
         const bool valid = i < a.n;
         const int64_t ic = valid ? i : a.n - 1;  // tail lanes recompute the last detection, store nothing
-        const int c = a.cam[ic], im = a.img[ic], k = a.key[ic];
-        const V2 m = uv[ic];
+        int c, im, k;
+        load_indices(a.tab, ic, c, im, k);
+        const double2v m = load_uv(a.tab, ic);
         const T *cs = cam_slab + c * CAM_STRIDE;
         const T *ps = pose_slab + im * POSE_STRIDE;
         const T X0 = points[3 * k], X1 = points[3 * k + 1], X2 = points[3 * k + 2];
@@ -341,103 +325,32 @@ __global__ __launch_bounds__(WG_THREADS) void ba_eval_kernel(const EvalArgs a) {
     }
 }
 
-// Row-split variant of the fused kernel (option "rowsplit"): a wave tile is 32 detections and lanes
-// l / l+32 compute the u / v row of the same detection (eval_detection_row).  Half the Jacobian
-// registers per lane -> 3 waves per SIMD instead of 2, and the transposed store needs one LDS pass
-// instead of two.  Costs ~50 % more VALU work (the shared part of the chain is evaluated by both
-// lanes), which this HBM-bound kernel has to spare.  Slabs are read through L1/L2.
-template <int CHAIN, typename T, int MODE, bool NT>
-__global__ __launch_bounds__(WG_THREADS, 3) void ba_eval_rowsplit_kernel(const EvalArgs a) {
-    constexpr int P = chain_P(CHAIN);
-    constexpr int P2 = 2 * P;
-    constexpr bool RES = (MODE & MODE_RESID) != 0;
-    using V2 = typename Vec2<T>::type;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int wave = threadIdx.x >> 6;
-    const int lane = threadIdx.x & 63;
-    const int d = lane & 31;
-    const bool second = lane >= 32;
-    T *tr = reinterpret_cast<T *>(smem_raw) + wave * (HALF * P2);
-    const T *cam_slab = static_cast<const T *>(a.cam_slab);
-    const T *pose_slab = static_cast<const T *>(a.pose_slab);
-    const T *points = static_cast<const T *>(a.points);
-    const V2 *uv = static_cast<const V2 *>(a.uv);
-    T *resid = static_cast<T *>(a.resid);
-    T *jac = static_cast<T *>(a.jac);
-    const int64_t total_jac = a.n * (int64_t)P2;
-    const int64_t tile0 = (int64_t)blockIdx.x * a.tiles_per_wg;   // tiles of HALF = 32 detections here
-    const int64_t tile1 = min(tile0 + (int64_t)a.tiles_per_wg, a.n_tiles);
-    for (int64_t tile = tile0 + wave; tile < tile1; tile += WAVES_PER_WG) {
-        const int64_t i = tile * HALF + d;
-        const bool valid = i < a.n;
-        const int64_t ic = valid ? i : a.n - 1;
-        const int c = a.cam[ic], im = a.img[ic], k = a.key[ic];
-        const V2 m = uv[ic];
-        T proj;
-        T Jr[P];
-        eval_detection_row<CHAIN, T>(cam_slab + c * CAM_STRIDE, pose_slab + im * POSE_STRIDE, points[3 * k], points[3 * k + 1],
-                                     points[3 * k + 2], second, proj, Jr);
-        if constexpr (RES) {  // branch-free (see ba_eval_kernel)
-            T *rp = valid ? resid + 2 * i + (second ? 1 : 0) : static_cast<T *>(a.sink) + (second ? 1 : 0);
-            store_out<T, NT>(rp, proj - (second ? m.y : m.x));
-        }
-        T *dst = tr + d * P2 + (second ? P : 0);
-#pragma unroll
-        for (int j = 0; j < P; ++j) dst[j] = Jr[j];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        constexpr int VS = 16 / sizeof(T);
-        using V16 = __attribute__((ext_vector_type(VS))) T;
-        constexpr int UNITS = HALF * P2 / VS;
-        const int64_t base = tile * HALF * (int64_t)P2;
-#pragma unroll
-        for (int q0 = 0; q0 < UNITS; q0 += 64) {
-            const int q = q0 + lane;
-            if (q < UNITS) {
-                const int64_t e = base + (int64_t)q * VS;
-                if (e + VS <= total_jac) {
-                    const V16 w = reinterpret_cast<const V16 *>(tr)[q];
-                    if constexpr (NT) __builtin_nontemporal_store(w, reinterpret_cast<V16 *>(jac + e));
-                    else *reinterpret_cast<V16 *>(jac + e) = w;
-                } else {
-                    for (int s = 0; s < VS; ++s)
-                        if (e + s < total_jac) jac[e + s] = tr[q * VS + s];
-                }
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
-}
-
 // Fixed-parameter compaction (replaces `data[:n_elements][good_mask]`, afb:627-651): every lane
 // writes the kept entries of its two rows at the static CSR offsets.  Reads slabs through L1/L2.
-template <int CHAIN, typename T, int MODE>
+// First version, kept as compact_variant = 0 for A/B against the tile kernel (FP64 outputs only).
+template <int CHAIN, int MODE>
 __global__ __launch_bounds__(WG_THREADS) void ba_compact_kernel(const EvalArgs a) {
     constexpr int P = chain_P(CHAIN);
     constexpr int P2 = 2 * P;
-    using V2 = typename Vec2<T>::type;
     const T *cam_slab = static_cast<const T *>(a.cam_slab);
     const T *pose_slab = static_cast<const T *>(a.pose_slab);
     const T *points = static_cast<const T *>(a.points);
-    const V2 *uv = static_cast<const V2 *>(a.uv);
     T *resid = static_cast<T *>(a.resid);
     T *data = static_cast<T *>(a.jac);
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += stride) {
-        const int c = a.cam[i], im = a.img[i], k = a.key[i];
-        const V2 m = uv[i];
+        int c, im, k;
+        load_indices(a.tab, i, c, im, k);
+        const double2v m = load_uv(a.tab, i);
         T u, v;
         T J[P2];
         eval_detection<CHAIN, T, (MODE & MODE_JAC) != 0>(cam_slab + c * CAM_STRIDE, pose_slab + im * POSE_STRIDE, points[3 * k],
                                                           points[3 * k + 1], points[3 * k + 2], u, v, J);
         if constexpr ((MODE & MODE_RESID) != 0) {
-            V2 r;
+            double2v r;
             r.x = u - m.x;
             r.y = v - m.y;
-            reinterpret_cast<V2 *>(resid)[i] = r;
+            reinterpret_cast<double2v *>(resid)[i] = r;
         }
         if constexpr ((MODE & MODE_JAC) != 0) {
             const uint32_t keep = a.keep[i];
@@ -469,7 +382,7 @@ __global__ __launch_bounds__(WG_THREADS) void ba_compact_kernel(const EvalArgs a
 //  * Packing is branch-free: entry j goes to slot popcount(keep & ((1 << j) - 1)) of its row, or to a
 //    per-lane dummy slot when the column is fixed or the lane belongs to the other pass (conditional
 //    blocks around the 2P stores would keep the whole Jacobian live in registers, see ba_eval_kernel).
-template <int CHAIN, typename T, int MODE, typename TO = T>
+template <int CHAIN, int MODE, typename TO>
 __global__ __launch_bounds__(WG_THREADS) void ba_compact_tile_kernel(const EvalArgs a) {
     constexpr int P = chain_P(CHAIN);
     constexpr int P2 = 2 * P;
@@ -477,7 +390,6 @@ __global__ __launch_bounds__(WG_THREADS) void ba_compact_tile_kernel(const EvalA
     constexpr int VS = 16 / sizeof(TO);
     constexpr int LINE = 128 / sizeof(TO);           // scalars per 128-byte line
     constexpr int WAVE_LDS = HALF * P2 + LINE + 64;  // packed range + alignment shift + one dummy slot per lane
-    using V2 = typename Vec2<T>::type;
     using O2 = typename Vec2<TO>::type;
     using V16 = __attribute__((ext_vector_type(VS))) TO;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -488,7 +400,6 @@ __global__ __launch_bounds__(WG_THREADS) void ba_compact_tile_kernel(const EvalA
     const T *cam_slab = static_cast<const T *>(a.cam_slab);
     const T *pose_slab = static_cast<const T *>(a.pose_slab);
     const T *points = static_cast<const T *>(a.points);
-    const V2 *uv = static_cast<const V2 *>(a.uv);
     TO *resid = static_cast<TO *>(a.resid);
     TO *data = static_cast<TO *>(a.jac);
     const int64_t tile0 = (int64_t)blockIdx.x * a.tiles_per_wg;
@@ -497,8 +408,9 @@ __global__ __launch_bounds__(WG_THREADS) void ba_compact_tile_kernel(const EvalA
         const int64_t i = tile * TILE + lane;
         const bool valid = i < a.n;
         const int64_t ic = valid ? i : a.n - 1;
-        const int c = a.cam[ic], im = a.img[ic], k = a.key[ic];
-        const V2 m = uv[ic];
+        int c, im, k;
+        load_indices(a.tab, ic, c, im, k);
+        const double2v m = load_uv(a.tab, ic);
         T u, v;
         T J[P2];
         eval_detection<CHAIN, T, JAC>(cam_slab + c * CAM_STRIDE, pose_slab + im * POSE_STRIDE, points[3 * k], points[3 * k + 1],
@@ -560,20 +472,34 @@ __global__ __launch_bounds__(WG_THREADS) void ba_compact_tile_kernel(const EvalA
 // Legacy residual-only cost (compiled_helpers.py:518-549, used by the initial pose
 // selection template_handler.py:535-592): pre-multiplied 3x4 projection matrices and pre-transformed
 // points im_points[image, key].  cam_tab row (24 scalars): P row-major 12 | fx cx fy cy | k0 k1 p0 p1 k2 | pad.
+// 44 B of traffic per detection: as in the residual-only mode of ba_eval_kernel the per-lane loads of the camera
+// table set the pace, so a tile that shares its camera fetches the 21 scalars with ONE coalesced load and
+// v_readlane broadcasts them into scalar registers.
 constexpr int LEGACY_STRIDE = 24;
-template <typename T>
-__global__ __launch_bounds__(256) void legacy_cost_kernel(const int32_t *__restrict__ cam, const int32_t *__restrict__ img,
-                                                          const int32_t *__restrict__ key, const void *__restrict__ uv_,
-                                                          const T *__restrict__ im_points, const T *__restrict__ cam_tab,
-                                                          T *__restrict__ errors, int64_t n, int64_t n_keys) {
-    using V2 = typename Vec2<T>::type;
-    const V2 *uv = static_cast<const V2 *>(uv_);
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const T *ct = cam_tab + (int64_t)cam[i] * LEGACY_STRIDE;
-        const T *X = im_points + 3 * ((int64_t)img[i] * n_keys + key[i]);
+__global__ __launch_bounds__(256) void legacy_cost_kernel(const DetTable tab, const T *__restrict__ im_points, const T *__restrict__ cam_tab,
+                                                          T *__restrict__ errors, int64_t n, int64_t n_keys, void *sink) {
+    const int lane = threadIdx.x & 63;
+    const int64_t n_tiles = (n + 63) / 64;
+    const int64_t waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t tile = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; tile < n_tiles; tile += waves) {
+        const int64_t i = tile * 64 + lane;
+        const bool valid = i < n;
+        const int64_t ic = valid ? i : n - 1;
+        int c, im, k;
+        load_indices(tab, ic, c, im, k);
+        const T *X = im_points + 3 * ((int64_t)im * n_keys + k);
         const T X0 = X[0], X1 = X[1], X2 = X[2];
-        const V2 m = uv[i];
+        const double2v m = load_uv(tab, ic);
+        T ct[21];
+        const int c0 = __builtin_amdgcn_readfirstlane(c);
+        if (__all(c == c0)) {
+            const T val = lane < 21 ? cam_tab[(int64_t)c0 * LEGACY_STRIDE + lane] : T(0);
+#pragma unroll
+            for (int j = 0; j < 21; ++j) ct[j] = readlane_scalar(val, j);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 21; ++j) ct[j] = cam_tab[(int64_t)c * LEGACY_STRIDE + j];
+        }
         T p0 = ct[0] * X0 + ct[1] * X1 + ct[2] * X2 + ct[3];        // ch:538  P [X;1]
         T p1 = ct[4] * X0 + ct[5] * X1 + ct[6] * X2 + ct[7];
         const T p2 = ct[8] * X0 + ct[9] * X1 + ct[10] * X2 + ct[11];
@@ -586,10 +512,10 @@ __global__ __launch_bounds__(256) void legacy_cost_kernel(const int32_t *__restr
         const T kup = T(1) + k0 * r2 + k1 * (r2 * r2) + k2 * (r2 * r2 * r2);
         const T xD = x * kup + T(2) * q0 * x * y + q1 * (r2 + T(2) * x * x);
         const T yD = y * kup + q0 * (r2 + T(2) * y * y) + T(2) * q1 * x * y;
-        V2 e;
+        double2v e;
         e.x = (xD * fx + cx) - m.x;                                  // ch:541-542
         e.y = (yD * fy + cy) - m.y;
-        __builtin_nontemporal_store(e, reinterpret_cast<V2 *>(errors) + i);
+        __builtin_nontemporal_store(e, valid ? reinterpret_cast<double2v *>(errors) + i : static_cast<double2v *>(sink));
     }
 }
 

@@ -22,7 +22,7 @@
 // non-zero accumulators with one global f64 atomic each.  Going straight to global atomics costs
 // 480 us at N = 1e6 (488 tiles per camera all hit the same 15 addresses, which serialise at the memory
 // side); wave xor-shuffle sums + LDS accumulators 73-93 us; the LDS panel form is the current one.
-// Parameter strings too large for LDS (> 64 KiB) fall back to direct global atomics.
+// Parameter strings too large for LDS (> 150 KiB with the panels) fall back to direct global atomics.
 // Atomic order makes the last bits of the sums run-to-run dependent (documented; the tests compare
 // with a tolerance).
 #pragma once
@@ -43,8 +43,7 @@ constexpr int RED_STRIDE = 65;             // odd stride: the column sums read c
 constexpr int RED_PANEL = RED_COLS * RED_STRIDE;  // doubles per wave
 
 struct MatfreeArgs {
-    const int32_t *cam, *img, *key;
-    const void *uv;
+    DetTable tab;
     const void *cam_slab, *pose_slab, *points;
     const double *vin;   // OP_JV / OP_JTJV: n_params; OP_JTU: 2N
     double *vout;        // OP_JV: 2N; others: n_params (zeroed by the host before the launch)
@@ -81,8 +80,9 @@ __device__ __forceinline__ void accumulate_group(const double *g, const int key,
     }
 }
 
-template <int CHAIN, typename T, int OP, bool LDS_ACC>
+template <int CHAIN, int OP, bool LDS_ACC>
 __global__ __launch_bounds__(256) void ba_matfree_kernel(const MatfreeArgs a) {
+    using T = double;
     extern __shared__ __attribute__((aligned(16))) double lds_acc[];
     if constexpr (LDS_ACC && OP != OP_JV) {
         for (int j = threadIdx.x; j < a.n_params; j += 256) lds_acc[j] = 0.0;
@@ -90,14 +90,12 @@ __global__ __launch_bounds__(256) void ba_matfree_kernel(const MatfreeArgs a) {
     }
     constexpr int P = chain_P(CHAIN);
     constexpr int P2 = 2 * P;
-    using V2 = __attribute__((ext_vector_type(2))) T;
     using D2 = __attribute__((ext_vector_type(2))) double;
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
     const T *cam_slab = static_cast<const T *>(a.cam_slab);
     const T *pose_slab = static_cast<const T *>(a.pose_slab);
     const T *points = static_cast<const T *>(a.points);
-    const V2 *uv = static_cast<const V2 *>(a.uv);
     const int64_t tile0 = (int64_t)blockIdx.x * a.tiles_per_wg;
     const int64_t tile1 = min(tile0 + (int64_t)a.tiles_per_wg, a.n_tiles);
     double cost_acc = 0.0;
@@ -105,8 +103,9 @@ __global__ __launch_bounds__(256) void ba_matfree_kernel(const MatfreeArgs a) {
         const int64_t i = tile * 64 + lane;
         const bool valid = i < a.n;
         const int64_t ic = valid ? i : a.n - 1;
-        const int c = a.cam[ic], im = a.img[ic], k = a.key[ic];
-        const V2 m = uv[ic];
+        int c, im, k;
+        load_indices(a.tab, ic, c, im, k);
+        const double2v m = load_uv(a.tab, ic);
         T u, v;
         T J[P2];
         eval_detection<CHAIN, T, true>(cam_slab + c * CAM_STRIDE, pose_slab + im * POSE_STRIDE, points[3 * k], points[3 * k + 1],

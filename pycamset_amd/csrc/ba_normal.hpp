@@ -1,5 +1,5 @@
-// ba_normal.hpp — block-reduced normal equations ("block-reduced J^T J / J^T r, then
-// all-reduce of the small result instead of all-gather of J").
+// ba_normal.hpp — block-reduced normal equations on the FP64 matrix cores ("block-reduced
+// J^T J / J^T r, then all-reduce of the small result instead of all-gather of J").
 //
 // Built on the GPU without ever writing J:
 //     H    = J^T J   upper triangle of the n_params x n_params matrix (row-major, full parameter-string space)
@@ -7,33 +7,38 @@
 //     cost = r^T r
 // This is what a Levenberg-Marquardt step needs from the Jacobian the reference hands to scipy
 // (optimisation_handling.py:88-98); with it one LM iteration costs one pass + a small dense solve
-// instead of ~150 matrix-free J^T(Jv) products (profiles/r01/lm_rig32_config3_device.log).
+// instead of ~150 matrix-free J^T(Jv) products.
 //
-// Structure.  A detection's 2 x P block touches the 15 columns of its camera, the 6 of its image
-// and (self / free chains) the 3 of its key.  In the reference's table order (cam -> image -> key) a run
-// of detections shares camera and image, so the "shared" (camera + pose) part of H is a sum of
-// X^T X over the run, X = [J_shared | r] being the run's (2 x detections) x NA augmented rows
-// (NA = 22, or 16 for the free chain): a small symmetric rank-k update whose NA (NA + 1) / 2 entries are
-// the run's contribution to the camera block, the pose block, the camera-pose block, g and the cost.
-//   * Every lane evaluates one detection (eval_detection, as the fused kernel does) and parks its two
-//     augmented rows in a wave-private LDS image (64 rows of 23 16-byte slots — an odd stride, so the
-//     ds_write_b128 are conflict-free; 23.6 KB per wave, 2 waves per workgroup, 3 workgroups per CU).
-//   * The upper triangle is cut row by row into chunks (p; q0 .. q0+4), one per lane (60 of 64 lanes for
-//     NA = 22).  A lane accumulates sum_l X[l][p] X[l][q] over the member lanes: per l one
-//     ds_read_b128 for the (u, v) pair of column p and one per q, at immediate offsets — all lanes read
-//     the same row l.  (First version: 4 scattered entries per lane, 8 ds_read2_b64 per l: 171 us on
-//     rig-32 — LDS-bandwidth-bound at 128 B/clk; this layout needs 6 reads of 16 B per 5 entries.)
-//   * Accumulators live in registers across tiles for as long as (cam, image) does not change; on a
-//     change (and at the end) they are added to H / g / cost with one global f64 atomic each.  A tile
-//     that mixes several (cam, image) pairs is processed pair by pair (wave-uniform member masks), so any
-//     table order gives the same result.  For a scattered table (every detection its own run: 18 ms on rig-32)
-//     the host hands over a (cam, image)-sorted visiting order instead — the sums do not depend on it.
-//   * The 3 point columns (self / free chains) differ per lane; their rows of H (point-point, shared-point) and
-//     of g come from ba_normal_point_kernel (end of this file: separate passes over key-sorted visiting
-//     orders), or — fallback — from per-detection global atomics in this kernel.
-//   * The read loop is software-pipelined by hand (NORMAL_DEPTH rows of operands in flight) and the lane ->
-//     chunk assignment comes from a table that keeps LDS slots 16 apart out of the same read group.
-// One pass / one kernel for the template chain; up to three kernels for the self chain.
+// Structure.  A detection's 2 x P block touches the 15 columns of its camera, the 6 of its image and (self / free
+// chains) the 3 of its key.  Over a RUN of detections that share two of those, the matching blocks of H are a
+// Gram matrix X^T X of the run's (2 x detections) rows — the one dense contraction of this engine, and the only
+// place where it uses MFMA (v_mfma_f64_16x16x4_f64: 64 cycles per issue = the FP64 vector rate on gfx950,
+// tools/probes/mfma_f64_probe.hip; the gain is operand delivery — one 8-byte LDS read per lane feeds 256 FMAs,
+// where the round-1 VALU form read 16 B per 2 FMAs and was LDS-bandwidth-bound: 72 us of LDS array time at N = 1e6).
+//
+//   PASS_SHARED  table order (cam -> image -> key; any order works, a scattered table is walked through a
+//                (cam, image)-sorted permutation): X = [J_cam (15) | J_pose (6) | r], 22 columns (16 for the free
+//                chain).  Runs = (cam, image).  Yields the camera, pose and camera-pose blocks, their part of g,
+//                and the cost.
+//   PASS_CAMKEY  (cam, key)-sorted order: X = [J_cam | J_point (3) | r].  Runs = (cam, key).  Yields the
+//                camera-point blocks E[c,k], the point blocks D[k] and the point part of g.
+//   PASS_IMGKEY  (image, key)-sorted order (self chain): X = [J_pose | J_point].  Yields the pose-point blocks F[i,k].
+//
+// Per tile of 64 detections a wave
+//   1. evaluates one detection per lane (eval_detection, as the fused kernel does) and writes its two rows
+//      column-major into a wave-private LDS image: column slot s holds the 2 x ROWS values of column s as 16-byte
+//      (u, v) pairs (ds_write_b128 at consecutive addresses), slot stride = 16 B mod 256 B so that the operand
+//      reads below spread over all banks;
+//   2. walks the image in k-steps of 4 rows (2 detections): every lane reads ONE double per operand window
+//      (ds_read_b64: lane l holds X[4s + (l >> 4)][slot_w(l & 15)]) and issues the step's MFMAs into accumulator
+//      tiles that live in registers for as long as the run lasts.  22 columns need the upper triangle of a 3 x 3
+//      arrangement of column groups G0 = 0-7, G1 = 8-15, G2 = 16-21; choosing the operands as
+//          D_a = (G0,G2)^T (G0,G1)      D_b = (G1,G2)^T (G1,G2)
+//      covers all six group pairs with TWO MFMAs per step instead of three (free chain: one; point passes: one);
+//   3. at a run boundary (wave-uniform bit mask from a ballot; a step that straddles one is split with masked
+//      operands) adds the finished accumulators to H / g / cost with one f64 atomic per entry.  In PASS_SHARED the
+//      entries that involve no pose column belong to the camera alone and stay in registers until the camera
+//      changes (otherwise ~200 serialised adds per address of a camera block).
 // Atomic order makes the last bits run-to-run dependent (documented; tests compare with a tolerance).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -44,10 +49,8 @@
 namespace pcs {
 
 struct NormalArgs {
-    const int32_t *cam, *img, *key;
-    const void *uv;
-    const int32_t *order;  // optional: visit the detections in this order (a (cam, image)-sorted permutation of a
-                           // scattered table; H, g and the cost do not depend on the row order), or NULL
+    DetTable tab;
+    const int32_t *order;  // visit the detections in this order (a sorted permutation), or NULL = table order
     const void *cam_slab, *pose_slab, *points;
     double *H;      // n_params x n_params, zeroed by the host; upper triangle written
     double *g;      // n_params, zeroed by the host
@@ -56,346 +59,301 @@ struct NormalArgs {
     int64_t extr_off, pose_off, point_off;
     int64_t n_params;
     int32_t tiles_per_wave;
-    int32_t skip_points;  // 1: the point columns are left to ba_normal_point_kernel
-    int32_t debug;  // profiling switches: 1 skip the dot loops, 2 skip the flush atomics, 4 / 8 skip the point-block / shared-point atomics
+    int32_t debug;  // profiling switch: 2 skips the flush atomics (results are wrong while set)
 };
 
+constexpr int PASS_SHARED = 0, PASS_CAMKEY = 1, PASS_IMGKEY = 2;
+constexpr int NORMAL_R = 30;                       // local id of the residual column
 constexpr int normal_shared_cols(int chain) { return chain == CHAIN_FREE ? 15 : 21; }
-// LDS row of one detection: NA 16-byte slots (J[0][p], J[1][p]), slot NS = (r_u, r_v), padded to an odd
-// number of slots so that the 8-lane groups of ds_write_b128 land on different banks
-constexpr int normal_row(int chain) { return 2 * (normal_shared_cols(chain) + 1) + 2; }  // doubles
-constexpr int NORMAL_ROWS = 64;  // detections per LDS image (the whole wave tile)
-constexpr int NORMAL_WAVES = 2;  // waves per workgroup: 2 x 23.6 KB of LDS -> 3 workgroups per CU
-constexpr int NORMAL_DEPTH = 4;  // rows of operands in flight in the dot loop
-// doubles after a wave's image: the dummy columns of short chunks and the last DEPTH - 1 prefetches read into it
-constexpr int normal_tail(int chain) { return (NORMAL_DEPTH - 1) * normal_row(chain) + 16; }
-
-// Entry ownership: the upper triangle (p <= q < NA) is cut, row by row, into chunks of up to CH
-// consecutive q; one chunk per lane.  CH is the smallest chunk length that fits 64 lanes.
-constexpr int normal_chunks(int na, int ch) {
-    int n = 0;
-    for (int p = 0; p < na; ++p) n += (na - p + ch - 1) / ch;
-    return n;
+// columns of the LDS image per pass
+constexpr int normal_slots(int chain, int pass) {
+    return pass == PASS_SHARED ? normal_shared_cols(chain) + 1 : pass == PASS_CAMKEY ? 19 : 9;
 }
-constexpr int normal_chunk_len(int na) {
-    int ch = 1;
-    while (normal_chunks(na, ch) > 64) ++ch;
-    return ch;
+constexpr int normal_mfmas(int chain, int pass) { return (pass == PASS_SHARED && chain != CHAIN_FREE) ? 2 : 1; }
+// bytes between column slots: 2 * ROWS doubles + 16 -> slot s starts on bank (4 s) mod 64
+constexpr int normal_slot_stride(int rows) { return 2 * rows * 8 + 16; }
+constexpr int normal_lds_bytes(int chain, int pass, int rows) { return normal_slots(chain, pass) * normal_slot_stride(rows); }
+
+// local column id (index into a J row; NORMAL_R = residual) stored in slot s of the image
+template <int CHAIN, int PASS>
+__host__ __device__ __forceinline__ constexpr int slot_col(int s) {
+    constexpr int NS = normal_shared_cols(CHAIN);     // = first point column of a J row (self: 21, free: 15)
+    if (PASS == PASS_SHARED) return s < NS ? s : NORMAL_R;
+    if (PASS == PASS_CAMKEY) return s < 15 ? s : s < 18 ? NS + (s - 15) : NORMAL_R;
+    return s < 6 ? 15 + s : NS + (s - 6);
 }
 
-// Lane -> chunk tables from tools/normal_lane_table.py (255 = idle lane).  ds_read_b128 serves a wave in four
-// 16-lane groups over 16 slots of 16 B, so two lanes of a group collide when their slots differ by exactly 16;
-// handing the chunks out in order leaves 4 such pairs for NA = 22 (SQ_LDS_BANK_CONFLICT = 34 % of the LDS
-// cycles); these assignments have none.
-// NA = 22, CH = 5: 60 chunks, 0 slot pairs 16 apart left (sequential order: 4)
-__device__ constexpr unsigned char NORMAL_P_22[64] = {1, 13, 13, 14, 8, 255, 9, 4, 1, 1, 11, 4, 5, 255, 9, 2, 21, 12, 255, 0, 0, 4, 255, 19, 7, 2, 0, 5, 2, 14, 0, 0, 2, 17, 3, 6, 3, 10, 7, 1, 1, 16, 15, 6, 11, 12, 8, 5, 3, 15, 8, 10, 6, 16, 7, 9, 5, 10, 20, 11, 4, 18, 3, 6};
-__device__ constexpr unsigned char NORMAL_Q_22[64] = {11, 18, 13, 19, 8, 255, 14, 4, 21, 1, 11, 14, 20, 255, 9, 7, 21, 12, 255, 0, 20, 19, 255, 19, 7, 17, 5, 5, 2, 14, 15, 10, 12, 17, 8, 11, 18, 20, 17, 6, 16, 21, 20, 16, 21, 17, 18, 10, 13, 15, 13, 15, 21, 16, 12, 19, 15, 10, 20, 16, 9, 18, 3, 6};
-// NA = 16, CH = 3: 51 chunks, 0 slot pairs 16 apart left (sequential order: 0)
-__device__ constexpr unsigned char NORMAL_P_16[64] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 3, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 6, 6, 6, 6, 7, 7, 7, 8, 8, 8, 9, 9, 9, 10, 10, 11, 11, 12, 12, 13, 14, 15, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255};
-__device__ constexpr unsigned char NORMAL_Q_16[64] = {0, 3, 6, 9, 12, 15, 1, 4, 7, 10, 13, 2, 5, 8, 11, 14, 3, 6, 9, 12, 15, 4, 7, 10, 13, 5, 8, 11, 14, 6, 9, 12, 15, 7, 10, 13, 8, 11, 14, 9, 12, 15, 10, 13, 11, 14, 12, 15, 13, 14, 15, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255};
+// operand window w of a pass: slot read by the lanes with (lane & 15) == j, or -1 (padding: any slot, result unused)
+template <int CHAIN, int PASS>
+__host__ __device__ __forceinline__ int window_slot(int w, int j) {
+    if (PASS == PASS_SHARED) {
+        if (CHAIN == CHAIN_FREE) return j;                                   // W0 = slots 0..15
+        if (w == 1) return j;                                                // W1 = (G0, G1)
+        const int g = w == 0 ? 0 : 8;                                        // W0 = (G0, G2), W2 = (G1, G2)
+        return j < 8 ? g + j : j < 14 ? 16 + (j - 8) : -1;
+    }
+    if (PASS == PASS_CAMKEY) {
+        if (w == 0) return j < 3 ? 15 + j : j == 3 ? 18 : j - 4;             // A = [pt | r | cam 0..11]
+        return j < 3 ? 15 + j : j < 6 ? 12 + (j - 3) : -1;                   // B = [pt | cam 12..14]
+    }
+    if (w == 0) return j < 6 ? j : -1;                                       // A = [pose]
+    return j < 3 ? 6 + j : -1;                                               // B = [pt]
+}
+template <int CHAIN, int PASS> constexpr int n_windows() { return (PASS == PASS_SHARED) ? (CHAIN == CHAIN_FREE ? 1 : 3) : 2; }
+// MFMA m multiplies window mfma_a(m)^T by window mfma_b(m)
+template <int CHAIN, int PASS> __host__ __device__ __forceinline__ constexpr int mfma_a(int m) { return PASS == PASS_SHARED ? (CHAIN == CHAIN_FREE ? 0 : m == 0 ? 0 : 2) : 0; }
+template <int CHAIN, int PASS> __host__ __device__ __forceinline__ constexpr int mfma_b(int m) { return PASS == PASS_SHARED ? (CHAIN == CHAIN_FREE ? 0 : m == 0 ? 1 : 2) : 1; }
 
-// global column of shared local column p for (cam c, image im)
-template <int CHAIN>
-__device__ __forceinline__ int64_t shared_col(const NormalArgs &a, int p, int c, int im) {
-    if (p < 9) return 9 * (int64_t)c + p;
-    if (CHAIN == CHAIN_FREE || p < 15) return a.extr_off + 6 * (int64_t)c + (p - 9);
-    return a.pose_off + 6 * (int64_t)im + (p - 15);
+// Is D_m[i][j] an entry this pass owns (each unordered column pair exactly once)?  sa / sb = its two slots.
+template <int CHAIN, int PASS>
+__host__ __device__ __forceinline__ bool entry_kept(int m, int i, int j, int &sa, int &sb) {
+    sa = window_slot<CHAIN, PASS>(mfma_a<CHAIN, PASS>(m), i);
+    sb = window_slot<CHAIN, PASS>(mfma_b<CHAIN, PASS>(m), j);
+    if (sa < 0 || sb < 0) return false;
+    if (PASS == PASS_SHARED) {
+        if (CHAIN == CHAIN_FREE) return i <= j;
+        if (m == 0) return i >= 8 || i <= j;          // G0 x (G0 upper | G1), G2 x (G0, G1) in full
+        return i <= j && !(i < 8 && j >= 8);          // G1 x G1 upper, G2 x G2 upper (G1 x G2 came from m = 0)
+    }
+    if (PASS == PASS_CAMKEY) {
+        if (i < 3) return j >= 3 || i <= j;           // pt x pt upper, pt x cam 12..14
+        return j < 3;                                 // r x pt, cam 0..11 x pt
+    }
+    return true;                                      // pose x pt
 }
 
-template <int CHAIN, typename T>
-__global__ __launch_bounds__(64 * NORMAL_WAVES) void ba_normal_kernel(const NormalArgs a) {
+using d4v = __attribute__((ext_vector_type(4))) double;
+
+template <int CHAIN, int PASS, int ROWS>
+__global__ __launch_bounds__(64, 2) void ba_normal_mfma_kernel(const NormalArgs a) {
+    static_assert(ROWS == 64 || ROWS == 32, "image holds a whole or half a tile");
+    static_assert(PASS == PASS_SHARED || CHAIN != CHAIN_TEMPLATE, "the template chain has no point columns");
+    static_assert(PASS != PASS_IMGKEY || CHAIN == CHAIN_SELF, "only the self chain couples poses and points");
+    using T = double;
     constexpr int P = chain_P(CHAIN);
     constexpr int P2 = 2 * P;
-    constexpr int NS = normal_shared_cols(CHAIN);
-    constexpr int NA = NS + 1;                 // shared columns + the residual column
-    constexpr int CH = normal_chunk_len(NA);   // 5 (NA = 22: 60 chunks), 3 (NA = 16: 51 chunks)
-    constexpr int ROW = normal_row(CHAIN);
-    static_assert((ROW / 2) % 2 == 1, "row must be an odd number of 16-byte slots");
-    static_assert(2 * CH <= 16 && NORMAL_ROWS % NORMAL_DEPTH == 0, "dummy columns must stay inside the tail pad");
-    using V2 = __attribute__((ext_vector_type(2))) T;
+    constexpr int NSLOT = normal_slots(CHAIN, PASS);
+    constexpr int NW = n_windows<CHAIN, PASS>();
+    constexpr int NM = normal_mfmas(CHAIN, PASS);
+    constexpr int KS = normal_slot_stride(ROWS);       // bytes
+    constexpr int STEPS = ROWS / 2;                    // k-steps (4 rows = 2 detections) per image
+    constexpr bool HAS_POSE = CHAIN != CHAIN_FREE;
     using D2 = __attribute__((ext_vector_type(2))) double;
 
-    extern __shared__ __attribute__((aligned(16))) double lds_rows[];
-    const int wave = threadIdx.x >> 6;
-    const int lane = threadIdx.x & 63;
-    double *X = lds_rows + wave * (NORMAL_ROWS * ROW + normal_tail(CHAIN));
-
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_image[];
+    const int lane = threadIdx.x;
     const T *cam_slab = static_cast<const T *>(a.cam_slab);
     const T *pose_slab = static_cast<const T *>(a.pose_slab);
     const T *points = static_cast<const T *>(a.points);
-    const V2 *uv = static_cast<const V2 *>(a.uv);
 
-    // this lane's chunk: row ep, columns eq0 .. eq0 + elen - 1
-    static_assert(NA == 22 || NA == 16, "lane tables exist for NA = 22 and 16");
-    const unsigned char tp = NA == 22 ? NORMAL_P_22[lane] : NORMAL_P_16[lane];
-    const unsigned char tq = NA == 22 ? NORMAL_Q_22[lane] : NORMAL_Q_16[lane];
-    const int ep = tp == 255 ? 0 : tp, eq0 = tp == 255 ? 0 : tq;
-    const int elen = tp == 255 ? 0 : min(CH, NA - eq0);
-    const D2 *xa = reinterpret_cast<const D2 *>(X) + ep;
-    const D2 *xb = reinterpret_cast<const D2 *>(X) + eq0;
-    double acc[CH];
+    // ---- per-lane constants: operand addresses and the entries this lane's accumulator registers stand for -------
+    int rd_off[NW];   // byte offset of this lane's operand of window w at k-step 0
 #pragma unroll
-    for (int j = 0; j < CH; ++j) acc[j] = 0.0;
-    int c_run = -1, i_run = -1;  // wave-uniform: the (cam, image) the accumulators belong to
-    double cost_acc = 0.0;
-
-    // Entries that involve no pose column (camera block, camera part of g, cost) belong to the camera alone:
-    // they stay in registers across image changes and are flushed when the camera changes.  The camera
-    // block of H otherwise receives one atomic per entry per (cam, image) run — ~260 serialised adds on
-    // each of its addresses; this way it is one per wave that touches the camera.
-    auto flush = [&](const bool cam_changed) {
-        if (c_run < 0) return;
+    for (int w = 0; w < NW; ++w) {
+        const int s = window_slot<CHAIN, PASS>(w, lane & 15);
+        rd_off[w] = (s < 0 ? 0 : s) * KS + (lane >> 4) * 8;
+    }
+    // D layout of v_mfma_f64_16x16x4_f64: register r of lane l = D[(l >> 4) + 4 r][l & 15].
+    // Entry descriptor of each accumulator register: two (group, offset) column codes, bit 16 = owned, bit 17 =
+    // involves a pose column.  Groups: 0 intrinsics, 1 extrinsics, 2 pose, 3 point, 4 residual.
+    constexpr int NS = normal_shared_cols(CHAIN);
+    auto col_code = [](const int lc) -> int {
+        if (lc == NORMAL_R) return 4;
+        if (lc < 9) return 0 | (lc << 3);
+        if (lc < 15) return 1 | ((lc - 9) << 3);
+        if (HAS_POSE && lc < NS) return 2 | ((lc - 15) << 3);
+        return 3 | ((lc - NS) << 3);
+    };
+    int ent[NM][4];
 #pragma unroll
-        for (int j = 0; j < CH; ++j) {
-            const int q = eq0 + j;
-            const bool pose_entry = CHAIN != CHAIN_FREE && (ep >= 15 || (q >= 15 && q < NS));
-            if (!cam_changed && !pose_entry) continue;
-            const double s = acc[j];
-            acc[j] = 0.0;
-            if (j >= elen || s == 0.0 || (a.debug & 2)) continue;
-            if (q == NS) {
-                if (ep == NS) cost_acc += s;
-                else unsafeAtomicAdd(a.g + shared_col<CHAIN>(a, ep, c_run, i_run), s);
-            } else {
-                const int64_t gp = shared_col<CHAIN>(a, ep, c_run, i_run), gq = shared_col<CHAIN>(a, q, c_run, i_run);
-                unsafeAtomicAdd(a.H + gp * a.n_params + gq, s);
-            }
+    for (int m = 0; m < NM; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int sa, sb;
+            const bool keep = entry_kept<CHAIN, PASS>(m, (lane >> 4) + 4 * r, lane & 15, sa, sb);
+            const int ca = col_code(slot_col<CHAIN, PASS>(keep ? sa : 0)), cb = col_code(slot_col<CHAIN, PASS>(keep ? sb : 0));
+            const bool pose = PASS == PASS_SHARED && ((ca & 7) == 2 || (cb & 7) == 2);
+            ent[m][r] = ca | (cb << 8) | (keep ? 1 << 16 : 0) | (pose ? 1 << 17 : 0);
         }
+    d4v acc[NM];
+#pragma unroll
+    for (int m = 0; m < NM; ++m) acc[m] = d4v{0.0, 0.0, 0.0, 0.0};
+
+    // the run the accumulators belong to (wave-uniform): SHARED (cam, image), CAMKEY (cam, key), IMGKEY (image, key)
+    int run_a = -1, run_b = -1;
+
+    // Add the finished entries to H / g / cost.  `everything` = false (PASS_SHARED, image changed but not the
+    // camera): only entries that involve a pose column are flushed and cleared.
+    auto flush = [&](const bool everything) {
+        if (run_a < 0) return;
+        const int cam = PASS == PASS_IMGKEY ? 0 : run_a;
+        const int img = PASS == PASS_SHARED ? run_b : run_a;     // only used where pose columns occur
+        const int key = run_b;                                   // only used in the point passes
+        // first global column of each group for this run (wave-uniform)
+        const int base0 = 9 * cam, base1 = (int)a.extr_off + 6 * cam, base2 = (int)a.pose_off + 6 * img, base3 = (int)a.point_off + 3 * key;
+#pragma unroll
+        for (int m = 0; m < NM; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                // the descriptor is opaque to the optimiser: left visible, hipcc precomputes every candidate address
+                // of every entry outside the tile loop (several hundred VGPRs, spilled)
+                int d = ent[m][r];
+                asm volatile("" : "+v"(d));
+                const bool now = everything || (d & (1 << 17));
+                const double s = acc[m][r];
+                acc[m][r] = now ? 0.0 : s;
+                // branch-free address: selects only, one predicated atomic
+                const int ga_grp = d & 7, gb_grp = (d >> 8) & 7;
+                const int ga = (ga_grp == 0 ? base0 : ga_grp == 1 ? base1 : ga_grp == 2 ? base2 : base3) + ((d >> 3) & 31);
+                const int gb = (gb_grp == 0 ? base0 : gb_grp == 1 ? base1 : gb_grp == 2 ? base2 : base3) + ((d >> 11) & 31);
+                const int64_t h_idx = (int64_t)min(ga, gb) * a.n_params + max(ga, gb);
+                const int64_t g_idx = ga_grp == 4 ? gb : ga;
+                double *ptr = (ga_grp == 4 && gb_grp == 4) ? a.cost : (ga_grp == 4 || gb_grp == 4) ? a.g + g_idx : a.H + h_idx;
+                if (now && (d & (1 << 16)) && s != 0.0 && !(a.debug & 2)) unsafeAtomicAdd(ptr, s);
+            }
     };
 
-    const int64_t wave_id = (int64_t)blockIdx.x * NORMAL_WAVES + wave;
-    const int64_t tile0 = wave_id * a.tiles_per_wave;
+    const int64_t tile0 = (int64_t)blockIdx.x * a.tiles_per_wave;
     const int64_t tile1 = min(tile0 + (int64_t)a.tiles_per_wave, a.n_tiles);
+    // The index words and the measurement of the NEXT tile are requested before this tile's arithmetic and MFMA loop
+    // start: that first level of the dependent load chain (detection -> slab / point addresses) is what a wave with one
+    // or two neighbours on its SIMD otherwise sits out (SQ_WAIT_ANY was 39 % of the wave cycles, profiles/r02).
+    auto det_index = [&](const int64_t tile) -> int64_t {
+        const int64_t i = tile * 64 + lane;
+        const int64_t is = i < a.n ? i : a.n - 1;
+        return a.order ? a.order[is] : is;
+    };
+    DetWords nxt_w{};
+    double2v nxt_m{};
+    if (tile0 < tile1) {
+        const int64_t ic = det_index(tile0);
+        nxt_w = load_words(a.tab, ic);
+        nxt_m = load_uv(a.tab, ic);
+    }
     for (int64_t tile = tile0; tile < tile1; ++tile) {
         const int64_t i = tile * 64 + lane;
         const bool valid = i < a.n;
-        const int64_t is = valid ? i : a.n - 1;
-        const int64_t ic = a.order ? a.order[is] : is;
-        const int c = a.cam[ic], im = (CHAIN != CHAIN_FREE) ? a.img[ic] : 0, k = a.key[ic];
-        const V2 m = uv[ic];
+        int c, im, k;
+        decode_words(a.tab, nxt_w, c, im, k);
+        if (!HAS_POSE) im = 0;
+        const double2v m = nxt_m;
+        if (tile + 1 < tile1) {
+            const int64_t icn = det_index(tile + 1);
+            nxt_w = load_words(a.tab, icn);
+            nxt_m = load_uv(a.tab, icn);
+        }
+        asm volatile("" ::: "memory");   // keep the requests up here
         T u, v;
         T J[P2];
-        eval_detection<CHAIN, T, true>(cam_slab + c * CAM_STRIDE, pose_slab + im * POSE_STRIDE, points[3 * k], points[3 * k + 1],
-                                       points[3 * k + 2], u, v, J);
-        const double r0 = (double)(u - m.x), r1 = (double)(v - m.y);
-
-        if constexpr (CHAIN != CHAIN_TEMPLATE) {
-            // point columns: per-detection rows of H and g (upper triangle: shared columns come first).  Fallback
-            // only — 54-72 global atomics per detection (2.1-2.7 ms at N = 1e6); the engine normally runs
-            // ba_normal_point_kernel over key-sorted visiting orders instead.
-            if (valid && !a.skip_points) {
-                const int64_t gX = a.point_off + 3 * (int64_t)k;
-                double jp0[3], jp1[3];
-#pragma unroll
-                for (int t = 0; t < 3; ++t) { jp0[t] = (double)J[NS + t]; jp1[t] = (double)J[P + NS + t]; }
-                if (!(a.debug & 4)) {
-#pragma unroll
-                    for (int t = 0; t < 3; ++t) {
-                        unsafeAtomicAdd(a.g + gX + t, jp0[t] * r0 + jp1[t] * r1);
-#pragma unroll
-                        for (int s = t; s < 3; ++s) unsafeAtomicAdd(a.H + (gX + t) * a.n_params + gX + s, jp0[t] * jp0[s] + jp1[t] * jp1[s]);
-                    }
-                }
-                if (!(a.debug & 8))
-#pragma unroll
-                for (int p = 0; p < NS; ++p) {
-                    double *row = a.H + shared_col<CHAIN>(a, p, c, im) * a.n_params + gX;
-                    const double j0 = (double)J[p], j1 = (double)J[P + p];
-#pragma unroll
-                    for (int t = 0; t < 3; ++t) unsafeAtomicAdd(row + t, j0 * jp0[t] + j1 * jp1[t]);
-                }
-            }
-        }
-
-        // the tile's 64 augmented rows -> LDS; J is dead after this, so the dot loops below have the
-        // registers to keep many ds_read_b128 in flight (with a 32-row image and J alive across two passes
-        // hipcc issued one read at a time: 470 cycles per row instead of ~100)
         {
-            D2 *dst = reinterpret_cast<D2 *>(X + lane * ROW);
-#pragma unroll
-            for (int p = 0; p < NS; ++p) {
-                D2 w;
-                w.x = (double)J[p];
-                w.y = (double)J[P + p];
-                dst[p] = w;
+            // Slabs: when the whole tile refers to one camera (image) its slab is fetched with ONE coalesced load and read
+            // through v_readlane (LaneSlab) instead of 48 (39) per-lane loads of the same address — with one-wave
+            // workgroups and ~2 waves per SIMD the latency of those loads is what this kernel waits for.  Tiles that mix
+            // cameras / images (run boundaries) take the per-lane loads.
+            const T X0 = points[3 * k], X1 = points[3 * k + 1], X2 = points[3 * k + 2];
+            const int c0 = __builtin_amdgcn_readfirstlane(c), im0 = __builtin_amdgcn_readfirstlane(im);
+            const bool cam_uni = __all(c == c0), img_uni = !HAS_POSE || __all(im == im0);
+            const T *csp = cam_slab + c * CAM_STRIDE, *psp = pose_slab + im * POSE_STRIDE;
+            if (PASS == PASS_SHARED && cam_uni && img_uni) {
+                const LaneSlab lc{cam_slab[c0 * CAM_STRIDE + min(lane, CAM_STRIDE - 1)]};
+                const LaneSlab lp{HAS_POSE ? pose_slab[im0 * POSE_STRIDE + min(lane, POSE_STRIDE - 1)] : 0.0};
+                eval_detection<CHAIN, T, true>(lc, lp, X0, X1, X2, u, v, J);
+            } else if (PASS == PASS_CAMKEY && cam_uni) {
+                const LaneSlab lc{cam_slab[c0 * CAM_STRIDE + min(lane, CAM_STRIDE - 1)]};
+                eval_detection<CHAIN, T, true>(lc, psp, X0, X1, X2, u, v, J);
+            } else if (PASS == PASS_IMGKEY && img_uni) {
+                const LaneSlab lp{pose_slab[im0 * POSE_STRIDE + min(lane, POSE_STRIDE - 1)]};
+                eval_detection<CHAIN, T, true>(csp, lp, X0, X1, X2, u, v, J);
+            } else {
+                eval_detection<CHAIN, T, true>(csp, psp, X0, X1, X2, u, v, J);
             }
-            D2 w;
-            w.x = r0;
-            w.y = r1;
-            dst[NS] = w;
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        uint64_t rem = __ballot(valid);
-        while (rem) {  // one (cam, image) pair of the tile at a time; all conditions are wave-uniform
-            const int leader = __builtin_ctzll(rem);
-            const int c0 = __builtin_amdgcn_readlane(c, leader), i0 = __builtin_amdgcn_readlane(im, leader);
-            const uint64_t member = __ballot(valid && c == c0 && im == i0) & rem;
-            if (c0 != c_run || i0 != i_run) {
-                flush(c0 != c_run);
-                c_run = c0;
-                i_run = i0;
-            }
-            if (a.debug & 1) {
-                acc[0] += 1.0;
-            } else if (member == ~0ull) {
-                // The whole tile is one run (the common case).  Software pipeline: the operands of row
-                // l + DEPTH - 1 are requested before row l is consumed; the compiler barrier keeps hipcc from
-                // sinking the ds_read_b128 back down to their uses (which it does otherwise: one read, one
-                // s_waitcnt 0, three VALU ops — the LDS latency fully exposed).  Rows past the image fall into
-                // the tail pad and are never used.
-                constexpr int DEPTH = NORMAL_DEPTH;
-                D2 pr[DEPTH], qr[DEPTH][CH];
+        const double r0 = u - m.x, r1 = v - m.y;
+
+        // run boundaries of this tile: bit d set = detection d starts a new run
+        const int ka = PASS == PASS_IMGKEY ? im : c, kb = PASS == PASS_SHARED ? im : k;
+        const int pa = __shfl_up(ka, 1), pb = __shfl_up(kb, 1);
+        const bool starts = valid && (lane == 0 ? (ka != run_a || kb != run_b) : (ka != pa || kb != pb));
+        const uint64_t bnd = __ballot(starts);
+
 #pragma unroll
-                for (int s = 0; s < DEPTH - 1; ++s) {
-                    pr[s] = xa[s * (ROW / 2)];
+        for (int h = 0; h < 64 / ROWS; ++h) {
+            // ---- this pass's detections -> LDS image (lanes past the end of the table write zero rows: they add nothing) -----------
+            if (ROWS == 64 || (lane >> 5) == h) {
+                unsigned char *dst = lds_image + (lane & (ROWS - 1)) * 16;
 #pragma unroll
-                    for (int j = 0; j < CH; ++j) qr[s][j] = xb[s * (ROW / 2) + j];
+                for (int s = 0; s < NSLOT; ++s) {
+                    const int lc = slot_col<CHAIN, PASS>(s);
+                    D2 w;
+                    if (lc == NORMAL_R) { w.x = r0; w.y = r1; }
+                    else { w.x = J[lc]; w.y = J[P + lc]; }
+                    *reinterpret_cast<D2 *>(dst + s * KS) = w;
                 }
-#pragma unroll 1
-                for (int l0 = 0; l0 < NORMAL_ROWS; l0 += DEPTH) {
-                    const D2 *xa0 = xa + l0 * (ROW / 2), *xb0 = xb + l0 * (ROW / 2);
+                if (!valid) {   // only the table's last tile has such lanes: their rows are overwritten with zeros
 #pragma unroll
-                    for (int s = 0; s < DEPTH; ++s) {
-                        constexpr int AHEAD = DEPTH - 1;
-                        const int slot = (s + AHEAD) % DEPTH;
-                        pr[slot] = xa0[(s + AHEAD) * (ROW / 2)];
+                    for (int s = 0; s < NSLOT; ++s) *reinterpret_cast<D2 *>(dst + s * KS) = D2{0.0, 0.0};
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+            const int d_base = h * ROWS;
+            const uint64_t bits = ROWS == 64 ? bnd : (bnd >> d_base) & 0xffffffffull;
+            auto operand = [&](const int w, const int s) { return *reinterpret_cast<const double *>(lds_image + rd_off[w] + s * 32); };
+            auto run_mfmas = [&](const double (&x)[NW]) {
 #pragma unroll
-                        for (int j = 0; j < CH; ++j) qr[slot][j] = xb0[(s + AHEAD) * (ROW / 2) + j];
-                        asm volatile("" ::: "memory");
+                for (int mm = 0; mm < NM; ++mm)
+                    acc[mm] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[mfma_a<CHAIN, PASS>(mm)], x[mfma_b<CHAIN, PASS>(mm)], acc[mm], 0, 0, 0);
+            };
+            auto new_run = [&](const int d) {   // detection d (tile-relative) starts a run
+                const int na = __builtin_amdgcn_readlane(ka, d), nb = __builtin_amdgcn_readlane(kb, d);
+                flush(PASS != PASS_SHARED || na != run_a);
+                run_a = na;
+                run_b = nb;
+            };
+            if (bits == 0) {
+                // the whole image continues the current run (the common case): operands of step s + 1 are requested
+                // before the MFMAs of step s are issued
+                double x[2][NW];
 #pragma unroll
-                        for (int j = 0; j < CH; ++j) acc[j] += pr[s].x * qr[s][j].x + pr[s].y * qr[s][j].y;
+                for (int w = 0; w < NW; ++w) x[0][w] = operand(w, 0);
+#pragma unroll
+                for (int s = 0; s < STEPS; ++s) {
+                    if (s + 1 < STEPS) {
+#pragma unroll
+                        for (int w = 0; w < NW; ++w) x[(s + 1) & 1][w] = operand(w, s + 1);
                     }
+                    asm volatile("" ::: "memory");
+                    run_mfmas(x[s & 1]);
                 }
             } else {
-#pragma unroll 4
-                for (int l = 0; l < NORMAL_ROWS; ++l) {
-                    if (member & (1ull << l)) {
-                        const D2 p2 = xa[l * (ROW / 2)];
+#pragma unroll 1
+                for (int s = 0; s < STEPS; ++s) {
+                    const int d0 = d_base + 2 * s;
+                    const uint32_t bb = (uint32_t)(bnd >> d0) & 3u;
+                    double x[NW];
 #pragma unroll
-                        for (int j = 0; j < CH; ++j) {
-                            const D2 q2 = xb[l * (ROW / 2) + j];
-                            acc[j] += p2.x * q2.x + p2.y * q2.y;
-                        }
+                    for (int w = 0; w < NW; ++w) x[w] = operand(w, s);
+                    if (bb & 1u) new_run(d0);
+                    if (bb & 2u) {   // the step straddles a boundary: rows of detection d0, flush, rows of d0 + 1
+                        double xa[NW], xb[NW];
+#pragma unroll
+                        for (int w = 0; w < NW; ++w) { xa[w] = lane < 32 ? x[w] : 0.0; xb[w] = lane < 32 ? 0.0 : x[w]; }
+                        run_mfmas(xa);
+                        new_run(d0 + 1);
+                        run_mfmas(xb);
+                    } else {
+                        run_mfmas(x);
                     }
                 }
             }
-            rem &= ~member;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
     flush(true);
-    const double cs = wave_sum(cost_acc);
-    if (lane == 0 && cs != 0.0) unsafeAtomicAdd(a.cost, cs);
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// Point columns of the self / free chains, pass by pass over key-sorted visiting orders.
-//
-// A detection's point block couples its key k to its camera (15 columns) and — self chain — to its image (6
-// columns).  Summed per detection that is 54-72 global f64 atomics each.  Visiting the detections sorted by
-// (cam, key) makes the contributions to one camera-point block E[c,k] (and to D[k], g[k]) a contiguous run of
-// lanes (one per image that sees the key, ~64 on rig-32); sorted by (image, key) the same holds for the pose-point
-// block F[i,k] (~10 cameras).  Each pass re-evaluates the detection (38 us of arithmetic at N = 1e6), forms its
-// products, sums them over the run with a segmented shuffle reduction (6 steps, lanes only add a neighbour that
-// carries the same key — runs are contiguous, so that is exact) and the first lane of every run adds the sums
-// to H / g with one atomic per entry.
-//   WHICH 0: order by (cam, key):    E[c,k] 15 x 3, D[k] 3 x 3 upper, g[k]                      (54 sums)
-//   WHICH 1: order by (image, key):  F[i,k] 6 x 3   (self chain only)                          (18 sums)
-template <int CHAIN, typename T, int WHICH>
-__global__ __launch_bounds__(256) void ba_normal_point_kernel(const NormalArgs a) {
-    static_assert(CHAIN != CHAIN_TEMPLATE && (WHICH == 0 || CHAIN == CHAIN_SELF), "no such pass");
-    constexpr int P = chain_P(CHAIN);
-    constexpr int P2 = 2 * P;
-    constexpr int NS = normal_shared_cols(CHAIN);
-    constexpr int NV = WHICH == 0 ? 45 + 6 + 3 : 18;
-    using V2 = __attribute__((ext_vector_type(2))) T;
-    const int lane = threadIdx.x & 63;
-    const T *cam_slab = static_cast<const T *>(a.cam_slab);
-    const T *pose_slab = static_cast<const T *>(a.pose_slab);
-    const T *points = static_cast<const T *>(a.points);
-    const V2 *uv = static_cast<const V2 *>(a.uv);
-    const int64_t n_waves = (int64_t)gridDim.x * 4, wave_id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    for (int64_t tile = wave_id; tile < a.n_tiles; tile += n_waves) {
-        const int64_t i = tile * 64 + lane;
-        const bool valid = i < a.n;
-        const int64_t ic = a.order[valid ? i : a.n - 1];
-        const int c = a.cam[ic], im = (CHAIN != CHAIN_FREE) ? a.img[ic] : 0, k = a.key[ic];
-        const V2 m = uv[ic];
-        T u, v;
-        T J[P2];
-        eval_detection<CHAIN, T, true>(cam_slab + c * CAM_STRIDE, pose_slab + im * POSE_STRIDE, points[3 * k], points[3 * k + 1],
-                                       points[3 * k + 2], u, v, J);
-        double jp0[3], jp1[3];
-#pragma unroll
-        for (int t = 0; t < 3; ++t) { jp0[t] = (double)J[NS + t]; jp1[t] = (double)J[P + NS + t]; }
-        double s[NV];
-        if constexpr (WHICH == 0) {
-            const double r0 = (double)(u - m.x), r1 = (double)(v - m.y);
-#pragma unroll
-            for (int p = 0; p < 15; ++p)
-#pragma unroll
-                for (int t = 0; t < 3; ++t) s[3 * p + t] = (double)J[p] * jp0[t] + (double)J[P + p] * jp1[t];
-            int e = 45;
-#pragma unroll
-            for (int t = 0; t < 3; ++t)
-#pragma unroll
-                for (int q = t; q < 3; ++q) s[e++] = jp0[t] * jp0[q] + jp1[t] * jp1[q];
-#pragma unroll
-            for (int t = 0; t < 3; ++t) s[51 + t] = jp0[t] * r0 + jp1[t] * r1;
-        } else {
-#pragma unroll
-            for (int p = 0; p < 6; ++p)
-#pragma unroll
-                for (int t = 0; t < 3; ++t) s[3 * p + t] = (double)J[15 + p] * jp0[t] + (double)J[P + 15 + p] * jp1[t];
-        }
-        // run key; invalid lanes get one that matches nothing and contribute zeros
-        const int ka = valid ? (WHICH == 0 ? c : im) : -1 - lane, kb = valid ? k : -1;
-        if (!valid) {
-#pragma unroll
-            for (int j = 0; j < NV; ++j) s[j] = 0.0;
-        }
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int na = __shfl_down(ka, off), nb = __shfl_down(kb, off);
-            const bool same = lane + off < 64 && na == ka && nb == kb;
-#pragma unroll
-            for (int j = 0; j < NV; ++j) {
-                const double t = __shfl_down(s[j], off);
-                s[j] += same ? t : 0.0;
-            }
-        }
-        const int pa = __shfl_up(ka, 1), pb = __shfl_up(kb, 1);
-        const bool leader = valid && (lane == 0 || pa != ka || pb != kb);
-        if (leader) {
-            const int64_t gX = a.point_off + 3 * (int64_t)k;
-            if constexpr (WHICH == 0) {
-#pragma unroll
-                for (int p = 0; p < 15; ++p) {
-                    double *row = a.H + shared_col<CHAIN>(a, p, c, im) * a.n_params + gX;
-#pragma unroll
-                    for (int t = 0; t < 3; ++t) unsafeAtomicAdd(row + t, s[3 * p + t]);
-                }
-                int e = 45;
-#pragma unroll
-                for (int t = 0; t < 3; ++t)
-#pragma unroll
-                    for (int q = t; q < 3; ++q) unsafeAtomicAdd(a.H + (gX + t) * a.n_params + gX + q, s[e++]);
-#pragma unroll
-                for (int t = 0; t < 3; ++t) unsafeAtomicAdd(a.g + gX + t, s[51 + t]);
-            } else {
-#pragma unroll
-                for (int p = 0; p < 6; ++p) {
-                    double *row = a.H + shared_col<CHAIN>(a, 15 + p, c, im) * a.n_params + gX;
-#pragma unroll
-                    for (int t = 0; t < 3; ++t) unsafeAtomicAdd(row + t, s[3 * p + t]);
-                }
-            }
-        }
-    }
 }
 
 }  // namespace pcs

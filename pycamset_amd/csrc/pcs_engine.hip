@@ -2,10 +2,11 @@
 //
 // gfx950 (CDNA4) only: wave64, 256 CUs in 8 XCDs, 160 KiB LDS per CU, HBM3E.
 // The path is an HBM-write-bound stream (380 B/detection for the FP64 template chain, of which
-// 352 B are stores); there is no dense contraction, so no MFMA.  See DESIGN.md.
+// 352 B are stores) with no dense contraction, so no MFMA there; the one contraction of the engine, the
+// block-reduced normal equations, runs on the FP64 matrix cores (ba_normal.hpp).  See DESIGN.md.
 //
 // Kernels: ba_kernels.hpp (evaluation, compaction, legacy cost), ba_matfree.hpp (J products without J),
-// ba_triangulate.hpp; device maths: ba_device.hpp.  This file: launch plumbing + the C ABI.
+// ba_normal.hpp (J^T J / J^T r), ba_triangulate.hpp; device maths: ba_device.hpp.  This file: launch plumbing + the C ABI.
 #include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
 
@@ -52,7 +53,7 @@ struct pcs_engine {
     int chain = 0, dtype = 0, device = 0, P = 0;
     int64_t n_cams = 0, n_imgs = 0, n_keys = 0, n_params = 0, n = 0;
     int64_t extr_off = 0, pose_off = 0, point_off = 0;
-    size_t esize = 8;   // bytes of the arithmetic / slab / measurement type
+    size_t msize = 8;   // bytes of a measurement scalar on the device (4 for PCS_F32); slabs and arithmetic are always FP64
     size_t osize = 8;   // bytes of the residual / Jacobian type written out (4 for PCS_F32 and PCS_MIXED)
     hipStream_t stream = nullptr;
     std::vector<hipEvent_t> ev;  // ring of (start, after slab_prep, after eval) triples
@@ -66,11 +67,15 @@ struct pcs_engine {
     int64_t eval_count = 0;
     hipStream_t last_stream = nullptr;
     // static inputs
-    int32_t *d_cam = nullptr, *d_img = nullptr, *d_key = nullptr;
+    int32_t *d_cam = nullptr, *d_img = nullptr, *d_key = nullptr;  // split index arrays (only when the packed word does not fit)
+    uint32_t *d_packed = nullptr;      // cam | image | key bit fields, one word per detection (DetTable, ba_device.hpp)
+    int key_bits = 0, img_bits = 0;
+    bool pack_indices = true;          // option "pack_indices" (A/B switch; takes effect at the next upload)
     int32_t *d_order = nullptr;  // (cam, image)-sorted visiting order of a scattered table (normal equations), or NULL
     int32_t *d_order_ck = nullptr, *d_order_ik = nullptr;  // (cam, key) / (image, key) orders for the point passes
     bool point_orders_tried = false;
-    bool normal_point_pass = true;
+    int normal_rows = 64;        // detections per LDS image of the normal-equations kernel (64 or 32)
+    int waves_per_wg = 0;        // fused kernel: waves per workgroup (0 = automatic: fewer for small tables)
     void *d_uv = nullptr;
     std::vector<int32_t> h_cam, h_img, h_key;
     bool have_template = false;
@@ -110,7 +115,6 @@ struct pcs_engine {
     int variant = -1;
     int64_t wgs_per_cu = 0;
     int compact_variant = 1;     // 1 = tile kernel with coalesced stores, 0 = per-lane stores
-    bool rowsplit = false;       // two lanes per detection (ba_eval_rowsplit_kernel)
     bool xcd_remap = false;      // contiguous eighth of the table per XCD group (experiment; no measured effect)
     double tile_locality = 1.0;  // fraction of 64-detection tiles touching <= 2 distinct (cam, image) pairs
     int64_t tiles_per_wg = 0;  // 0 = derive from wgs_per_cu
@@ -124,6 +128,187 @@ extern "C" {
 int pcs_version(void) { return 100; }
 const char *pcs_last_error(void) { return g_err.c_str(); }
 
+// ---- batched triangulation: a handle that owns the camera table, the observation buffers and the
+// kernel's scratch, so that repeated calls (CameraSet.multi_cam_triangulate per frame set, cameras/camera_set.py:343-402)
+// pay neither allocations nor — with device-resident inputs — copies.
+struct pcs_triangulator {
+    int device = 0;
+    int64_t n_cams = 0;
+    bool have_cams = false;
+    hipStream_t stream = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    bool timed = false;
+    double *d_tab = nullptr;
+    // handle-owned copies of host inputs (grown on demand)
+    int32_t *d_cam = nullptr; double *d_uv = nullptr; int64_t *d_start = nullptr;
+    int64_t obs_capacity = 0, uv_capacity = 0, pts_capacity = 0;
+    // scratch + default output
+    void *d_scr = nullptr, *d_scl = nullptr; double *d_pts = nullptr;
+    int64_t scr_capacity = 0, scl_capacity = 0, out_capacity = 0;
+    // current problem (device pointers: handle-owned or the caller's)
+    const int32_t *cur_cam = nullptr; const double *cur_uv = nullptr; const int64_t *cur_start = nullptr;
+    int64_t n_obs = 0, n_pts = -1;
+    int lanes = 4;   // lanes per point: 1, 2, 4, 8 or 16 (profiles/r01/tri_legacy_bench.log: 4 is fastest at 2-22 views)
+};
+
+static int tri_grow(void **buf, int64_t *cap, int64_t need, size_t elem) {
+    if (need <= *cap) return PCS_OK;
+    if (*buf) HIPCHK(hipFree(*buf));
+    *buf = nullptr;
+    *cap = 0;
+    HIPCHK(hipMalloc(buf, elem * (size_t)need));
+    *cap = need;
+    return PCS_OK;
+}
+
+int pcs_tri_create(pcs_triangulator **out, int device, int64_t n_cams) {
+    if (!out || n_cams <= 0) return fail(PCS_ERR_ARG, "pcs_tri_create: bad arguments");
+    *out = nullptr;
+    const int ndev = pcs_device_count();
+    if (ndev <= 0) return fail(PCS_ERR_NODEVICE, "pcs_tri_create: no HIP device visible (no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(PCS_ERR_ARG, "pcs_tri_create: device out of range");
+    HIPCHK(hipSetDevice(device));
+    pcs_triangulator *t = new pcs_triangulator();
+    t->device = device;
+    t->n_cams = n_cams;
+    const char *lanes_env = getenv("PCS_TRI_LANES");   // A/B switch
+    const int lanes = lanes_env ? atoi(lanes_env) : 4;
+    t->lanes = (lanes == 1 || lanes == 2 || lanes == 8 || lanes == 16) ? lanes : 4;
+    hipError_t e = hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&t->e0);
+    if (e == hipSuccess) e = hipEventCreate(&t->e1);
+    if (e == hipSuccess) e = hipMalloc(&t->d_tab, sizeof(double) * n_cams * TRI_CAM_STRIDE);
+    if (e != hipSuccess) {
+        const int rc = fail(PCS_ERR_HIP, "pcs_tri_create: %s", hipGetErrorString(e));
+        pcs_tri_destroy(t);
+        return rc;
+    }
+    *out = t;
+    return PCS_OK;
+}
+
+int pcs_tri_destroy(pcs_triangulator *t) {
+    if (!t) return PCS_OK;
+    (void)hipSetDevice(t->device);
+    if (t->stream) (void)hipStreamSynchronize(t->stream);
+    for (void *b : {(void *)t->d_tab, (void *)t->d_cam, (void *)t->d_uv, (void *)t->d_start, t->d_scr, t->d_scl, (void *)t->d_pts})
+        if (b) (void)hipFree(b);
+    if (t->e0) (void)hipEventDestroy(t->e0);
+    if (t->e1) (void)hipEventDestroy(t->e1);
+    if (t->stream) (void)hipStreamDestroy(t->stream);
+    delete t;
+    return PCS_OK;
+}
+
+int pcs_tri_set_cameras(pcs_triangulator *t, const double *proj, const double *intrinsics, const double *dists) {
+    if (!t || !proj || !intrinsics || !dists) return fail(PCS_ERR_ARG, "pcs_tri_set_cameras: bad arguments");
+    std::vector<double> tab((size_t)t->n_cams * TRI_CAM_STRIDE, 0.0);
+    for (int64_t c = 0; c < t->n_cams; ++c) {
+        double *r = tab.data() + c * TRI_CAM_STRIDE;
+        for (int k = 0; k < 12; ++k) r[k] = proj[12 * c + k];
+        const double *K = intrinsics + 9 * c;
+        r[22] = K[0]; r[23] = K[2]; r[24] = K[4]; r[25] = K[5];
+        for (int k = 0; k < 5; ++k) r[26 + k] = dists[5 * c + k];
+    }
+    HIPCHK(hipSetDevice(t->device));
+    HIPCHK(hipStreamSynchronize(t->stream));
+    HIPCHK(hipMemcpy(t->d_tab, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice));
+    t->have_cams = true;
+    return PCS_OK;
+}
+
+int pcs_tri_set_observations(pcs_triangulator *t, int64_t n_obs, const int32_t *cam, const double *uv, int64_t n_pts, const int64_t *start_inds) {
+    if (!t || n_obs < 0 || n_pts < 0 || !start_inds || (n_obs > 0 && (!cam || !uv))) return fail(PCS_ERR_ARG, "pcs_tri_set_observations: bad arguments");
+    if (start_inds[0] != 0 || start_inds[n_pts] != n_obs) return fail(PCS_ERR_ARG, "pcs_tri_set_observations: start_inds must run from 0 to n_obs");
+    for (int64_t j = 0; j < n_pts; ++j)
+        if (start_inds[j + 1] < start_inds[j]) return fail(PCS_ERR_ARG, "pcs_tri_set_observations: start_inds must be non-decreasing");
+    for (int64_t r = 0; r < n_obs; ++r)
+        if (cam[r] < 0 || cam[r] >= t->n_cams) return fail(PCS_ERR_RANGE, "observation %lld has camera %d outside [0,%lld)", (long long)r, cam[r], (long long)t->n_cams);
+    HIPCHK(hipSetDevice(t->device));
+    HIPCHK(hipStreamSynchronize(t->stream));
+    t->n_pts = -1;
+    int rc = tri_grow((void **)&t->d_cam, &t->obs_capacity, std::max<int64_t>(1, n_obs), sizeof(int32_t));
+    if (rc) return rc;
+    rc = tri_grow((void **)&t->d_uv, &t->uv_capacity, std::max<int64_t>(1, n_obs), 2 * sizeof(double));
+    if (rc) return rc;
+    rc = tri_grow((void **)&t->d_start, &t->pts_capacity, n_pts + 1, sizeof(int64_t));
+    if (rc) return rc;
+    if (n_obs) {
+        HIPCHK(hipMemcpyAsync(t->d_cam, cam, sizeof(int32_t) * n_obs, hipMemcpyHostToDevice, t->stream));
+        HIPCHK(hipMemcpyAsync(t->d_uv, uv, sizeof(double) * 2 * n_obs, hipMemcpyHostToDevice, t->stream));
+    }
+    HIPCHK(hipMemcpyAsync(t->d_start, start_inds, sizeof(int64_t) * (n_pts + 1), hipMemcpyHostToDevice, t->stream));
+    HIPCHK(hipStreamSynchronize(t->stream));   // the caller may reuse its host arrays
+    t->cur_cam = t->d_cam; t->cur_uv = t->d_uv; t->cur_start = t->d_start;
+    t->n_obs = n_obs; t->n_pts = n_pts;
+    return PCS_OK;
+}
+
+int pcs_tri_set_observations_device(pcs_triangulator *t, int64_t n_obs, const int32_t *d_cam, const double *d_uv, int64_t n_pts, const int64_t *d_start_inds) {
+    if (!t || n_obs < 0 || n_pts < 0 || !d_start_inds || (n_obs > 0 && (!d_cam || !d_uv))) return fail(PCS_ERR_ARG, "pcs_tri_set_observations_device: bad arguments");
+    t->cur_cam = d_cam; t->cur_uv = d_uv; t->cur_start = d_start_inds;   // caller-owned, not range-checked (stay on the device)
+    t->n_obs = n_obs; t->n_pts = n_pts;
+    return PCS_OK;
+}
+
+int pcs_tri_run(pcs_triangulator *t, double *d_pts, void *stream) {
+    if (!t) return fail(PCS_ERR_ARG, "pcs_tri_run: bad arguments");
+    if (!t->have_cams) return fail(PCS_ERR_STATE, "pcs_tri_run: cameras not set");
+    if (t->n_pts < 0) return fail(PCS_ERR_STATE, "pcs_tri_run: observations not set");
+    if (t->n_pts == 0) return PCS_OK;
+    HIPCHK(hipSetDevice(t->device));
+    hipStream_t s = stream ? (hipStream_t)stream : t->stream;
+    int rc = tri_grow(&t->d_scr, &t->scr_capacity, std::max<int64_t>(1, t->n_obs), 4 * sizeof(double));   // Householder row r_i per observation
+    if (rc) return rc;
+    rc = tri_grow(&t->d_scl, &t->scl_capacity, std::max<int64_t>(1, t->n_obs), 2 * sizeof(double));   // (1 / E_i, lambda_i)
+    if (rc) return rc;
+    if (!d_pts) {
+        rc = tri_grow((void **)&t->d_pts, &t->out_capacity, t->n_pts, 3 * sizeof(double));
+        if (rc) return rc;
+        d_pts = t->d_pts;
+    }
+    const int lanes = t->lanes;
+    const dim3 grid((unsigned)((t->n_pts * lanes + 255) / 256));
+#define PCS_TRI_LAUNCH(G_)                                                                                                     \
+    hipExtLaunchKernelGGL(triangulate_kernel<G_>, grid, dim3(256), 0, s, t->e0, t->e1, 0, t->cur_cam, (const double2 *)t->cur_uv, \
+                          t->cur_start, (const double *)t->d_tab, (double4 *)t->d_scr, (double2 *)t->d_scl, d_pts, t->n_pts)
+    if (lanes == 1) PCS_TRI_LAUNCH(1);
+    else if (lanes == 2) PCS_TRI_LAUNCH(2);
+    else if (lanes == 8) PCS_TRI_LAUNCH(8);
+    else if (lanes == 16) PCS_TRI_LAUNCH(16);
+    else PCS_TRI_LAUNCH(4);
+#undef PCS_TRI_LAUNCH
+    HIPCHK(hipGetLastError());
+    t->timed = true;
+    return PCS_OK;
+}
+
+int pcs_tri_points(pcs_triangulator *t, double *pts) {
+    if (!t || !pts) return fail(PCS_ERR_ARG, "pcs_tri_points: bad arguments");
+    if (t->n_pts < 0 || !t->d_pts || t->out_capacity < t->n_pts) return fail(PCS_ERR_STATE, "pcs_tri_points: no handle-owned result (run with d_pts = NULL first)");
+    HIPCHK(hipSetDevice(t->device));
+    if (t->n_pts) HIPCHK(hipMemcpyAsync(pts, t->d_pts, sizeof(double) * 3 * t->n_pts, hipMemcpyDeviceToHost, t->stream));
+    HIPCHK(hipStreamSynchronize(t->stream));
+    return PCS_OK;
+}
+
+int pcs_tri_synchronize(pcs_triangulator *t, void *stream) {
+    if (!t) return fail(PCS_ERR_ARG, "pcs_tri_synchronize: bad arguments");
+    HIPCHK(hipSetDevice(t->device));
+    HIPCHK(hipStreamSynchronize(stream ? (hipStream_t)stream : t->stream));
+    return PCS_OK;
+}
+
+int pcs_tri_last_kernel_ms(pcs_triangulator *t, float *kernel_ms) {
+    if (!t || !kernel_ms) return fail(PCS_ERR_ARG, "pcs_tri_last_kernel_ms: bad arguments");
+    if (!t->timed) return fail(PCS_ERR_STATE, "pcs_tri_last_kernel_ms: nothing has run yet");
+    HIPCHK(hipEventSynchronize(t->e1));
+    HIPCHK(hipEventElapsedTime(kernel_ms, t->e0, t->e1));
+    return PCS_OK;
+}
+
+// stateless convenience form: one temporary handle per call (allocations + copies every time — use the handle API
+// for repeated calls)
 int pcs_triangulate(int device, int64_t n_obs, const int32_t *cam, const double *uv, int64_t n_pts, const int64_t *start_inds,
                     int64_t n_cams, const double *proj, const double *intrinsics, const double *dists, double *pts,
                     float *kernel_ms) {
@@ -131,75 +316,18 @@ int pcs_triangulate(int device, int64_t n_obs, const int32_t *cam, const double 
         (n_obs > 0 && (!cam || !uv)))
         return fail(PCS_ERR_ARG, "pcs_triangulate: bad arguments");
     if (n_pts == 0) return PCS_OK;
-    if (start_inds[0] != 0 || start_inds[n_pts] != n_obs) return fail(PCS_ERR_ARG, "pcs_triangulate: start_inds must run from 0 to n_obs");
-    for (int64_t j = 0; j < n_pts; ++j)
-        if (start_inds[j + 1] < start_inds[j]) return fail(PCS_ERR_ARG, "pcs_triangulate: start_inds must be non-decreasing");
-    for (int64_t r = 0; r < n_obs; ++r)
-        if (cam[r] < 0 || cam[r] >= n_cams) return fail(PCS_ERR_RANGE, "observation %lld has camera %d outside [0,%lld)", (long long)r, cam[r], (long long)n_cams);
-    int ndev = pcs_device_count();
-    if (ndev <= 0) return fail(PCS_ERR_NODEVICE, "pcs_triangulate: no HIP device visible (no CPU fallback)");
-    if (device < 0 || device >= ndev) return fail(PCS_ERR_ARG, "pcs_triangulate: device out of range");
-    HIPCHK(hipSetDevice(device));
-    std::vector<double> tab((size_t)n_cams * TRI_CAM_STRIDE, 0.0);
-    for (int64_t c = 0; c < n_cams; ++c) {
-        double *t = tab.data() + c * TRI_CAM_STRIDE;
-        const double *P = proj + 12 * c;
-        for (int k = 0; k < 12; ++k) t[k] = P[k];
-        const double *K = intrinsics + 9 * c;
-        t[22] = K[0]; t[23] = K[2]; t[24] = K[4]; t[25] = K[5];
-        for (int k = 0; k < 5; ++k) t[26 + k] = dists[5 * c + k];
-    }
-    int32_t *d_cam = nullptr; double *d_uv = nullptr, *d_tab = nullptr, *d_pts = nullptr, *d_scl = nullptr; int64_t *d_start = nullptr; void *d_scr = nullptr;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    int rc = PCS_OK;
-    auto cleanup = [&]() {
-        for (void *b : {(void *)d_cam, (void *)d_uv, (void *)d_tab, (void *)d_pts, (void *)d_start, d_scr, (void *)d_scl})
-            if (b) (void)hipFree(b);
-        if (e0) (void)hipEventDestroy(e0);
-        if (e1) (void)hipEventDestroy(e1);
-    };
-#define TRICHK(expr)                                                                                       \
-    do {                                                                                                   \
-        hipError_t _e = (expr);                                                                            \
-        if (_e != hipSuccess) { rc = fail(PCS_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); cleanup(); return rc; } \
-    } while (0)
-    TRICHK(hipMalloc(&d_cam, sizeof(int32_t) * std::max<int64_t>(1, n_obs)));
-    TRICHK(hipMalloc(&d_uv, sizeof(double) * 2 * std::max<int64_t>(1, n_obs)));
-    TRICHK(hipMalloc(&d_scr, sizeof(double) * 4 * std::max<int64_t>(1, n_obs)));  // Householder row r_i per observation
-    TRICHK(hipMalloc(&d_scl, sizeof(double) * 2 * std::max<int64_t>(1, n_obs)));  // (1 / E_i, lambda_i)
-    TRICHK(hipMalloc(&d_tab, sizeof(double) * tab.size()));
-    TRICHK(hipMalloc(&d_pts, sizeof(double) * 3 * n_pts));
-    TRICHK(hipMalloc(&d_start, sizeof(int64_t) * (n_pts + 1)));
-    TRICHK(hipEventCreate(&e0));
-    TRICHK(hipEventCreate(&e1));
-    if (n_obs) {
-        TRICHK(hipMemcpy(d_cam, cam, sizeof(int32_t) * n_obs, hipMemcpyHostToDevice));
-        TRICHK(hipMemcpy(d_uv, uv, sizeof(double) * 2 * n_obs, hipMemcpyHostToDevice));
-    }
-    TRICHK(hipMemcpy(d_tab, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice));
-    TRICHK(hipMemcpy(d_start, start_inds, sizeof(int64_t) * (n_pts + 1), hipMemcpyHostToDevice));
-    // lanes per point: PCS_TRI_LANES in {1, 2, 4, 8, 16} (A/B switch; default from profiles/r01/tri_legacy_bench.log)
-    const char *lanes_env = getenv("PCS_TRI_LANES");
-    const int lanes = lanes_env ? atoi(lanes_env) : 4;
-    const dim3 grid((unsigned)((n_pts * (lanes == 1 || lanes == 2 || lanes == 8 || lanes == 16 ? lanes : 4) + 255) / 256));
-#define PCS_TRI_LAUNCH(G_)                                                                                                   \
-    hipExtLaunchKernelGGL(triangulate_kernel<G_>, grid, dim3(256), 0, nullptr, e0, e1, 0, (const int32_t *)d_cam, (const double2 *)d_uv, \
-                          (const int64_t *)d_start, (const double *)d_tab, (double4 *)d_scr, (double2 *)d_scl, d_pts, n_pts)
-    if (lanes == 1) PCS_TRI_LAUNCH(1);
-    else if (lanes == 2) PCS_TRI_LAUNCH(2);
-    else if (lanes == 8) PCS_TRI_LAUNCH(8);
-    else if (lanes == 16) PCS_TRI_LAUNCH(16);
-    else PCS_TRI_LAUNCH(4);
-#undef PCS_TRI_LAUNCH
-    TRICHK(hipGetLastError());
-    TRICHK(hipMemcpy(pts, d_pts, sizeof(double) * 3 * n_pts, hipMemcpyDeviceToHost));
-    if (kernel_ms) {
-        TRICHK(hipEventSynchronize(e1));
-        TRICHK(hipEventElapsedTime(kernel_ms, e0, e1));
-    }
-#undef TRICHK
-    cleanup();
-    return PCS_OK;
+    pcs_triangulator *t = nullptr;
+    int rc = pcs_tri_create(&t, device, n_cams);
+    if (rc) return rc;
+    rc = pcs_tri_set_cameras(t, proj, intrinsics, dists);
+    if (!rc) rc = pcs_tri_set_observations(t, n_obs, cam, uv, n_pts, start_inds);
+    if (!rc) rc = pcs_tri_run(t, nullptr, nullptr);
+    if (!rc) rc = pcs_tri_points(t, pts);
+    if (!rc && kernel_ms) rc = pcs_tri_last_kernel_ms(t, kernel_ms);
+    const std::string keep = g_err;   // pcs_tri_destroy must not clobber the message
+    pcs_tri_destroy(t);
+    g_err = keep;
+    return rc;
 }
 
 int pcs_host_alloc(void **out, int64_t bytes) {
@@ -283,7 +411,7 @@ int pcs_create(pcs_engine **out, int chain, int dtype, int64_t n_cams, int64_t n
     h->dtype = dtype;
     h->device = device;
     h->P = chain_P(chain);
-    h->esize = dtype == PCS_F32 ? 4 : 8;
+    h->msize = dtype == PCS_F32 ? 4 : 8;
     h->osize = dtype == PCS_F64 ? 8 : 4;
     h->n_cams = n_cams;
     h->n_imgs = chain == PCS_CHAIN_FREE ? 0 : n_imgs;
@@ -314,10 +442,10 @@ int pcs_create(pcs_engine **out, int chain, int dtype, int64_t n_cams, int64_t n
     for (auto &e : h->ev) CREATE_CHK(hipEventCreate(&e));
     CREATE_CHK(hipMalloc(&h->d_param, sizeof(double) * h->n_params));
     CREATE_CHK(hipHostMalloc(reinterpret_cast<void **>(&h->h_param), sizeof(double) * h->n_params, hipHostMallocDefault));
-    CREATE_CHK(hipMalloc(&h->d_cam_slab, h->esize * n_cams * CAM_STRIDE));
-    CREATE_CHK(hipMalloc(&h->d_pose_slab, h->esize * std::max<int64_t>(1, h->n_imgs) * POSE_STRIDE));
-    CREATE_CHK(hipMalloc(&h->d_points, h->esize * padded_points(n_keys)));
-    CREATE_CHK(hipMemset(h->d_points, 0, h->esize * padded_points(n_keys)));
+    CREATE_CHK(hipMalloc(&h->d_cam_slab, sizeof(double) * n_cams * CAM_STRIDE));
+    CREATE_CHK(hipMalloc(&h->d_pose_slab, sizeof(double) * std::max<int64_t>(1, h->n_imgs) * POSE_STRIDE));
+    CREATE_CHK(hipMalloc(&h->d_points, sizeof(double) * padded_points(n_keys)));
+    CREATE_CHK(hipMemset(h->d_points, 0, sizeof(double) * padded_points(n_keys)));
     CREATE_CHK(hipMalloc(&h->d_sink, 64));
 #undef CREATE_CHK
     *out = h;
@@ -328,7 +456,7 @@ int pcs_destroy(pcs_engine *h) {
     if (!h) return PCS_OK;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
-    void *bufs[] = {h->d_cam, h->d_img, h->d_key, h->d_order, h->d_order_ck, h->d_order_ik, h->d_uv, h->d_param, h->d_cam_slab, h->d_pose_slab, h->d_points,
+    void *bufs[] = {h->d_cam, h->d_img, h->d_key, h->d_packed, h->d_order, h->d_order_ck, h->d_order_ik, h->d_uv, h->d_param, h->d_cam_slab, h->d_pose_slab, h->d_points,
                     h->d_resid, h->d_jac, h->d_keep, h->d_row_off, h->d_data, h->d_vin, h->d_vout, h->d_cost, h->d_im_points, h->d_cam_tab, h->d_sink, h->d_H};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
@@ -374,7 +502,7 @@ static int upload_detections(pcs_engine *h, std::vector<int32_t> &cam, std::vect
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(h->stream));
     h->point_orders_tried = false;
-    for (void **b : {(void **)&h->d_cam, (void **)&h->d_img, (void **)&h->d_key, (void **)&h->d_order, (void **)&h->d_order_ck,
+    for (void **b : {(void **)&h->d_cam, (void **)&h->d_img, (void **)&h->d_key, (void **)&h->d_packed, (void **)&h->d_order, (void **)&h->d_order_ck,
                      (void **)&h->d_order_ik, &h->d_uv, &h->d_resid, &h->d_jac,
                      (void **)&h->d_keep, (void **)&h->d_row_off, &h->d_data}) {
         if (*b) HIPCHK(hipFree(*b));
@@ -383,14 +511,26 @@ static int upload_detections(pcs_engine *h, std::vector<int32_t> &cam, std::vect
     h->jac_capacity = h->resid_capacity = h->data_capacity = 0;
     h->nnz = -1;
     if (n == 0) return PCS_OK;
-    HIPCHK(hipMalloc(&h->d_cam, sizeof(int32_t) * n));
-    HIPCHK(hipMalloc(&h->d_img, sizeof(int32_t) * n));
-    HIPCHK(hipMalloc(&h->d_key, sizeof(int32_t) * n));
-    HIPCHK(hipMalloc(&h->d_uv, h->esize * 2 * n));
-    HIPCHK(hipMemcpy(h->d_cam, h->h_cam.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(h->d_img, h->h_img.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(h->d_key, h->h_key.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice));
-    if (h->esize == 8) {
+    // index word: cam | image | key bit fields when they fit 32 bits (12 -> 4 bytes per detection), else three arrays
+    auto bits_for = [](int64_t count) { int b = 0; while (((int64_t)1 << b) < count) ++b; return b; };
+    h->key_bits = bits_for(h->n_keys);
+    h->img_bits = h->chain == PCS_CHAIN_FREE ? 0 : bits_for(h->n_imgs);   // the free chain has no image column (its values are not range-checked)
+    if (h->pack_indices && h->key_bits + h->img_bits + bits_for(h->n_cams) <= 32 && h->key_bits + h->img_bits <= 31) {
+        std::vector<uint32_t> w(n);
+        for (int64_t i = 0; i < n; ++i)
+            w[i] = ((uint32_t)h->h_cam[i] << (h->key_bits + h->img_bits)) | ((h->img_bits ? (uint32_t)h->h_img[i] : 0u) << h->key_bits) | (uint32_t)h->h_key[i];
+        HIPCHK(hipMalloc(&h->d_packed, sizeof(uint32_t) * n));
+        HIPCHK(hipMemcpy(h->d_packed, w.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice));
+    } else {
+        HIPCHK(hipMalloc(&h->d_cam, sizeof(int32_t) * n));
+        HIPCHK(hipMalloc(&h->d_img, sizeof(int32_t) * n));
+        HIPCHK(hipMalloc(&h->d_key, sizeof(int32_t) * n));
+        HIPCHK(hipMemcpy(h->d_cam, h->h_cam.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(h->d_img, h->h_img.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(h->d_key, h->h_key.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice));
+    }
+    HIPCHK(hipMalloc(&h->d_uv, h->msize * 2 * n));
+    if (h->msize == 8) {
         HIPCHK(hipMemcpy(h->d_uv, uv, sizeof(double) * 2 * n, hipMemcpyHostToDevice));
     } else {
         std::vector<float> f(2 * n);
@@ -442,14 +582,7 @@ int pcs_set_template(pcs_engine *h, const double *points) {
     if (h->chain != PCS_CHAIN_TEMPLATE) return fail(PCS_ERR_ARG, "pcs_set_template: only the template chain has constant points");
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(h->stream));
-    const int64_t cnt = 3 * h->n_keys;
-    if (h->esize == 8) {
-        HIPCHK(hipMemcpy(h->d_points, points, sizeof(double) * cnt, hipMemcpyHostToDevice));
-    } else {
-        std::vector<float> f(cnt);
-        for (int64_t i = 0; i < cnt; ++i) f[i] = (float)points[i];
-        HIPCHK(hipMemcpy(h->d_points, f.data(), sizeof(float) * cnt, hipMemcpyHostToDevice));
-    }
+    HIPCHK(hipMemcpy(h->d_points, points, sizeof(double) * 3 * h->n_keys, hipMemcpyHostToDevice));
     h->have_template = true;
     return PCS_OK;
 }
@@ -469,14 +602,18 @@ int pcs_set_option(pcs_engine *h, const char *key, int64_t value) {
         h->eval_count = 0;
     } else if (!strcmp(key, "xcd_remap")) {
         h->xcd_remap = value != 0;
-    } else if (!strcmp(key, "rowsplit")) {
-        h->rowsplit = value != 0;
+    } else if (!strcmp(key, "waves_per_wg")) {
+        if (value < 0 || value > WAVES_PER_WG || value == 3) return fail(PCS_ERR_ARG, "waves_per_wg must be 0 (automatic), 1, 2 or 4");
+        h->waves_per_wg = (int)value;
+    } else if (!strcmp(key, "pack_indices")) {
+        h->pack_indices = value != 0;   // takes effect at the next pcs_set_detections*
+    } else if (!strcmp(key, "normal_rows")) {
+        if (value != 32 && value != 64) return fail(PCS_ERR_ARG, "normal_rows must be 32 or 64");
+        h->normal_rows = (int)value;
     } else if (!strcmp(key, "matfree_lds")) {
         h->matfree_lds = value != 0;
     } else if (!strcmp(key, "normal_debug")) {
         h->normal_debug = (int)value;
-    } else if (!strcmp(key, "normal_point_pass")) {
-        h->normal_point_pass = value != 0;
     } else if (!strcmp(key, "compact_variant")) {
         if (value < 0 || value > 1) return fail(PCS_ERR_ARG, "compact_variant must be 0 or 1");
         h->compact_variant = (int)value;
@@ -508,10 +645,22 @@ int pcs_set_option(pcs_engine *h, const char *key, int64_t value) {
 // dispatch itself, without the extra barrier packets that hipEventRecord would put between kernels.
 struct EvPair { hipEvent_t start, stop; };
 
-template <int CHAIN, typename T, int MODE, int VARIANT, typename TO>
-static hipError_t launch_eval_v(const EvalArgs &a, dim3 grid, size_t lds, hipStream_t s, EvPair ev) {
-    auto kern = ba_eval_kernel<CHAIN, T, MODE, VARIANT, TO>;
-    static size_t configured[64] = {0};  // per device: largest dynamic-LDS size already enabled for this kernel
+static DetTable det_table(const pcs_engine *h) {
+    DetTable t{};
+    t.packed = h->d_packed;
+    t.cam = h->d_cam; t.img = h->d_img; t.key = h->d_key;
+    t.uv = h->d_uv;
+    t.key_bits = h->key_bits; t.img_bits = h->img_bits;
+    t.uv_f32 = h->msize == 4;
+    return t;
+}
+
+template <int CHAIN, int MODE, int VARIANT, typename TO>
+static hipError_t launch_eval_v(const EvalArgs &a, dim3 grid, int threads, size_t lds, hipStream_t s, EvPair ev) {
+    auto kern = ba_eval_kernel<CHAIN, MODE, VARIANT, TO>;
+    // per device: largest dynamic-LDS size already enabled for this kernel (one handle = one host thread at a time;
+    // handles driven from different threads only race on a value that is monotone and idempotent to set)
+    static size_t configured[64] = {0};
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (lds > 48 * 1024 && lds > configured[dev & 63]) {
@@ -519,91 +668,72 @@ static hipError_t launch_eval_v(const EvalArgs &a, dim3 grid, size_t lds, hipStr
         if (e != hipSuccess) return e;
         configured[dev & 63] = lds;
     }
-    hipExtLaunchKernelGGL(kern, grid, dim3(WG_THREADS), (std::uint32_t)lds, s, ev.start, ev.stop, 0, a);
+    hipExtLaunchKernelGGL(kern, grid, dim3(threads), (std::uint32_t)lds, s, ev.start, ev.stop, 0, a);
     return hipGetLastError();
 }
 
-template <int CHAIN, typename T, int MODE, typename TO>
-static hipError_t launch_eval_m(int variant, const EvalArgs &a, dim3 grid, size_t lds, hipStream_t s, EvPair ev) {
+template <int CHAIN, int MODE, typename TO>
+static hipError_t launch_eval_m(int variant, const EvalArgs &a, dim3 grid, int threads, size_t lds, hipStream_t s, EvPair ev) {
     switch (variant) {
-        case 0: return launch_eval_v<CHAIN, T, MODE, 0, TO>(a, grid, lds, s, ev);
-        case 1: return launch_eval_v<CHAIN, T, MODE, 1, TO>(a, grid, lds, s, ev);
-        case 2: return launch_eval_v<CHAIN, T, MODE, 2, TO>(a, grid, lds, s, ev);
-        case 3: return launch_eval_v<CHAIN, T, MODE, 3, TO>(a, grid, lds, s, ev);
-        case 4: return launch_eval_v<CHAIN, T, MODE, 4, TO>(a, grid, lds, s, ev);
-        case 5: return launch_eval_v<CHAIN, T, MODE, 5, TO>(a, grid, lds, s, ev);
-        case 6: return launch_eval_v<CHAIN, T, MODE, 6, TO>(a, grid, lds, s, ev);
-        default: return launch_eval_v<CHAIN, T, MODE, 7, TO>(a, grid, lds, s, ev);
+        case 0: return launch_eval_v<CHAIN, MODE, 0, TO>(a, grid, threads, lds, s, ev);
+        case 1: return launch_eval_v<CHAIN, MODE, 1, TO>(a, grid, threads, lds, s, ev);
+        case 2: return launch_eval_v<CHAIN, MODE, 2, TO>(a, grid, threads, lds, s, ev);
+        case 3: return launch_eval_v<CHAIN, MODE, 3, TO>(a, grid, threads, lds, s, ev);
+        case 4: return launch_eval_v<CHAIN, MODE, 4, TO>(a, grid, threads, lds, s, ev);
+        case 5: return launch_eval_v<CHAIN, MODE, 5, TO>(a, grid, threads, lds, s, ev);
+        case 6: return launch_eval_v<CHAIN, MODE, 6, TO>(a, grid, threads, lds, s, ev);
+        default: return launch_eval_v<CHAIN, MODE, 7, TO>(a, grid, threads, lds, s, ev);
     }
 }
 
-template <int CHAIN, typename T, typename TO>
-static hipError_t launch_eval_c(int mode, int variant, const EvalArgs &a, dim3 grid, size_t lds, hipStream_t s, EvPair ev) {
+template <int CHAIN, typename TO>
+static hipError_t launch_eval_c(int mode, int variant, const EvalArgs &a, dim3 grid, int threads, size_t lds, hipStream_t s, EvPair ev) {
     switch (mode) {
-        case MODE_RESID: return launch_eval_m<CHAIN, T, MODE_RESID, TO>(variant & ~VAR_TRANSPOSE, a, grid, lds, s, ev);
-        case MODE_JAC: return launch_eval_m<CHAIN, T, MODE_JAC, TO>(variant, a, grid, lds, s, ev);
-        default: return launch_eval_m<CHAIN, T, MODE_RESID | MODE_JAC, TO>(variant, a, grid, lds, s, ev);
+        case MODE_RESID: return launch_eval_m<CHAIN, MODE_RESID, TO>(variant & ~VAR_TRANSPOSE, a, grid, threads, lds, s, ev);
+        case MODE_JAC: return launch_eval_m<CHAIN, MODE_JAC, TO>(variant, a, grid, threads, lds, s, ev);
+        default: return launch_eval_m<CHAIN, MODE_RESID | MODE_JAC, TO>(variant, a, grid, threads, lds, s, ev);
     }
 }
 
-template <typename T, typename TO = T>
-static hipError_t launch_eval_t(int chain, int mode, int variant, const EvalArgs &a, dim3 grid, size_t lds, hipStream_t s, EvPair ev) {
+template <typename TO>
+static hipError_t launch_eval_t(int chain, int mode, int variant, const EvalArgs &a, dim3 grid, int threads, size_t lds, hipStream_t s, EvPair ev) {
     switch (chain) {
-        case CHAIN_TEMPLATE: return launch_eval_c<CHAIN_TEMPLATE, T, TO>(mode, variant, a, grid, lds, s, ev);
-        case CHAIN_SELF: return launch_eval_c<CHAIN_SELF, T, TO>(mode, variant, a, grid, lds, s, ev);
-        default: return launch_eval_c<CHAIN_FREE, T, TO>(mode, variant, a, grid, lds, s, ev);
+        case CHAIN_TEMPLATE: return launch_eval_c<CHAIN_TEMPLATE, TO>(mode, variant, a, grid, threads, lds, s, ev);
+        case CHAIN_SELF: return launch_eval_c<CHAIN_SELF, TO>(mode, variant, a, grid, threads, lds, s, ev);
+        default: return launch_eval_c<CHAIN_FREE, TO>(mode, variant, a, grid, threads, lds, s, ev);
     }
 }
 
-template <int CHAIN, typename T>
-static hipError_t launch_rowsplit_c(int mode, bool nt, const EvalArgs &a, dim3 grid, size_t lds, hipStream_t s, EvPair ev) {
-#define PCS_RS(MODE_, NT_) hipExtLaunchKernelGGL((ba_eval_rowsplit_kernel<CHAIN, T, MODE_, NT_>), grid, dim3(WG_THREADS), (std::uint32_t)lds, s, ev.start, ev.stop, 0, a)
-    if (mode == MODE_JAC) { if (nt) PCS_RS(MODE_JAC, true); else PCS_RS(MODE_JAC, false); }
-    else { if (nt) PCS_RS(MODE_RESID | MODE_JAC, true); else PCS_RS(MODE_RESID | MODE_JAC, false); }
-#undef PCS_RS
-    return hipGetLastError();
-}
-
-template <typename T>
-static hipError_t launch_rowsplit_t(int chain, int mode, bool nt, const EvalArgs &a, dim3 grid, size_t lds, hipStream_t s, EvPair ev) {
-    switch (chain) {
-        case CHAIN_TEMPLATE: return launch_rowsplit_c<CHAIN_TEMPLATE, T>(mode, nt, a, grid, lds, s, ev);
-        case CHAIN_SELF: return launch_rowsplit_c<CHAIN_SELF, T>(mode, nt, a, grid, lds, s, ev);
-        default: return launch_rowsplit_c<CHAIN_FREE, T>(mode, nt, a, grid, lds, s, ev);
-    }
-}
-
-template <int CHAIN, typename T, typename TO>
+template <int CHAIN, typename TO>
 static hipError_t launch_compact_tile_c(int mode, const EvalArgs &a, dim3 grid, size_t lds, hipStream_t s) {
-    if (mode == MODE_RESID) hipLaunchKernelGGL((ba_compact_tile_kernel<CHAIN, T, MODE_RESID, TO>), grid, dim3(WG_THREADS), lds, s, a);
-    else if (mode == MODE_JAC) hipLaunchKernelGGL((ba_compact_tile_kernel<CHAIN, T, MODE_JAC, TO>), grid, dim3(WG_THREADS), lds, s, a);
-    else hipLaunchKernelGGL((ba_compact_tile_kernel<CHAIN, T, MODE_RESID | MODE_JAC, TO>), grid, dim3(WG_THREADS), lds, s, a);
+    if (mode == MODE_RESID) hipLaunchKernelGGL((ba_compact_tile_kernel<CHAIN, MODE_RESID, TO>), grid, dim3(WG_THREADS), lds, s, a);
+    else if (mode == MODE_JAC) hipLaunchKernelGGL((ba_compact_tile_kernel<CHAIN, MODE_JAC, TO>), grid, dim3(WG_THREADS), lds, s, a);
+    else hipLaunchKernelGGL((ba_compact_tile_kernel<CHAIN, MODE_RESID | MODE_JAC, TO>), grid, dim3(WG_THREADS), lds, s, a);
     return hipGetLastError();
 }
 
-template <typename T, typename TO = T>
+template <typename TO>
 static hipError_t launch_compact_tile_t(int chain, int mode, const EvalArgs &a, dim3 grid, size_t lds, hipStream_t s) {
     switch (chain) {
-        case CHAIN_TEMPLATE: return launch_compact_tile_c<CHAIN_TEMPLATE, T, TO>(mode, a, grid, lds, s);
-        case CHAIN_SELF: return launch_compact_tile_c<CHAIN_SELF, T, TO>(mode, a, grid, lds, s);
-        default: return launch_compact_tile_c<CHAIN_FREE, T, TO>(mode, a, grid, lds, s);
+        case CHAIN_TEMPLATE: return launch_compact_tile_c<CHAIN_TEMPLATE, TO>(mode, a, grid, lds, s);
+        case CHAIN_SELF: return launch_compact_tile_c<CHAIN_SELF, TO>(mode, a, grid, lds, s);
+        default: return launch_compact_tile_c<CHAIN_FREE, TO>(mode, a, grid, lds, s);
     }
 }
 
-template <int CHAIN, typename T>
+template <int CHAIN>
 static hipError_t launch_compact_c(int mode, const EvalArgs &a, dim3 grid, hipStream_t s) {
-    if (mode == MODE_RESID) hipLaunchKernelGGL((ba_compact_kernel<CHAIN, T, MODE_RESID>), grid, dim3(WG_THREADS), 0, s, a);
-    else if (mode == MODE_JAC) hipLaunchKernelGGL((ba_compact_kernel<CHAIN, T, MODE_JAC>), grid, dim3(WG_THREADS), 0, s, a);
-    else hipLaunchKernelGGL((ba_compact_kernel<CHAIN, T, MODE_RESID | MODE_JAC>), grid, dim3(WG_THREADS), 0, s, a);
+    if (mode == MODE_RESID) hipLaunchKernelGGL((ba_compact_kernel<CHAIN, MODE_RESID>), grid, dim3(WG_THREADS), 0, s, a);
+    else if (mode == MODE_JAC) hipLaunchKernelGGL((ba_compact_kernel<CHAIN, MODE_JAC>), grid, dim3(WG_THREADS), 0, s, a);
+    else hipLaunchKernelGGL((ba_compact_kernel<CHAIN, MODE_RESID | MODE_JAC>), grid, dim3(WG_THREADS), 0, s, a);
     return hipGetLastError();
 }
 
-template <typename T>
 static hipError_t launch_compact_t(int chain, int mode, const EvalArgs &a, dim3 grid, hipStream_t s) {
     switch (chain) {
-        case CHAIN_TEMPLATE: return launch_compact_c<CHAIN_TEMPLATE, T>(mode, a, grid, s);
-        case CHAIN_SELF: return launch_compact_c<CHAIN_SELF, T>(mode, a, grid, s);
-        default: return launch_compact_c<CHAIN_FREE, T>(mode, a, grid, s);
+        case CHAIN_TEMPLATE: return launch_compact_c<CHAIN_TEMPLATE>(mode, a, grid, s);
+        case CHAIN_SELF: return launch_compact_c<CHAIN_SELF>(mode, a, grid, s);
+        default: return launch_compact_c<CHAIN_FREE>(mode, a, grid, s);
     }
 }
 
@@ -613,79 +743,76 @@ static int launch_slab_prep(pcs_engine *h, const double *d_prm, hipStream_t s, h
     const int64_t ents = h->n_cams + (has_pose ? h->n_imgs : 0);
     int64_t threads = ents;
     if (copy_points) threads = std::max<int64_t>(threads, std::min<int64_t>(3 * h->n_keys, 1 << 16));
-    const dim3 grid((unsigned)((threads + 127) / 128));
-    if (h->esize == 8)
-        hipExtLaunchKernelGGL(slab_prep_kernel<double>, grid, dim3(128), 0, s, start, nullptr, 0, d_prm, (double *)h->d_cam_slab,
-                              (double *)h->d_pose_slab, (double *)h->d_points, (int)h->n_cams, (int)h->n_imgs, (int)h->n_keys,
-                              h->extr_off, h->pose_off, h->point_off, has_pose, copy_points);
-    else
-        hipExtLaunchKernelGGL(slab_prep_kernel<float>, grid, dim3(128), 0, s, start, nullptr, 0, d_prm, (float *)h->d_cam_slab,
-                              (float *)h->d_pose_slab, (float *)h->d_points, (int)h->n_cams, (int)h->n_imgs, (int)h->n_keys,
-                              h->extr_off, h->pose_off, h->point_off, has_pose, copy_points);
+    const dim3 grid((unsigned)((threads + 63) / 64));
+    hipExtLaunchKernelGGL(slab_prep_kernel, grid, dim3(64), 0, s, start, nullptr, 0, d_prm, (double *)h->d_cam_slab,
+                          (double *)h->d_pose_slab, (double *)h->d_points, (int)h->n_cams, (int)h->n_imgs, (int)h->n_keys,
+                          h->extr_off, h->pose_off, h->point_off, has_pose, copy_points);
     HIPCHK(hipGetLastError());
     h->linearized = true;
     return PCS_OK;
 }
 
-template <int CHAIN, typename T, bool LDS_ACC>
+template <int CHAIN, bool LDS_ACC>
 static hipError_t launch_matfree_c(int op, const MatfreeArgs &a, dim3 grid, size_t lds, hipStream_t s) {
     if (lds > 48 * 1024) {  // opt in to more than the default dynamic-LDS cap
-        const void *fns[] = {(const void *)ba_matfree_kernel<CHAIN, T, OP_JTU, LDS_ACC>, (const void *)ba_matfree_kernel<CHAIN, T, OP_JTJV, LDS_ACC>,
-                             (const void *)ba_matfree_kernel<CHAIN, T, OP_DIAG, LDS_ACC>, (const void *)ba_matfree_kernel<CHAIN, T, OP_GRAD, LDS_ACC>};
+        const void *fns[] = {(const void *)ba_matfree_kernel<CHAIN, OP_JTU, LDS_ACC>, (const void *)ba_matfree_kernel<CHAIN, OP_JTJV, LDS_ACC>,
+                             (const void *)ba_matfree_kernel<CHAIN, OP_DIAG, LDS_ACC>, (const void *)ba_matfree_kernel<CHAIN, OP_GRAD, LDS_ACC>};
         hipError_t e = hipFuncSetAttribute(fns[op - 1], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
     switch (op) {
-        case OP_JV: hipLaunchKernelGGL((ba_matfree_kernel<CHAIN, T, OP_JV, false>), grid, dim3(256), 0, s, a); break;
-        case OP_JTU: hipLaunchKernelGGL((ba_matfree_kernel<CHAIN, T, OP_JTU, LDS_ACC>), grid, dim3(256), lds, s, a); break;
-        case OP_JTJV: hipLaunchKernelGGL((ba_matfree_kernel<CHAIN, T, OP_JTJV, LDS_ACC>), grid, dim3(256), lds, s, a); break;
-        case OP_DIAG: hipLaunchKernelGGL((ba_matfree_kernel<CHAIN, T, OP_DIAG, LDS_ACC>), grid, dim3(256), lds, s, a); break;
-        default: hipLaunchKernelGGL((ba_matfree_kernel<CHAIN, T, OP_GRAD, LDS_ACC>), grid, dim3(256), lds, s, a); break;
+        case OP_JV: hipLaunchKernelGGL((ba_matfree_kernel<CHAIN, OP_JV, false>), grid, dim3(256), 0, s, a); break;
+        case OP_JTU: hipLaunchKernelGGL((ba_matfree_kernel<CHAIN, OP_JTU, LDS_ACC>), grid, dim3(256), lds, s, a); break;
+        case OP_JTJV: hipLaunchKernelGGL((ba_matfree_kernel<CHAIN, OP_JTJV, LDS_ACC>), grid, dim3(256), lds, s, a); break;
+        case OP_DIAG: hipLaunchKernelGGL((ba_matfree_kernel<CHAIN, OP_DIAG, LDS_ACC>), grid, dim3(256), lds, s, a); break;
+        default: hipLaunchKernelGGL((ba_matfree_kernel<CHAIN, OP_GRAD, LDS_ACC>), grid, dim3(256), lds, s, a); break;
     }
     return hipGetLastError();
 }
 
-template <typename T>
 static hipError_t launch_matfree_t(int chain, int op, bool lds_acc, const MatfreeArgs &a, dim3 grid, size_t lds, hipStream_t s) {
     if (lds_acc) {
         switch (chain) {
-            case CHAIN_TEMPLATE: return launch_matfree_c<CHAIN_TEMPLATE, T, true>(op, a, grid, lds, s);
-            case CHAIN_SELF: return launch_matfree_c<CHAIN_SELF, T, true>(op, a, grid, lds, s);
-            default: return launch_matfree_c<CHAIN_FREE, T, true>(op, a, grid, lds, s);
+            case CHAIN_TEMPLATE: return launch_matfree_c<CHAIN_TEMPLATE, true>(op, a, grid, lds, s);
+            case CHAIN_SELF: return launch_matfree_c<CHAIN_SELF, true>(op, a, grid, lds, s);
+            default: return launch_matfree_c<CHAIN_FREE, true>(op, a, grid, lds, s);
         }
     }
     switch (chain) {
-        case CHAIN_TEMPLATE: return launch_matfree_c<CHAIN_TEMPLATE, T, false>(op, a, grid, 0, s);
-        case CHAIN_SELF: return launch_matfree_c<CHAIN_SELF, T, false>(op, a, grid, 0, s);
-        default: return launch_matfree_c<CHAIN_FREE, T, false>(op, a, grid, 0, s);
+        case CHAIN_TEMPLATE: return launch_matfree_c<CHAIN_TEMPLATE, false>(op, a, grid, 0, s);
+        case CHAIN_SELF: return launch_matfree_c<CHAIN_SELF, false>(op, a, grid, 0, s);
+        default: return launch_matfree_c<CHAIN_FREE, false>(op, a, grid, 0, s);
     }
 }
 
-template <typename T>
-static hipError_t launch_normal_t(int chain, const NormalArgs &a, dim3 grid, size_t lds, hipStream_t s) {
-    switch (chain) {
-        case CHAIN_TEMPLATE: hipLaunchKernelGGL((ba_normal_kernel<CHAIN_TEMPLATE, T>), grid, dim3(64 * NORMAL_WAVES), lds, s, a); break;
-        case CHAIN_SELF: hipLaunchKernelGGL((ba_normal_kernel<CHAIN_SELF, T>), grid, dim3(64 * NORMAL_WAVES), lds, s, a); break;
-        default: hipLaunchKernelGGL((ba_normal_kernel<CHAIN_FREE, T>), grid, dim3(64 * NORMAL_WAVES), lds, s, a); break;
+// one pass of the normal-equations kernel (ba_normal.hpp); the workgroup is one wave
+template <int CHAIN, int PASS>
+static hipError_t launch_normal_p(int rows, const NormalArgs &a, dim3 grid, hipStream_t s) {
+    if (rows == 32) hipLaunchKernelGGL((ba_normal_mfma_kernel<CHAIN, PASS, 32>), grid, dim3(64), normal_lds_bytes(CHAIN, PASS, 32), s, a);
+    else hipLaunchKernelGGL((ba_normal_mfma_kernel<CHAIN, PASS, 64>), grid, dim3(64), normal_lds_bytes(CHAIN, PASS, 64), s, a);
+    return hipGetLastError();
+}
+
+static hipError_t launch_normal(int chain, int pass, int rows, const NormalArgs &a, dim3 grid, hipStream_t s) {
+    if (pass == PASS_SHARED) {
+        switch (chain) {
+            case CHAIN_TEMPLATE: return launch_normal_p<CHAIN_TEMPLATE, PASS_SHARED>(rows, a, grid, s);
+            case CHAIN_SELF: return launch_normal_p<CHAIN_SELF, PASS_SHARED>(rows, a, grid, s);
+            default: return launch_normal_p<CHAIN_FREE, PASS_SHARED>(rows, a, grid, s);
+        }
     }
-    return hipGetLastError();
+    if (pass == PASS_CAMKEY)
+        return chain == CHAIN_SELF ? launch_normal_p<CHAIN_SELF, PASS_CAMKEY>(rows, a, grid, s) : launch_normal_p<CHAIN_FREE, PASS_CAMKEY>(rows, a, grid, s);
+    return launch_normal_p<CHAIN_SELF, PASS_IMGKEY>(rows, a, grid, s);
 }
 
-template <typename T>
-static hipError_t launch_normal_point_t(int chain, int which, const NormalArgs &a, dim3 grid, hipStream_t s) {
-    if (chain == CHAIN_SELF && which == 0) hipLaunchKernelGGL((ba_normal_point_kernel<CHAIN_SELF, T, 0>), grid, dim3(256), 0, s, a);
-    else if (chain == CHAIN_SELF) hipLaunchKernelGGL((ba_normal_point_kernel<CHAIN_SELF, T, 1>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((ba_normal_point_kernel<CHAIN_FREE, T, 0>), grid, dim3(256), 0, s, a);
-    return hipGetLastError();
-}
-
-// (cam, key)- and (image, key)-sorted visiting orders for ba_normal_point_kernel: built on the host at the first
-// normal-equations call of a self / free engine (two stable sorts, ~0.1 s at 1e6 detections)
+// (cam, key)- and (image, key)-sorted visiting orders for the point passes of the normal equations: built on the host
+// at the first normal-equations call of a self / free engine (two stable sorts, ~0.1 s at 1e6 detections)
 static int ensure_point_orders(pcs_engine *h) {
     if (h->point_orders_tried || h->chain == PCS_CHAIN_TEMPLATE) return PCS_OK;
     h->point_orders_tried = true;
     const int64_t n = h->n;
-    if (n <= 0 || n > INT32_MAX) return PCS_OK;
+    if (n <= 0) return PCS_OK;
     std::vector<int32_t> order(n);
     for (int pass = 0; pass < (h->chain == PCS_CHAIN_SELF ? 2 : 1); ++pass) {
         const std::vector<int32_t> &major = pass == 0 ? h->h_cam : h->h_img;
@@ -700,52 +827,43 @@ static int ensure_point_orders(pcs_engine *h) {
     return PCS_OK;
 }
 
-// slab_prep + ba_normal_kernel on `s`; d_prm holds the parameter string; outputs are zeroed here.
+// slab_prep + the normal-equations passes on `s`; d_prm holds the parameter string; outputs are zeroed here.
 static int enqueue_normal(pcs_engine *h, const double *d_prm, double *d_H, double *d_g, double *d_cost, hipStream_t s) {
     if (h->n <= 0) return fail(PCS_ERR_STATE, "no detections set");
+    if (h->n > INT32_MAX) return fail(PCS_ERR_ARG, "normal equations: tables beyond 2^31 rows are not supported (visiting orders are int32)");
     if (h->chain == PCS_CHAIN_TEMPLATE && !h->have_template) return fail(PCS_ERR_STATE, "template points not set");
     HIPCHK(hipSetDevice(h->device));
-    if (h->normal_point_pass) {
-        int rc0 = ensure_point_orders(h);
-        if (rc0) return rc0;
-    }
-    const bool point_pass = h->normal_point_pass && h->d_order_ck && (h->chain != PCS_CHAIN_SELF || h->d_order_ik);
+    int rc0 = ensure_point_orders(h);
+    if (rc0) return rc0;
     HIPCHK(hipMemsetAsync(d_H, 0, sizeof(double) * h->n_params * h->n_params, s));
     HIPCHK(hipMemsetAsync(d_g, 0, sizeof(double) * h->n_params, s));
     HIPCHK(hipMemsetAsync(d_cost, 0, sizeof(double), s));
     int rc = launch_slab_prep(h, d_prm, s);
     if (rc) return rc;
     NormalArgs a{};
-    a.cam = h->d_cam; a.img = h->d_img; a.key = h->d_key; a.uv = h->d_uv;
-    a.order = h->d_order;
+    a.tab = det_table(h);
     a.cam_slab = h->d_cam_slab; a.pose_slab = h->d_pose_slab; a.points = h->d_points;
     a.H = d_H; a.g = d_g; a.cost = d_cost;
     a.n = h->n; a.n_tiles = (h->n + TILE - 1) / TILE;
     a.extr_off = h->extr_off; a.pose_off = h->pose_off; a.point_off = h->point_off;
     a.n_params = h->n_params;
-    // every wave walks a contiguous range of tiles, so its register accumulators survive across tiles;
-    // LDS (23.6 KB per wave) allows 3 two-wave workgroups per CU
-    const int64_t wpc = h->wgs_per_cu > 0 ? h->wgs_per_cu : 3;
-    const int64_t target_waves = (int64_t)h->n_cu * wpc * NORMAL_WAVES;
+    a.debug = h->normal_debug;
+    // every wave walks a contiguous range of tiles, so its register accumulators survive across tiles.  One-wave
+    // workgroups; the LDS image (22.9 KB for 22 columns x 64 rows) allows 7 per CU; two rounds of waves even out the tail.
+    const int64_t wpc = h->wgs_per_cu > 0 ? h->wgs_per_cu : 14;
+    const int64_t target_waves = (int64_t)h->n_cu * wpc;
     const int64_t tpw = std::max<int64_t>(1, (a.n_tiles + target_waves - 1) / target_waves);
     a.tiles_per_wave = (int32_t)tpw;
-    a.skip_points = point_pass ? 1 : 0;
-    a.debug = h->normal_debug;
-    const int64_t waves = (a.n_tiles + tpw - 1) / tpw;
-    const dim3 grid((unsigned)((waves + NORMAL_WAVES - 1) / NORMAL_WAVES));
-    const size_t lds = sizeof(double) * (size_t)NORMAL_WAVES * (NORMAL_ROWS * normal_row(h->chain) + normal_tail(h->chain));
+    const dim3 grid((unsigned)((a.n_tiles + tpw - 1) / tpw));
     hipEvent_t *ev = h->ev.data() + 3 * (h->ev_count % h->ev_ring);
     HIPCHK(hipEventRecord(ev[0], s));
     HIPCHK(hipEventRecord(ev[1], s));
-    hipError_t e = h->esize == 8 ? launch_normal_t<double>(h->chain, a, grid, lds, s) : launch_normal_t<float>(h->chain, a, grid, lds, s);
-    if (e != hipSuccess) return fail(PCS_ERR_HIP, "normal-equations kernel launch failed: %s", hipGetErrorString(e));
-    if (point_pass) {  // point columns: one pass per coupling over its key-sorted order (ba_normal.hpp)
-        const dim3 pgrid((unsigned)std::min<int64_t>((a.n_tiles + 3) / 4, (int64_t)h->n_cu * 8));
-        for (int which = 0; which < (h->chain == PCS_CHAIN_SELF ? 2 : 1); ++which) {
-            a.order = which == 0 ? h->d_order_ck : h->d_order_ik;
-            e = h->esize == 8 ? launch_normal_point_t<double>(h->chain, which, a, pgrid, s) : launch_normal_point_t<float>(h->chain, which, a, pgrid, s);
-            if (e != hipSuccess) return fail(PCS_ERR_HIP, "normal-equations point kernel launch failed: %s", hipGetErrorString(e));
-        }
+    const int n_pass = h->chain == PCS_CHAIN_TEMPLATE ? 1 : h->chain == PCS_CHAIN_SELF ? 3 : 2;
+    for (int pass = 0; pass < n_pass; ++pass) {
+        a.order = pass == PASS_SHARED ? h->d_order : pass == PASS_CAMKEY ? h->d_order_ck : h->d_order_ik;
+        if (pass != PASS_SHARED && !a.order) return fail(PCS_ERR_STATE, "normal equations: key-sorted visiting order missing");
+        hipError_t e = launch_normal(h->chain, pass, h->normal_rows, a, grid, s);
+        if (e != hipSuccess) return fail(PCS_ERR_HIP, "normal-equations kernel launch failed: %s", hipGetErrorString(e));
     }
     HIPCHK(hipEventRecord(ev[2], s));
     ++h->ev_count;
@@ -769,7 +887,7 @@ static int enqueue_eval(pcs_engine *h, const double *d_prm, void *d_resid, void 
         if (rc0) return rc0;
     }
     EvalArgs a{};
-    a.cam = h->d_cam; a.img = h->d_img; a.key = h->d_key; a.uv = h->d_uv;
+    a.tab = det_table(h);
     a.cam_slab = h->d_cam_slab; a.pose_slab = h->d_pose_slab; a.points = h->d_points;
     a.resid = d_resid; a.jac = d_out; a.sink = h->d_sink;
     a.xcd_remap = h->xcd_remap ? 1 : 0;
@@ -779,10 +897,9 @@ static int enqueue_eval(pcs_engine *h, const double *d_prm, void *d_resid, void 
         a.keep = h->d_keep; a.row_off = h->d_row_off;
         if (timed) HIPCHK(hipEventRecord(ev[1], s));
         hipError_t e;
-        if (h->compact_variant == 0 && h->dtype != PCS_MIXED) {  // per-lane stores (first version, kept for A/B)
+        if (h->compact_variant == 0 && h->dtype == PCS_F64) {  // per-lane stores (first version, kept for A/B)
             const int64_t blocks = std::min<int64_t>((h->n + WG_THREADS - 1) / WG_THREADS, (int64_t)h->n_cu * 8);
-            e = h->esize == 8 ? launch_compact_t<double>(h->chain, mode, a, dim3((unsigned)blocks), s)
-                                    : launch_compact_t<float>(h->chain, mode, a, dim3((unsigned)blocks), s);
+            e = launch_compact_t(h->chain, mode, a, dim3((unsigned)blocks), s);
         } else {
             const int64_t wpc = h->wgs_per_cu > 0 ? h->wgs_per_cu : 16;
             const int64_t target_wgs = (int64_t)h->n_cu * wpc;
@@ -793,56 +910,40 @@ static int enqueue_eval(pcs_engine *h, const double *d_prm, void *d_resid, void 
             const size_t vs = 16 / h->osize;
             const size_t wave_lds = ((size_t)HALF * 2 * h->P + 128 / h->osize + 64 + vs - 1) / vs * vs;  // scalars, as in the kernel
             const size_t lds = (mode & MODE_JAC) ? h->osize * (size_t)WAVES_PER_WG * wave_lds : 0;
-            e = h->dtype == PCS_F64     ? launch_compact_tile_t<double>(h->chain, mode, a, dim3((unsigned)grid), lds, s)
-                : h->dtype == PCS_F32 ? launch_compact_tile_t<float>(h->chain, mode, a, dim3((unsigned)grid), lds, s)
-                                      : launch_compact_tile_t<double, float>(h->chain, mode, a, dim3((unsigned)grid), lds, s);
+            e = h->osize == 8 ? launch_compact_tile_t<double>(h->chain, mode, a, dim3((unsigned)grid), lds, s)
+                              : launch_compact_tile_t<float>(h->chain, mode, a, dim3((unsigned)grid), lds, s);
         }
         if (e != hipSuccess) return fail(PCS_ERR_HIP, "compact kernel launch failed: %s", hipGetErrorString(e));
         if (timed) HIPCHK(hipEventRecord(ev[2], s));
-    } else if (h->rowsplit && (mode & MODE_JAC) && h->dtype != PCS_MIXED) {
-        const bool nt = h->variant < 0 || (h->variant & VAR_NT);
-        a.n_tiles = (h->n + HALF - 1) / HALF;
-        int64_t tpw = h->tiles_per_wg;
-        if (tpw <= 0) {
-            const int64_t wpc = h->wgs_per_cu > 0 ? h->wgs_per_cu : 16;
-            const int64_t target_wgs = (int64_t)h->n_cu * wpc;
-            tpw = (a.n_tiles + target_wgs - 1) / target_wgs;
-            tpw = std::max<int64_t>(WAVES_PER_WG, (tpw + WAVES_PER_WG - 1) / WAVES_PER_WG * WAVES_PER_WG);
-        }
-        a.tiles_per_wg = (int32_t)tpw;
-        const int64_t grid = (a.n_tiles + tpw - 1) / tpw;
-        const size_t lds = h->esize * (size_t)WAVES_PER_WG * HALF * 2 * h->P;
-        const EvPair evp{ev[1], ev[2]};
-        hipError_t e = h->esize == 8 ? launch_rowsplit_t<double>(h->chain, mode, nt, a, dim3((unsigned)grid), lds, s, evp)
-                                           : launch_rowsplit_t<float>(h->chain, mode, nt, a, dim3((unsigned)grid), lds, s, evp);
-        if (e != hipSuccess) return fail(PCS_ERR_HIP, "rowsplit kernel launch failed: %s", hipGetErrorString(e));
     } else {
         const bool local = h->tile_locality >= 0.5;
         int variant = h->variant >= 0 ? h->variant : (VAR_TRANSPOSE | VAR_NT | (local ? 0 : VAR_SLAB_LDS));
         if (!(mode & MODE_JAC)) variant &= ~VAR_TRANSPOSE;
-        // LDS budget: slabs + points (+ 4 wave-private transpose regions)
-        const size_t slab_bytes = h->esize * (size_t)(h->n_cams * CAM_STRIDE + h->n_imgs * POSE_STRIDE + padded_points(h->n_keys));
-        const size_t tr_bytes = (variant & VAR_TRANSPOSE) ? h->osize * (size_t)WAVES_PER_WG * HALF * lds_row_stride(2 * h->P, (int)h->osize) : 0;
+        // waves per workgroup: 4 for large tables; a small table (config 2: 1 600 tiles on 256 CUs) is cut into
+        // one-wave workgroups so that every CU gets several and the tail of the grid stays short
+        int waves = h->waves_per_wg;
+        if (waves <= 0) waves = (variant & VAR_SLAB_LDS) ? WAVES_PER_WG : a.n_tiles >= (int64_t)h->n_cu * 32 ? WAVES_PER_WG : a.n_tiles >= (int64_t)h->n_cu * 16 ? 2 : 1;
+        // LDS budget: slabs + points (+ one wave-private transpose region per wave)
+        const size_t slab_bytes = sizeof(double) * (size_t)(h->n_cams * CAM_STRIDE + h->n_imgs * POSE_STRIDE + padded_points(h->n_keys));
+        const size_t tr_bytes = (variant & VAR_TRANSPOSE) ? h->osize * (size_t)waves * HALF * lds_row_stride(2 * h->P, (int)h->osize) : 0;
         if ((variant & VAR_SLAB_LDS) && slab_bytes + tr_bytes > h->lds_limit) variant &= ~VAR_SLAB_LDS;  // read slabs through L1/L2
         const size_t lds = ((variant & VAR_SLAB_LDS) ? slab_bytes : 0) + tr_bytes;
         int64_t tpw = h->tiles_per_wg;
         if (tpw <= 0 && h->wgs_per_cu <= 0 && !(variant & VAR_SLAB_LDS)) {
             // slabs through L1/L2: one tile per wave, as many workgroups as that takes.  Up to 1e6 detections this
-            // is what 16 workgroups per CU give anyway; at 1e7 it beats 10 tiles per wave by 17 % (FP32: 275 us
-            // against 330 us, profiles/r01/sweeps.md)
-            tpw = WAVES_PER_WG;
+            // is what 16 workgroups per CU give anyway; at 1e7 it beats 10 tiles per wave by 17 % (profiles/r01/sweeps.md)
+            tpw = waves;
         } else if (tpw <= 0) {
             const int64_t wpc = h->wgs_per_cu > 0 ? h->wgs_per_cu : 2;  // LDS-staged slabs: few long-lived workgroups
             const int64_t target_wgs = (int64_t)h->n_cu * wpc;
             tpw = (a.n_tiles + target_wgs - 1) / target_wgs;
-            tpw = std::max<int64_t>(WAVES_PER_WG, (tpw + WAVES_PER_WG - 1) / WAVES_PER_WG * WAVES_PER_WG);
+            tpw = std::max<int64_t>(waves, (tpw + waves - 1) / waves * waves);
         }
         a.tiles_per_wg = (int32_t)tpw;
         const int64_t grid = (a.n_tiles + tpw - 1) / tpw;
         const EvPair evp{ev[1], ev[2]};  // start / stop of the evaluation kernel itself
-        hipError_t e = h->dtype == PCS_F64   ? launch_eval_t<double>(h->chain, mode, variant, a, dim3((unsigned)grid), lds, s, evp)
-                       : h->dtype == PCS_F32 ? launch_eval_t<float>(h->chain, mode, variant, a, dim3((unsigned)grid), lds, s, evp)
-                                             : launch_eval_t<double, float>(h->chain, mode, variant, a, dim3((unsigned)grid), lds, s, evp);
+        hipError_t e = h->osize == 8 ? launch_eval_t<double>(h->chain, mode, variant, a, dim3((unsigned)grid), 64 * waves, lds, s, evp)
+                                     : launch_eval_t<float>(h->chain, mode, variant, a, dim3((unsigned)grid), 64 * waves, lds, s, evp);
         if (e != hipSuccess) return fail(PCS_ERR_HIP, "eval kernel launch failed: %s", hipGetErrorString(e));
     }
     if (timed) {
@@ -851,6 +952,19 @@ static int enqueue_eval(pcs_engine *h, const double *d_prm, void *d_resid, void 
     }
     h->last_stream = s;
     return PCS_OK;
+}
+
+template <int CHAIN, int PASS>
+static void fill_entry_map(int32_t *out) {
+    for (int m = 0; m < 2; ++m)
+        for (int lane = 0; lane < 64; ++lane)
+            for (int r = 0; r < 4; ++r) {
+                int sa = -1, sb = -1;
+                const bool keep = m < normal_mfmas(CHAIN, PASS) && entry_kept<CHAIN, PASS>(m, (lane >> 4) + 4 * r, lane & 15, sa, sb);
+                int32_t *o = out + ((m * 64 + lane) * 4 + r) * 2;
+                o[0] = keep ? slot_col<CHAIN, PASS>(sa) : -1;
+                o[1] = keep ? slot_col<CHAIN, PASS>(sb) : -1;
+            }
 }
 
 static int stage_params(pcs_engine *h, const double *param_str, hipStream_t s) {
@@ -1053,10 +1167,10 @@ int pcs_legacy_cost(pcs_engine *h, const double *im_points, const double *proj, 
     const int64_t n_pts = h->n_imgs * h->n_keys * 3;
     if (n_pts > h->im_points_capacity) {
         if (h->d_im_points) HIPCHK(hipFree(h->d_im_points));
-        HIPCHK(hipMalloc(&h->d_im_points, h->esize * n_pts));
+        HIPCHK(hipMalloc(&h->d_im_points, sizeof(double) * n_pts));
         h->im_points_capacity = n_pts;
     }
-    if (!h->d_cam_tab) HIPCHK(hipMalloc(&h->d_cam_tab, h->esize * h->n_cams * LEGACY_STRIDE));
+    if (!h->d_cam_tab) HIPCHK(hipMalloc(&h->d_cam_tab, sizeof(double) * h->n_cams * LEGACY_STRIDE));
     int rc = ensure_scratch(h, true, false, false);
     if (rc) return rc;
     std::vector<double> tab((size_t)h->n_cams * LEGACY_STRIDE, 0.0);
@@ -1068,32 +1182,20 @@ int pcs_legacy_cost(pcs_engine *h, const double *im_points, const double *proj, 
         for (int j = 0; j < 5; ++j) t[16 + j] = dists[5 * c + j];
     }
     HIPCHK(hipStreamSynchronize(s));
-    if (h->esize == 8) {
-        HIPCHK(hipMemcpyAsync(h->d_im_points, im_points, sizeof(double) * n_pts, hipMemcpyHostToDevice, s));
-        HIPCHK(hipMemcpyAsync(h->d_cam_tab, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice, s));
-        HIPCHK(hipStreamSynchronize(s));
-    } else {
-        std::vector<float> f(n_pts), g(tab.size());
-        for (int64_t i = 0; i < n_pts; ++i) f[i] = (float)im_points[i];
-        for (size_t i = 0; i < tab.size(); ++i) g[i] = (float)tab[i];
-        HIPCHK(hipMemcpyAsync(h->d_im_points, f.data(), sizeof(float) * n_pts, hipMemcpyHostToDevice, s));
-        HIPCHK(hipMemcpyAsync(h->d_cam_tab, g.data(), sizeof(float) * g.size(), hipMemcpyHostToDevice, s));
-        HIPCHK(hipStreamSynchronize(s));
-    }
-    const dim3 grid((unsigned)std::min<int64_t>((h->n + 255) / 256, (int64_t)h->n_cu * 16));
+    HIPCHK(hipMemcpyAsync(h->d_im_points, im_points, sizeof(double) * n_pts, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(h->d_cam_tab, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));   // `tab` is a local
+    const int64_t n_tiles = (h->n + 63) / 64;
+    const dim3 grid((unsigned)std::min<int64_t>((n_tiles + 3) / 4, (int64_t)h->n_cu * 16));
     hipEvent_t *ev = h->ev.data() + 3 * (h->ev_count % h->ev_ring);
     HIPCHK(hipEventRecord(ev[0], s));  // keeps (ev0, ev1) a valid pair for pcs_last_kernel_ms
-    if (h->esize == 8)
-        hipExtLaunchKernelGGL(legacy_cost_kernel<double>, grid, dim3(256), 0, s, ev[1], ev[2], 0, h->d_cam, h->d_img, h->d_key, h->d_uv,
-                              (const double *)h->d_im_points, (const double *)h->d_cam_tab, (double *)h->d_resid, h->n, h->n_keys);
-    else
-        hipExtLaunchKernelGGL(legacy_cost_kernel<float>, grid, dim3(256), 0, s, ev[1], ev[2], 0, h->d_cam, h->d_img, h->d_key, h->d_uv,
-                              (const float *)h->d_im_points, (const float *)h->d_cam_tab, (float *)h->d_resid, h->n, h->n_keys);
+    hipExtLaunchKernelGGL(legacy_cost_kernel, grid, dim3(256), 0, s, ev[1], ev[2], 0, det_table(h), (const double *)h->d_im_points,
+                          (const double *)h->d_cam_tab, (double *)h->d_resid, h->n, h->n_keys, h->d_sink);
     HIPCHK(hipGetLastError());
     ++h->ev_count;
     h->events_valid = true;
     h->last_stream = s;
-    return download(h, errors, h->d_resid, 2 * h->n, s, h->esize);
+    return download(h, errors, h->d_resid, 2 * h->n, s, sizeof(double));
 }
 
 int pcs_linearize(pcs_engine *h, const double *param_str) {
@@ -1131,7 +1233,7 @@ int pcs_matfree(pcs_engine *h, int op, const double *in, double *out, double *co
     if (op != OP_JV) HIPCHK(hipMemsetAsync(h->d_vout, 0, sizeof(double) * n_out, s));
     if (op == OP_GRAD) HIPCHK(hipMemsetAsync(h->d_cost, 0, sizeof(double), s));
     MatfreeArgs a{};
-    a.cam = h->d_cam; a.img = h->d_img; a.key = h->d_key; a.uv = h->d_uv;
+    a.tab = det_table(h);
     a.cam_slab = h->d_cam_slab; a.pose_slab = h->d_pose_slab; a.points = h->d_points;
     a.vin = h->d_vin; a.vout = h->d_vout; a.cost = h->d_cost;
     a.n = h->n; a.n_tiles = (h->n + TILE - 1) / TILE;
@@ -1151,8 +1253,7 @@ int pcs_matfree(pcs_engine *h, int op, const double *in, double *out, double *co
     hipEvent_t *ev = h->ev.data() + 3 * (h->ev_count % h->ev_ring);
     HIPCHK(hipEventRecord(ev[0], s));
     HIPCHK(hipEventRecord(ev[1], s));
-    hipError_t e = h->esize == 8 ? launch_matfree_t<double>(h->chain, op, lds_acc, a, grid, lds, s)
-                                       : launch_matfree_t<float>(h->chain, op, lds_acc, a, grid, lds, s);
+    hipError_t e = launch_matfree_t(h->chain, op, lds_acc, a, grid, lds, s);
     if (e != hipSuccess) return fail(PCS_ERR_HIP, "matfree kernel launch failed: %s", hipGetErrorString(e));
     HIPCHK(hipEventRecord(ev[2], s));
     ++h->ev_count;
@@ -1250,6 +1351,23 @@ int pcs_kernel_ms_samples(pcs_engine *h, int64_t capacity, float *slab_prep_ms, 
         HIPCHK(hipEventElapsedTime(eval_ms + i, ev[1], ev[2]));
     }
     *count = n;
+    return PCS_OK;
+}
+
+int pcs_normal_entry_map(int chain, int pass, int32_t *out) {
+    if (!out || chain < 0 || chain > 2 || pass < 0 || pass > 2) return fail(PCS_ERR_ARG, "pcs_normal_entry_map: bad arguments");
+    if ((pass != PASS_SHARED && chain == CHAIN_TEMPLATE) || (pass == PASS_IMGKEY && chain != CHAIN_SELF))
+        return fail(PCS_ERR_ARG, "pcs_normal_entry_map: chain %d has no pass %d", chain, pass);
+    if (pass == PASS_SHARED) {
+        if (chain == CHAIN_TEMPLATE) fill_entry_map<CHAIN_TEMPLATE, PASS_SHARED>(out);
+        else if (chain == CHAIN_SELF) fill_entry_map<CHAIN_SELF, PASS_SHARED>(out);
+        else fill_entry_map<CHAIN_FREE, PASS_SHARED>(out);
+    } else if (pass == PASS_CAMKEY) {
+        if (chain == CHAIN_SELF) fill_entry_map<CHAIN_SELF, PASS_CAMKEY>(out);
+        else fill_entry_map<CHAIN_FREE, PASS_CAMKEY>(out);
+    } else {
+        fill_entry_map<CHAIN_SELF, PASS_IMGKEY>(out);
+    }
     return PCS_OK;
 }
 

@@ -8,9 +8,11 @@ import numpy as np
 JAC_RTOL = 1e-10
 ROW_FLOOR = 1e-6
 RES_RTOL = 1e-10
-# FP32 engine (config 5): single-precision arithmetic on ~1e3 px projections, cancelling chain-rule sums
-F32_JAC_RTOL = 5e-3
-F32_RES_ATOL = 2e-3  # pixels
+# FP32 engine (config 5): FP32 measurements in, FP32 residual / Jacobian out, FP64 arithmetic on FP64 slabs in between
+# (round 1's all-float arithmetic lost 5e-3 to cancellation in the chain rule and was removed).  Jacobian: one rounding
+# to float at the store; residual: the measurement itself is rounded to float on upload (half an ulp of ~1e3 px = 6e-5 px).
+F32_JAC_RTOL = 1.2e-7
+F32_RES_ATOL = 2e-4  # pixels
 # mixed engine: FP64 arithmetic, one rounding to FP32 at the store (2^-24 = 6e-8 relative per value)
 MIXED_JAC_RTOL = 1.2e-7
 MIXED_RES_RTOL = 1.2e-7

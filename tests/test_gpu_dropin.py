@@ -311,7 +311,8 @@ def test_matrix_free_products_match_sparse_products_of_the_oracle_jacobian(chain
 def test_block_reduced_normal_equations_match_the_oracle_jacobian(chain, dtype):
     """H = J^T J, g = J^T r, cost = r^T r in one pass (no J in memory) against the same products of the
     oracle's Jacobian.  A Gram matrix obeys |H_ij| <= sqrt(H_ii H_jj), so that is the scale of the
-    tolerance: |dH_ij| <= 1e-10 sqrt(H_ii H_jj) in FP64 (atomics reorder the sums), 2e-3 for FP32 engines."""
+    tolerance: |dH_ij| <= 1e-10 sqrt(H_ii H_jj) (atomics reorder the sums; the arithmetic is FP64 for every dtype).  An
+    F32 engine holds the measurements as float, so g and the cost — the only outputs that depend on them — agree to 1e-6."""
     from pycamset_amd.engine import Engine
     rig = synthetic.config_rig(1)
     ps = orc.build_param_list(*H.chain_slabs(rig, chain))
@@ -323,7 +324,8 @@ def test_block_reduced_normal_equations_match_the_oracle_jacobian(chain, dtype):
     g_ref = J.T @ r.reshape(-1)
     c_ref = float(np.sum(r * r))
     scale = np.sqrt(np.outer(np.diag(H_ref), np.diag(H_ref)))
-    tol = 1e-10 if dtype == "f64" else 2e-3
+    tol = 1e-10
+    tol_r = 1e-10 if dtype == "f64" else 1e-6
     rng = np.random.default_rng(0)
     orders = {"sorted": np.arange(rig.n_det), "shuffled": rng.permutation(rig.n_det),
               # runs of 7 detections: every tile mixes several (cam, image) pairs but keeps some run structure
@@ -339,15 +341,14 @@ def test_block_reduced_normal_equations_match_the_oracle_jacobian(chain, dtype):
         err = np.max(np.abs(Hs - H_ref) / np.where(scale > 0, scale, 1.0))
         assert err <= tol, (name, err)
         assert np.all(Hs[H_ref == 0] == 0), "structural zeros stay zero"
-        assert np.max(np.abs(g - g_ref)) <= tol * np.max(np.abs(g_ref)), name
-        assert abs(cost - c_ref) <= tol * c_ref, name
+        assert np.max(np.abs(g - g_ref)) <= tol_r * np.max(np.abs(g_ref)), name
+        assert abs(cost - c_ref) <= tol_r * c_ref, name
         H2, g2, c2 = e.normal_equations(ps)           # second call: buffers are re-zeroed
-        assert np.allclose(H2, Hs, rtol=1e-9 if dtype == "f64" else 1e-6, atol=0) and np.allclose(H2, H2.T)
-        if chain != "template":   # the fallback for the point columns (per-detection atomics) gives the same matrix
-            e.set_option("normal_point_pass", 0)
-            H3, g3, c3 = e.normal_equations(ps)
-            assert np.max(np.abs(H3 - H_ref) / np.where(scale > 0, scale, 1.0)) <= tol, name
-            assert np.max(np.abs(g3 - g_ref)) <= tol * np.max(np.abs(g_ref)), name
+        assert np.allclose(H2, Hs, rtol=1e-9, atol=1e-9 * np.max(np.abs(Hs))) and np.allclose(H2, H2.T)
+        e.set_option("normal_rows", 32)               # half-tile LDS images: same matrix
+        H3, g3, c3 = e.normal_equations(ps)
+        assert np.max(np.abs(H3 - H_ref) / np.where(scale > 0, scale, 1.0)) <= tol, name
+        assert np.max(np.abs(g3 - g_ref)) <= tol_r * np.max(np.abs(g_ref)) and abs(c3 - c_ref) <= tol_r * c_ref, name
         e.close()
 
 

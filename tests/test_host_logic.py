@@ -370,31 +370,32 @@ def test_device_lm_driver_logic_on_cpu_operator():
         lm_solve(h, x0.copy(), operator=op, linear_solver="qr")
 
 
-def test_normal_kernel_lane_tables_are_a_conflict_free_partition():
-    """csrc/ba_normal.hpp hard-codes which chunk of the J^T J triangle every lane owns (tools/normal_lane_table.py).
-    The tables must cover every entry (p <= q < NA) exactly once and keep slots 16 apart out of the same
-    ds_read_b128 lane group (idle lanes read slot 0)."""
-    import importlib.util
-    import re
-    root = Path(__file__).resolve().parent.parent
-    spec = importlib.util.spec_from_file_location("normal_lane_table", root / "tools" / "normal_lane_table.py")
-    tool = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(tool)
-    src = (root / "pycamset_amd" / "csrc" / "ba_normal.hpp").read_text()
-    for na, ch in ((22, 5), (16, 3)):
-        tabs = {}
-        for name in ("P", "Q"):
-            m = re.search(rf"NORMAL_{name}_{na}\[64\] = \{{([^}}]*)\}}", src)
-            tabs[name] = [int(v) for v in m.group(1).split(",")]
-            assert len(tabs[name]) == 64
-        assign = [None if p == 255 else (p, q) for p, q in zip(tabs["P"], tabs["Q"])]
-        assert all((a is None) == (q == 255) for a, q in zip(assign, tabs["Q"]))
-        covered = []
-        for a in assign:
-            if a is not None:
-                p, q0 = a
-                assert 0 <= p <= q0 < na
-                covered += [(p, q) for q in range(q0, min(q0 + ch, na))]
-        assert sorted(covered) == [(p, q) for p in range(na) for q in range(p, na)], "every entry exactly once"
-        assert tool.conflicts(assign) == 0
-        assert sorted(a for a in assign if a is not None) == sorted(tool.chunks(na, ch))
+def test_normal_equation_entry_maps_own_every_pair_exactly_once():
+    """csrc/ba_normal.hpp hard-codes which entry of H / g / cost every MFMA accumulator register stands for (operand
+    windows + the keep rule).  Per chain and pass, the owned registers must cover every needed column pair exactly
+    once — pcs_normal_entry_map is a host function, so this runs without a GPU."""
+    from ctypes import POINTER, c_int32
+    from pycamset_amd import _capi
+    lib = _capi.lib()
+    R = 30
+
+    def owned(chain, p):
+        out = np.full((2, 64, 4, 2), -7, dtype=np.int32)
+        _capi.check(lib.pcs_normal_entry_map(_capi.CHAIN_IDS[chain], p, out.ctypes.data_as(POINTER(c_int32))))
+        pairs = [tuple(sorted(x)) for x in out.reshape(-1, 2).tolist() if x[0] >= 0]
+        assert all((a < 0) == (b < 0) for a, b in out.reshape(-1, 2).tolist())
+        return pairs
+
+    def upper(cols):
+        return sorted((a, b) for i, a in enumerate(cols) for b in cols[i:])
+
+    for chain, n_shared in (("template", 21), ("self", 21), ("free", 15)):
+        cols = list(range(n_shared)) + [R]
+        assert sorted(owned(chain, 0)) == upper(cols), chain                     # shared pass: whole upper triangle
+    for chain, pt0 in (("self", 21), ("free", 15)):
+        pts, cam = [pt0, pt0 + 1, pt0 + 2], list(range(15))
+        need = sorted([tuple(sorted((c, q))) for c in cam for q in pts] + upper(pts) + [(q, R) for q in pts])
+        assert sorted(owned(chain, 1)) == need, chain                            # E[c,k], D[k], g[k]
+    assert sorted(owned("self", 2)) == sorted((p, q) for p in range(15, 21) for q in (21, 22, 23))   # F[i,k]
+    for chain, p in (("template", 1), ("template", 2), ("free", 2)):
+        assert lib.pcs_normal_entry_map(_capi.CHAIN_IDS[chain], p, np.zeros(1024, np.int32).ctypes.data_as(POINTER(c_int32))) == _capi.PCS_ERR_ARG

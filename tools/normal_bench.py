@@ -29,22 +29,22 @@ for cfg, chain, shuffle in configs:
     gd = torch.empty(n, dtype=torch.float64, device="cuda")
     cd = torch.empty(1, dtype=torch.float64, device="cuda")
     print(f"# {rig.name} chain {chain} N={det.shape[0]} n_params={n} shuffled={shuffle}  H = {n*n*8/1e6:.1f} MB")
-    if "--phases" in sys.argv:   # option normal_debug: 1 = skip the dot loops, 2 = skip the flush atomics (results are wrong)
-        for dbg in ((3, 1, 2, 0) if chain == "template" else (12, 8, 4, 0)):   # 4 = no point-block atomics, 8 = no shared-point atomics
+    if "--phases" in sys.argv:   # option normal_debug: 2 = skip the flush atomics (results are wrong)
+        for dbg in (2, 0):
             e.set_option("normal_debug", dbg)
             ks = []
             for _ in range(8):
                 e.normal_equations_device(ps, Hd.data_ptr(), gd.data_ptr(), cd.data_ptr()); e.synchronize(); ks.append(e.last_kernel_ms()[1])
-            print(f"normal_debug {dbg}: kernel {np.median(ks[2:])*1e3:8.1f} us")
+            print(f"normal_debug {dbg}: kernels {np.median(ks[2:])*1e3:8.1f} us")
         e.set_option("normal_debug", 0)
-    if chain != "template":
-        for pp in (0, 1):   # per-detection point atomics against the key-sorted point passes
-            e.set_option("normal_point_pass", pp)
-            ks = []
-            for _ in range(8):
-                e.normal_equations_device(ps, Hd.data_ptr(), gd.data_ptr(), cd.data_ptr()); e.synchronize(); ks.append(e.last_kernel_ms()[1])
-            print(f"normal_point_pass {pp}: kernels {np.median(ks[2:])*1e3:8.1f} us")
-    for wpc in ((0,) if "--only-default" in sys.argv else (0, 1, 2, 3, 4, 8)):
+    for rows in (64, 32):
+        e.set_option("normal_rows", rows)
+        ks = []
+        for _ in range(8):
+            e.normal_equations_device(ps, Hd.data_ptr(), gd.data_ptr(), cd.data_ptr()); e.synchronize(); ks.append(e.last_kernel_ms()[1])
+        print(f"normal_rows {rows}: kernels {np.median(ks[2:])*1e3:8.1f} us")
+    e.set_option("normal_rows", 64)
+    for wpc in ((0,) if "--only-default" in sys.argv else (0, 7, 14, 21, 28, 56)):
         e.set_option("wgs_per_cu", wpc)
         for _ in range(2):
             e.normal_equations_device(ps, Hd.data_ptr(), gd.data_ptr(), cd.data_ptr())

@@ -33,7 +33,8 @@ def main():
     ap.add_argument("--mode", default="both", choices=["both", "jac", "resid"])
     ap.add_argument("--tag", default="")
     ap.add_argument("--xcd", default="0", help="comma list of 0/1: XCD-contiguous tile remap")
-    ap.add_argument("--rowsplit", default="0", help="comma list of 0/1: also sweep the row-split kernel")
+    ap.add_argument("--waves", default="0", help="comma list of waves per workgroup (0 = automatic, 1, 2, 4)")
+    ap.add_argument("--pack", type=int, default=1, help="0: three int32 index arrays instead of the packed 32-bit word")
     a = ap.parse_args()
     rig = synthetic.config_rig(a.config, n_imgs=a.n_imgs, scale=a.scale)
     det = rig.detections
@@ -42,6 +43,7 @@ def main():
     N = det.shape[0]
     ps = np.concatenate([x.ravel() for x in slabs(rig, a.chain)])
     e = Engine(a.chain, rig.n_cams, rig.n_imgs, rig.n_keys, dtype=a.dtype)
+    e.set_option("pack_indices", a.pack)
     e.set_detections_table(det)
     if a.chain == "template":
         e.set_template(rig.points)
@@ -51,11 +53,11 @@ def main():
     d_p = torch.from_numpy(ps).cuda()
     pr = d_r.data_ptr() if a.mode in ("both", "resid") else None
     pj = d_j.data_ptr() if a.mode in ("both", "jac") else None
-    combos = [(int(v), int(w), int(rs), int(x)) for x in a.xcd.split(",") for rs in a.rowsplit.split(",") for v in a.variants.split(",") for w in a.wgs.split(",")]
+    combos = [(int(v), int(w), int(rs), int(x)) for x in a.xcd.split(",") for rs in a.waves.split(",") for v in a.variants.split(",") for w in a.wgs.split(",")]
     times = {c: [] for c in combos}
     for rnd in range(a.rounds + 1):
         for c in combos:
-            e.set_option("variant", c[0]); e.set_option("wgs_per_cu", c[1]); e.set_option("rowsplit", c[2]); e.set_option("xcd_remap", c[3])
+            e.set_option("variant", c[0]); e.set_option("wgs_per_cu", c[1]); e.set_option("waves_per_wg", c[2]); e.set_option("xcd_remap", c[3])
             for _ in range(3):
                 e.eval_device_resident(d_p.data_ptr(), pr, pj)
             e.synchronize()
@@ -64,11 +66,11 @@ def main():
     bpd = BPD[(a.chain, a.dtype)] if a.mode == "both" else (44 if a.mode == "resid" else BPD[(a.chain, a.dtype)] - 16)
     out = {}
     slab_kb = (rig.n_cams * 48 + (0 if a.chain == "free" else rig.n_imgs * 40) + 3 * rig.n_keys) * (8 if a.dtype == "f64" else 4) / 1024
-    print(f"# config {a.config} chain {a.chain} {a.dtype} N={N} imgs={rig.n_imgs} slabs={slab_kb:.0f} KiB shuffle={a.shuffle} mode={a.mode}")
+    print(f"# config {a.config} chain {a.chain} {a.dtype} pack={a.pack} N={N} imgs={rig.n_imgs} slabs={slab_kb:.0f} KiB shuffle={a.shuffle} mode={a.mode}")
     for c in combos:
         med, mn = float(np.median(times[c])), float(np.min(times[c]))
         gbs = N * bpd / (med * 1e-3) / 1e9
-        print(f"xcd {c[3]} rowsplit {c[2]} variant {c[0]} wgs/cu {c[1]:3d}: median {med*1e3:8.1f} us  min {mn*1e3:8.1f} us  {gbs:7.1f} GB/s  {gbs/80:.1f}% of 8 TB/s")
+        print(f"xcd {c[3]} waves/wg {c[2]} variant {c[0]} wgs/cu {c[1]:3d}: median {med*1e3:8.1f} us  min {mn*1e3:8.1f} us  {gbs:7.1f} GB/s  {gbs/80:.1f}% of 8 TB/s")
         out[f"x{c[3]}_rs{c[2]}_v{c[0]}_w{c[1]}"] = {"median_us": med * 1e3, "min_us": mn * 1e3, "GBps": gbs}
     Path("gpurun_out").mkdir(exist_ok=True)
     json.dump(out, open(f"gpurun_out/sweep_{a.config}_{a.chain}_{a.dtype}{'_shuf' if a.shuffle else ''}_{a.mode}{a.tag}.json", "w"), indent=1)
