@@ -59,7 +59,8 @@ struct NormalArgs {
     int64_t extr_off, pose_off, point_off;
     int64_t n_params;
     int32_t tiles_per_wave;
-    int32_t debug;  // profiling switch: 2 skips the flush atomics (results are wrong while set)
+    int32_t debug;  // profiling switches (results are wrong while set): 2 no flush atomics, 8 no MFMA phase, 16 no evaluation,
+                    // 32 run boundaries ignored, 64 no LDS image writes
 };
 
 constexpr int PASS_SHARED = 0, PASS_CAMKEY = 1, PASS_IMGKEY = 2;
@@ -245,7 +246,11 @@ __global__ __launch_bounds__(64, 2) void ba_normal_mfma_kernel(const NormalArgs 
         asm volatile("" ::: "memory");   // keep the requests up here
         T u, v;
         T J[P2];
-        {
+        if (a.debug & 16) {   // profiling: no evaluation
+            u = m.x; v = m.y;
+#pragma unroll
+            for (int j = 0; j < P2; ++j) J[j] = (double)(lane + j);
+        } else {
             // Slabs: when the whole tile refers to one camera (image) its slab is fetched with ONE coalesced load and read
             // through v_readlane (LaneSlab) instead of 48 (39) per-lane loads of the same address — with one-wave
             // workgroups and ~2 waves per SIMD the latency of those loads is what this kernel waits for.  Tiles that mix
@@ -269,6 +274,10 @@ __global__ __launch_bounds__(64, 2) void ba_normal_mfma_kernel(const NormalArgs 
             }
         }
         const double r0 = u - m.x, r1 = v - m.y;
+        // The requests for the next tile (issued above) have had the whole evaluation to arrive; consume them HERE, before
+        // the MFMA phase can issue flush atomics.  vmcnt retires in order on gfx9: waiting for these loads at the top of the
+        // next tile would also wait for every atomic issued after them (12 us of the kernel at N = 1e6).
+        asm volatile("" ::"v"(nxt_w.w0), "v"(nxt_w.w1), "v"(nxt_w.w2), "v"(nxt_m.x), "v"(nxt_m.y));
 
         // run boundaries of this tile: bit d set = detection d starts a new run
         const int ka = PASS == PASS_IMGKEY ? im : c, kb = PASS == PASS_SHARED ? im : k;
@@ -279,7 +288,7 @@ __global__ __launch_bounds__(64, 2) void ba_normal_mfma_kernel(const NormalArgs 
 #pragma unroll
         for (int h = 0; h < 64 / ROWS; ++h) {
             // ---- this pass's detections -> LDS image (lanes past the end of the table write zero rows: they add nothing) -----------
-            if (ROWS == 64 || (lane >> 5) == h) {
+            if (!(a.debug & 64) && (ROWS == 64 || (lane >> 5) == h)) {   // debug 64: profiling, no LDS image
                 unsigned char *dst = lds_image + (lane & (ROWS - 1)) * 16;
 #pragma unroll
                 for (int s = 0; s < NSLOT; ++s) {
@@ -299,7 +308,7 @@ __global__ __launch_bounds__(64, 2) void ba_normal_mfma_kernel(const NormalArgs 
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
             const int d_base = h * ROWS;
-            const uint64_t bits = ROWS == 64 ? bnd : (bnd >> d_base) & 0xffffffffull;
+            const uint64_t bits = (a.debug & 32) ? 0ull : ROWS == 64 ? bnd : (bnd >> d_base) & 0xffffffffull;   // debug 32: profiling, ignore run boundaries
             auto operand = [&](const int w, const int s) { return *reinterpret_cast<const double *>(lds_image + rd_off[w] + s * 32); };
             auto run_mfmas = [&](const double (&x)[NW]) {
 #pragma unroll
@@ -312,29 +321,62 @@ __global__ __launch_bounds__(64, 2) void ba_normal_mfma_kernel(const NormalArgs 
                 run_a = na;
                 run_b = nb;
             };
-            if (bits == 0) {
-                // the whole image continues the current run (the common case): operands of step s + 1 are requested
-                // before the MFMAs of step s are issued
+            // k-steps [s0, s1) of the image, all inside the current run: rolled loop, the operands of step s + 1 are
+            // requested before the MFMAs of step s are issued (the MFMAs of one step take 64 cycles each — the LDS latency)
+            auto run_steps = [&](const int s0, const int s1) {
+                if (s0 >= s1) return;
                 double x[2][NW];
 #pragma unroll
-                for (int w = 0; w < NW; ++w) x[0][w] = operand(w, 0);
+                for (int w = 0; w < NW; ++w) x[0][w] = operand(w, s0);
+                int s = s0;
+                // Order per step: wait for THIS step's operands, request the next step's, issue the MFMAs.  hipcc places its
+                // s_waitcnt directly before the first use of a loaded register and — left alone — sinks the next step's
+                // ds_reads below the MFMAs (one register set, s_waitcnt 0 before every MFMA pair: 150 cycles per MFMA
+                // instead of 64).  `touch` is an empty asm that uses the operands, so the wait lands before the next requests
+                // are issued; sched_barrier(0) keeps the three groups in this order.
+                auto touch = [&](const double (&v)[NW]) {
 #pragma unroll
-                for (int s = 0; s < STEPS; ++s) {
-                    if (s + 1 < STEPS) {
+                    for (int w = 0; w < NW; ++w) asm volatile("" ::"v"(v[w]));
+                };
+                for (; s + 1 < s1; s += 2) {   // two steps per trip: the operand buffers alternate without register moves
+                    touch(x[0]);
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (int w = 0; w < NW; ++w) x[(s + 1) & 1][w] = operand(w, s + 1);
-                    }
-                    asm volatile("" ::: "memory");
-                    run_mfmas(x[s & 1]);
+                    for (int w = 0; w < NW; ++w) x[1][w] = operand(w, s + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    run_mfmas(x[0]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    touch(x[1]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) x[0][w] = operand(w, min(s + 2, STEPS - 1));
+                    __builtin_amdgcn_sched_barrier(0);
+                    run_mfmas(x[1]);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
+                if (s < s1) run_mfmas(x[0]);
+            };
+            if (a.debug & 8) {
+                // profiling: no MFMA phase
             } else {
-#pragma unroll 1
-                for (int s = 0; s < STEPS; ++s) {
-                    const int d0 = d_base + 2 * s;
+                // Walk the image from boundary to boundary.  `bits` >> 2 s0 = boundary flags of the detections not yet
+                // consumed; the step that holds the next flagged detection is handled on its own (flush, or split when the
+                // run changes between its two detections), everything before it goes through run_steps.
+                int s0 = 0;
+                while (s0 < STEPS) {
+                    const uint64_t rem = bits >> (2 * s0);
+                    if (rem == 0) {
+                        run_steps(s0, STEPS);
+                        break;
+                    }
+                    const int nb = __builtin_ctzll(rem);      // detections until the next run start
+                    const int sb = s0 + (nb >> 1);            // its k-step
+                    run_steps(s0, sb);
+                    const int d0 = d_base + 2 * sb;
                     const uint32_t bb = (uint32_t)(bnd >> d0) & 3u;
                     double x[NW];
 #pragma unroll
-                    for (int w = 0; w < NW; ++w) x[w] = operand(w, s);
+                    for (int w = 0; w < NW; ++w) x[w] = operand(w, sb);
                     if (bb & 1u) new_run(d0);
                     if (bb & 2u) {   // the step straddles a boundary: rows of detection d0, flush, rows of d0 + 1
                         double xa[NW], xb[NW];
@@ -346,6 +388,7 @@ __global__ __launch_bounds__(64, 2) void ba_normal_mfma_kernel(const NormalArgs 
                     } else {
                         run_mfmas(x);
                     }
+                    s0 = sb + 1;
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

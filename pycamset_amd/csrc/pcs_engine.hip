@@ -849,8 +849,9 @@ static int enqueue_normal(pcs_engine *h, const double *d_prm, double *d_H, doubl
     a.n_params = h->n_params;
     a.debug = h->normal_debug;
     // every wave walks a contiguous range of tiles, so its register accumulators survive across tiles.  One-wave
-    // workgroups; the LDS image (22.9 KB for 22 columns x 64 rows) allows 7 per CU; two rounds of waves even out the tail.
-    const int64_t wpc = h->wgs_per_cu > 0 ? h->wgs_per_cu : 14;
+    // workgroups; the LDS image (22.9 KB for 22 columns x 64 rows) allows 7 per CU, and exactly one resident round of
+    // waves is fastest (92 us against 105 us with two rounds on rig-32, profiles/r02/sweeps.md).
+    const int64_t wpc = h->wgs_per_cu > 0 ? h->wgs_per_cu : 7;
     const int64_t target_waves = (int64_t)h->n_cu * wpc;
     const int64_t tpw = std::max<int64_t>(1, (a.n_tiles + target_waves - 1) / target_waves);
     a.tiles_per_wave = (int32_t)tpw;
