@@ -51,31 +51,109 @@ def bundle_adj_parrallel_solver(dct, im_points, projection_matrixes, intrinsics,
 last_triangulate_kernel_ms = None
 
 
+class Triangulator:
+    """Owner of one ``pcs_triangulator`` handle (include/pcs_hip.h): the camera table, device copies of the
+    observations, the kernel's scratch and the output live on the device across calls, so repeated
+    triangulations with the same cameras (``CameraSet.multi_cam_triangulate`` per set of frames,
+    cameras/camera_set.py:343-402) allocate nothing and — with device-resident inputs — copy nothing."""
+
+    def __init__(self, n_cams: int, device: int = 0):
+        import ctypes
+
+        from . import _capi
+
+        self._capi, self._ct = _capi, ctypes
+        self._h = ctypes.c_void_p()
+        _capi.check(_capi.lib().pcs_tri_create(ctypes.byref(self._h), int(device), int(n_cams)))
+        self.n_cams, self.device, self.n_pts = int(n_cams), int(device), 0
+        self._cam_key = None
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._capi.lib().pcs_tri_destroy(self._h)
+            self._h = self._ct.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_cameras(self, proj, intr, dist):
+        P = np.ascontiguousarray(proj, dtype=np.float64)
+        K = np.ascontiguousarray(intr, dtype=np.float64)
+        D = np.ascontiguousarray(np.asarray(dist, dtype=np.float64).reshape(P.shape[0], -1))
+        if P.shape != (self.n_cams, 3, 4) or K.shape != (self.n_cams, 3, 3) or D.shape != (self.n_cams, 5):
+            raise ValueError("expected proj (C,3,4), intr (C,3,3), dist (C,5)")
+        key = hash(P.tobytes() + K.tobytes() + D.tobytes())
+        if key != self._cam_key:   # the same cameras across calls: nothing to upload
+            dp = self._ct.POINTER(self._ct.c_double)
+            self._capi.check(self._capi.lib().pcs_tri_set_cameras(self._h, P.ctypes.data_as(dp), K.ctypes.data_as(dp), D.ctypes.data_as(dp)))
+            self._cam_key = key
+
+    def set_observations(self, cam, uv, start_inds):
+        """Host arrays (copied to handle-owned device buffers): cam (n_obs,) int, uv (n_obs, 2), start_inds (n_pts + 1,)."""
+        cam = np.ascontiguousarray(cam, dtype=np.int32)
+        uv = np.ascontiguousarray(uv, dtype=np.float64)
+        start = np.ascontiguousarray(start_inds, dtype=np.int64)
+        ct = self._ct
+        self._capi.check(self._capi.lib().pcs_tri_set_observations(
+            self._h, cam.shape[0], cam.ctypes.data_as(ct.POINTER(ct.c_int32)), uv.ctypes.data_as(ct.POINTER(ct.c_double)),
+            start.shape[0] - 1, start.ctypes.data_as(ct.POINTER(ct.c_int64))))
+        self.n_pts = start.shape[0] - 1
+
+    def set_observations_device(self, n_obs: int, d_cam: int, d_uv: int, n_pts: int, d_start: int):
+        """Raw device addresses (e.g. ``tensor.data_ptr()``) of int32 cam, float64 uv, int64 start_inds: used in place."""
+        ct = self._ct
+        self._capi.check(self._capi.lib().pcs_tri_set_observations_device(self._h, int(n_obs), ct.c_void_p(d_cam), ct.c_void_p(d_uv),
+                                                                          int(n_pts), ct.c_void_p(d_start)))
+        self.n_pts = int(n_pts)
+
+    def run(self, d_pts: int | None = None, stream: int | None = None):
+        """Queue the kernel (asynchronous).  ``d_pts`` = device address of an (n_pts, 3) float64 buffer, or None for the
+        handle-owned output (fetch it with ``points()``)."""
+        from .engine import _stream_arg
+        self._capi.check(self._capi.lib().pcs_tri_run(self._h, self._ct.c_void_p(d_pts or 0), _stream_arg(stream)))
+
+    def synchronize(self, stream: int | None = None):
+        from .engine import _stream_arg
+        self._capi.check(self._capi.lib().pcs_tri_synchronize(self._h, _stream_arg(stream)))
+
+    def points(self) -> np.ndarray:
+        pts = np.empty((max(self.n_pts, 0), 3))
+        if self.n_pts > 0:
+            self._capi.check(self._capi.lib().pcs_tri_points(self._h, pts.ctypes.data_as(self._ct.POINTER(self._ct.c_double))))
+        return pts
+
+    def last_kernel_ms(self) -> float:
+        ms = self._ct.c_float(0.0)
+        self._capi.check(self._capi.lib().pcs_tri_last_kernel_ms(self._h, self._ct.byref(ms)))
+        return float(ms.value)
+
+
+_tri_cache: dict = {}
+
+
 def nb_triangulate_full(data, proj, start_inds, intr, dist, device: int = 0) -> np.ndarray:
     """``data`` rows = [cam, ..., u, v] sorted by point; ``start_inds`` (n_pts + 1) like the reference
-    (compiled_helpers.py:609-643).  Returns (n_pts, 3)."""
-    import ctypes
-
-    from . import _capi
-
+    (compiled_helpers.py:609-643).  Returns (n_pts, 3).  A ``Triangulator`` per (device, camera count) is kept
+    across calls: camera table and buffers are reused."""
     global last_triangulate_kernel_ms
     data = np.asarray(data, dtype=np.float64)
-    cam = np.ascontiguousarray(data[:, 0].astype(np.int32))
-    uv = np.ascontiguousarray(data[:, -2:])
-    start = np.ascontiguousarray(start_inds, dtype=np.int64)
-    P = np.ascontiguousarray(proj, dtype=np.float64)
-    K = np.ascontiguousarray(intr, dtype=np.float64)
-    D = np.ascontiguousarray(np.asarray(dist, dtype=np.float64).reshape(P.shape[0], -1))
-    if P.shape[1:] != (3, 4) or K.shape != (P.shape[0], 3, 3) or D.shape[1] != 5:
-        raise ValueError("expected proj (C,3,4), intr (C,3,3), dist (C,5)")
-    n_pts = start.shape[0] - 1
-    pts = np.empty((max(n_pts, 0), 3))
-    ms = ctypes.c_float(0.0)
-    dp, ip, lp = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int64)
-    _capi.check(_capi.lib().pcs_triangulate(device, cam.shape[0], cam.ctypes.data_as(ip), uv.ctypes.data_as(dp), n_pts,
-                                            start.ctypes.data_as(lp), P.shape[0], P.ctypes.data_as(dp), K.ctypes.data_as(dp),
-                                            D.ctypes.data_as(dp), pts.ctypes.data_as(dp), ctypes.byref(ms)))
-    last_triangulate_kernel_ms = float(ms.value)
+    P = np.asarray(proj, dtype=np.float64)
+    start = np.asarray(start_inds, dtype=np.int64)
+    if start.shape[0] <= 1:
+        return np.empty((0, 3))
+    key = (int(device), int(P.shape[0]))
+    tri = _tri_cache.get(key)
+    if tri is None:
+        _tri_cache.clear()
+        tri = _tri_cache[key] = Triangulator(P.shape[0], device)
+    tri.set_cameras(P, intr, dist)
+    tri.set_observations(data[:, 0].astype(np.int32), data[:, -2:], start)
+    tri.run()
+    pts = tri.points()
+    last_triangulate_kernel_ms = tri.last_kernel_ms()
     return pts
 
 

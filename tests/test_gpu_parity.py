@@ -683,3 +683,49 @@ def test_soa_upload_engine_buffers_and_timing_options(Engine):
     with pytest.raises(_capi.PcsError):
         e.set_option("event_ring", 0)
     e.close()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "mixed"])
+def test_config5_at_full_size(Engine, dtype):
+    """BASELINE config 5 at its stated size (128 cameras x 500 poses x 486 keys, ~1e7 detections, FP32 bytes) — outputs stay
+    on the device (1.7 GB of Jacobian).  Checks: (1) oracle on a strided sample plus head and ragged tail, at the dtype's
+    tolerance; (2) permutation equivariance, bit for bit; (3) two contiguous shards concatenate to the full evaluation,
+    bit for bit (the sharded 8-GPU form of the config is exactly this, per rank)."""
+    import torch
+    rig = synthetic.config_rig(5)
+    N, P = rig.n_det, 21
+    assert N > 9.5e6 and (rig.n_cams, rig.n_imgs, rig.n_keys) == (128, 500, 486)
+    ps = orc.build_param_list(rig.intr, rig.extr, rig.poses)
+
+    def run(det):
+        e = make_engine(Engine, rig, "template", dtype=dtype, det=det)
+        n = det.shape[0]
+        d_r = torch.empty((n, 2), dtype=torch.float32, device="cuda")
+        d_j = torch.empty((n, 2 * P), dtype=torch.float32, device="cuda")
+        e.eval_device(ps, d_r.data_ptr(), d_j.data_ptr())
+        e.synchronize()
+        e.close()
+        return d_r, d_j
+
+    d_r, d_j = run(rig.detections)
+    assert bool(torch.isfinite(d_j).all()) and bool(torch.isfinite(d_r).all())
+    idx = np.unique(np.concatenate([np.arange(0, N, 997), np.arange(300), np.arange(N - 300, N)]))
+    ref_j, ref_r = orc.full_jac_dense("template", rig.detections[idx], ps, rig.points, threads=8, with_resid=True,
+                                      counts=(rig.n_cams, rig.n_imgs, rig.n_keys))
+    t_idx = torch.from_numpy(idx).cuda()
+    j = d_j[t_idx].cpu().numpy().astype(np.float64).reshape(-1, P)
+    r = d_r[t_idx].cpu().numpy().astype(np.float64)
+    assert H.jac_rel_err(j, ref_j) <= (H.F32_JAC_RTOL if dtype == "f32" else H.MIXED_JAC_RTOL)
+    if dtype == "f32":
+        assert np.max(np.abs(r - ref_r)) <= H.F32_RES_ATOL
+    else:
+        assert np.max(np.abs(r - ref_r) / np.maximum(np.abs(ref_r), 1e-3)) <= H.MIXED_RES_RTOL
+    perm = np.random.default_rng(5).permutation(N)
+    p_r, p_j = run(rig.detections[perm])
+    t_perm = torch.from_numpy(perm).cuda()
+    assert bool(torch.equal(p_j, d_j[t_perm])) and bool(torch.equal(p_r, d_r[t_perm]))
+    del p_r, p_j
+    cut = (N // 2 // 64) * 64 + 17            # not a tile boundary
+    a_r, a_j = run(rig.detections[:cut])
+    b_r, b_j = run(rig.detections[cut:])
+    assert bool(torch.equal(torch.cat([a_j, b_j]), d_j)) and bool(torch.equal(torch.cat([a_r, b_r]), d_r))

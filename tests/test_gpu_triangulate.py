@@ -105,3 +105,49 @@ def test_triangulation_at_scale_and_errors():
         hip_ch.nb_triangulate_full(bad, P, start, K, D)
     assert e.value.code == _capi.PCS_ERR_RANGE
     assert hip_ch.nb_triangulate_full(rec[:0], P, np.array([0]), K, D).shape == (0, 3)
+
+
+def test_triangulator_handle_resident_inputs_and_repeated_calls():
+    """The handle API (pcs_tri_*): device-resident inputs / outputs give the bits of the host path, the handle survives
+    problems of different sizes and camera sets, and misuse fails with a status code instead of reading garbage."""
+    import torch
+    rig = synthetic.make_rig("tri-h", 6, 5, synthetic.charuco_points(7, 6.0), seed=4, visibility=0.7, n_rings=2)
+    rec, start, P, K, D, _ = rig_inputs(rig)
+    ref = hip_ch.nb_triangulate_full(rec, P, start, K, D)
+    tri = hip_ch.Triangulator(rig.n_cams)
+    with pytest.raises(_capi.PcsError) as ex:          # nothing set yet
+        tri.run()
+    assert ex.value.code == _capi.PCS_ERR_STATE
+    tri.set_cameras(P, K, D)
+    with pytest.raises(_capi.PcsError):
+        tri.run()                                      # observations missing
+    cam = rec[:, 0].astype(np.int32)
+    tri.set_observations(cam, rec[:, -2:], start)
+    tri.run()
+    assert np.array_equal(tri.points(), ref)
+    # device-resident: caller-owned tensors in, caller-owned tensor out, on torch's current stream
+    d_cam, d_uv = torch.from_numpy(cam).cuda(), torch.from_numpy(np.ascontiguousarray(rec[:, -2:])).cuda()
+    d_st = torch.from_numpy(np.ascontiguousarray(start, dtype=np.int64)).cuda()
+    d_pts = torch.zeros((len(start) - 1, 3), dtype=torch.float64, device="cuda")
+    tri.set_observations_device(cam.shape[0], d_cam.data_ptr(), d_uv.data_ptr(), len(start) - 1, d_st.data_ptr())
+    stream = torch.cuda.current_stream().cuda_stream
+    for _ in range(3):
+        tri.run(d_pts.data_ptr(), stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_pts.cpu().numpy(), ref) and tri.last_kernel_ms() > 0
+    # a smaller problem on the same handle (buffers are reused), then the first one again
+    half = len(start) // 2
+    tri.set_observations(cam[: start[half]], rec[: start[half], -2:], start[: half + 1])
+    tri.run()
+    assert np.array_equal(tri.points(), ref[:half])
+    tri.set_observations(cam, rec[:, -2:], start)
+    tri.run()
+    assert np.array_equal(tri.points(), ref)
+    bad = cam.copy()
+    bad[3] = rig.n_cams
+    with pytest.raises(_capi.PcsError) as ex:
+        tri.set_observations(bad, rec[:, -2:], start)
+    assert ex.value.code == _capi.PCS_ERR_RANGE
+    with pytest.raises(ValueError):
+        tri.set_cameras(P[:-1], K[:-1], D[:-1])
+    tri.close()
