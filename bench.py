@@ -181,6 +181,58 @@ def cpu_baseline(rig, chain, param_str, budget_s: float):
     return out
 
 
+def lm_end_to_end(config: int, with_scipy: bool, scipy_nfev: int = 8):
+    """End-to-end solve of the config's calibration problem through the drop-in boundary (outside the timed region,
+    never part of `value`):
+      device  pycamset_amd.optimisation_handling.run_bundle_adjustment(handler, solver='device') — block-reduced normal
+              equations + Schur / Cholesky on the GPU, J never leaves HBM (row f2);
+      scipy   the reference's own call, scipy.optimize.least_squares(loss_fn, x0, jac=jac_fn, x_scale='jac')
+              (optimisation_handling.py:88-98) driven by the HIP closures with the default page-locked output ring —
+              bounded by `scipy_nfev` evaluations because it is PCIe- and lsmr-bound (only with --lm-compare)."""
+    from scipy.optimize import least_squares
+
+    from pycamset_amd import handlers, synthetic
+    from pycamset_amd.detections import TargetDetection
+    from pycamset_amd.device_solver import lm_solve
+
+    class _Camset:
+        def __init__(self, n):
+            self.names = [f"cam_{i}" for i in range(n)]
+
+        def get_names(self):
+            return list(self.names)
+
+        def get_n_cams(self):
+            return len(self.names)
+
+    class _Target:
+        def __init__(self, pts):
+            self.point_data = np.asarray(pts)[None]
+
+    rig = synthetic.config_rig(config)
+    cs = _Camset(rig.n_cams)
+    h = handlers.TemplateBundleHandler(cs, _Target(rig.points), TargetDetection(cs.get_names(), rig.detections),
+                                       fixed_params={"cam_0": {"ext": rig.extr_true[0].copy()}}, options={"verbosity": 0, "max_nfev": 30})
+    bp = h.bundlePrimitive
+    x0 = np.concatenate([rig.intr[bp.intr_unfixed].ravel(), rig.extr[bp.extr_unfixed].ravel(), rig.poses[bp.poses_unfixed].ravel()])
+    loss_fn = h.make_loss_fun(1)
+    err = lambda r: float(np.mean(np.linalg.norm(np.asarray(r).reshape(-1, 2), axis=1)))  # noqa: E731
+    out = {"workload": f"{rig.name}: {rig.n_det} detections, {x0.size} free parameters", "start_error_px": err(loss_fn(x0))}
+    lm_solve(h, x0.copy(), max_iter=2, linear_solver="cholesky")   # rocSOLVER start-up (~0.2 s, once per process)
+    t0 = time.perf_counter()
+    dev = lm_solve(h, x0.copy(), max_iter=30, linear_solver="cholesky")
+    out["device_lm"] = {"seconds": time.perf_counter() - t0, "iterations": dev.nit, "nfev": dev.nfev, "cost": dev.cost,
+                        "final_error_px": err(loss_fn(dev.x)), "status": dev.message}
+    if with_scipy:
+        jac_fn = h.make_loss_jac(1)
+        t0 = time.perf_counter()
+        res = least_squares(loss_fn, x0.copy(), jac=jac_fn, x_scale="jac", max_nfev=scipy_nfev, verbose=0)
+        out["scipy_hip_closures"] = {"seconds": time.perf_counter() - t0, "nfev": int(res.nfev), "njev": int(res.njev), "cost": float(res.cost),
+                                     "final_error_px": err(res.fun), "max_nfev": scipy_nfev,
+                                     "note": "least_squares(..., x_scale='jac') -> trf + lsmr on the host; every Jacobian crosses PCIe as CSR"}
+    return out
+
+
 def pmc_traffic(workload_key: str):
     """(HBM bytes per launch, where they come from): the committed rocprofv3 PMC summary of this same command —
     FETCH_SIZE and WRITE_SIZE need passes of their own (MI355X_MICROARCH.md), so they cannot be taken inside this run."""
@@ -217,6 +269,9 @@ def main():
     ap.add_argument("--stream-to-host", action="store_true",
                     help="config-5 mode: every step also copies the Jacobian to page-locked host memory on a side "
                          "stream (double buffered); the step rate is then PCIe-bound and reported as such")
+    ap.add_argument("--lm-compare", action="store_true",
+                    help="also solve configs 2 and 3 end to end with scipy least_squares on the HIP closures (tens of seconds); "
+                         "the device LM solve of the bench's own rig is always reported under 'lm_end_to_end'")
     ap.add_argument("--host-path", action="store_true",
                     help="also time the host-buffer boundary (pcs_eval: H2D params + kernels + D2H of residual and Jacobian); "
                          "reported under 'host_boundary', never in 'value'")
@@ -500,6 +555,12 @@ def main():
             line["host_boundary"] = {"ms_per_call": hs * 1e3, "rows_per_s": 2.0 * N / hs,
                                      "d2h_GBps": (2 * N * (P + 1)) * 8 / hs / 1e9,
                                      "note": "Engine.eval: pageable NumPy outputs, PCIe D2H of the dense Jacobian dominates"}
+        if world == 1 and args.scale == 1.0 and (args.lm_compare or (args.config in (2, 3) and not args.no_normal_probe)):
+            try:  # a probe: its failure must not cost the bench line
+                cfgs = (2, 3) if args.lm_compare else (args.config,)
+                line["lm_end_to_end"] = {f"config_{c}": lm_end_to_end(c, with_scipy=args.lm_compare, scipy_nfev=8 if c == 2 else 4) for c in cfgs}
+            except Exception as exc:  # noqa: BLE001
+                line["lm_end_to_end"] = {"error": f"{type(exc).__name__}: {exc}"}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(rig, chain, ps, args.cpu_seconds)
         print(json.dumps(line), flush=True)

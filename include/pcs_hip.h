@@ -13,6 +13,11 @@
  *     for the calling thread's most recent failure.  No exception crosses the ABI.
  *   - the caller owns every buffer it passes; the engine owns its device buffers for the
  *     lifetime of the handle.  One handle = one host thread at a time.
+ *   - streams: the *_device entry points take a stream; work a handle queues on different streams is ordered
+ *     by the engine (an event recorded after every enqueue is waited for before the shared slabs, the staging
+ *     buffer or the masks are touched again), so consecutive calls may use different streams.  What the engine
+ *     cannot order is the CALLER's use of the output buffers: synchronise the stream a call was queued on (or
+ *     pcs_synchronize) before reading them from another stream or from the host.
  *   - numerical inf/nan (e.g. a point on the camera plane, z = 0) pass through unchanged,
  *     as in the reference's numba code.
  *   - there is NO CPU fallback: without a HIP device pcs_create fails with PCS_ERR_NODEVICE.

@@ -65,7 +65,13 @@ struct pcs_engine {
     // so bench.py samples every 10th launch of its timed region instead of all of them.
     int64_t timing_every = 1;
     int64_t eval_count = 0;
-    hipStream_t last_stream = nullptr;
+    // Ordering across streams: `done` is recorded after everything the engine queues; the next piece of work that
+    // touches the shared slabs / staging buffer / masks first waits for it — on the host where the host writes
+    // (staging buffer, uploads), with hipStreamWaitEvent where another stream takes over.  (Round 1 kept a raw stream
+    // handle and synchronised it later: a caller stream may be destroyed by then.)
+    hipEvent_t done = nullptr;
+    hipStream_t done_stream = nullptr;
+    bool have_done = false;
     // static inputs
     int32_t *d_cam = nullptr, *d_img = nullptr, *d_key = nullptr;  // split index arrays (only when the packed word does not fit)
     uint32_t *d_packed = nullptr;      // cam | image | key bit fields, one word per detection (DetTable, ba_device.hpp)
@@ -120,6 +126,22 @@ struct pcs_engine {
     int64_t tiles_per_wg = 0;  // 0 = derive from wgs_per_cu
     size_t lds_limit = 160 * 1024;
 };
+
+// everything queued so far has finished (host-side wait)
+static hipError_t wait_done_host(pcs_engine *h) { return h->have_done ? hipEventSynchronize(h->done) : hipSuccess; }
+// work queued on `s` from here on runs after everything queued so far, whatever stream that was on.  Same stream as the
+// previous enqueue: stream order already gives that.  Another stream: a device-side wait — except for the legacy
+// default-stream handle, on which hipStreamWaitEvent of this runtime faults; the (rare) switch to or from it waits on the host.
+static hipError_t order_after_done(pcs_engine *h, hipStream_t s) {
+    if (!h->have_done || s == h->done_stream) return hipSuccess;
+    if (s == hipStreamLegacy || s == nullptr || h->done_stream == hipStreamLegacy) return hipEventSynchronize(h->done);
+    return hipStreamWaitEvent(s, h->done, 0);
+}
+static hipError_t mark_done(pcs_engine *h, hipStream_t s) {
+    h->have_done = true;
+    h->done_stream = s;   // compared only, never used as a handle again
+    return hipEventRecord(h->done, s);
+}
 
 static int64_t padded_points(int64_t n_keys) { return (n_keys * 3 + 3) & ~(int64_t)3; }
 
@@ -349,14 +371,25 @@ int pcs_membench(int device, int kind, int64_t bytes, int iters, int blocks_per_
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device));
     void *src = nullptr, *dst = nullptr;
-    HIPCHK(hipMalloc(&dst, bytes));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    auto cleanup = [&]() {
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+        if (src) (void)hipFree(src);
+        if (dst) (void)hipFree(dst);
+    };
+#define MBCHK(expr)                                                                                              \
+    do {                                                                                                         \
+        hipError_t _e = (expr);                                                                                  \
+        if (_e != hipSuccess) { const int _rc = fail(PCS_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); cleanup(); return _rc; } \
+    } while (0)
+    MBCHK(hipMalloc(&dst, bytes));
     if (kind == 2 || kind == 3) {
-        HIPCHK(hipMalloc(&src, bytes));
-        HIPCHK(hipMemset(src, 1, bytes));
+        MBCHK(hipMalloc(&src, bytes));
+        MBCHK(hipMemset(src, 1, bytes));
     }
-    hipEvent_t e0, e1;
-    HIPCHK(hipEventCreate(&e0));
-    HIPCHK(hipEventCreate(&e1));
+    MBCHK(hipEventCreate(&e0));
+    MBCHK(hipEventCreate(&e1));
     const int64_t n16 = bytes / 16;
     const dim3 grid((unsigned)std::min<int64_t>((n16 + 255) / 256, (int64_t)prop.multiProcessorCount * std::max(1, blocks_per_cu)));
     auto launch = [&]() {
@@ -373,17 +406,15 @@ int pcs_membench(int device, int kind, int64_t bytes, int iters, int blocks_per_
         }
     };
     for (int i = 0; i < 3; ++i) launch();
-    HIPCHK(hipEventRecord(e0, nullptr));
+    MBCHK(hipEventRecord(e0, nullptr));
     for (int i = 0; i < iters; ++i) launch();
-    HIPCHK(hipEventRecord(e1, nullptr));
-    HIPCHK(hipEventSynchronize(e1));
+    MBCHK(hipEventRecord(e1, nullptr));
+    MBCHK(hipEventSynchronize(e1));
     float ms = 0;
-    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    MBCHK(hipEventElapsedTime(&ms, e0, e1));
+#undef MBCHK
     *mean_ms = ms / iters;
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    if (src) (void)hipFree(src);
-    (void)hipFree(dst);
+    cleanup();
     return PCS_OK;
 }
 
@@ -440,6 +471,7 @@ int pcs_create(pcs_engine **out, int chain, int dtype, int64_t n_cams, int64_t n
     CREATE_CHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     h->ev.assign(3, nullptr);
     for (auto &e : h->ev) CREATE_CHK(hipEventCreate(&e));
+    CREATE_CHK(hipEventCreateWithFlags(&h->done, hipEventDisableTiming));
     CREATE_CHK(hipMalloc(&h->d_param, sizeof(double) * h->n_params));
     CREATE_CHK(hipHostMalloc(reinterpret_cast<void **>(&h->h_param), sizeof(double) * h->n_params, hipHostMallocDefault));
     CREATE_CHK(hipMalloc(&h->d_cam_slab, sizeof(double) * n_cams * CAM_STRIDE));
@@ -463,6 +495,7 @@ int pcs_destroy(pcs_engine *h) {
     if (h->h_param) (void)hipHostFree(h->h_param);
     for (auto &e : h->ev)
         if (e) (void)hipEventDestroy(e);
+    if (h->done) (void)hipEventDestroy(h->done);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return PCS_OK;
@@ -500,6 +533,7 @@ static int upload_detections(pcs_engine *h, std::vector<int32_t> &cam, std::vect
         h->tile_locality = tiles ? (double)good / (double)tiles : 1.0;
     }
     HIPCHK(hipSetDevice(h->device));
+    HIPCHK(wait_done_host(h));
     HIPCHK(hipStreamSynchronize(h->stream));
     h->point_orders_tried = false;
     for (void **b : {(void **)&h->d_cam, (void **)&h->d_img, (void **)&h->d_key, (void **)&h->d_packed, (void **)&h->d_order, (void **)&h->d_order_ck,
@@ -581,6 +615,7 @@ int pcs_set_template(pcs_engine *h, const double *points) {
     if (!h || !points) return fail(PCS_ERR_ARG, "pcs_set_template: bad arguments");
     if (h->chain != PCS_CHAIN_TEMPLATE) return fail(PCS_ERR_ARG, "pcs_set_template: only the template chain has constant points");
     HIPCHK(hipSetDevice(h->device));
+    HIPCHK(wait_done_host(h));
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipMemcpy(h->d_points, points, sizeof(double) * 3 * h->n_keys, hipMemcpyHostToDevice));
     h->have_template = true;
@@ -621,7 +656,7 @@ int pcs_set_option(pcs_engine *h, const char *key, int64_t value) {
         // keep the HIP-event triples of the last `value` evaluations (pcs_kernel_ms_mean averages them)
         if (value < 1 || value > 100000) return fail(PCS_ERR_ARG, "event_ring must be in [1,100000]");
         HIPCHK(hipSetDevice(h->device));
-        HIPCHK(hipStreamSynchronize(h->last_stream ? h->last_stream : h->stream));
+        HIPCHK(wait_done_host(h));
         for (auto &e : h->ev)
             if (e) (void)hipEventDestroy(e);
         h->ev.assign(3 * value, nullptr);
@@ -738,6 +773,7 @@ static hipError_t launch_compact_t(int chain, int mode, const EvalArgs &a, dim3 
 }
 
 static int launch_slab_prep(pcs_engine *h, const double *d_prm, hipStream_t s, hipEvent_t start = nullptr) {
+    HIPCHK(order_after_done(h, s));   // the slabs are shared: an evaluation still reading them on another stream goes first
     const int has_pose = h->chain != PCS_CHAIN_FREE;
     const int copy_points = h->chain != PCS_CHAIN_TEMPLATE;
     const int64_t ents = h->n_cams + (has_pose ? h->n_imgs : 0);
@@ -869,7 +905,7 @@ static int enqueue_normal(pcs_engine *h, const double *d_prm, double *d_H, doubl
     HIPCHK(hipEventRecord(ev[2], s));
     ++h->ev_count;
     h->events_valid = true;
-    h->last_stream = s;
+    HIPCHK(mark_done(h, s));
     return PCS_OK;
 }
 
@@ -951,7 +987,7 @@ static int enqueue_eval(pcs_engine *h, const double *d_prm, void *d_resid, void 
         ++h->ev_count;
         h->events_valid = true;
     }
-    h->last_stream = s;
+    HIPCHK(mark_done(h, s));
     return PCS_OK;
 }
 
@@ -970,9 +1006,10 @@ static void fill_entry_map(int32_t *out) {
 
 static int stage_params(pcs_engine *h, const double *param_str, hipStream_t s) {
     // the pinned staging buffer is reused: wait until the previous copy out of it has been consumed
-    HIPCHK(hipStreamSynchronize(h->last_stream ? h->last_stream : s));
+    HIPCHK(wait_done_host(h));
     memcpy(h->h_param, param_str, sizeof(double) * h->n_params);
     HIPCHK(hipMemcpyAsync(h->d_param, h->h_param, sizeof(double) * h->n_params, hipMemcpyHostToDevice, s));
+    HIPCHK(mark_done(h, s));
     return PCS_OK;
 }
 
@@ -1125,6 +1162,7 @@ int pcs_set_unfixed(pcs_engine *h, const uint8_t *unfixed, int64_t *nnz_out) {
         pos += 2 * __builtin_popcount(keep[i]);
     }
     HIPCHK(hipSetDevice(h->device));
+    HIPCHK(wait_done_host(h));   // an evaluation on any stream may still read the masks
     HIPCHK(hipStreamSynchronize(h->stream));
     if (!h->d_keep) HIPCHK(hipMalloc(&h->d_keep, sizeof(uint32_t) * h->n));
     if (!h->d_row_off) HIPCHK(hipMalloc(&h->d_row_off, sizeof(int64_t) * h->n));
@@ -1195,7 +1233,7 @@ int pcs_legacy_cost(pcs_engine *h, const double *im_points, const double *proj, 
     HIPCHK(hipGetLastError());
     ++h->ev_count;
     h->events_valid = true;
-    h->last_stream = s;
+    HIPCHK(mark_done(h, s));
     return download(h, errors, h->d_resid, 2 * h->n, s, sizeof(double));
 }
 
@@ -1206,8 +1244,10 @@ int pcs_linearize(pcs_engine *h, const double *param_str) {
     HIPCHK(hipSetDevice(h->device));
     int rc = stage_params(h, param_str, h->stream);
     if (rc) return rc;
-    h->last_stream = h->stream;
-    return launch_slab_prep(h, h->d_param, h->stream);
+    rc = launch_slab_prep(h, h->d_param, h->stream);
+    if (rc) return rc;
+    HIPCHK(mark_done(h, h->stream));
+    return PCS_OK;
 }
 
 int pcs_matfree(pcs_engine *h, int op, const double *in, double *out, double *cost) {
@@ -1216,7 +1256,7 @@ int pcs_matfree(pcs_engine *h, int op, const double *in, double *out, double *co
     if (!h->linearized) return fail(PCS_ERR_STATE, "pcs_matfree: call pcs_linearize (or an evaluation) first");
     HIPCHK(hipSetDevice(h->device));
     hipStream_t s = h->stream;
-    if (h->last_stream && h->last_stream != s) HIPCHK(hipStreamSynchronize(h->last_stream));  // slabs may come from a caller stream
+    HIPCHK(order_after_done(h, s));  // the slabs may have been prepared on a caller stream
     const int64_t n_in = (op == OP_JTU) ? 2 * h->n : (op == OP_JV || op == OP_JTJV) ? h->n_params : 0;
     const int64_t n_out = (op == OP_JV) ? 2 * h->n : h->n_params;
     if (n_in > h->vin_capacity) {
@@ -1259,7 +1299,7 @@ int pcs_matfree(pcs_engine *h, int op, const double *in, double *out, double *co
     HIPCHK(hipEventRecord(ev[2], s));
     ++h->ev_count;
     h->events_valid = true;
-    h->last_stream = s;
+    HIPCHK(mark_done(h, s));
     HIPCHK(hipMemcpyAsync(out, h->d_vout, sizeof(double) * n_out, hipMemcpyDeviceToHost, s));
     if (op == OP_GRAD && cost) HIPCHK(hipMemcpyAsync(cost, h->d_cost, sizeof(double), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));

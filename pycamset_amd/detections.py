@@ -24,7 +24,7 @@ class TargetDetection:
 
     @property
     def max_ims(self) -> int:  # td:74-78
-        temp = int(np.max(self._data[:, 1])) + 1
+        temp = int(np.max(self._data[:, 1])) + 1 if self._data is not None and self._data.shape[0] else 0   # an empty shard keeps its stated max_ims
         self._max_ims = max(temp, self._max_ims)
         return self._max_ims
 

@@ -51,23 +51,31 @@ class JacobianOperator:
     def _red(self, v):
         return self.reduce_fn(v) if self.reduce_fn is not None else v
 
+    # A rank whose shard is EMPTY (ceil(N / world) rows per rank can leave the last ranks without any: N = 9, world = 4)
+    # contributes zeros and still takes part in every collective — raising there would leave the other ranks blocked
+    # in their all-reduce.
+    @property
+    def _empty(self) -> bool:
+        return self.eng.n == 0
+
     def linearize(self, param_str):
-        self.eng.linearize(param_str)
+        if not self._empty:
+            self.eng.linearize(param_str)
 
     def jv(self, v_free):          # (2N_local,) — stays per rank
-        return self.eng.jv(self._expand(v_free))
+        return np.zeros(0) if self._empty else self.eng.jv(self._expand(v_free))
 
     def jtu(self, u):
-        return self._red(self.eng.jtu(u)[self.free])
+        return self._red(np.zeros(self.n_free) if self._empty else self.eng.jtu(u)[self.free])
 
     def jtjv(self, v_free):
-        return self._red(self.eng.jtjv(self._expand(v_free))[self.free])
+        return self._red(np.zeros(self.n_free) if self._empty else self.eng.jtjv(self._expand(v_free))[self.free])
 
     def diag(self):
-        return self._red(self.eng.jtj_diag()[self.free])
+        return self._red(np.zeros(self.n_free) if self._empty else self.eng.jtj_diag()[self.free])
 
     def grad(self):
-        g, c = self.eng.grad()
+        g, c = (np.zeros(self.eng.n_params), 0.0) if self._empty else self.eng.grad()
         if self.reduce_fn is not None:
             packed = self.reduce_fn(np.concatenate([g[self.free], [c]]))
             return packed[:-1], float(packed[-1])
@@ -143,7 +151,10 @@ class NormalEquations:
         torch = self.torch
         with torch.cuda.device(self._H.device):
             stream = torch.cuda.current_stream().cuda_stream
-            self.eng.normal_equations_device(param_str, self._H.data_ptr(), self._g.data_ptr(), self._c.data_ptr(), stream)
+            if self.eng.n == 0:   # empty shard: zeros, but the all-reduce below still happens (see JacobianOperator)
+                self._H.zero_(); self._g.zero_(); self._c.zero_()
+            else:
+                self.eng.normal_equations_device(param_str, self._H.data_ptr(), self._g.data_ptr(), self._c.data_ptr(), stream)
             U = self._H if self._all_free else self._H[self._idx][:, self._idx]
             g = self._g if self._all_free else self._g[self._idx]
             U, g, c = reduce_normal_equations(U, g, self._c, self.reduce_fn)

@@ -152,9 +152,12 @@ class optimisation_function:  # afb:111-685
             raise ValueError("detections must be the flattened (N, 5) table [cam, im, key, u, v]")
         key = (det.shape, hash(det.tobytes()))
         if self._engine is None or key != self._engine_key:
-            C, I, K = _counts(det)
-            if self.counts is not None:
-                C, I, K = (max(a, b) for a, b in zip(self.counts, (C, I, K)))
+            if det.shape[0] == 0 and self.counts is not None:
+                C, I, K = self.counts    # an empty shard of a sharded table: the global layout, no detections
+            else:
+                C, I, K = _counts(det)
+                if self.counts is not None:
+                    C, I, K = (max(a, b) for a, b in zip(self.counts, (C, I, K)))
             eng = Engine(self.chain, C, I, K, dtype=self.dtype, device=self.device)
             eng.set_detections_table(det)
             self._engine, self._engine_key = eng, key

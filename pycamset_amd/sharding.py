@@ -20,7 +20,10 @@ def shard_rows(n: int, world: int) -> int:
 
 
 def padded_shard(det: np.ndarray, rank: int, world: int) -> np.ndarray:
-    """Rank ``rank``'s contiguous block of the table padded to equal length by cyclic repetition."""
+    """Rank ``rank``'s contiguous block of the table padded to equal length by cyclic repetition.
+    For GATHERING blocks only (the padding is dropped after the gather): sums over shards — J^T J, J^T r, the cost —
+    must use the unpadded ranges ``det[rank * per : (rank + 1) * per]`` (possibly empty for the last ranks), or the
+    repeated rows are counted twice."""
     per = shard_rows(det.shape[0], world)
     idx = (np.arange(rank * per, (rank + 1) * per)) % det.shape[0]
     return np.ascontiguousarray(det[idx])

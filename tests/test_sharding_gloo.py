@@ -196,3 +196,43 @@ def test_sharded_normal_equations_allreduce(tmp_path):
     world = 2
     mp.spawn(_worker_normal_eq, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     assert all((tmp_path / f"ok{r}").exists() for r in range(world))
+
+
+def _worker_empty_shard(rank, world, port, out_dir):
+    """N = 9 detections on 4 ranks: ceil(9 / 4) = 3 rows per rank leaves rank 3 with none.  Its operator must contribute
+    zeros and still enter every all-reduce (the other ranks used to block forever)."""
+    sys.path.insert(0, str(REPO))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import ba_oracle as orc
+        from pycamset_amd import sharding, synthetic
+        from pycamset_amd.device_solver import JacobianOperator
+
+        rig = synthetic.tiny_rig(seed=4, n_cams=3, n_imgs=5, n_keys=9)
+        det = rig.detections[:9].copy()
+        det[-1, :3] = [rig.n_cams - 1, rig.n_imgs - 1, rig.n_keys - 1]
+        counts = (rig.n_cams, rig.n_imgs, rig.n_keys)
+        ps = orc.build_param_list(rig.intr, rig.extr, rig.poses)
+        per = sharding.shard_rows(det.shape[0], world)
+        mine = det[rank * per: (rank + 1) * per]
+        assert (mine.shape[0] == 0) == (rank == 3)
+        mask = np.ones(ps.shape[0], bool)
+        op = JacobianOperator(_OracleEngine("template", mine, counts, rig.points), mask, reduce_fn=sharding.allreduce_sum_fn())
+        op.linearize(ps)
+        full = JacobianOperator(_OracleEngine("template", det, counts, rig.points), mask)
+        full.linearize(ps)
+        v = np.random.default_rng(1).standard_normal(op.n_free)
+        assert np.allclose(op.jtjv(v), full.jtjv(v), rtol=1e-12, atol=1e-9) and np.allclose(op.diag(), full.diag(), rtol=1e-12, atol=1e-12)
+        g, c = op.grad()
+        gf, cf = full.grad()
+        assert np.allclose(g, gf, rtol=1e-12, atol=1e-9) and abs(c - cf) <= 1e-12 * cf
+        Path(out_dir, f"ok{rank}").write_text("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_empty_shard_contributes_zeros_and_does_not_deadlock(tmp_path):
+    world = 4
+    mp.spawn(_worker_empty_shard, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(world))
