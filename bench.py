@@ -258,6 +258,9 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0, help="visibility scale (<1: smaller N, for quick checks)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="N > 1: 'strong' shards the ONE rig of the config over the ranks (default), 'weak' gives every rank its own rig")
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="one-GPU projection of strong scaling: evaluate only rank 0's shard of a K-way split of the rig "
+                         "(value then counts that shard's rows only; reported under config.emulated_world)")
     ap.add_argument("--collective", default="none", choices=["none", "allgather"],
                     help="'allgather' puts the RCCL all-gather of residual+Jacobian blocks inside the timed step")
     ap.add_argument("--variant", type=int, default=None)
@@ -309,6 +312,9 @@ def main():
     chain = args.chain or CONFIG_CHAIN[args.config]
     dtype = args.dtype or CONFIG_DTYPE[args.config]
     prob = rank_problem(args.config, chain, rank, world, args.scaling, args.scale)
+    if args.emulate_world > 1 and world == 1:
+        prob = rank_problem(args.config, chain, 0, args.emulate_world, "strong", args.scale)
+        prob["n_total"] = prob["n_real"]          # only this shard is evaluated here
     rig, det, ps = prob["rig"], prob["det"], prob["param_str"]
     N = det.shape[0]            # rows this rank evaluates (incl. cyclic padding of the last shard)
 
@@ -484,7 +490,7 @@ def main():
         bpd = BYTES_PER_DET[(chain, dtype)]
         achieved = N * bpd / (eval_ms * 1e-3) / 1e9
         name = rig.name.split("/")[0]
-        traffic, traffic_source = pmc_traffic(f"{name}/{chain}/{dtype}") if (world == 1 and args.scale == 1.0) else (None, None)
+        traffic, traffic_source = pmc_traffic(f"{name}/{chain}/{dtype}") if (world == 1 and args.scale == 1.0 and args.emulate_world <= 1) else (None, None)
         in_bytes = 20 if dtype == "f32" else 28
         shard_txt = (f"{n_total} detections" if world == 1 else
                      f"{n_total} detections sharded into contiguous blocks of {per} per GPU" if args.scaling == "strong" else
@@ -512,6 +518,7 @@ def main():
                 "collective_in_step": args.collective if world > 1 else "none",
                 "jacobian_streamed_to_host": bool(args.stream_to_host),
                 "parallelism": f"obs-shard x{world}",
+                **({"emulated_world": args.emulate_world} if args.emulate_world > 1 and world == 1 else {}),
             },
             "roofline": {
                 "bound": "hbm",
@@ -555,7 +562,7 @@ def main():
             line["host_boundary"] = {"ms_per_call": hs * 1e3, "rows_per_s": 2.0 * N / hs,
                                      "d2h_GBps": (2 * N * (P + 1)) * 8 / hs / 1e9,
                                      "note": "Engine.eval: pageable NumPy outputs, PCIe D2H of the dense Jacobian dominates"}
-        if world == 1 and args.scale == 1.0 and (args.lm_compare or (args.config in (2, 3) and not args.no_normal_probe)):
+        if world == 1 and args.scale == 1.0 and args.emulate_world <= 1 and (args.lm_compare or (args.config in (2, 3) and not args.no_normal_probe)):
             try:  # a probe: its failure must not cost the bench line
                 cfgs = (2, 3) if args.lm_compare else (args.config,)
                 line["lm_end_to_end"] = {f"config_{c}": lm_end_to_end(c, with_scipy=args.lm_compare, scipy_nfev=8 if c == 2 else 4) for c in cfgs}
