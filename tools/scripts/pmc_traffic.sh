@@ -5,8 +5,8 @@ TAG=$1; shift
 cd /tmp && export TMPDIR=/tmp
 R=/root/repo
 O=$R/gpurun_out/pmc_traffic_$TAG
-rm -rf $O
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-normal-probe "$@" > $O.fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-normal-probe "$@" > $O.write.log 2>&1
+mkdir -p $R/gpurun_out; rm -rf $O
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-normal-probe "$@" > $O.fetch.log 2>&1 < /dev/null
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-normal-probe "$@" > $O.write.log 2>&1 < /dev/null
 python3 $R/tools/pmc_summary.py $O ba_eval > $R/gpurun_out/pmc_traffic_$TAG.json
 cat $R/gpurun_out/pmc_traffic_$TAG.json
