@@ -174,7 +174,9 @@ int pcs_normal_equations_device(pcs_engine *h, const double *param_str, double *
 /* Which entry of H / g / cost every accumulator register of the normal-equations kernel stands for (host function, no
  * GPU needed): out[m][lane][r][2], m < 2 MFMAs, lane < 64, r < 4 registers = the two local column ids (index into
  * a J row, 30 = the residual column) of D_m[(lane >> 4) + 4 r][lane & 15], or -1, -1 where the register is not owned.
- * pass 0 = shared (camera + pose + residual), 1 = (cam, key) point pass, 2 = (image, key) point pass.
+ * pass 0 = shared (camera + pose + residual), 1 = (cam, key) point pass, 2 = (image, key) point pass.  Pass 2 is a
+ * segmented sum in matrix form: its registers hold 16 runs at a time — register r of lane l belongs to local run
+ * (l >> 4) + 4 r and to the product of the pose column out[..][0] with the point column out[..][1].
  * Diagnostic aid: tests/test_host_logic.py checks that every needed column pair is owned exactly once. */
 int pcs_normal_entry_map(int chain, int pass, int32_t *out);
 
@@ -203,7 +205,7 @@ int pcs_kernel_ms_mean(pcs_engine *h, int64_t *count, float *slab_prep_ms, float
  * the sample list of general_utils.benchmark(), utils/general_utils.py:62-104). */
 int pcs_kernel_ms_samples(pcs_engine *h, int64_t capacity, float *slab_prep_ms, float *eval_ms, int64_t *count);
 /* Tuning knobs ("variant", "wgs_per_cu", "tiles_per_wg", "event_ring", "timing_every",
- * "compact_variant", "matfree_lds", "xcd_remap", "waves_per_wg", "pack_indices", "normal_rows"; "normal_debug" is a
+ * "compact_variant", "matfree_lds", "xcd_remap", "waves_per_wg", "pack_indices", "normal_rows", "normal_imgkey_product"; "normal_debug" is a
  * profiling switch of pcs_normal_equations that skips the flush atomics — results are wrong while it is non-zero);
  * see DESIGN.md.
  * Unknown keys -> PCS_ERR_ARG. */

@@ -399,4 +399,143 @@ __global__ __launch_bounds__(64, 2) void ba_normal_mfma_kernel(const NormalArgs 
     flush(true);
 }
 
+// ---------------------------------------------------------------------------------------------
+// PASS_IMGKEY in product form (self chain): F[i,k] = sum over the detections of (image i, key k) of J_pose^T J_point.
+// ---------------------------------------------------------------------------------------------
+// An (image, key) run is only as long as the number of cameras that see the feature (2 .. n_cams), so a tile of 64
+// detections holds 5 - 30 runs and the boundary walk of ba_normal_mfma_kernel degenerates: every k-step straddles a
+// boundary, the accumulator tile holds 18 useful entries of 256, and each run pays its own flush (132 us at
+// N = 1.1e6, more than the shared pass).  Here the segmented sum itself is the matrix product:
+//     D[run][c] = sum_d S[run][d] * P[d][c]
+// with S the 0/1 membership of the tile's detections in its (up to 16) runs and P[d][c = 3 p + x] the detection's 18
+// products Ju[pose p] Ju[point x] + Jv[pose p] Jv[point x].  P goes through a wave-private LDS image (column-major,
+// 8 bytes per detection); S needs no storage — lane (i, q) of the A operand compares detection 4 s + q with the first
+// and one-past-last detection of run i.  16 k-steps x 2 MFMAs (columns 0-15, 16-17) per batch of 16 runs, no boundary
+// handling, and one flush per tile: 4 + 4 atomic instructions.  A tile starts a new run (partial sums of a run that
+// spans tiles meet in the atomics), so nothing is carried between tiles.
+constexpr int IK_COLS = 18;
+constexpr int IK_SLOT = 64 * 8 + 16;                       // bytes per column: 64 detections + pad (slot c starts on bank 4 c)
+constexpr int IK_RUNS = IK_COLS * IK_SLOT;                 // byte offset of the run table: 65 x {first detection, image, key, -}
+constexpr int normal_imgkey_lds_bytes() { return IK_RUNS + 65 * 16; }
+
+// entry of accumulator register r of MFMA m in lane l: local run (l >> 4) + 4 r, product column 16 m + (l & 15)
+__host__ __device__ __forceinline__ constexpr int imgkey_col(int m, int lane) { return 16 * m + (lane & 15); }
+
+__global__ __launch_bounds__(64, 2) void ba_normal_imgkey_kernel(const NormalArgs a) {
+    using T = double;
+    constexpr int CHAIN = CHAIN_SELF;
+    constexpr int P = chain_P(CHAIN);
+    constexpr int P2 = 2 * P;
+    constexpr int NS = normal_shared_cols(CHAIN);
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_image[];
+    const int lane = threadIdx.x;
+    const T *cam_slab = static_cast<const T *>(a.cam_slab);
+    const T *pose_slab = static_cast<const T *>(a.pose_slab);
+    const T *points = static_cast<const T *>(a.points);
+    using I4 = __attribute__((ext_vector_type(4))) int;
+    I4 *runs = reinterpret_cast<I4 *>(lds_image + IK_RUNS);
+
+    const int li = lane & 15, lq = lane >> 4;
+    // B operand of MFMA m at k-step s: P[4 s + q][16 m + j]; lanes whose column does not exist read a valid slot, result unused
+    const int rd0 = li * IK_SLOT + lq * 8;
+    const int rd1 = (16 + (li & 1)) * IK_SLOT + lq * 8;
+    const int c0 = imgkey_col(0, lane), c1 = imgkey_col(1, lane);
+    // parameter-string offsets of this lane's two product columns: row = pose column p, column = point column x
+    const int row0 = (int)a.pose_off + c0 / 3, col0 = (int)a.point_off + c0 % 3;
+    const int row1 = (int)a.pose_off + (c1 < IK_COLS ? c1 / 3 : 0), col1 = (int)a.point_off + (c1 < IK_COLS ? c1 % 3 : 0);
+
+    auto det_index = [&](const int64_t tile) -> int64_t {
+        const int64_t i = tile * 64 + lane;
+        const int64_t is = i < a.n ? i : a.n - 1;
+        return a.order ? a.order[is] : is;
+    };
+    const int64_t tile0 = (int64_t)blockIdx.x * a.tiles_per_wave;
+    const int64_t tile1 = min(tile0 + (int64_t)a.tiles_per_wave, a.n_tiles);
+    DetWords nxt_w{};
+    if (tile0 < tile1) nxt_w = load_words(a.tab, det_index(tile0));
+    for (int64_t tile = tile0; tile < tile1; ++tile) {
+        const bool valid = tile * 64 + lane < a.n;
+        int c, im, k;
+        decode_words(a.tab, nxt_w, c, im, k);
+        if (tile + 1 < tile1) nxt_w = load_words(a.tab, det_index(tile + 1));
+        asm volatile("" ::: "memory");
+        T J[P2];
+        if (a.debug & 16) {
+#pragma unroll
+            for (int j = 0; j < P2; ++j) J[j] = (double)(lane + j);
+        } else {
+            T u, v;
+            const T X0 = points[3 * k], X1 = points[3 * k + 1], X2 = points[3 * k + 2];
+            const int im0 = __builtin_amdgcn_readfirstlane(im);
+            const T *csp = cam_slab + c * CAM_STRIDE;
+            if (__all(im == im0)) {
+                const LaneSlab lp{pose_slab[im0 * POSE_STRIDE + min(lane, POSE_STRIDE - 1)]};
+                eval_detection<CHAIN, T, true>(csp, lp, X0, X1, X2, u, v, J);
+            } else {
+                eval_detection<CHAIN, T, true>(csp, pose_slab + im * POSE_STRIDE, X0, X1, X2, u, v, J);
+            }
+        }
+        asm volatile("" ::"v"(nxt_w.w0), "v"(nxt_w.w1), "v"(nxt_w.w2));   // consume the prefetch before any atomic is issued (ba_normal_mfma_kernel)
+
+        // runs of this tile: lane 0 always starts one
+        const int pi = __shfl_up(im, 1), pk = __shfl_up(k, 1);
+        const bool starts = lane == 0 || (valid && (im != pi || k != pk));
+        const uint64_t bnd = __ballot(starts);
+        const int n_runs = __popcll(bnd);
+        const int rl = __popcll(bnd & ((2ull << lane) - 1ull)) - 1;     // local run of this lane's detection
+
+        // ---- LDS: product columns and the run table ---------------------------------------------------------------------
+        if (!(a.debug & 64)) {
+            unsigned char *dst = lds_image + lane * 8;
+#pragma unroll
+            for (int cc = 0; cc < IK_COLS; ++cc) {
+                const int p = 15 + cc / 3, x = NS + cc % 3;
+                const double prod = valid ? J[p] * J[x] + J[P + p] * J[P + x] : 0.0;
+                *reinterpret_cast<double *>(dst + cc * IK_SLOT) = prod;
+            }
+        }
+        runs[lane + 1] = I4{64, 0, 0, 0};                               // sentinel: runs past the last one are empty
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (starts) runs[rl] = I4{lane, im, k, 0};
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        if (!(a.debug & 8)) {
+            for (int b0 = 0; b0 < n_runs; b0 += 16) {
+                const int lo = runs[b0 + li].x, hi = runs[b0 + li + 1].x;        // detections [lo, hi) form run b0 + li
+                double bx0[16], bx1[16];
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    bx0[s] = *reinterpret_cast<const double *>(lds_image + rd0 + s * 32);
+                    bx1[s] = *reinterpret_cast<const double *>(lds_image + rd1 + s * 32);
+                }
+                d4v acc0{0.0, 0.0, 0.0, 0.0}, acc1{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    const int d = 4 * s + lq;
+                    const double member = (d >= lo && d < hi) ? 1.0 : 0.0;
+                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(member, bx0[s], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(member, bx1[s], acc1, 0, 0, 0);
+                }
+                // flush: register r = run b0 + q + 4 r
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int run = b0 + lq + 4 * r;
+                    const I4 e = runs[min(run, 64)];
+                    const bool live = run < n_runs && !(a.debug & 2);
+                    const int64_t base = (int64_t)(6 * e.y) * a.n_params + 3 * e.z;
+                    const double s0 = acc0[r], s1 = acc1[r];
+                    if (live && s0 != 0.0) unsafeAtomicAdd(a.H + base + (int64_t)row0 * a.n_params + col0, s0);
+                    if (live && c1 < IK_COLS && s1 != 0.0) unsafeAtomicAdd(a.H + base + (int64_t)row1 * a.n_params + col1, s1);
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
 }  // namespace pcs

@@ -10,6 +10,8 @@
 #include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include <algorithm>
 #include <cstdarg>
 #include <cstdint>
@@ -110,6 +112,7 @@ struct pcs_engine {
     int64_t im_points_capacity = 0;
     bool linearized = false;
     int normal_debug = 0;
+    int normal_imgkey_product = 1;   // pose-point blocks by ba_normal_imgkey_kernel (0: the boundary-walking pass, kept for A/B)
     bool matfree_lds = true;  // accumulate J^T products in workgroup-private LDS before the global atomics
     // launch geometry
     int n_cu = 256;
@@ -649,6 +652,8 @@ int pcs_set_option(pcs_engine *h, const char *key, int64_t value) {
         h->matfree_lds = value != 0;
     } else if (!strcmp(key, "normal_debug")) {
         h->normal_debug = (int)value;
+    } else if (!strcmp(key, "normal_imgkey_product")) {
+        h->normal_imgkey_product = value != 0;
     } else if (!strcmp(key, "compact_variant")) {
         if (value < 0 || value > 1) return fail(PCS_ERR_ARG, "compact_variant must be 0 or 1");
         h->compact_variant = (int)value;
@@ -693,15 +698,17 @@ static DetTable det_table(const pcs_engine *h) {
 template <int CHAIN, int MODE, int VARIANT, typename TO>
 static hipError_t launch_eval_v(const EvalArgs &a, dim3 grid, int threads, size_t lds, hipStream_t s, EvPair ev) {
     auto kern = ba_eval_kernel<CHAIN, MODE, VARIANT, TO>;
-    // per device: largest dynamic-LDS size already enabled for this kernel (one handle = one host thread at a time;
-    // handles driven from different threads only race on a value that is monotone and idempotent to set)
-    static size_t configured[64] = {0};
+    // per device: largest dynamic-LDS size already enabled for this kernel.  Handles driven from different host threads
+    // may get here together: the value is monotone and setting the attribute twice is harmless, so an atomic max is enough
+    static std::atomic<size_t> configured[64];
     int dev = 0;
     (void)hipGetDevice(&dev);
-    if (lds > 48 * 1024 && lds > configured[dev & 63]) {
+    std::atomic<size_t> &cfg = configured[dev & 63];
+    if (lds > 48 * 1024 && lds > cfg.load(std::memory_order_acquire)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        configured[dev & 63] = lds;
+        size_t seen = cfg.load(std::memory_order_relaxed);
+        while (seen < lds && !cfg.compare_exchange_weak(seen, lds, std::memory_order_release, std::memory_order_relaxed)) {}
     }
     hipExtLaunchKernelGGL(kern, grid, dim3(threads), (std::uint32_t)lds, s, ev.start, ev.stop, 0, a);
     return hipGetLastError();
@@ -899,7 +906,13 @@ static int enqueue_normal(pcs_engine *h, const double *d_prm, double *d_H, doubl
     for (int pass = 0; pass < n_pass; ++pass) {
         a.order = pass == PASS_SHARED ? h->d_order : pass == PASS_CAMKEY ? h->d_order_ck : h->d_order_ik;
         if (pass != PASS_SHARED && !a.order) return fail(PCS_ERR_STATE, "normal equations: key-sorted visiting order missing");
-        hipError_t e = launch_normal(h->chain, pass, h->normal_rows, a, grid, s);
+        hipError_t e;
+        if (pass == PASS_IMGKEY && h->normal_imgkey_product) {
+            hipLaunchKernelGGL(ba_normal_imgkey_kernel, grid, dim3(64), normal_imgkey_lds_bytes(), s, a);
+            e = hipGetLastError();
+        } else {
+            e = launch_normal(h->chain, pass, h->normal_rows, a, grid, s);
+        }
         if (e != hipSuccess) return fail(PCS_ERR_HIP, "normal-equations kernel launch failed: %s", hipGetErrorString(e));
     }
     HIPCHK(hipEventRecord(ev[2], s));
@@ -1407,7 +1420,15 @@ int pcs_normal_entry_map(int chain, int pass, int32_t *out) {
         if (chain == CHAIN_SELF) fill_entry_map<CHAIN_SELF, PASS_CAMKEY>(out);
         else fill_entry_map<CHAIN_FREE, PASS_CAMKEY>(out);
     } else {
-        fill_entry_map<CHAIN_SELF, PASS_IMGKEY>(out);
+        // ba_normal_imgkey_kernel: register r of MFMA m in lane l = (local run (l >> 4) + 4 r, product column 16 m + (l & 15))
+        for (int m = 0; m < 2; ++m)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int r = 0; r < 4; ++r) {
+                    const int c = imgkey_col(m, lane);
+                    int32_t *o = out + ((m * 64 + lane) * 4 + r) * 2;
+                    o[0] = c < IK_COLS ? 15 + c / 3 : -1;
+                    o[1] = c < IK_COLS ? normal_shared_cols(CHAIN_SELF) + c % 3 : -1;
+                }
     }
     return PCS_OK;
 }

@@ -349,6 +349,10 @@ def test_block_reduced_normal_equations_match_the_oracle_jacobian(chain, dtype):
         H3, g3, c3 = e.normal_equations(ps)
         assert np.max(np.abs(H3 - H_ref) / np.where(scale > 0, scale, 1.0)) <= tol, name
         assert np.max(np.abs(g3 - g_ref)) <= tol_r * np.max(np.abs(g_ref)) and abs(c3 - c_ref) <= tol_r * c_ref, name
+        if chain == "self":                           # pose-point blocks by the boundary-walking pass (kept for A/B): same matrix
+            e.set_option("normal_imgkey_product", 0)
+            H4, _, _ = e.normal_equations(ps)
+            assert np.max(np.abs(H4 - H_ref) / np.where(scale > 0, scale, 1.0)) <= tol, name
         e.close()
 
 

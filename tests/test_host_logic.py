@@ -396,6 +396,18 @@ def test_normal_equation_entry_maps_own_every_pair_exactly_once():
         pts, cam = [pt0, pt0 + 1, pt0 + 2], list(range(15))
         need = sorted([tuple(sorted((c, q))) for c in cam for q in pts] + upper(pts) + [(q, R) for q in pts])
         assert sorted(owned(chain, 1)) == need, chain                            # E[c,k], D[k], g[k]
-    assert sorted(owned("self", 2)) == sorted((p, q) for p in range(15, 21) for q in (21, 22, 23))   # F[i,k]
+    # F[i,k] (ba_normal_imgkey_kernel): the accumulators hold 16 runs at a time — register r of lane l belongs to local
+    # run (l >> 4) + 4 r — and every run must own each pose x point pair exactly once
+    out = np.full((2, 64, 4, 2), -7, dtype=np.int32)
+    _capi.check(lib.pcs_normal_entry_map(_capi.CHAIN_IDS["self"], 2, out.ctypes.data_as(POINTER(c_int32))))
+    per_run = {}
+    for m in range(2):
+        for lane in range(64):
+            for r in range(4):
+                if out[m, lane, r, 0] >= 0:
+                    per_run.setdefault((lane >> 4) + 4 * r, []).append(tuple(out[m, lane, r].tolist()))
+    assert sorted(per_run) == list(range(16))
+    for pairs in per_run.values():
+        assert sorted(pairs) == sorted((p, q) for p in range(15, 21) for q in (21, 22, 23))
     for chain, p in (("template", 1), ("template", 2), ("free", 2)):
         assert lib.pcs_normal_entry_map(_capi.CHAIN_IDS[chain], p, np.zeros(1024, np.int32).ctypes.data_as(POINTER(c_int32))) == _capi.PCS_ERR_ARG
