@@ -175,8 +175,9 @@ int pcs_normal_equations_device(pcs_engine *h, const double *param_str, double *
  * GPU needed): out[m][lane][r][2], m < 2 MFMAs, lane < 64, r < 4 registers = the two local column ids (index into
  * a J row, 30 = the residual column) of D_m[(lane >> 4) + 4 r][lane & 15], or -1, -1 where the register is not owned.
  * pass 0 = shared (camera + pose + residual), 1 = (cam, key) point pass, 2 = (image, key) point pass.  Pass 2 is a
- * segmented sum in matrix form: its registers hold 16 runs at a time — register r of lane l belongs to local run
- * (l >> 4) + 4 r and to the product of the pose column out[..][0] with the point column out[..][1].
+ * segmented sum in matrix form: its registers hold, for 16 runs at a time, the symmetric 3 x 3 sum over the
+ * pose-translation columns (local ids 18..20) from which the run's pose-point block is finished; register r of lane l
+ * belongs to local run (l >> 4) + 4 r.
  * Diagnostic aid: tests/test_host_logic.py checks that every needed column pair is owned exactly once. */
 int pcs_normal_entry_map(int chain, int pass, int32_t *out);
 

@@ -60,7 +60,8 @@ struct NormalArgs {
     int64_t n_params;
     int32_t tiles_per_wave;
     int32_t debug;  // profiling switches (results are wrong while set): 2 no flush atomics, 8 no MFMA phase, 16 no evaluation,
-                    // 32 run boundaries ignored, 64 no LDS image writes
+                    // 32 run boundaries ignored, 64 no LDS image writes; host side: 256 / 512 / 1024 skip the shared /
+                    // (cam, key) / (image, key) pass
 };
 
 constexpr int PASS_SHARED = 0, PASS_CAMKEY = 1, PASS_IMGKEY = 2;
@@ -400,49 +401,50 @@ __global__ __launch_bounds__(64, 2) void ba_normal_mfma_kernel(const NormalArgs 
 }
 
 // ---------------------------------------------------------------------------------------------
-// PASS_IMGKEY in product form (self chain): F[i,k] = sum over the detections of (image i, key k) of J_pose^T J_point.
+// PASS_IMGKEY (self chain) as a segmented sum: F[i,k] = sum over the detections of (image i, key k) of J_pose^T J_point.
 // ---------------------------------------------------------------------------------------------
 // An (image, key) run is only as long as the number of cameras that see the feature (2 .. n_cams), so a tile of 64
 // detections holds 5 - 30 runs and the boundary walk of ba_normal_mfma_kernel degenerates: every k-step straddles a
 // boundary, the accumulator tile holds 18 useful entries of 256, and each run pays its own flush (132 us at
-// N = 1.1e6, more than the shared pass).  Here the segmented sum itself is the matrix product:
-//     D[run][c] = sum_d S[run][d] * P[d][c]
-// with S the 0/1 membership of the tile's detections in its (up to 16) runs and P[d][c = 3 p + x] the detection's 18
-// products Ju[pose p] Ju[point x] + Jv[pose p] Jv[point x].  P goes through a wave-private LDS image (column-major,
-// 8 bytes per detection); S needs no storage — lane (i, q) of the A operand compares detection 4 s + q with the first
-// and one-past-last detection of run i.  16 k-steps x 2 MFMAs (columns 0-15, 16-17) per batch of 16 runs, no boundary
-// handling, and one flush per tile: 4 + 4 atomic instructions.  A tile starts a new run (partial sums of a run that
-// spans tiles meet in the atomics), so nothing is carried between tiles.
-constexpr int IK_COLS = 18;
-constexpr int IK_SLOT = 64 * 8 + 16;                       // bytes per column: 64 detections + pad (slot c starts on bank 4 c)
-constexpr int IK_RUNS = IK_COLS * IK_SLOT;                 // byte offset of the run table: 65 x {first detection, image, key, -}
-constexpr int normal_imgkey_lds_bytes() { return IK_RUNS + 65 * 16; }
+// N = 1.1e6, more than the shared pass).  Two observations replace it:
+//
+//  (1) Inside a run the pose and the point are fixed, and both column groups are the SAME 2 x 3 block S = A_x R_e
+//      (eval_detection) times run constants:  J_pose = S [Q_r | I],  J_point = S R_p,  Q_r[:, a] = (dR_p / dr_a) X.
+//      So the run needs only the symmetric 3 x 3 sum  G = sum_d S_d^T S_d  (6 numbers instead of 18), and
+//          F[t_c, x] = (G R_p)[c][x]        F[r_a, x] = (Q_r^T G R_p)[a][x]
+//      is finished once per run by the lane that owns the run.  The evaluation shrinks with it: no intrinsic, extrinsic
+//      or pose-rotation columns are formed per detection.
+//  (2) The segmented sum is itself a matrix product, D[run][c] = sum_d M[run][d] P[d][c], with M the 0/1 membership of
+//      the tile's detections in (up to 16) runs and P[d][c] the detection's 6 products S_u[a] S_u[b] + S_v[a] S_v[b].
+//      P goes through a wave-private LDS image (column-major, 8 bytes per detection); M needs no storage — lane (i, q)
+//      of the A operand compares detection 4 s + q with the first and one-past-last detection of run i.  16 k-steps of
+//      one v_mfma_f64_16x16x4_f64 per batch of 16 runs, no boundary handling.
+// A tile starts a new run (the parts of a run that spans tiles meet in the atomics), so nothing is carried between
+// tiles.  Rounding differs from summing the 18 products directly by a few ulp of |Q_r| |G| |R_p| — far inside the
+// run-to-run spread the atomics already have.
+constexpr int IK_COLS = 6;                                 // (a, b) pairs of the symmetric 3 x 3, a <= b
+constexpr int IK_SLOT = 64 * 8 + 16;                       // bytes per product column: 64 detections + pad (slot c starts on bank 4 c)
+constexpr int IK_RUNS = IK_COLS * IK_SLOT;                 // run table: 65 x {first detection, image, key, -}
+constexpr int IK_GRAM = IK_RUNS + 65 * 16;                 // finished sums: 64 runs x 6 doubles
+constexpr int normal_imgkey_lds_bytes() { return IK_GRAM + 64 * IK_COLS * 8; }
 
-// entry of accumulator register r of MFMA m in lane l: local run (l >> 4) + 4 r, product column 16 m + (l & 15)
-__host__ __device__ __forceinline__ constexpr int imgkey_col(int m, int lane) { return 16 * m + (lane & 15); }
-
-__global__ __launch_bounds__(64, 2) void ba_normal_imgkey_kernel(const NormalArgs a) {
+__global__ __launch_bounds__(64, 3) void ba_normal_imgkey_kernel(const NormalArgs a) {
     using T = double;
     constexpr int CHAIN = CHAIN_SELF;
     constexpr int P = chain_P(CHAIN);
     constexpr int P2 = 2 * P;
-    constexpr int NS = normal_shared_cols(CHAIN);
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_image[];
     const int lane = threadIdx.x;
     const T *cam_slab = static_cast<const T *>(a.cam_slab);
     const T *pose_slab = static_cast<const T *>(a.pose_slab);
     const T *points = static_cast<const T *>(a.points);
     using I4 = __attribute__((ext_vector_type(4))) int;
+    using D2 = __attribute__((ext_vector_type(2))) double;
     I4 *runs = reinterpret_cast<I4 *>(lds_image + IK_RUNS);
 
     const int li = lane & 15, lq = lane >> 4;
-    // B operand of MFMA m at k-step s: P[4 s + q][16 m + j]; lanes whose column does not exist read a valid slot, result unused
-    const int rd0 = li * IK_SLOT + lq * 8;
-    const int rd1 = (16 + (li & 1)) * IK_SLOT + lq * 8;
-    const int c0 = imgkey_col(0, lane), c1 = imgkey_col(1, lane);
-    // parameter-string offsets of this lane's two product columns: row = pose column p, column = point column x
-    const int row0 = (int)a.pose_off + c0 / 3, col0 = (int)a.point_off + c0 % 3;
-    const int row1 = (int)a.pose_off + (c1 < IK_COLS ? c1 / 3 : 0), col1 = (int)a.point_off + (c1 < IK_COLS ? c1 % 3 : 0);
+    // B operand at k-step s: P[4 s + q][j]; lanes whose column does not exist read a valid slot, result unused
+    const int rd = min(li, IK_COLS - 1) * IK_SLOT + lq * 8;
 
     auto det_index = [&](const int64_t tile) -> int64_t {
         const int64_t i = tile * 64 + lane;
@@ -459,21 +461,24 @@ __global__ __launch_bounds__(64, 2) void ba_normal_imgkey_kernel(const NormalArg
         decode_words(a.tab, nxt_w, c, im, k);
         if (tile + 1 < tile1) nxt_w = load_words(a.tab, det_index(tile + 1));
         asm volatile("" ::: "memory");
-        T J[P2];
+        // S = A_x R_e = the pose-translation columns of the detection's block (everything else eval_detection forms is dead code here)
+        T Su[3], Sv[3];
+        const T X0 = points[3 * k], X1 = points[3 * k + 1], X2 = points[3 * k + 2];
+        // the image's slab across the lanes (one coalesced load, read back through v_readlane): usable when the tile holds one image
+        const int im0 = __builtin_amdgcn_readfirstlane(im);
+        const bool img_uni = __all(im == im0);
+        const LaneSlab lp{pose_slab[im0 * POSE_STRIDE + min(lane, POSE_STRIDE - 1)]};
         if (a.debug & 16) {
 #pragma unroll
-            for (int j = 0; j < P2; ++j) J[j] = (double)(lane + j);
+            for (int j = 0; j < 3; ++j) { Su[j] = (double)(lane + j); Sv[j] = (double)(lane - j); }
         } else {
             T u, v;
-            const T X0 = points[3 * k], X1 = points[3 * k + 1], X2 = points[3 * k + 2];
-            const int im0 = __builtin_amdgcn_readfirstlane(im);
+            T J[P2];
             const T *csp = cam_slab + c * CAM_STRIDE;
-            if (__all(im == im0)) {
-                const LaneSlab lp{pose_slab[im0 * POSE_STRIDE + min(lane, POSE_STRIDE - 1)]};
-                eval_detection<CHAIN, T, true>(csp, lp, X0, X1, X2, u, v, J);
-            } else {
-                eval_detection<CHAIN, T, true>(csp, pose_slab + im * POSE_STRIDE, X0, X1, X2, u, v, J);
-            }
+            if (img_uni) eval_detection<CHAIN, T, true>(csp, lp, X0, X1, X2, u, v, J);
+            else eval_detection<CHAIN, T, true>(csp, pose_slab + im * POSE_STRIDE, X0, X1, X2, u, v, J);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { Su[j] = J[18 + j]; Sv[j] = J[P + 18 + j]; }
         }
         asm volatile("" ::"v"(nxt_w.w0), "v"(nxt_w.w1), "v"(nxt_w.w2));   // consume the prefetch before any atomic is issued (ba_normal_mfma_kernel)
 
@@ -487,12 +492,12 @@ __global__ __launch_bounds__(64, 2) void ba_normal_imgkey_kernel(const NormalArg
         // ---- LDS: product columns and the run table ---------------------------------------------------------------------
         if (!(a.debug & 64)) {
             unsigned char *dst = lds_image + lane * 8;
+            int cc = 0;
 #pragma unroll
-            for (int cc = 0; cc < IK_COLS; ++cc) {
-                const int p = 15 + cc / 3, x = NS + cc % 3;
-                const double prod = valid ? J[p] * J[x] + J[P + p] * J[P + x] : 0.0;
-                *reinterpret_cast<double *>(dst + cc * IK_SLOT) = prod;
-            }
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = i; j < 3; ++j, ++cc)
+                    *reinterpret_cast<double *>(dst + cc * IK_SLOT) = valid ? Su[i] * Su[j] + Sv[i] * Sv[j] : 0.0;
         }
         runs[lane + 1] = I4{64, 0, 0, 0};                               // sentinel: runs past the last one are empty
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -502,36 +507,74 @@ __global__ __launch_bounds__(64, 2) void ba_normal_imgkey_kernel(const NormalArg
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
+        const bool owner = lane < n_runs;
+        const I4 mine = runs[owner ? lane : 0];   // lane = run: first detection, image, key
+
         if (!(a.debug & 8)) {
             for (int b0 = 0; b0 < n_runs; b0 += 16) {
                 const int lo = runs[b0 + li].x, hi = runs[b0 + li + 1].x;        // detections [lo, hi) form run b0 + li
-                double bx0[16], bx1[16];
+                double bx[16];
 #pragma unroll
-                for (int s = 0; s < 16; ++s) {
-                    bx0[s] = *reinterpret_cast<const double *>(lds_image + rd0 + s * 32);
-                    bx1[s] = *reinterpret_cast<const double *>(lds_image + rd1 + s * 32);
-                }
-                d4v acc0{0.0, 0.0, 0.0, 0.0}, acc1{0.0, 0.0, 0.0, 0.0};
+                for (int s = 0; s < 16; ++s) bx[s] = *reinterpret_cast<const double *>(lds_image + rd + s * 32);
+                d4v acc{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                 for (int s = 0; s < 16; ++s) {
                     const int d = 4 * s + lq;
                     const double member = (d >= lo && d < hi) ? 1.0 : 0.0;
-                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(member, bx0[s], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(member, bx1[s], acc1, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(member, bx[s], acc, 0, 0, 0);
                 }
-                // flush: register r = run b0 + q + 4 r
+                // register r of lane (column li, q) = run b0 + q + 4 r
+                if (li < IK_COLS) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int run = b0 + lq + 4 * r;
-                    const I4 e = runs[min(run, 64)];
-                    const bool live = run < n_runs && !(a.debug & 2);
-                    const int64_t base = (int64_t)(6 * e.y) * a.n_params + 3 * e.z;
-                    const double s0 = acc0[r], s1 = acc1[r];
-                    if (live && s0 != 0.0) unsafeAtomicAdd(a.H + base + (int64_t)row0 * a.n_params + col0, s0);
-                    if (live && c1 < IK_COLS && s1 != 0.0) unsafeAtomicAdd(a.H + base + (int64_t)row1 * a.n_params + col1, s1);
+                    for (int r = 0; r < 4; ++r)
+                        *reinterpret_cast<double *>(lds_image + IK_GRAM + ((b0 + lq + 4 * r) * IK_COLS + li) * 8) = acc[r];
                 }
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        // ---- lane = run: F = [Q_r | I]^T G R_p -----------------------------------------------------------------------------------
+        // The run's point is the one its first detection already holds (a lane shuffle); its pose slab is the tile's LaneSlab
+        // when the tile holds one image (no memory access at all), else 36 gathered loads.  Atomics even for a run strictly
+        // inside the tile, which owns its block of H outright: plain 8-byte stores into the freshly zeroed H were measured
+        // 8 x slower than the atomics (188 us against 57 us for this kernel, profiles/r02/sweeps.md).
+        auto finish = [&](const auto ps) {
+            const T Xr0 = __shfl(X0, mine.x), Xr1 = __shfl(X1, mine.x), Xr2 = __shfl(X2, mine.x);
+            T Rp[9], Qr[9];
+#pragma unroll
+            for (int j = 0; j < 9; ++j) Rp[j] = ps[POSE_R + j];
+#pragma unroll
+            for (int aa = 0; aa < 3; ++aa)
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc)
+                    Qr[cc * 3 + aa] = ps[POSE_DR + aa * 9 + cc * 3 + 0] * Xr0 + ps[POSE_DR + aa * 9 + cc * 3 + 1] * Xr1 + ps[POSE_DR + aa * 9 + cc * 3 + 2] * Xr2;
+            const D2 *gp = reinterpret_cast<const D2 *>(lds_image + IK_GRAM + (owner ? lane : 0) * IK_COLS * 8);
+            const D2 g01 = gp[0], g23 = gp[1], g45 = gp[2];
+            const double G[3][3] = {{g01.x, g01.y, g23.x}, {g01.y, g23.y, g45.x}, {g23.x, g45.x, g45.y}};
+            double GR[3][3];
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc)
+#pragma unroll
+                for (int x = 0; x < 3; ++x) GR[cc][x] = G[cc][0] * Rp[x] + G[cc][1] * Rp[3 + x] + G[cc][2] * Rp[6 + x];
+            const bool live = owner && !(a.debug & 2);
+            double *Hrow = a.H + ((int64_t)a.pose_off + 6 * mine.y) * a.n_params + a.point_off + 3 * mine.z;
+            auto emit = [&](double *ptr, const double val) {
+                if (live && val != 0.0) unsafeAtomicAdd(ptr, val);
+            };
+#pragma unroll
+            for (int aa = 0; aa < 3; ++aa)
+#pragma unroll
+                for (int x = 0; x < 3; ++x)
+                    emit(Hrow + (int64_t)aa * a.n_params + x, Qr[aa] * GR[0][x] + Qr[3 + aa] * GR[1][x] + Qr[6 + aa] * GR[2][x]);
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc)
+#pragma unroll
+                for (int x = 0; x < 3; ++x) emit(Hrow + (int64_t)(3 + cc) * a.n_params + x, GR[cc][x]);
+        };
+        if (img_uni) finish(lp);
+        else finish(pose_slab + mine.y * POSE_STRIDE);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

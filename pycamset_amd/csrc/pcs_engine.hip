@@ -112,6 +112,7 @@ struct pcs_engine {
     int64_t im_points_capacity = 0;
     bool linearized = false;
     int normal_debug = 0;
+    int normal_imgkey_wgs_per_cu = 0;   // 0 = default (48)
     int normal_imgkey_product = 1;   // pose-point blocks by ba_normal_imgkey_kernel (0: the boundary-walking pass, kept for A/B)
     bool matfree_lds = true;  // accumulate J^T products in workgroup-private LDS before the global atomics
     // launch geometry
@@ -654,6 +655,8 @@ int pcs_set_option(pcs_engine *h, const char *key, int64_t value) {
         h->normal_debug = (int)value;
     } else if (!strcmp(key, "normal_imgkey_product")) {
         h->normal_imgkey_product = value != 0;
+    } else if (!strcmp(key, "normal_imgkey_wgs_per_cu")) {
+        h->normal_imgkey_wgs_per_cu = (int)value;
     } else if (!strcmp(key, "compact_variant")) {
         if (value < 0 || value > 1) return fail(PCS_ERR_ARG, "compact_variant must be 0 or 1");
         h->compact_variant = (int)value;
@@ -894,23 +897,30 @@ static int enqueue_normal(pcs_engine *h, const double *d_prm, double *d_H, doubl
     // every wave walks a contiguous range of tiles, so its register accumulators survive across tiles.  One-wave
     // workgroups; the LDS image (22.9 KB for 22 columns x 64 rows) allows 7 per CU, and exactly one resident round of
     // waves is fastest (92 us against 105 us with two rounds on rig-32, profiles/r02/sweeps.md).
-    const int64_t wpc = h->wgs_per_cu > 0 ? h->wgs_per_cu : 7;
-    const int64_t target_waves = (int64_t)h->n_cu * wpc;
-    const int64_t tpw = std::max<int64_t>(1, (a.n_tiles + target_waves - 1) / target_waves);
-    a.tiles_per_wave = (int32_t)tpw;
-    const dim3 grid((unsigned)((a.n_tiles + tpw - 1) / tpw));
+    auto geometry = [&](const int64_t wpc) {
+        const int64_t target_waves = (int64_t)h->n_cu * wpc;
+        const int64_t tpw = std::max<int64_t>(1, (a.n_tiles + target_waves - 1) / target_waves);
+        a.tiles_per_wave = (int32_t)tpw;
+        return dim3((unsigned)((a.n_tiles + tpw - 1) / tpw));
+    };
     hipEvent_t *ev = h->ev.data() + 3 * (h->ev_count % h->ev_ring);
     HIPCHK(hipEventRecord(ev[0], s));
     HIPCHK(hipEventRecord(ev[1], s));
     const int n_pass = h->chain == PCS_CHAIN_TEMPLATE ? 1 : h->chain == PCS_CHAIN_SELF ? 3 : 2;
     for (int pass = 0; pass < n_pass; ++pass) {
+        if (h->normal_debug & (256 << pass)) continue;   // profiling: time the passes one by one
         a.order = pass == PASS_SHARED ? h->d_order : pass == PASS_CAMKEY ? h->d_order_ck : h->d_order_ik;
         if (pass != PASS_SHARED && !a.order) return fail(PCS_ERR_STATE, "normal equations: key-sorted visiting order missing");
         hipError_t e;
         if (pass == PASS_IMGKEY && h->normal_imgkey_product) {
+            // 7 KB of LDS and 167 VGPRs per wave: 12 resident per CU.  The kernel waits on dependent loads and on its
+            // atomics, so short waves (one or two tiles each, 48 per CU) that keep every slot refilled are fastest
+            // (59 / 56 / 55 / 59 us for 12 / 24 / 48 / 96 per CU at N = 1e6, profiles/r02/sweeps.md)
+            const dim3 grid = geometry(h->normal_imgkey_wgs_per_cu > 0 ? h->normal_imgkey_wgs_per_cu : 48);
             hipLaunchKernelGGL(ba_normal_imgkey_kernel, grid, dim3(64), normal_imgkey_lds_bytes(), s, a);
             e = hipGetLastError();
         } else {
+            const dim3 grid = geometry(h->wgs_per_cu > 0 ? h->wgs_per_cu : 7);
             e = launch_normal(h->chain, pass, h->normal_rows, a, grid, s);
         }
         if (e != hipSuccess) return fail(PCS_ERR_HIP, "normal-equations kernel launch failed: %s", hipGetErrorString(e));
@@ -1420,14 +1430,16 @@ int pcs_normal_entry_map(int chain, int pass, int32_t *out) {
         if (chain == CHAIN_SELF) fill_entry_map<CHAIN_SELF, PASS_CAMKEY>(out);
         else fill_entry_map<CHAIN_FREE, PASS_CAMKEY>(out);
     } else {
-        // ba_normal_imgkey_kernel: register r of MFMA m in lane l = (local run (l >> 4) + 4 r, product column 16 m + (l & 15))
+        // ba_normal_imgkey_kernel: register r of lane l = entry (a, b), a <= b, of the run's 3 x 3 sum G = S^T S over the
+        // pose-translation columns 18..20 (column l & 15 in the order 00 01 02 11 12 22), for local run (l >> 4) + 4 r
+        static const int ga[IK_COLS] = {0, 0, 0, 1, 1, 2}, gb[IK_COLS] = {0, 1, 2, 1, 2, 2};
         for (int m = 0; m < 2; ++m)
             for (int lane = 0; lane < 64; ++lane)
                 for (int r = 0; r < 4; ++r) {
-                    const int c = imgkey_col(m, lane);
+                    const int c = lane & 15;
                     int32_t *o = out + ((m * 64 + lane) * 4 + r) * 2;
-                    o[0] = c < IK_COLS ? 15 + c / 3 : -1;
-                    o[1] = c < IK_COLS ? normal_shared_cols(CHAIN_SELF) + c % 3 : -1;
+                    o[0] = (m == 0 && c < IK_COLS) ? 18 + ga[c] : -1;
+                    o[1] = (m == 0 && c < IK_COLS) ? 18 + gb[c] : -1;
                 }
     }
     return PCS_OK;

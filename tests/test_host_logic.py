@@ -396,8 +396,9 @@ def test_normal_equation_entry_maps_own_every_pair_exactly_once():
         pts, cam = [pt0, pt0 + 1, pt0 + 2], list(range(15))
         need = sorted([tuple(sorted((c, q))) for c in cam for q in pts] + upper(pts) + [(q, R) for q in pts])
         assert sorted(owned(chain, 1)) == need, chain                            # E[c,k], D[k], g[k]
-    # F[i,k] (ba_normal_imgkey_kernel): the accumulators hold 16 runs at a time — register r of lane l belongs to local
-    # run (l >> 4) + 4 r — and every run must own each pose x point pair exactly once
+    # F[i,k] (ba_normal_imgkey_kernel): the accumulators hold, for 16 runs at a time, the symmetric 3 x 3 sum over the
+    # pose-translation columns 18..20 that the pose-point block is finished from; register r of lane l belongs to local
+    # run (l >> 4) + 4 r, and every run must own each of the 6 entries exactly once
     out = np.full((2, 64, 4, 2), -7, dtype=np.int32)
     _capi.check(lib.pcs_normal_entry_map(_capi.CHAIN_IDS["self"], 2, out.ctypes.data_as(POINTER(c_int32))))
     per_run = {}
@@ -408,6 +409,6 @@ def test_normal_equation_entry_maps_own_every_pair_exactly_once():
                     per_run.setdefault((lane >> 4) + 4 * r, []).append(tuple(out[m, lane, r].tolist()))
     assert sorted(per_run) == list(range(16))
     for pairs in per_run.values():
-        assert sorted(pairs) == sorted((p, q) for p in range(15, 21) for q in (21, 22, 23))
+        assert sorted(pairs) == upper([18, 19, 20])
     for chain, p in (("template", 1), ("template", 2), ("free", 2)):
         assert lib.pcs_normal_entry_map(_capi.CHAIN_IDS[chain], p, np.zeros(1024, np.int32).ctypes.data_as(POINTER(c_int32))) == _capi.PCS_ERR_ARG
