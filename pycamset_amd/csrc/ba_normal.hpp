@@ -156,16 +156,20 @@ __global__ __launch_bounds__(64, 2) void ba_normal_mfma_kernel(const NormalArgs 
         rd_off[w] = (s < 0 ? 0 : s) * KS + (lane >> 4) * 8;
     }
     // D layout of v_mfma_f64_16x16x4_f64: register r of lane l = D[(l >> 4) + 4 r][l & 15].
-    // Entry descriptor of each accumulator register: two (group, offset) column codes, bit 16 = owned, bit 17 =
-    // involves a pose column.  Groups: 0 intrinsics, 1 extrinsics, 2 pose, 3 point, 4 residual.
+    // Where a finished register goes.  Its two columns are (group, offset) pairs — groups in parameter-string order:
+    // 0 intrinsics, 1 extrinsics, 2 pose, 3 point, 4 = the residual column — and the destination is
+    //     H + 8 ((base[gR] + oR) n_params + base[gC] + oC)    (gR, oR) <= (gC, oC)
+    //     g + 8 (base[g] + o)                                  one of the two is the residual
+    //     cost                                                 both are
+    // with base[] the first global column of each group for the current run.  Everything static is folded into one
+    // descriptor per register, K = oR n_params + oC | row selector | column selector | pointer selector | owned | pose,
+    // and the run-dependent part is looked up across lanes (ds_bpermute) in a table the flush refreshes with eight
+    // v_writelane: lanes 0-3 hold 8 n_params base[g], lanes 8-11 hold 8 base[g], lanes 4 and 12 stay zero.  No selects:
+    // hipcc turned the select chains of the first version into ~10 exec-mask branches per register (800 instructions and
+    // 80 branches per flush, 12 us of the 92 at N = 1e6).
     constexpr int NS = normal_shared_cols(CHAIN);
-    auto col_code = [](const int lc) -> int {
-        if (lc == NORMAL_R) return 4;
-        if (lc < 9) return 0 | (lc << 3);
-        if (lc < 15) return 1 | ((lc - 9) << 3);
-        if (HAS_POSE && lc < NS) return 2 | ((lc - 15) << 3);
-        return 3 | ((lc - NS) << 3);
-    };
+    auto col_group = [](const int lc) -> int { return lc == NORMAL_R ? 4 : lc < 9 ? 0 : lc < 15 ? 1 : (HAS_POSE && lc < NS) ? 2 : 3; };
+    auto col_offset = [](const int lc) -> int { return lc == NORMAL_R ? 0 : lc < 9 ? lc : lc < 15 ? lc - 9 : (HAS_POSE && lc < NS) ? lc - 15 : lc - NS; };
     int ent[NM][4];
 #pragma unroll
     for (int m = 0; m < NM; ++m)
@@ -173,10 +177,20 @@ __global__ __launch_bounds__(64, 2) void ba_normal_mfma_kernel(const NormalArgs 
         for (int r = 0; r < 4; ++r) {
             int sa, sb;
             const bool keep = entry_kept<CHAIN, PASS>(m, (lane >> 4) + 4 * r, lane & 15, sa, sb);
-            const int ca = col_code(slot_col<CHAIN, PASS>(keep ? sa : 0)), cb = col_code(slot_col<CHAIN, PASS>(keep ? sb : 0));
-            const bool pose = PASS == PASS_SHARED && ((ca & 7) == 2 || (cb & 7) == 2);
-            ent[m][r] = ca | (cb << 8) | (keep ? 1 << 16 : 0) | (pose ? 1 << 17 : 0);
+            const int la = slot_col<CHAIN, PASS>(keep ? sa : 0), lb = slot_col<CHAIN, PASS>(keep ? sb : 0);
+            int gR = col_group(la), oR = col_offset(la), gC = col_group(lb), oC = col_offset(lb);
+            const bool pose = PASS == PASS_SHARED && (gR == 2 || gC == 2);
+            if (gR > gC || (gR == gC && oR > oC)) { int t = gR; gR = gC; gC = t; t = oR; oR = oC; oC = t; }   // row <= column; the residual (4) ends up as the column
+            int K, selR, selC, selP;
+            if (gR == 4) { K = 0; selR = 4; selC = 4; selP = 2; }                       // r . r
+            else if (gC == 4) { K = oR; selR = 4; selC = gR; selP = 1; }                // J^T r
+            else { K = oR * (int)a.n_params + oC; selR = gR; selC = gC; selP = 0; }
+            ent[m][r] = K | (selR << 19) | (selC << 22) | (selP << 25) | (keep ? 1 << 27 : 0) | (pose ? 1 << 28 : 0);
         }
+    // lanes 16, 17, 18: the three output pointers
+    const uint64_t out_ptr = lane == 17 ? (uint64_t)a.g : lane == 18 ? (uint64_t)a.cost : (uint64_t)a.H;
+    const int ptr_lo = (int)(uint32_t)out_ptr, ptr_hi = (int)(uint32_t)(out_ptr >> 32);
+    int base_tab = 0;
     d4v acc[NM];
 #pragma unroll
     for (int m = 0; m < NM; ++m) acc[m] = d4v{0.0, 0.0, 0.0, 0.0};
@@ -192,26 +206,41 @@ __global__ __launch_bounds__(64, 2) void ba_normal_mfma_kernel(const NormalArgs 
         const int img = PASS == PASS_SHARED ? run_b : run_a;     // only used where pose columns occur
         const int key = run_b;                                   // only used in the point passes
         // first global column of each group for this run (wave-uniform)
-        const int base0 = 9 * cam, base1 = (int)a.extr_off + 6 * cam, base2 = (int)a.pose_off + 6 * img, base3 = (int)a.point_off + 3 * key;
+        const int base[4] = {9 * cam, (int)a.extr_off + 6 * cam, (int)a.pose_off + 6 * img, (int)a.point_off + 3 * key};
+        const int n8 = 8 * (int)a.n_params;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int row8 = __builtin_amdgcn_readfirstlane(n8 * base[g]), col8 = __builtin_amdgcn_readfirstlane(8 * base[g]);
+            asm("v_writelane_b32 %0, %1, %2" : "+v"(base_tab) : "s"(row8), "n"(g));
+            asm("v_writelane_b32 %0, %1, %2" : "+v"(base_tab) : "s"(col8), "n"(8 + g));
+        }
+        // all destinations first (4 lane look-ups per register, no branch in between, so their latencies overlap) ...
+        uint64_t dst[NM][4];
+        int dsc[NM][4];
 #pragma unroll
         for (int m = 0; m < NM; ++m)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                // the descriptor is opaque to the optimiser: left visible, hipcc precomputes every candidate address
-                // of every entry outside the tile loop (several hundred VGPRs, spilled)
                 int d = ent[m][r];
-                asm volatile("" : "+v"(d));
-                const bool now = everything || (d & (1 << 17));
+                asm volatile("" : "+v"(d));   // opaque: nothing of the address arithmetic is to be hoisted out of the tile loop
+                const uint32_t off = (uint32_t)__builtin_amdgcn_ds_bpermute((d >> 17) & (7 << 2), base_tab) +
+                                     (uint32_t)__builtin_amdgcn_ds_bpermute(32 + ((d >> 20) & (7 << 2)), base_tab) + 8u * (uint32_t)(d & 0x7ffff);
+                const int psel = 64 + ((d >> 23) & (3 << 2));
+                const uint64_t pb = ((uint64_t)(uint32_t)__builtin_amdgcn_ds_bpermute(psel, ptr_hi) << 32) | (uint32_t)__builtin_amdgcn_ds_bpermute(psel, ptr_lo);
+                dst[m][r] = pb + off;
+                dsc[m][r] = d;
+            }
+        // ... then one predicated atomic per register
+#pragma unroll
+        for (int m = 0; m < NM; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int d = dsc[m][r];
+                const bool now = everything || (d & (1 << 28));
                 const double s = acc[m][r];
                 acc[m][r] = now ? 0.0 : s;
-                // branch-free address: selects only, one predicated atomic
-                const int ga_grp = d & 7, gb_grp = (d >> 8) & 7;
-                const int ga = (ga_grp == 0 ? base0 : ga_grp == 1 ? base1 : ga_grp == 2 ? base2 : base3) + ((d >> 3) & 31);
-                const int gb = (gb_grp == 0 ? base0 : gb_grp == 1 ? base1 : gb_grp == 2 ? base2 : base3) + ((d >> 11) & 31);
-                const int64_t h_idx = (int64_t)min(ga, gb) * a.n_params + max(ga, gb);
-                const int64_t g_idx = ga_grp == 4 ? gb : ga;
-                double *ptr = (ga_grp == 4 && gb_grp == 4) ? a.cost : (ga_grp == 4 || gb_grp == 4) ? a.g + g_idx : a.H + h_idx;
-                if (now && (d & (1 << 16)) && s != 0.0 && !(a.debug & 2)) unsafeAtomicAdd(ptr, s);
+                if (now && (d & (1 << 27)) && s != 0.0 && !(a.debug & 2))
+                    __builtin_amdgcn_global_atomic_fadd_f64(reinterpret_cast<__attribute__((address_space(1))) double *>(dst[m][r]), s);
             }
     };
 
@@ -539,7 +568,7 @@ __global__ __launch_bounds__(64, 3) void ba_normal_imgkey_kernel(const NormalArg
         // The run's point is the one its first detection already holds (a lane shuffle); its pose slab is the tile's LaneSlab
         // when the tile holds one image (no memory access at all), else 36 gathered loads.  Atomics even for a run strictly
         // inside the tile, which owns its block of H outright: plain 8-byte stores into the freshly zeroed H were measured
-        // 8 x slower than the atomics (188 us against 57 us for this kernel, profiles/r02/sweeps.md).
+        // 3 - 4 x slower than the atomics (188 us, 218 us with nontemporal stores, against 57 us for this kernel, profiles/r02/sweeps.md).
         auto finish = [&](const auto ps) {
             const T Xr0 = __shfl(X0, mine.x), Xr1 = __shfl(X1, mine.x), Xr2 = __shfl(X2, mine.x);
             T Rp[9], Qr[9];

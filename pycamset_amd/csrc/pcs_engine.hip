@@ -878,6 +878,8 @@ static int enqueue_normal(pcs_engine *h, const double *d_prm, double *d_H, doubl
     if (h->n <= 0) return fail(PCS_ERR_STATE, "no detections set");
     if (h->n > INT32_MAX) return fail(PCS_ERR_ARG, "normal equations: tables beyond 2^31 rows are not supported (visiting orders are int32)");
     if (h->chain == PCS_CHAIN_TEMPLATE && !h->have_template) return fail(PCS_ERR_STATE, "template points not set");
+    // the flush addresses H with 32-bit byte offsets: 8 n^2 < 2^32 (a 4.3 GB matrix)
+    if (h->n_params > 23170) return fail(PCS_ERR_ARG, "normal equations: more than 23170 parameters (dense H beyond 4 GiB) is not supported");
     HIPCHK(hipSetDevice(h->device));
     int rc0 = ensure_point_orders(h);
     if (rc0) return rc0;
