@@ -411,6 +411,15 @@ __global__ __launch_bounds__(WG_THREADS) void ba_compact_tile_kernel(const EvalA
         int c, im, k;
         load_indices(a.tab, ic, c, im, k);
         const double2v m = load_uv(a.tab, ic);
+        // the mask and the CSR offset are streamed like the indices: requested HERE, with them.  Left where they are used,
+        // hipcc issues the two loads after the evaluation and the wave sits out a full memory latency per tile.
+        uint32_t keep_raw = 0;
+        int64_t off_raw = 0;
+        if constexpr (JAC) {
+            keep_raw = a.keep[ic];
+            off_raw = a.row_off[ic];
+        }
+        asm volatile("" ::: "memory");
         T u, v;
         T J[P2];
         eval_detection<CHAIN, T, JAC>(cam_slab + c * CAM_STRIDE, pose_slab + im * POSE_STRIDE, points[3 * k], points[3 * k + 1],
@@ -422,10 +431,9 @@ __global__ __launch_bounds__(WG_THREADS) void ba_compact_tile_kernel(const EvalA
             __builtin_nontemporal_store(r, valid ? reinterpret_cast<O2 *>(resid) + i : static_cast<O2 *>(a.sink));
         }
         if constexpr (JAC) {
-            const uint32_t keep_raw = a.keep[ic];
             const uint32_t keep = valid ? keep_raw : 0u;
             const int cnt = __popc(keep);
-            const int64_t off = a.row_off[ic] + (valid ? 0 : 2 * (int64_t)__popc(keep_raw));  // tail lanes: end of data
+            const int64_t off = off_raw + (valid ? 0 : 2 * (int64_t)__popc(keep_raw));  // tail lanes: end of data
             const int64_t off0 = __shfl(off, 0);                  // first entry of the tile
             const int lo = (int)(off - off0);                     // this detection's offset inside the tile range
             const int mid = __shfl(lo, HALF);                     // pass boundary
