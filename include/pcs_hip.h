@@ -164,7 +164,8 @@ int pcs_matfree(pcs_engine *h, int op, const double *in, double *out, double *co
  * from the Jacobian that optimisation_handling.py:88-98 hands to scipy), built in one pass without
  * writing J:  H = J^T J  (n_params x n_params row-major, FULL parameter-string space, only the UPPER
  * triangle incl. the diagonal is written, the rest is zero),  g = J^T r  (n_params),  cost = r^T r.
- * float64 whatever the engine dtype.  The sums use f64 atomics: the last bits depend on arrival order.
+ * float64 whatever the engine dtype.  The sums use f64 atomics: the last bits depend on arrival order.  The kernels address H
+ * with 32-bit byte offsets: n_params <= 23170 (a 4.3 GB matrix), PCS_ERR_ARG beyond.
  *   pcs_normal_equations         host buffers (engine-owned device scratch, blocking)
  *   pcs_normal_equations_device  device buffers of the caller, queued on `stream` (NULL = engine stream);
  *                                the call zeroes them first.  Observation shards: all-reduce H, g, cost. */
@@ -205,10 +206,10 @@ int pcs_kernel_ms_mean(pcs_engine *h, int64_t *count, float *slab_prep_ms, float
  * written, *count = how many.  bench.py takes its median / min / mean from these (the reference's analogue is
  * the sample list of general_utils.benchmark(), utils/general_utils.py:62-104). */
 int pcs_kernel_ms_samples(pcs_engine *h, int64_t capacity, float *slab_prep_ms, float *eval_ms, int64_t *count);
-/* Tuning knobs ("variant", "wgs_per_cu", "tiles_per_wg", "event_ring", "timing_every",
- * "compact_variant", "matfree_lds", "xcd_remap", "waves_per_wg", "pack_indices", "normal_rows", "normal_imgkey_product"; "normal_debug" is a
- * profiling switch of pcs_normal_equations that skips the flush atomics — results are wrong while it is non-zero);
- * see DESIGN.md.
+/* Tuning knobs ("variant", "wgs_per_cu", "tiles_per_wg", "event_ring", "timing_every", "compact_variant",
+ * "matfree_lds", "xcd_remap", "waves_per_wg", "pack_indices", "normal_rows", "normal_imgkey_product",
+ * "normal_imgkey_wgs_per_cu"; "normal_debug" is a bit mask of profiling switches of pcs_normal_equations — phases
+ * or whole passes are skipped and the results are wrong while it is non-zero); see DESIGN.md.
  * Unknown keys -> PCS_ERR_ARG. */
 int pcs_set_option(pcs_engine *h, const char *key, int64_t value);
 /*
