@@ -922,7 +922,9 @@ static int enqueue_normal(pcs_engine *h, const double *d_prm, double *d_H, doubl
             hipLaunchKernelGGL(ba_normal_imgkey_kernel, grid, dim3(64), normal_imgkey_lds_bytes(), s, a);
             e = hipGetLastError();
         } else {
-            const dim3 grid = geometry(h->wgs_per_cu > 0 ? h->wgs_per_cu : 7);
+            // the shared pass's image (22.9 KB) allows 7 waves per CU; the (cam, key) pass's (19.8 KB) allows 8 = two per SIMD,
+            // 65.5 against 70.0 us on rig-32-self (profiles/r02/sweeps.md)
+            const dim3 grid = geometry(h->wgs_per_cu > 0 ? h->wgs_per_cu : pass == PASS_CAMKEY ? 8 : 7);
             e = launch_normal(h->chain, pass, h->normal_rows, a, grid, s);
         }
         if (e != hipSuccess) return fail(PCS_ERR_HIP, "normal-equations kernel launch failed: %s", hipGetErrorString(e));
