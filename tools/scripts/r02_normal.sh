@@ -11,7 +11,7 @@ echo "[r02_normal] walk variant of the pose-point pass"; timeout -k 10 200 pytho
 echo "[r02_normal] free"; timeout -k 10 200 python tools/normal_quick.py free 0,1536,1280 7 > $O/normal_phases_free.log 2>&1 < /dev/null
 for chain in template self free; do
   echo "[r02_normal] rocprofv3 stats $chain"
-  timeout -k 10 300 bash tools/scripts/prof_stats.sh normal_$chain $R/tools/normal_quick.py $chain 0 7 > $O/prof_$chain.log 2>&1 < /dev/null
+  timeout -k 10 300 bash tools/scripts/prof_stats.sh normal_$chain $R/tools/normal_quick.py $chain 0 0 > $O/prof_$chain.log 2>&1 < /dev/null
   cp $R/gpurun_out/r02/normal_${chain}_kernel_stats.csv $O/ 2>/dev/null
 done
 echo "[r02_normal] done"; ls $O
