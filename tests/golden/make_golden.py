@@ -306,20 +306,25 @@ def handler_case(mods, rig, chain, *, keydims=None, fixed=None, options=None, ma
     target = _DuckTarget(rig.points) if keydims is None else _DuckTargetND(rig.points, keydims)
     det = mods.TargetDetection(cam_names=camset.get_names(), data=dets.copy(), max_ims=max_ims)
     mods.th.DEFAULT_OPTIONS.update({"fixed_pose": 0})   # the reference mutates its module-level default dict (th:108-110)
-    cls = {"template": mods.th.TemplateBundleHandler, "self": mods.sbh.SelfBundleHandler}[chain]
+    cls = {"template": mods.th.TemplateBundleHandler, "self": mods.sbh.SelfBundleHandler, "free": mods.fph.FreePointBundleHandler}[chain]
     opts = {"verbosity": 0}
     opts.update(options or {})
     h = cls(camset, target, det, fixed_params=fixed, options=opts)
     bp = h.bundlePrimitive
-    C, I = bp.intr.shape[0], bp.poses.shape[0]
+    has_pose = chain != "free"   # the free-point chain has no target poses (fph:47-100)
+    C, I = bp.intr.shape[0], bp.poses.shape[0] if has_pose else 0
     intr = np.zeros((C, 9)); extr = np.zeros((C, 6)); poses = np.zeros((I, 6))
-    intr[: rig.n_cams], extr[: rig.n_cams], poses[: rig.n_imgs] = rig.intr, rig.extr, rig.poses
+    intr[: rig.n_cams], extr[: rig.n_cams] = rig.intr, rig.extr
+    if has_pose:
+        poses[: rig.n_imgs] = rig.poses
     if C > rig.n_cams:   # cameras / images nobody observed: any finite value
         intr[rig.n_cams:], extr[rig.n_cams:] = rig.intr[:1], rig.extr[:1]
     if I > rig.n_imgs:
         poses[rig.n_imgs:] = 0.01
-    parts = [intr[bp.intr_unfixed].ravel(), extr[bp.extr_unfixed].ravel(), poses[bp.poses_unfixed].ravel()]
-    if chain == "self":
+    parts = [intr[bp.intr_unfixed].ravel(), extr[bp.extr_unfixed].ravel()]
+    if has_pose:
+        parts.append(poses[bp.poses_unfixed].ravel())
+    if chain != "template":
         parts.append(rig.points.ravel()[bp.bdpt_unfixed])
     x = np.concatenate(parts)
     loss, jac = h.make_loss_fun(2), h.make_loss_jac(2)
@@ -327,12 +332,15 @@ def handler_case(mods, rig, chain, *, keydims=None, fixed=None, options=None, ma
     J = jac(x.copy())
     out = dict(detections=dets, points=rig.points, x=x, resid=r, data=np.array(J.data), indices=np.array(J.indices),
                indptr=np.array(J.indptr), shape=np.array(J.shape), intr_unfixed=np.array(bp.intr_unfixed),
-               extr_unfixed=np.array(bp.extr_unfixed), poses_unfixed=np.array(bp.poses_unfixed),
-               intr_slab=np.array(bp.intr), extr_slab=np.array(bp.extr), poses_slab=np.array(bp.poses),
+               extr_unfixed=np.array(bp.extr_unfixed), intr_slab=np.array(bp.intr), extr_slab=np.array(bp.extr),
                n_cams=np.array(C), max_ims=np.array(max_ims),
                keydims=np.array(keydims if keydims is not None else (1, rig.n_keys)))
-    if chain == "self":
+    if has_pose:
+        out["poses_unfixed"] = np.array(bp.poses_unfixed)
+        out["poses_slab"] = np.array(bp.poses)
+    if chain != "template":
         out["bdpt_unfixed"] = np.array(bp.bdpt_unfixed)
+    if chain == "self":
         out["visible_feature_mask"] = np.array(h.visible_feature_mask)
     return out
 
@@ -351,6 +359,8 @@ def round2_vectors(mods):
         "handler_self_ccube": dict(chain="self", keydims=(6, 81), fixed=both, options={"fixed_pose": 3}),
         # fixed_pose=None: NumPy treats a None index as newaxis, so the reference fixes (and zeroes) EVERY pose (th:134-137)
         "handler_template_fixedpose_none": dict(chain="template", keydims=(6, 81), fixed=None, options={"fixed_pose": None}),
+        # the free-point chain (no target poses; images are plain frames of a static scene) on the same table: fph:47-186
+        "handler_free_ccube": dict(chain="free", keydims=(6, 81), fixed=both, options={}),
     }
     for name, kw in cases.items():
         res = handler_case(mods, ccube, **kw)

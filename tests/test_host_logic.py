@@ -83,6 +83,7 @@ R2_CASES = {
     "handler_template_ccube": ("template", {"fixed_pose": 3}),
     "handler_self_ccube": ("self", {"fixed_pose": 3}),
     "handler_template_fixedpose_none": ("template", {"fixed_pose": None}),
+    "handler_free_ccube": ("free", {}),
     "quirk_template_last_image_unobserved": ("template", {}),
     "quirk_self_last_key_unobserved": ("self", {}),
     "quirk_self_last_image_unobserved": ("self", {}),
@@ -135,22 +136,27 @@ def test_ccube_shaped_and_edge_handlers_against_reference_goldens(golden_dir, na
     h, chain = make_handler_r2(g, name)
     bp = h.bundlePrimitive
     assert np.array_equal(bp.intr_unfixed, g["intr_unfixed"]) and np.array_equal(bp.extr_unfixed, g["extr_unfixed"])
-    assert np.array_equal(bp.poses_unfixed, g["poses_unfixed"])
-    if chain == "self":
+    if chain != "free":
+        assert np.array_equal(bp.poses_unfixed, g["poses_unfixed"])
+    if chain != "template":
         assert np.array_equal(bp.bdpt_unfixed, g["bdpt_unfixed"])
+    if chain == "self":
         assert np.array_equal(h.visible_feature_mask, g["visible_feature_mask"])
     if name == "handler_template_fixedpose_none":
         assert not bp.poses_unfixed.any()          # a None index fixes every pose (th:134-137)
     x = g["x"]
     slabs = h.get_bundle_adjustment_inputs(x.copy())
-    assert np.array_equal(slabs[0], g["intr_slab"]) and np.array_equal(slabs[1], g["extr_slab"]) and np.array_equal(slabs[2], g["poses_slab"])
+    assert np.array_equal(slabs[0], g["intr_slab"]) and np.array_equal(slabs[1], g["extr_slab"])
+    if chain != "free":
+        assert np.array_equal(slabs[2], g["poses_slab"])
     param_str = h.op_fun.build_param_list(*slabs)
     mask = h._jac_mask()
     assert int(mask.sum()) == x.shape[0] == g["shape"][1]
     det = h._flat_detections()
     assert det.shape[1] == 5
     counts = h.op_fun.counts
-    assert counts == (bp.intr.shape[0], bp.poses.shape[0], int(np.prod(g["keydims"])))
+    n_imgs = bp.poses.shape[0] if chain != "free" else counts[1]   # the free chain has no pose group: any image count lays out the same string
+    assert counts == (bp.intr.shape[0], n_imgs, int(np.prod(g["keydims"])))
     assert orc.param_struct(chain, det, counts)[2] == param_str.shape[0] == mask.shape[0]
     idx, ptr, m = orc.csr_structure(chain, det, mask, counts)
     assert np.array_equal(idx, g["indices"]) and np.array_equal(ptr, g["indptr"])
