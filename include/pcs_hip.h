@@ -208,7 +208,7 @@ int pcs_kernel_ms_mean(pcs_engine *h, int64_t *count, float *slab_prep_ms, float
 int pcs_kernel_ms_samples(pcs_engine *h, int64_t capacity, float *slab_prep_ms, float *eval_ms, int64_t *count);
 /* Tuning knobs ("variant", "wgs_per_cu", "tiles_per_wg", "event_ring", "timing_every", "compact_variant",
  * "matfree_lds", "xcd_remap", "waves_per_wg", "pack_indices", "normal_rows", "normal_imgkey_product",
- * "normal_imgkey_wgs_per_cu"; "normal_debug" is a bit mask of profiling switches of pcs_normal_equations — phases
+ * "normal_imgkey_wgs_per_cu", "normal_sort_tables"; "normal_debug" is a bit mask of profiling switches of pcs_normal_equations — phases
  * or whole passes are skipped and the results are wrong while it is non-zero); see DESIGN.md.
  * Unknown keys -> PCS_ERR_ARG. */
 int pcs_set_option(pcs_engine *h, const char *key, int64_t value);

@@ -81,6 +81,10 @@ struct pcs_engine {
     bool pack_indices = true;          // option "pack_indices" (A/B switch; takes effect at the next upload)
     int32_t *d_order = nullptr;  // (cam, image)-sorted visiting order of a scattered table (normal equations), or NULL
     int32_t *d_order_ck = nullptr, *d_order_ik = nullptr;  // (cam, key) / (image, key) orders for the point passes
+    // the detection table copied out in the visiting orders (index words; measurements except for the (image, key) pass): the
+    // passes then stream their inputs instead of gathering 4 + 16 scattered bytes per detection through the order
+    void *d_sorted[3][5] = {};   // per pass (shared — only for a scattered table —, (cam, key), (image, key)): packed, cam, img, key, uv
+    int sort_tables = 1;         // option: 0 = walk the original table through the visiting order (A/B)
     bool point_orders_tried = false;
     int normal_rows = 64;        // detections per LDS image of the normal-equations kernel (64 or 32)
     int waves_per_wg = 0;        // fused kernel: waves per workgroup (0 = automatic: fewer for small tables)
@@ -496,6 +500,9 @@ int pcs_destroy(pcs_engine *h) {
                     h->d_resid, h->d_jac, h->d_keep, h->d_row_off, h->d_data, h->d_vin, h->d_vout, h->d_cost, h->d_im_points, h->d_cam_tab, h->d_sink, h->d_H};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
+    for (auto &t : h->d_sorted)
+        for (void *b : t)
+            if (b) (void)hipFree(b);
     if (h->h_param) (void)hipHostFree(h->h_param);
     for (auto &e : h->ev)
         if (e) (void)hipEventDestroy(e);
@@ -546,6 +553,11 @@ static int upload_detections(pcs_engine *h, std::vector<int32_t> &cam, std::vect
         if (*b) HIPCHK(hipFree(*b));
         *b = nullptr;
     }
+    for (auto &t : h->d_sorted)
+        for (void *&b : t) {
+            if (b) HIPCHK(hipFree(b));
+            b = nullptr;
+        }
     h->jac_capacity = h->resid_capacity = h->data_capacity = 0;
     h->nnz = -1;
     if (n == 0) return PCS_OK;
@@ -653,6 +665,8 @@ int pcs_set_option(pcs_engine *h, const char *key, int64_t value) {
         h->matfree_lds = value != 0;
     } else if (!strcmp(key, "normal_debug")) {
         h->normal_debug = (int)value;
+    } else if (!strcmp(key, "normal_sort_tables")) {
+        h->sort_tables = value != 0;
     } else if (!strcmp(key, "normal_imgkey_product")) {
         h->normal_imgkey_product = value != 0;
     } else if (!strcmp(key, "normal_imgkey_wgs_per_cu")) {
@@ -852,24 +866,58 @@ static hipError_t launch_normal(int chain, int pass, int rows, const NormalArgs 
     return launch_normal_p<CHAIN_SELF, PASS_IMGKEY>(rows, a, grid, s);
 }
 
+// dst[i] = src[order[i]] (one-off, at the first normal-equations call)
+template <typename E>
+__global__ void gather_rows_kernel(const int32_t *__restrict__ order, const E *__restrict__ src, E *__restrict__ dst, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[order[i]];
+}
+template <typename E>
+static hipError_t gather_rows(const int32_t *order, const void *src, void **dst, int64_t n, hipStream_t s) {
+    hipError_t e = hipMalloc(dst, sizeof(E) * n);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(gather_rows_kernel<E>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, order, static_cast<const E *>(src), static_cast<E *>(*dst), n);
+    return hipGetLastError();
+}
+
 // (cam, key)- and (image, key)-sorted visiting orders for the point passes of the normal equations: built on the host
 // at the first normal-equations call of a self / free engine (two stable sorts, ~0.1 s at 1e6 detections)
 static int ensure_point_orders(pcs_engine *h) {
-    if (h->point_orders_tried || h->chain == PCS_CHAIN_TEMPLATE) return PCS_OK;
+    if (h->point_orders_tried) return PCS_OK;
     h->point_orders_tried = true;
     const int64_t n = h->n;
     if (n <= 0) return PCS_OK;
-    std::vector<int32_t> order(n);
-    for (int pass = 0; pass < (h->chain == PCS_CHAIN_SELF ? 2 : 1); ++pass) {
-        const std::vector<int32_t> &major = pass == 0 ? h->h_cam : h->h_img;
-        for (int64_t i = 0; i < n; ++i) order[i] = (int32_t)i;
-        std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) {
-            return major[x] != major[y] ? major[x] < major[y] : h->h_key[x] < h->h_key[y];
-        });
-        int32_t **dst = pass == 0 ? &h->d_order_ck : &h->d_order_ik;
-        HIPCHK(hipMalloc(dst, sizeof(int32_t) * n));
-        HIPCHK(hipMemcpy(*dst, order.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice));
+    if (h->chain != PCS_CHAIN_TEMPLATE) {
+        std::vector<int32_t> order(n);
+        for (int pass = 0; pass < (h->chain == PCS_CHAIN_SELF ? 2 : 1); ++pass) {
+            const std::vector<int32_t> &major = pass == 0 ? h->h_cam : h->h_img;
+            for (int64_t i = 0; i < n; ++i) order[i] = (int32_t)i;
+            std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) {
+                return major[x] != major[y] ? major[x] < major[y] : h->h_key[x] < h->h_key[y];
+            });
+            int32_t **dst = pass == 0 ? &h->d_order_ck : &h->d_order_ik;
+            HIPCHK(hipMalloc(dst, sizeof(int32_t) * n));
+            HIPCHK(hipMemcpy(*dst, order.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice));
+        }
     }
+    // the table in each visiting order: the shared pass of a scattered table, the (cam, key) pass, the (image, key) pass (which
+    // reads no measurements)
+    const int32_t *orders[3] = {h->d_order, h->d_order_ck, h->d_order_ik};
+    using u2 = __attribute__((ext_vector_type(2))) uint32_t;
+    using u4 = __attribute__((ext_vector_type(4))) uint32_t;
+    for (int pass = 0; pass < 3; ++pass) {
+        if (!orders[pass]) continue;
+        void **t = h->d_sorted[pass];
+        if (h->d_packed) {
+            HIPCHK(gather_rows<uint32_t>(orders[pass], h->d_packed, &t[0], n, h->stream));
+        } else {
+            HIPCHK(gather_rows<uint32_t>(orders[pass], h->d_cam, &t[1], n, h->stream));
+            HIPCHK(gather_rows<uint32_t>(orders[pass], h->d_img, &t[2], n, h->stream));
+            HIPCHK(gather_rows<uint32_t>(orders[pass], h->d_key, &t[3], n, h->stream));
+        }
+        if (pass != PASS_IMGKEY) HIPCHK(h->msize == 4 ? gather_rows<u2>(orders[pass], h->d_uv, &t[4], n, h->stream) : gather_rows<u4>(orders[pass], h->d_uv, &t[4], n, h->stream));
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
     return PCS_OK;
 }
 
@@ -913,6 +961,16 @@ static int enqueue_normal(pcs_engine *h, const double *d_prm, double *d_H, doubl
         if (h->normal_debug & (256 << pass)) continue;   // profiling: time the passes one by one
         a.order = pass == PASS_SHARED ? h->d_order : pass == PASS_CAMKEY ? h->d_order_ck : h->d_order_ik;
         if (pass != PASS_SHARED && !a.order) return fail(PCS_ERR_STATE, "normal equations: key-sorted visiting order missing");
+        a.tab = det_table(h);
+        if (a.order && h->sort_tables) {   // the pass's own copy of the table, already in visiting order
+            void *const *t = h->d_sorted[pass];
+            if (t[0] || t[1]) {
+                a.tab.packed = static_cast<const uint32_t *>(t[0]);
+                a.tab.cam = static_cast<const int32_t *>(t[1]); a.tab.img = static_cast<const int32_t *>(t[2]); a.tab.key = static_cast<const int32_t *>(t[3]);
+                if (t[4]) a.tab.uv = t[4];
+                a.order = nullptr;
+            }
+        }
         hipError_t e;
         if (pass == PASS_IMGKEY && h->normal_imgkey_product) {
             // 7 KB of LDS and 167 VGPRs per wave: 12 resident per CU.  The kernel waits on dependent loads and on its

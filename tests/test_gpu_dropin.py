@@ -355,6 +355,21 @@ def test_block_reduced_normal_equations_match_the_oracle_jacobian(chain, dtype):
         H3, g3, c3 = e.normal_equations(ps)
         assert np.max(np.abs(H3 - H_ref) / np.where(scale > 0, scale, 1.0)) <= tol, name
         assert np.max(np.abs(g3 - g_ref)) <= tol_r * np.max(np.abs(g_ref)) and abs(c3 - c_ref) <= tol_r * c_ref, name
+        e.set_option("normal_rows", 64)
+        e.set_option("normal_sort_tables", 0)         # passes walk the original table through their visiting orders (A/B): same matrix
+        H5, g5, c5 = e.normal_equations(ps)
+        assert np.max(np.abs(H5 - H_ref) / np.where(scale > 0, scale, 1.0)) <= tol, name
+        assert np.max(np.abs(g5 - g_ref)) <= tol_r * np.max(np.abs(g_ref)) and abs(c5 - c_ref) <= tol_r * c_ref, name
+        e.set_option("normal_sort_tables", 1)
+        if name == "shuffled":                        # three int32 index arrays instead of the packed word: the sorted copies too
+            e6 = Engine(chain, rig.n_cams, rig.n_imgs, rig.n_keys, dtype=dtype)
+            e6.set_option("pack_indices", 0)
+            e6.set_detections_table(rig.detections[perm])
+            if tm is not None:
+                e6.set_template(tm)
+            H6, g6, c6 = e6.normal_equations(ps)
+            assert np.max(np.abs(H6 - H_ref) / np.where(scale > 0, scale, 1.0)) <= tol, name
+            assert np.max(np.abs(g6 - g_ref)) <= tol_r * np.max(np.abs(g_ref)) and abs(c6 - c_ref) <= tol_r * c_ref, name
         if chain == "self":                           # pose-point blocks by the boundary-walking pass (kept for A/B): same matrix
             e.set_option("normal_imgkey_product", 0)
             H4, _, _ = e.normal_equations(ps)

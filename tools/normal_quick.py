@@ -15,6 +15,7 @@ e = Engine(chain, rig.n_cams, rig.n_imgs, rig.n_keys); e.set_detections_table(ri
 if chain == "template": e.set_template(rig.points)
 Hd = torch.empty((n, n), dtype=torch.float64, device="cuda"); gd = torch.empty(n, dtype=torch.float64, device="cuda"); cd = torch.empty(1, dtype=torch.float64, device="cuda")
 for arg in [x for x in sys.argv if x.startswith("--ikw=")]: sys.argv.remove(arg); e.set_option("normal_imgkey_wgs_per_cu", int(arg[6:]))
+for arg in [x for x in sys.argv if x.startswith("--sort=")]: sys.argv.remove(arg); e.set_option("normal_sort_tables", int(arg[7:]))
 if "--walk" in sys.argv: sys.argv.remove("--walk"); e.set_option("normal_imgkey_product", 0)
 dbgs = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0]
 for dbg in dbgs:
