@@ -60,7 +60,7 @@ struct NormalArgs {
     int64_t n_params;
     int32_t tiles_per_wave;
     int32_t debug;  // profiling switches (results are wrong while set): 2 no flush atomics, 8 no MFMA phase, 16 no evaluation,
-                    // 32 run boundaries ignored, 64 no LDS image writes; host side: 256 / 512 / 1024 skip the shared /
+                    // 32 run boundaries ignored, 64 no LDS image writes, 128 flush = clear only; host side: 256 / 512 / 1024 skip the shared /
                     // (cam, key) / (image, key) pass
 };
 
@@ -202,6 +202,13 @@ __global__ __launch_bounds__(64, 2) void ba_normal_mfma_kernel(const NormalArgs 
     // camera): only entries that involve a pose column are flushed and cleared.
     auto flush = [&](const bool everything) {
         if (run_a < 0) return;
+        if (a.debug & 128) {   // profiling: clear the finished entries, no look-ups, no atomics
+#pragma unroll
+            for (int m = 0; m < NM; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[m][r] = (everything || (ent[m][r] & (1 << 28))) ? 0.0 : acc[m][r];
+            return;
+        }
         const int cam = PASS == PASS_IMGKEY ? 0 : run_a;
         const int img = PASS == PASS_SHARED ? run_b : run_a;     // only used where pose columns occur
         const int key = run_b;                                   // only used in the point passes
