@@ -931,11 +931,26 @@ static int enqueue_normal(pcs_engine *h, const double *d_prm, double *d_H, doubl
     HIPCHK(hipSetDevice(h->device));
     int rc0 = ensure_point_orders(h);
     if (rc0) return rc0;
-    HIPCHK(hipMemsetAsync(d_H, 0, sizeof(double) * h->n_params * h->n_params, s));
-    HIPCHK(hipMemsetAsync(d_g, 0, sizeof(double) * h->n_params, s));
-    HIPCHK(hipMemsetAsync(d_cost, 0, sizeof(double), s));
-    int rc = launch_slab_prep(h, d_prm, s);
-    if (rc) return rc;
+    if (reinterpret_cast<uintptr_t>(d_H) % 16 == 0) {   // slab_prep and the zeroing of the outputs in one launch
+        HIPCHK(order_after_done(h, s));
+        const int has_pose = h->chain != PCS_CHAIN_FREE, copy_points = h->chain != PCS_CHAIN_TEMPLATE;
+        int64_t threads = h->n_cams + (has_pose ? h->n_imgs : 0);
+        if (copy_points) threads = std::max<int64_t>(threads, std::min<int64_t>(3 * h->n_keys, 1 << 16));
+        const int prep_blocks = (int)((threads + 63) / 64);
+        const int64_t n_h = h->n_params * h->n_params;
+        const int zero_blocks = (int)std::min<int64_t>((n_h / 2 + 63) / 64 + 1, (int64_t)h->n_cu * 32);
+        hipLaunchKernelGGL(normal_prologue_kernel, dim3((unsigned)(prep_blocks + zero_blocks)), dim3(64), 0, s, d_prm, (double *)h->d_cam_slab,
+                           (double *)h->d_pose_slab, (double *)h->d_points, (int)h->n_cams, (int)h->n_imgs, (int)h->n_keys, h->extr_off,
+                           h->pose_off, h->point_off, has_pose, copy_points, prep_blocks, d_H, n_h, d_g, h->n_params, d_cost);
+        HIPCHK(hipGetLastError());
+        h->linearized = true;
+    } else {
+        HIPCHK(hipMemsetAsync(d_H, 0, sizeof(double) * h->n_params * h->n_params, s));
+        HIPCHK(hipMemsetAsync(d_g, 0, sizeof(double) * h->n_params, s));
+        HIPCHK(hipMemsetAsync(d_cost, 0, sizeof(double), s));
+        int rc = launch_slab_prep(h, d_prm, s);
+        if (rc) return rc;
+    }
     NormalArgs a{};
     a.tab = det_table(h);
     a.cam_slab = h->d_cam_slab; a.pose_slab = h->d_pose_slab; a.points = h->d_points;
