@@ -370,6 +370,20 @@ def test_block_reduced_normal_equations_match_the_oracle_jacobian(chain, dtype):
             H6, g6, c6 = e6.normal_equations(ps)
             assert np.max(np.abs(H6 - H_ref) / np.where(scale > 0, scale, 1.0)) <= tol, name
             assert np.max(np.abs(g6 - g_ref)) <= tol_r * np.max(np.abs(g_ref)) and abs(c6 - c_ref) <= tol_r * c_ref, name
+        if name == "sorted":                          # caller-owned device buffers; H on an odd 8-byte boundary takes the memset prologue
+            import torch
+            n = ps.shape[0]
+            buf = torch.full((n * n + 1,), 7.0, dtype=torch.float64, device="cuda")
+            gd = torch.full((n,), 7.0, dtype=torch.float64, device="cuda")
+            cd = torch.full((1,), 7.0, dtype=torch.float64, device="cuda")
+            for off in (0, 1):
+                Hd = buf[off: off + n * n]
+                e.normal_equations_device(ps, Hd.data_ptr(), gd.data_ptr(), cd.data_ptr())
+                e.synchronize()
+                Hu7 = Hd.cpu().numpy().reshape(n, n)
+                H7 = Hu7 + np.triu(Hu7, 1).T
+                assert np.max(np.abs(H7 - H_ref) / np.where(scale > 0, scale, 1.0)) <= tol, (name, off)
+                assert np.max(np.abs(gd.cpu().numpy() - g_ref)) <= tol_r * np.max(np.abs(g_ref)) and abs(float(cd.cpu()[0]) - c_ref) <= tol_r * c_ref
         if chain == "self":                           # pose-point blocks by the boundary-walking pass (kept for A/B): same matrix
             e.set_option("normal_imgkey_product", 0)
             H4, _, _ = e.normal_equations(ps)
