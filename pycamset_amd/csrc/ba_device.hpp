@@ -98,6 +98,18 @@ struct LaneSlab {
     __device__ __forceinline__ double operator[](const int j) const { return readlane_scalar(v, j); }
 };
 
+// A parameter slab read with SCALAR loads: the base address is wave-uniform (built from v_readfirstlane values), and a pointer
+// in the constant address space makes hipcc emit s_load_dwordx{2..16} through the scalar cache instead of one vector load +
+// two v_readlane per value.  The slabs are written by the previous kernel (slab_prep), so they are constant here.  Worth it
+// while the values fit the ~100 SGPRs: the residual-only and legacy kernels (33 / 21 values: 9.9 -> 9.0 us at N = 1e6);
+// the 87 values of a full Jacobian evaluation do not, and are kept across lanes instead (LaneSlab).
+struct ScalarSlab {
+    using CP = const __attribute__((address_space(4))) double *;
+    CP p;
+    __device__ __forceinline__ explicit ScalarSlab(const double *q) : p((CP)(uintptr_t)q) {}
+    __device__ __forceinline__ double operator[](const int j) const { return p[j]; }
+};
+
 // Rodrigues rotation and its derivative from a rotation vector, in double whatever the slab
 // dtype.  Same formulas and the same theta < 1e-10 branches as ch:205-234 and ch:244-286
 // (pose 0 is exactly zero by default, template_handler.py:134-137, so the branch is live).

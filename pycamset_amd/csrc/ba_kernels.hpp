@@ -221,24 +221,16 @@ __global__ __launch_bounds__(WG_THREADS) void ba_eval_kernel(const EvalArgs a) {
         T u, v;
         T J[P2];
         if constexpr (!JAC && !SLAB_LDS) {
-            // Residual only: 44 B of traffic per detection, so the ~17 wide slab loads of a tile set the
-            // pace (13.6 us at N = 1e6).  When the tile shares its camera and image (the reference's table
-            // order), 33 lanes fetch the 21 + 12 slab scalars with ONE coalesced load and v_readlane
-            // broadcasts them into scalar registers (10.4 us); other tiles take the per-lane loads.
+            // Residual only: 36-44 B of traffic per detection; what the launch is short of is issue slots, not bandwidth (a plain
+            // copy of the same bytes takes 6.7 us).  When the tile shares its camera and image (the reference's table order) the
+            // 21 + 12 slab scalars come through SCALAR loads (ScalarSlab): 13.6 us with per-lane loads, 10.0 with one coalesced
+            // load + v_readlane broadcasts (round 1), 9.0 now; other tiles take the per-lane loads.
             // (The same idea for the fused kernel — staging a tile's slabs in a wave-private LDS strip —
             // was measured and dropped: the second code path costs 12-36 VGPRs and the HBM-bound kernel
             // gains nothing, profiles/r01/sweeps.md.)
             const int c0 = __builtin_amdgcn_readfirstlane(c), im0 = __builtin_amdgcn_readfirstlane(im);
             if (__all(c == c0 && im == im0)) {
-                constexpr int NC = 21, NP = (CHAIN != CHAIN_FREE) ? 12 : 0;
-                const T *src = lane < NC ? cam_slab + c0 * CAM_STRIDE + lane : pose_slab + im0 * POSE_STRIDE + (lane - NC);
-                const T val = lane < NC + NP ? *src : T(0);
-                T cs_s[NC], ps_s[12];
-#pragma unroll
-                for (int j = 0; j < NC; ++j) cs_s[j] = readlane_scalar(val, j);
-#pragma unroll
-                for (int j = 0; j < NP; ++j) ps_s[j] = readlane_scalar(val, NC + j);
-                eval_detection<CHAIN, T, false>(cs_s, ps_s, X0, X1, X2, u, v, J);
+                eval_detection<CHAIN, T, false>(ScalarSlab(cam_slab + c0 * CAM_STRIDE), ScalarSlab(pose_slab + im0 * POSE_STRIDE), X0, X1, X2, u, v, J);
             } else {
                 eval_detection<CHAIN, T, false>(cs, ps, X0, X1, X2, u, v, J);
             }
@@ -510,8 +502,7 @@ __global__ __launch_bounds__(WG_THREADS) void ba_compact_tile_kernel(const EvalA
 // selection template_handler.py:535-592): pre-multiplied 3x4 projection matrices and pre-transformed
 // points im_points[image, key].  cam_tab row (24 scalars): P row-major 12 | fx cx fy cy | k0 k1 p0 p1 k2 | pad.
 // 44 B of traffic per detection: as in the residual-only mode of ba_eval_kernel the per-lane loads of the camera
-// table set the pace, so a tile that shares its camera fetches the 21 scalars with ONE coalesced load and
-// v_readlane broadcasts them into scalar registers.
+// table set the pace, so a tile that shares its camera fetches the 21 scalars with scalar loads (ScalarSlab).
 constexpr int LEGACY_STRIDE = 24;
 __global__ __launch_bounds__(256) void legacy_cost_kernel(const DetTable tab, const T *__restrict__ im_points, const T *__restrict__ cam_tab,
                                                           T *__restrict__ errors, int64_t n, int64_t n_keys, void *sink) {
@@ -530,9 +521,9 @@ __global__ __launch_bounds__(256) void legacy_cost_kernel(const DetTable tab, co
         T ct[21];
         const int c0 = __builtin_amdgcn_readfirstlane(c);
         if (__all(c == c0)) {
-            const T val = lane < 21 ? cam_tab[(int64_t)c0 * LEGACY_STRIDE + lane] : T(0);
+            const ScalarSlab cs(cam_tab + (int64_t)c0 * LEGACY_STRIDE);   // scalar loads (ba_device.hpp)
 #pragma unroll
-            for (int j = 0; j < 21; ++j) ct[j] = readlane_scalar(val, j);
+            for (int j = 0; j < 21; ++j) ct[j] = cs[j];
         } else {
 #pragma unroll
             for (int j = 0; j < 21; ++j) ct[j] = cam_tab[(int64_t)c * LEGACY_STRIDE + j];
