@@ -443,8 +443,14 @@ __global__ __launch_bounds__(WG_THREADS) void ba_compact_tile_kernel(const EvalA
         asm volatile("" ::: "memory");
         T u, v;
         T J[P2];
-        eval_detection<CHAIN, T, JAC>(cam_slab + c * CAM_STRIDE, pose_slab + im * POSE_STRIDE, points[3 * k], points[3 * k + 1],
-                                      points[3 * k + 2], u, v, J);
+        {
+            const T X0 = points[3 * k], X1 = points[3 * k + 1], X2 = points[3 * k + 2];
+            const int c0 = __builtin_amdgcn_readfirstlane(c), im0 = __builtin_amdgcn_readfirstlane(im);
+            if (__all(c == c0 && im == im0))   // one camera and one image in the tile: slabs through scalar loads (ba_device.hpp)
+                eval_detection<CHAIN, T, JAC>(ScalarSlab(cam_slab + c0 * CAM_STRIDE), ScalarSlab(pose_slab + im0 * POSE_STRIDE), X0, X1, X2, u, v, J);
+            else
+                eval_detection<CHAIN, T, JAC>(cam_slab + c * CAM_STRIDE, pose_slab + im * POSE_STRIDE, X0, X1, X2, u, v, J);
+        }
         if constexpr ((MODE & MODE_RESID) != 0) {  // branch-free (see ba_eval_kernel)
             O2 r;
             r.x = (TO)(u - m.x);
