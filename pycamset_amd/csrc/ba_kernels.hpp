@@ -234,6 +234,18 @@ __global__ __launch_bounds__(WG_THREADS) void ba_eval_kernel(const EvalArgs a) {
             } else {
                 eval_detection<CHAIN, T, false>(cs, ps, X0, X1, X2, u, v, J);
             }
+        } else if constexpr (JAC && !SLAB_LDS) {
+            // Fused kernel, slabs through L1/L2: a tile with one camera and one image (the reference's table order: 156
+            // detections per (camera, image) on rig-32) takes its 48 + 39 slab values through SCALAR loads (ScalarSlab) instead of
+            // 87 vector loads in which all 64 lanes ask for the same address.  That frees the vector memory path for the store
+            // stream: 66.3 -> 64.6 us (chain T), 70.7 -> 65.3 us (chain S), f32 outputs 35.3 -> 33.0 us, rig-128 345 -> 318 us,
+            // interleaved on one box (profiles/r02/sweeps.md).  (The round-1 / early round-2 attempts held the slab across lanes
+            // and paid 174 v_readlane per tile for it: no gain.)  Other tiles take the per-lane loads; same arithmetic, same bits.
+            const int c0 = __builtin_amdgcn_readfirstlane(c), im0 = __builtin_amdgcn_readfirstlane(im);
+            if (__all(c == c0 && im == im0))
+                eval_detection<CHAIN, T, JAC>(ScalarSlab(cam_slab + c0 * CAM_STRIDE), ScalarSlab(pose_slab + im0 * POSE_STRIDE), X0, X1, X2, u, v, J);
+            else
+                eval_detection<CHAIN, T, JAC>(cs, ps, X0, X1, X2, u, v, J);
         } else {
             eval_detection<CHAIN, T, JAC>(cs, ps, X0, X1, X2, u, v, J);
         }
