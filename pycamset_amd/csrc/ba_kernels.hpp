@@ -148,7 +148,7 @@ __global__ void normal_prologue_kernel(const double *__restrict__ prm, T *__rest
 // fewer for small ones so that the grid still covers every CU several times); wave w takes tiles w, w + waves, ...
 // of the workgroup's run of tiles.
 template <int CHAIN, int MODE, int VARIANT, typename TO>
-__global__ __launch_bounds__(WG_THREADS) void ba_eval_kernel(const EvalArgs a) {
+__global__ __launch_bounds__(WG_THREADS, (sizeof(TO) == 4 && (MODE & MODE_JAC)) ? 3 : 1) void ba_eval_kernel(const EvalArgs a) {
     constexpr int P = chain_P(CHAIN);
     constexpr int P2 = 2 * P;
     constexpr bool SLAB_LDS = (VARIANT & VAR_SLAB_LDS) != 0;
