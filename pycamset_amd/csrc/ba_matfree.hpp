@@ -108,8 +108,14 @@ __global__ __launch_bounds__(256) void ba_matfree_kernel(const MatfreeArgs a) {
         const double2v m = load_uv(a.tab, ic);
         T u, v;
         T J[P2];
-        eval_detection<CHAIN, T, true>(cam_slab + c * CAM_STRIDE, pose_slab + im * POSE_STRIDE, points[3 * k], points[3 * k + 1],
-                                       points[3 * k + 2], u, v, J);
+        {
+            const T X0 = points[3 * k], X1 = points[3 * k + 1], X2 = points[3 * k + 2];
+            const int c0 = __builtin_amdgcn_readfirstlane(c), im0 = __builtin_amdgcn_readfirstlane(im);
+            if (__all(c == c0 && im == im0))   // one camera and one image in the tile: slabs through scalar loads (ScalarSlab, ba_device.hpp)
+                eval_detection<CHAIN, T, true>(ScalarSlab(cam_slab + c0 * CAM_STRIDE), ScalarSlab(pose_slab + im0 * POSE_STRIDE), X0, X1, X2, u, v, J);
+            else
+                eval_detection<CHAIN, T, true>(cam_slab + c * CAM_STRIDE, pose_slab + im * POSE_STRIDE, X0, X1, X2, u, v, J);
+        }
         // global columns of this detection's P local parameters
         const int64_t cI = 9 * (int64_t)c, cE = a.extr_off + 6 * (int64_t)c;
         const int64_t cP = a.pose_off + 6 * (int64_t)im, cX = a.point_off + 3 * (int64_t)k;
