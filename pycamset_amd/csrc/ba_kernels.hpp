@@ -242,10 +242,20 @@ __global__ __launch_bounds__(WG_THREADS, (sizeof(TO) == 4 && (MODE & MODE_JAC)) 
             // interleaved on one box (profiles/r02/sweeps.md).  (The round-1 / early round-2 attempts held the slab across lanes
             // and paid 174 v_readlane per tile for it: no gain.)  Other tiles take the per-lane loads; same arithmetic, same bits.
             const int c0 = __builtin_amdgcn_readfirstlane(c), im0 = __builtin_amdgcn_readfirstlane(im);
-            if (__all(c == c0 && im == im0))
+            const bool first = c == c0 && im == im0;
+            if (__all(first)) {
                 eval_detection<CHAIN, T, JAC>(ScalarSlab(cam_slab + c0 * CAM_STRIDE), ScalarSlab(pose_slab + im0 * POSE_STRIDE), X0, X1, X2, u, v, J);
-            else
-                eval_detection<CHAIN, T, JAC>(cs, ps, X0, X1, X2, u, v, J);
+            } else {
+                // a tile that straddles ONE run boundary (41 % of the tiles on rig-32): its two parts are uniform, each takes its own
+                // scalar slabs under its half of the exec mask (chain S 80.5 -> 75.8 us, chain T 68.7 -> 67.9 us on a slow box)
+                const int c1 = __builtin_amdgcn_readlane(c, 63), im1 = __builtin_amdgcn_readlane(im, 63);
+                if (__all(first || (c == c1 && im == im1))) {
+                    if (first) eval_detection<CHAIN, T, JAC>(ScalarSlab(cam_slab + c0 * CAM_STRIDE), ScalarSlab(pose_slab + im0 * POSE_STRIDE), X0, X1, X2, u, v, J);
+                    else eval_detection<CHAIN, T, JAC>(ScalarSlab(cam_slab + c1 * CAM_STRIDE), ScalarSlab(pose_slab + im1 * POSE_STRIDE), X0, X1, X2, u, v, J);
+                } else {
+                    eval_detection<CHAIN, T, JAC>(cs, ps, X0, X1, X2, u, v, J);
+                }
+            }
         } else {
             eval_detection<CHAIN, T, JAC>(cs, ps, X0, X1, X2, u, v, J);
         }
