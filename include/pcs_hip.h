@@ -148,7 +148,8 @@ int pcs_eval_compact_device(pcs_engine *h, const double *param_str, void *d_resi
  * Matrix-free products with the Jacobian at a linearisation point: J is never
  * materialised.  Replaces what scipy does with the reference's CSR Jacobian
  * (optimisation_handling.py:88-98: x_scale='jac' column norms, J^T f, lsmr mat-vecs).
- * pcs_linearize prepares the slabs at `param_str` (any pcs_eval* call does so too).
+ * pcs_linearize prepares the slabs at `param_str` (so does a pcs_eval* call that launched slab_prep — not a one-launch step,
+ * option "fuse_prep": pcs_matfree then returns PCS_ERR_STATE until pcs_linearize has run).
  * pcs_matfree ops (vectors on the host, FULL parameter-string space, float64):
  *   0 JV    in: n_params            out: 2N        out = J in
  *   1 JTU   in: 2N                  out: n_params  out = J^T in
@@ -165,10 +166,12 @@ int pcs_matfree(pcs_engine *h, int op, const double *in, double *out, double *co
  * writing J:  H = J^T J  (n_params x n_params row-major, FULL parameter-string space, only the UPPER
  * triangle incl. the diagonal is written, the rest is zero),  g = J^T r  (n_params),  cost = r^T r.
  * float64 whatever the engine dtype.  The sums use f64 atomics: the last bits depend on arrival order.  The kernels address H
- * with 32-bit byte offsets: n_params <= 23170 (a 4.3 GB matrix), PCS_ERR_ARG beyond.
+ * with 32-bit byte offsets: n_params <= PCS_NORMAL_MAX_PARAMS = 23170 (a 4.3 GB matrix); both entry points return
+ * PCS_ERR_ARG beyond it, before anything is allocated.
  *   pcs_normal_equations         host buffers (engine-owned device scratch, blocking)
  *   pcs_normal_equations_device  device buffers of the caller, queued on `stream` (NULL = engine stream);
  *                                the call zeroes them first.  Observation shards: all-reduce H, g, cost. */
+#define PCS_NORMAL_MAX_PARAMS 23170
 int pcs_normal_equations(pcs_engine *h, const double *param_str, double *H, double *g, double *cost);
 int pcs_normal_equations_device(pcs_engine *h, const double *param_str, double *d_H, double *d_g, double *d_cost, void *stream);
 
@@ -196,7 +199,9 @@ int pcs_legacy_cost(pcs_engine *h, const double *im_points, const double *proj, 
 
 /* Block until everything queued on `stream` (NULL = engine stream) has finished. */
 int pcs_synchronize(pcs_engine *h, void *stream);
-/* Duration of the most recent evaluation's kernels (HIP events on the launch stream), ms. */
+/* Duration of the most recent evaluation's kernels, ms: each kernel's OWN start / stop events (hipExtLaunchKernelGGL on the
+ * launch stream), so slab_prep_ms is the slab_prep kernel's duration without the gap to the next launch — the figure
+ * rocprofv3 reports.  A one-launch step (option "fuse_prep") has no slab_prep kernel: slab_prep_ms = 0. */
 int pcs_last_kernel_ms(pcs_engine *h, float *slab_prep_ms, float *eval_ms);
 /* Mean kernel durations over the evaluations kept in the event ring (option "event_ring" = R keeps
  * the last R evaluations; the ring is reset when the option is set).  Used by bench.py for the
@@ -207,6 +212,9 @@ int pcs_kernel_ms_mean(pcs_engine *h, int64_t *count, float *slab_prep_ms, float
  * the sample list of general_utils.benchmark(), utils/general_utils.py:62-104). */
 int pcs_kernel_ms_samples(pcs_engine *h, int64_t capacity, float *slab_prep_ms, float *eval_ms, int64_t *count);
 /* Tuning knobs ("variant", "wgs_per_cu", "tiles_per_wg", "event_ring", "timing_every", "compact_variant",
+ * "fuse_prep" (-1 automatic / 0 / 1: one launch per step — every wave of the evaluation kernel prepares the R, t, dR/dr
+ * slabs of its own tile instead of a slab_prep launch in front; automatic = tables of at most "fuse_prep_max_n" detections
+ * in the reference's run order; same slab element functions, same bits; the matrix-free operators then need pcs_linearize),
  * "matfree_lds", "xcd_remap", "waves_per_wg", "pack_indices", "normal_rows", "normal_imgkey_product",
  * "normal_imgkey_wgs_per_cu", "normal_sort_tables"; "normal_debug" is a bit mask of profiling switches of pcs_normal_equations — phases
  * or whole passes are skipped and the results are wrong while it is non-zero); see DESIGN.md.
@@ -227,7 +235,10 @@ int pcs_set_option(pcs_engine *h, const char *key, int64_t value);
  *   pcs_tri_set_observations_device  the same arrays already in device memory (caller-owned, not copied, not checked)
  *   pcs_tri_run                      queue the kernel on `stream` (NULL = the handle's own stream); d_pts = device
  *                                    buffer (n_pts,3) of the caller, or NULL = handle-owned output
- *   pcs_tri_points                   copy the handle-owned output to the host (blocking)
+ *   pcs_tri_points                   copy the handle-owned output to the host (blocking; PCS_ERR_STATE when the last run
+ *                                    wrote to a caller buffer instead)
+ * Runs on different streams are ordered by the handle (scratch and output are shared): an event recorded after every run
+ * is waited for by the next run, by pcs_tri_points and by the setters, whatever stream the run was queued on.
  * pcs_triangulate is the stateless convenience form (temporary handle: allocations and copies on every call).
  */
 typedef struct pcs_triangulator pcs_triangulator;

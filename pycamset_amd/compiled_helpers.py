@@ -161,10 +161,20 @@ def group_reconstructable(data: np.ndarray):
     """The grouping CameraSet.multi_cam_triangulate does before calling nb_triangulate_full
     (cameras/camera_set.py:371-378): keep (image, key) groups seen by more than one camera, in the
     table's order, and return (reconstructable_data, start_ind)."""
-    data = np.asarray(data, dtype=np.float64)
-    _, inv, count = np.unique(data[:, 1:-2], axis=0, return_inverse=True, return_counts=True)
-    viable_mask = count > 1
-    reconstructable_data = data[viable_mask[inv].squeeze()]
-    _, im_index, im_counts = np.unique(reconstructable_data[:, 1:-2], axis=0, return_index=True, return_counts=True)
-    start_ind = np.append(0, np.cumsum(im_counts[np.argsort(im_index)]))
-    return reconstructable_data, start_ind
+    table = np.asarray(data, dtype=np.float64)
+    if table.shape[0] == 0:
+        return table, np.zeros(1, dtype=np.int64)
+    # one id per (image, key...) feature; how many cameras saw it; where it first appears in the table
+    _, feature = np.unique(table[:, 1:-2], axis=0, return_inverse=True)
+    feature = feature.reshape(-1)
+    seen_by = np.bincount(feature)
+    keep = seen_by[feature] >= 2                    # one view cannot be triangulated
+    kept = table[keep]
+    kept_feature = feature[keep]
+    first_row = np.full(seen_by.shape[0], kept.shape[0], dtype=np.int64)
+    np.minimum.at(first_row, kept_feature, np.arange(kept.shape[0]))
+    in_table_order = np.argsort(first_row[seen_by >= 2], kind="stable")
+    sizes = seen_by[seen_by >= 2][in_table_order]
+    starts = np.zeros(sizes.shape[0] + 1, dtype=np.int64)
+    np.cumsum(sizes, out=starts[1:])
+    return kept, starts

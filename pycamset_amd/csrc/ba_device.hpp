@@ -166,6 +166,90 @@ __device__ inline void rodrigues_and_jac(const double r0, const double r1, const
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same rotation slab, ONE ELEMENT PER LANE (round 3).  q in [0, 36): q < 9 -> R[q], else dR[q - 9]
+// (dR[a*9 + row*3 + col] = d R[row][col] / d r_a).  Every operation is written out with explicit roundings
+// (no implicit contraction), so the element a lane computes does not depend on which kernel it was inlined
+// into: the stand-alone slab_prep_kernel and the evaluation kernels that prepare their own slabs per wave
+// (ba_eval_kernel<..., PREP = true>) produce the same bits.  Same formulas and the same theta < 1e-10 branches
+// as ch:205-234 / ch:244-286 (see rodrigues_and_jac above, which the host-visible maths was checked against).
+struct RotTerms {
+    double r0, r1, r2;   // rotation vector
+    double it, st, ct;   // 1 / theta, sin(theta), cos(theta)
+    bool small;          // theta < 1e-10: R = I, dR = generators
+};
+__device__ __forceinline__ RotTerms rot_terms(const double r0, const double r1, const double r2) {
+#pragma clang fp contract(off)
+    RotTerms t;
+    t.r0 = r0; t.r1 = r1; t.r2 = r2;
+    const double theta = sqrt(__builtin_fma(r2, r2, __builtin_fma(r1, r1, r0 * r0)));
+    t.small = theta < 1e-10;
+    t.it = 1.0 / (t.small ? 1.0 : theta);
+    sincos(theta, &t.st, &t.ct);
+    return t;
+}
+__device__ __forceinline__ double sel3(const int i, const double a, const double b, const double c) { return i == 0 ? a : i == 1 ? b : c; }
+// d [r]x[row][col] / d r_a: +1 / -1 / 0 (the generators; ch:246-254 and the drx table of ch:270-277)
+__device__ __forceinline__ double skew_gen(const int a, const int row, const int col) {
+    // [r]x = {0,-z,y, z,0,-x, -y,x,0}: entry (row, col) = -eps(row, col, m) r_m
+    if (row == col || a == row || a == col) return 0.0;
+    return ((col - row + 3) % 3 == 1) ? -1.0 : 1.0;   // (0,1),(1,2),(2,0) carry the minus sign
+}
+__device__ __forceinline__ double rot_element(const RotTerms &t, const int q) {
+#pragma clang fp contract(off)
+    const bool is_R = q < 9;
+    const int e = is_R ? q : q - 9;
+    const int a = is_R ? 0 : e / 9;          // derivative axis (dR only)
+    const int k = is_R ? e : e - 9 * a;
+    const int row = k / 3, col = k - 3 * row;
+    const int m = 3 - row - col;             // the axis of the skew entry (row != col)
+    const double sgn = (row == col) ? 0.0 : (((col - row + 3) % 3 == 1) ? -1.0 : 1.0);
+    if (t.small) {
+        if (is_R) return row == col ? 1.0 : 0.0;
+        return skew_gen(a, row, col);
+    }
+    if (is_R) {
+        // R = ct I + (1 - ct) / theta^2 r r^T + st / theta [r]x       (un-normalised r, ch:213-234)
+        const double f = (1.0 - t.ct) * (t.it * t.it);
+        const double s = t.st * t.it;
+        const double v = (sel3(row, t.r0, t.r1, t.r2) * sel3(col, t.r0, t.r1, t.r2)) * f;
+        if (row == col) return v + t.ct;
+        return __builtin_fma(sgn * sel3(m, t.r0, t.r1, t.r2), s, v);
+    }
+    // dR/dr_a = a0 I + a1 rr^T + a2 d(rr^T)/dr_a + a3 [r]x + a4 d[r]x/dr_a on the unit axis (ch:256-286)
+    const double x = t.r0 * t.it, y = t.r1 * t.it, z = t.r2 * t.it;
+    const double ri = sel3(a, x, y, z), ar = sel3(row, x, y, z), ac = sel3(col, x, y, z);
+    const double ct_1 = 1.0 - t.ct;
+    const double a0 = -t.st * ri;
+    const double a1 = (t.st - (2.0 * ct_1) * t.it) * ri;
+    const double a2 = ct_1 * t.it;
+    const double a3 = (t.ct - t.st * t.it) * ri;
+    const double a4 = t.st * t.it;
+    const double eye = row == col ? 1.0 : 0.0;
+    const double rrt = ar * ac;
+    const double drrt = (a == row ? ac : 0.0) + (a == col ? ar : 0.0);
+    const double rx = row == col ? 0.0 : sgn * sel3(m, x, y, z);
+    double v = a0 * eye;
+    v = __builtin_fma(a1, rrt, v);
+    v = __builtin_fma(a2, drrt, v);
+    v = __builtin_fma(a3, rx, v);
+    v = __builtin_fma(a4, skew_gen(a, row, col), v);
+    return v;
+}
+// where element q of a rotation goes inside a camera / pose slab
+__device__ __forceinline__ int cam_slot_of(const int q) { return q < 9 ? CAM_R + q : CAM_DR + (q - 9); }
+__device__ __forceinline__ int pose_slot_of(const int q) { return q < 9 ? POSE_R + q : POSE_DR + (q - 9); }
+
+// The reference's projection multiplies by the focal length and divides by it again before distorting (fbi:32-35:
+// u = (fx x + px z) / z, x_n = (u - px) / fx), so a focal length of 0, NaN or +-inf makes BOTH residual rows of that
+// camera's detections non-finite, while its Jacobian formulas (fbi:62-134) never form that quotient.  The kernels divide
+// x / z directly; to keep the reference's behaviour the slab copy of the principal point (used by the residual only:
+// u = xD fx + px, d u / d px = 1 is a constant) is NaN for such a camera.  Pinned by tests/golden/block_*_focal_nonfinite.npz.
+__device__ __forceinline__ double principal_or_nan(const double v, const int slot, const double fx, const double fy) {
+    const bool ok = fx != 0.0 && fy != 0.0 && (fx - fx) == 0.0 && (fy - fy) == 0.0;   // finite and non-zero
+    return ((slot == 1 || slot == 3) && !ok) ? __builtin_nan("") : v;
+}
+
 // One detection through the chain.
 //   cs : camera slab (CAM_STRIDE scalars), ps : pose slab (POSE_STRIDE scalars, unused for CHAIN_FREE)
 //   X  : template point (CHAIN_TEMPLATE) or free 3-D point (CHAIN_SELF / CHAIN_FREE)

@@ -1,7 +1,8 @@
 // ba_kernels.hpp — the HIP kernels of the bundle-adjustment engine (gfx950 / CDNA4 only).
 //
-//   slab_prep_kernel         K0: one thread per camera / pose -> R, t, dR/dr slabs (ba_device.hpp);
-//                            also copies the 3-D points of chains SELF / FREE out of the parameter string.
+//   slab_prep_kernel         K0: one thread per slab element -> R, t, dR/dr slabs of every camera / pose (ba_device.hpp);
+//                            also copies the 3-D points of chains SELF / FREE out of the parameter string.  Small tables
+//                            skip it: ba_eval_kernel<..., PREP = true> prepares the slabs of its tile per wave (one launch per step).
 //   ba_eval_kernel           K1-K4: fused residual + dense 2xP Jacobian block per detection.  One lane
 //                            owns one detection of a 64-detection tile; slabs + points are read through
 //                            L1/L2 or staged in LDS; the Jacobian tile is transposed through LDS so that
@@ -70,53 +71,87 @@ struct EvalArgs {
     // compaction (ba_compact_* only)
     const uint32_t *keep;    // per detection: bit j set = local column j is free
     const int64_t *row_off;  // per detection: offset of its u row in the CSR data array
+    // one-launch step (PREP kernels only): the parameter string itself and its group offsets
+    const double *prm;
+    int64_t extr_off, pose_off, point_off;
 };
+
+// Slab of ONE (camera, image) pair prepared by the wave that needs it, in a wave-private LDS strip laid out like the
+// global slabs: [0, CAM_STRIDE) camera | [CAM_STRIDE, CAM_STRIDE + POSE_STRIDE) pose.  72 rotation elements on 64 lanes:
+// lanes 0-35 take the camera's, lanes 36-63 the pose's first 28, lanes 36-43 also its last 8 (same rot_terms); the 15 plain
+// copies (intrinsics, two translations) ride on lanes 0-14.  ~1 sincos + 2 element formulas per lane and 4 L2-resident loads:
+// ~0.4 us on a wave's critical path against 4.5 us + a launch gap for slab_prep_kernel — what a table of <= ~4e5
+// detections (every real pyCamSet calibration, config 2, an 8-way shard of config 3) spends a third of its step on.
+constexpr int PAIR_SLAB = CAM_STRIDE + POSE_STRIDE;
+template <int CHAIN>
+__device__ __forceinline__ void prep_pair_slab(T *__restrict__ strip, const double *__restrict__ prm, const int c0, const int im0, const int lane,
+                                               const int64_t extr_off, const int64_t pose_off) {
+    constexpr bool HAS_POSE = CHAIN != CHAIN_FREE;
+    const bool on_pose = HAS_POSE && lane >= 36;
+    const double *p6 = on_pose ? prm + pose_off + 6 * (int64_t)im0 : prm + extr_off + 6 * (int64_t)c0;
+    const double r0 = p6[0], r1 = p6[1], r2 = p6[2];
+    // plain copies: lanes 0-8 intrinsics, 9-11 t_e, 12-14 t_p
+    const double *cp = lane < 9 ? prm + 9 * (int64_t)c0 + lane : lane < 12 ? prm + extr_off + 6 * (int64_t)c0 + 3 + (lane - 9) : prm + pose_off + 6 * (int64_t)im0 + 3 + (lane - 12);
+    const bool copies = lane < (HAS_POSE ? 15 : 12);
+    const double cv = principal_or_nan(*(copies ? cp : prm), lane, prm[9 * (int64_t)c0], prm[9 * (int64_t)c0 + 2]);
+    const RotTerms t = rot_terms(r0, r1, r2);
+    const int q = on_pose ? lane - 36 : min(lane, 35);
+    const double e1 = rot_element(t, q);
+    if (on_pose) strip[CAM_STRIDE + pose_slot_of(q)] = e1;
+    else if (lane < 36) strip[cam_slot_of(q)] = e1;
+    if constexpr (HAS_POSE) {
+        const double e2 = rot_element(t, min(q + 28, 35));
+        if (lane >= 36 && lane < 44) strip[CAM_STRIDE + pose_slot_of(q + 28)] = e2;
+    }
+    if (copies) strip[lane < 9 ? lane : lane < 12 ? CAM_T + (lane - 9) : CAM_STRIDE + POSE_T + (lane - 12)] = cv;
+}
 
 // ---------------------------------------------------------------------------------------------
 // K0  slab preparation
 // ---------------------------------------------------------------------------------------------
 // param_str layout: afb make_param_struct (abstract_function_blocks.py:777-820), see pcs_hip.h.
-// thread e of n_threads: one camera / pose slab (e < n_cams + n_imgs) and a strided share of the point copy
-__device__ __forceinline__ void slab_prep_entity(const int e, const int n_threads, const double *__restrict__ prm, T *__restrict__ cam_slab,
-                                                 T *__restrict__ pose_slab, T *__restrict__ points, int n_cams, int n_imgs, int n_keys,
-                                                 int64_t extr_off, int64_t pose_off, int64_t point_off, int has_pose, int copy_points) {
-    if (e < n_cams + (has_pose ? n_imgs : 0)) {
-        const bool is_cam = e < n_cams;
-        const double *p6 = is_cam ? prm + extr_off + 6 * (int64_t)e : prm + pose_off + 6 * (int64_t)(e - n_cams);
-        double R[9], dR[27];
-        rodrigues_and_jac(p6[0], p6[1], p6[2], R, dR);
-        if (is_cam) {
-            T *o = cam_slab + (int64_t)e * CAM_STRIDE;
-#pragma unroll
-            for (int j = 0; j < 9; ++j) o[j] = prm[9 * (int64_t)e + j];
-#pragma unroll
-            for (int j = 0; j < 9; ++j) o[CAM_R + j] = R[j];
-#pragma unroll
-            for (int j = 0; j < 3; ++j) o[CAM_T + j] = p6[3 + j];
-#pragma unroll
-            for (int j = 0; j < 27; ++j) o[CAM_DR + j] = dR[j];
-        } else {
-            T *o = pose_slab + (int64_t)(e - n_cams) * POSE_STRIDE;
-#pragma unroll
-            for (int j = 0; j < 9; ++j) o[POSE_R + j] = R[j];
-#pragma unroll
-            for (int j = 0; j < 3; ++j) o[POSE_T + j] = p6[3 + j];
-#pragma unroll
-            for (int j = 0; j < 27; ++j) o[POSE_DR + j] = dR[j];
-            o[39] = T(0);
-        }
+// One thread per SLAB ELEMENT (round 3; one thread per camera / pose before): thread t of n_threads owns element
+// t of [n_cams x CAM_STRIDE | n_imgs x POSE_STRIDE] — a copy of a parameter (intrinsics, translations), or one entry of
+// R / dR/dr through rot_terms + rot_element (ba_device.hpp), the same two functions the evaluation kernels use when they
+// prepare their slabs themselves (PREP), so both paths hold the same bits — and a strided share of the point copy.
+__host__ __device__ inline int64_t slab_prep_threads(int64_t n_cams, int64_t n_imgs, int has_pose) {
+    return (int64_t)n_cams * CAM_STRIDE + (has_pose ? (int64_t)n_imgs * POSE_STRIDE : 0);
+}
+__device__ __forceinline__ void slab_prep_element(const int64_t t, const int64_t n_threads, const double *__restrict__ prm, T *__restrict__ cam_slab,
+                                                  T *__restrict__ pose_slab, T *__restrict__ points, int n_cams, int n_imgs, int n_keys,
+                                                  int64_t extr_off, int64_t pose_off, int64_t point_off, int has_pose, int copy_points) {
+    const int64_t n_cam_el = (int64_t)n_cams * CAM_STRIDE;
+    if (t < n_cam_el) {
+        const int64_t c = t / CAM_STRIDE;
+        const int slot = (int)(t - c * CAM_STRIDE);
+        const double *p6 = prm + extr_off + 6 * c;
+        T v;
+        if (slot < CAM_R) v = principal_or_nan(prm[9 * c + slot], slot, prm[9 * c], prm[9 * c + 2]);
+        else if (slot >= CAM_T && slot < CAM_DR) v = p6[3 + slot - CAM_T];
+        else v = rot_element(rot_terms(p6[0], p6[1], p6[2]), slot < CAM_T ? slot - CAM_R : 9 + slot - CAM_DR);
+        cam_slab[t] = v;
+    } else if (has_pose && t < n_cam_el + (int64_t)n_imgs * POSE_STRIDE) {
+        const int64_t u = t - n_cam_el;
+        const int64_t im = u / POSE_STRIDE;
+        const int slot = (int)(u - im * POSE_STRIDE);
+        const double *p6 = prm + pose_off + 6 * im;
+        T v;
+        if (slot >= POSE_T && slot < POSE_DR) v = p6[3 + slot - POSE_T];
+        else if (slot == POSE_STRIDE - 1) v = T(0);
+        else v = rot_element(rot_terms(p6[0], p6[1], p6[2]), slot < POSE_T ? slot - POSE_R : 9 + slot - POSE_DR);
+        pose_slab[u] = v;
     }
     if (copy_points) {
-        const int total = n_keys * 3;
-        for (int j = e; j < total; j += n_threads) points[j] = prm[point_off + j];
+        const int64_t total = (int64_t)n_keys * 3;
+        for (int64_t j = t; j < total; j += n_threads) points[j] = prm[point_off + j];
     }
 }
 
 __global__ void slab_prep_kernel(const double *__restrict__ prm, T *__restrict__ cam_slab, T *__restrict__ pose_slab,
                                  T *__restrict__ points, int n_cams, int n_imgs, int n_keys, int64_t extr_off,
                                  int64_t pose_off, int64_t point_off, int has_pose, int copy_points) {
-    slab_prep_entity(blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x, prm, cam_slab, pose_slab, points, n_cams, n_imgs, n_keys,
-                     extr_off, pose_off, point_off, has_pose, copy_points);
+    slab_prep_element((int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x, prm, cam_slab, pose_slab, points, n_cams, n_imgs,
+                      n_keys, extr_off, pose_off, point_off, has_pose, copy_points);
 }
 
 // Prologue of a normal-equations build in ONE launch: the first prep_blocks workgroups prepare the slabs, the others zero
@@ -127,8 +162,8 @@ __global__ void normal_prologue_kernel(const double *__restrict__ prm, T *__rest
                                        int64_t pose_off, int64_t point_off, int has_pose, int copy_points, int prep_blocks,
                                        double *__restrict__ Hm, int64_t n_h, double *__restrict__ g, int64_t n_g, double *__restrict__ cost) {
     if ((int)blockIdx.x < prep_blocks) {
-        slab_prep_entity(blockIdx.x * blockDim.x + threadIdx.x, prep_blocks * blockDim.x, prm, cam_slab, pose_slab, points, n_cams, n_imgs, n_keys,
-                         extr_off, pose_off, point_off, has_pose, copy_points);
+        slab_prep_element((int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)prep_blocks * blockDim.x, prm, cam_slab, pose_slab, points, n_cams,
+                          n_imgs, n_keys, extr_off, pose_off, point_off, has_pose, copy_points);
         return;
     }
     using D2 = typename Vec2<double>::type;
@@ -147,11 +182,16 @@ __global__ void normal_prologue_kernel(const double *__restrict__ prm, T *__rest
 // TO = type of the residual and Jacobian written out.  The workgroup has blockDim.x / 64 waves (4 for large tables,
 // fewer for small ones so that the grid still covers every CU several times); wave w takes tiles w, w + waves, ...
 // of the workgroup's run of tiles.
-template <int CHAIN, int MODE, int VARIANT, typename TO>
-__global__ __launch_bounds__(WG_THREADS, (sizeof(TO) == 4 && (MODE & MODE_JAC)) ? 3 : 1) void ba_eval_kernel(const EvalArgs a) {
+// PREP (round 3, "one launch per step"): no slab_prep_kernel ran; the wave prepares the slab of every (camera, image) pair
+// of its tile itself (prep_pair_slab) and evaluates the pair's detections from that LDS strip, pair after pair — one
+// iteration for a tile inside a run of the reference's table order, two for a tile that straddles a run boundary.  Points
+// of chains SELF / FREE come straight from the parameter string.
+template <int CHAIN, int MODE, int VARIANT, typename TO, bool PREP = false>
+__global__ __launch_bounds__(WG_THREADS, (sizeof(TO) == 4 && (MODE & MODE_JAC) && !PREP) ? 3 : 1) void ba_eval_kernel(const EvalArgs a) {
     constexpr int P = chain_P(CHAIN);
     constexpr int P2 = 2 * P;
     constexpr bool SLAB_LDS = (VARIANT & VAR_SLAB_LDS) != 0;
+    static_assert(!(PREP && SLAB_LDS), "a wave that prepares its own slabs does not stage the global ones");
     constexpr bool TRANSPOSE = (VARIANT & VAR_TRANSPOSE) != 0;
     constexpr bool NT = (VARIANT & VAR_NT) != 0;
     constexpr bool JAC = (MODE & MODE_JAC) != 0;
@@ -191,6 +231,12 @@ __global__ __launch_bounds__(WG_THREADS, (sizeof(TO) == 4 && (MODE & MODE_JAC)) 
     const int wave = threadIdx.x >> 6;
     const int n_waves = n_threads >> 6;
     const int lane = threadIdx.x & 63;
+    T *strip = smem;   // PREP: wave-private pair slab
+    if constexpr (PREP) {
+        strip = smem + wave * PAIR_SLAB;
+        lds_used = n_waves * PAIR_SLAB;
+        if constexpr (CHAIN != CHAIN_TEMPLATE) points = a.prm + a.point_off;
+    }
     constexpr int LROW = lds_row_stride(P2, (int)sizeof(TO));
     TO *tr = reinterpret_cast<TO *>(smem + lds_used) + wave * (HALF * LROW);  // wave-private transpose region (TRANSPOSE only)
 
@@ -220,7 +266,26 @@ __global__ __launch_bounds__(WG_THREADS, (sizeof(TO) == 4 && (MODE & MODE_JAC)) 
         const T X0 = points[3 * k], X1 = points[3 * k + 1], X2 = points[3 * k + 2];
         T u, v;
         T J[P2];
-        if constexpr (!JAC && !SLAB_LDS) {
+        if constexpr (PREP) {
+            bool todo = true;   // tail lanes repeat the last detection: they belong to its pair
+            while (true) {
+                const uint64_t rem = __ballot(todo);
+                if (!rem) break;
+                const int src = __builtin_ctzll(rem);
+                const int c0 = __builtin_amdgcn_readlane(c, src);
+                const int im0 = CHAIN != CHAIN_FREE ? __builtin_amdgcn_readlane(im, src) : 0;
+                prep_pair_slab<CHAIN>(strip, a.prm, c0, im0, lane, a.extr_off, a.pose_off);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const bool mine = todo && c == c0 && (CHAIN == CHAIN_FREE || im == im0);
+                if (mine) eval_detection<CHAIN, T, JAC>(static_cast<const T *>(strip), static_cast<const T *>(strip + CAM_STRIDE), X0, X1, X2, u, v, J);
+                todo = todo && !mine;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();   // the next pair overwrites the strip
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+        } else if constexpr (!JAC && !SLAB_LDS) {
             // Residual only: 36-44 B of traffic per detection; what the launch is short of is issue slots, not bandwidth (a plain
             // copy of the same bytes takes 6.7 us).  When the tile shares its camera and image (the reference's table order) the
             // 21 + 12 slab scalars come through SCALAR loads (ScalarSlab): 13.6 us with per-lane loads, 10.0 with one coalesced

@@ -58,8 +58,12 @@ struct pcs_engine {
     size_t msize = 8;   // bytes of a measurement scalar on the device (4 for PCS_F32); slabs and arithmetic are always FP64
     size_t osize = 8;   // bytes of the residual / Jacobian type written out (4 for PCS_F32 and PCS_MIXED)
     hipStream_t stream = nullptr;
-    std::vector<hipEvent_t> ev;  // ring of (start, after slab_prep, after eval) triples
-    int64_t ev_ring = 1;         // triples in the ring
+    // ring of event quadruples: (slab_prep start, slab_prep stop, evaluation start, evaluation stop).  Both kernels carry their OWN
+    // start / stop events (hipExtLaunchKernelGGL), so slab_prep's figure is its duration, not duration + the gap to the next
+    // launch (round 2 reported start-to-start, 2.5 x what rocprofv3 sees); a one-launch step (PREP) has no slab_prep: 0.
+    std::vector<hipEvent_t> ev;
+    std::vector<uint8_t> ev_has_prep;   // per quadruple: a slab_prep launch was timed
+    int64_t ev_ring = 1;         // quadruples in the ring
     int64_t ev_count = 0;        // evaluations recorded since the ring was (re)created
     bool events_valid = false;
     // Attach start/stop events to the kernel launches of every `timing_every`-th evaluation (0 = never).
@@ -74,6 +78,8 @@ struct pcs_engine {
     hipEvent_t done = nullptr;
     hipStream_t done_stream = nullptr;
     bool have_done = false;
+    bool done_pending = false;   // `done` still has to be recorded on done_stream (see flush_done)
+    bool lazy_done = true;       // option "lazy_done_event" (A/B switch)
     // static inputs
     int32_t *d_cam = nullptr, *d_img = nullptr, *d_key = nullptr;  // split index arrays (only when the packed word does not fit)
     uint32_t *d_packed = nullptr;      // cam | image | key bit fields, one word per detection (DetTable, ba_device.hpp)
@@ -131,24 +137,67 @@ struct pcs_engine {
     int compact_variant = 1;     // 1 = tile kernel with coalesced stores, 0 = per-lane stores
     bool xcd_remap = false;      // contiguous eighth of the table per XCD group (experiment; no measured effect)
     double tile_locality = 1.0;  // fraction of 64-detection tiles touching <= 2 distinct (cam, image) pairs
+    double tile_segments = 1.0;  // mean number of (cam, image) runs per 64-detection tile (1.0 = every tile inside one run)
+    // One-launch step: the evaluation kernel prepares the slabs of its tile per wave instead of a slab_prep launch in front
+    // (ba_eval_kernel<..., PREP>).  -1 = automatic: tables of at most fuse_prep_max_n detections whose tiles hold few runs.
+    int fuse_prep = -1;
+    int64_t fuse_prep_max_n = 400000;
     int64_t tiles_per_wg = 0;  // 0 = derive from wgs_per_cu
     size_t lds_limit = 160 * 1024;
 };
 
+// `done` is recorded LAZILY where that is safe (round 3): an event record is a packet of its own between two launches, and a
+// small step (config 2, an 8-way shard) paid for one after every evaluation although nothing ever waited for it.  For work
+// queued on the engine's own stream or on the default stream (handles that outlive every call) mark_done only notes the
+// stream; the record happens when somebody needs to wait — it then covers everything queued on that stream so far, a
+// superset.  Work on any other caller stream is recorded at once: that stream may be destroyed before the next call.
+static hipError_t flush_done(pcs_engine *h) {
+    if (!h->done_pending) return hipSuccess;
+    h->done_pending = false;
+    return hipEventRecord(h->done, h->done_stream);
+}
 // everything queued so far has finished (host-side wait)
-static hipError_t wait_done_host(pcs_engine *h) { return h->have_done ? hipEventSynchronize(h->done) : hipSuccess; }
+static hipError_t wait_done_host(pcs_engine *h) {
+    if (!h->have_done) return hipSuccess;
+    hipError_t e = flush_done(h);
+    return e != hipSuccess ? e : hipEventSynchronize(h->done);
+}
 // work queued on `s` from here on runs after everything queued so far, whatever stream that was on.  Same stream as the
 // previous enqueue: stream order already gives that.  Another stream: a device-side wait — except for the legacy
 // default-stream handle, on which hipStreamWaitEvent of this runtime faults; the (rare) switch to or from it waits on the host.
 static hipError_t order_after_done(pcs_engine *h, hipStream_t s) {
     if (!h->have_done || s == h->done_stream) return hipSuccess;
+    hipError_t e = flush_done(h);
+    if (e != hipSuccess) return e;
     if (s == hipStreamLegacy || s == nullptr || h->done_stream == hipStreamLegacy) return hipEventSynchronize(h->done);
     return hipStreamWaitEvent(s, h->done, 0);
 }
 static hipError_t mark_done(pcs_engine *h, hipStream_t s) {
+    // (every enqueue calls order_after_done(h, s) first, so work on an earlier stream is already ordered before `s`)
     h->have_done = true;
-    h->done_stream = s;   // compared only, never used as a handle again
+    h->done_stream = s;   // used as a handle again only when it is the engine's own stream or the default stream
+    if (h->lazy_done && (s == h->stream || s == hipStreamLegacy)) {
+        h->done_pending = true;
+        return hipSuccess;
+    }
+    h->done_pending = false;
     return hipEventRecord(h->done, s);
+}
+
+// the event quadruple the next timed piece of work records into (see pcs_engine::ev)
+static hipEvent_t *ring_slot(pcs_engine *h, bool has_prep) {
+    const int64_t i = h->ev_count % h->ev_ring;
+    h->ev_has_prep[i] = has_prep ? 1 : 0;
+    return h->ev.data() + 4 * i;
+}
+// (slab_prep ms — 0 when that quadruple timed no slab_prep launch —, evaluation ms) of quadruple i; waits for it
+static int ring_read(pcs_engine *h, int64_t i, float *prep_ms, float *eval_ms) {
+    hipEvent_t *ev = h->ev.data() + 4 * i;
+    HIPCHK(hipEventSynchronize(ev[3]));
+    *prep_ms = 0.f;
+    if (h->ev_has_prep[i]) HIPCHK(hipEventElapsedTime(prep_ms, ev[0], ev[1]));
+    HIPCHK(hipEventElapsedTime(eval_ms, ev[2], ev[3]));
+    return PCS_OK;
 }
 
 static int64_t padded_points(int64_t n_keys) { return (n_keys * 3 + 3) & ~(int64_t)3; }
@@ -179,7 +228,16 @@ struct pcs_triangulator {
     const int32_t *cur_cam = nullptr; const double *cur_uv = nullptr; const int64_t *cur_start = nullptr;
     int64_t n_obs = 0, n_pts = -1;
     int lanes = 4;   // lanes per point: 1, 2, 4, 8 or 16 (profiles/r01/tri_legacy_bench.log: 4 is fastest at 2-22 views)
+    // Ordering across streams, as in pcs_engine: `done` is recorded after every run; whatever touches the camera table, the
+    // handle-owned observation copies, the scratch or the output next first waits for it — on the host where the host
+    // writes or reads, with hipStreamWaitEvent where a run moves to another stream (scratch and output are shared).
+    hipEvent_t done = nullptr;
+    hipStream_t done_stream = nullptr;
+    bool have_done = false;
+    bool out_owned = false;   // the last run wrote the handle-owned output (pcs_tri_points has something to return)
 };
+
+static hipError_t tri_wait_done_host(pcs_triangulator *t) { return t->have_done ? hipEventSynchronize(t->done) : hipSuccess; }
 
 static int tri_grow(void **buf, int64_t *cap, int64_t need, size_t elem) {
     if (need <= *cap) return PCS_OK;
@@ -207,6 +265,7 @@ int pcs_tri_create(pcs_triangulator **out, int device, int64_t n_cams) {
     hipError_t e = hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&t->e0);
     if (e == hipSuccess) e = hipEventCreate(&t->e1);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&t->done, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc(&t->d_tab, sizeof(double) * n_cams * TRI_CAM_STRIDE);
     if (e != hipSuccess) {
         const int rc = fail(PCS_ERR_HIP, "pcs_tri_create: %s", hipGetErrorString(e));
@@ -221,10 +280,12 @@ int pcs_tri_destroy(pcs_triangulator *t) {
     if (!t) return PCS_OK;
     (void)hipSetDevice(t->device);
     if (t->stream) (void)hipStreamSynchronize(t->stream);
+    (void)tri_wait_done_host(t);   // a run on a caller stream may still read the tables
     for (void *b : {(void *)t->d_tab, (void *)t->d_cam, (void *)t->d_uv, (void *)t->d_start, t->d_scr, t->d_scl, (void *)t->d_pts})
         if (b) (void)hipFree(b);
     if (t->e0) (void)hipEventDestroy(t->e0);
     if (t->e1) (void)hipEventDestroy(t->e1);
+    if (t->done) (void)hipEventDestroy(t->done);
     if (t->stream) (void)hipStreamDestroy(t->stream);
     delete t;
     return PCS_OK;
@@ -241,6 +302,7 @@ int pcs_tri_set_cameras(pcs_triangulator *t, const double *proj, const double *i
         for (int k = 0; k < 5; ++k) r[26 + k] = dists[5 * c + k];
     }
     HIPCHK(hipSetDevice(t->device));
+    HIPCHK(tri_wait_done_host(t));   // a run queued on ANY stream may still read the table
     HIPCHK(hipStreamSynchronize(t->stream));
     HIPCHK(hipMemcpy(t->d_tab, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice));
     t->have_cams = true;
@@ -255,6 +317,7 @@ int pcs_tri_set_observations(pcs_triangulator *t, int64_t n_obs, const int32_t *
     for (int64_t r = 0; r < n_obs; ++r)
         if (cam[r] < 0 || cam[r] >= t->n_cams) return fail(PCS_ERR_RANGE, "observation %lld has camera %d outside [0,%lld)", (long long)r, cam[r], (long long)t->n_cams);
     HIPCHK(hipSetDevice(t->device));
+    HIPCHK(tri_wait_done_host(t));   // a run queued on ANY stream may still read the observation copies
     HIPCHK(hipStreamSynchronize(t->stream));
     t->n_pts = -1;
     int rc = tri_grow((void **)&t->d_cam, &t->obs_capacity, std::max<int64_t>(1, n_obs), sizeof(int32_t));
@@ -271,6 +334,7 @@ int pcs_tri_set_observations(pcs_triangulator *t, int64_t n_obs, const int32_t *
     HIPCHK(hipStreamSynchronize(t->stream));   // the caller may reuse its host arrays
     t->cur_cam = t->d_cam; t->cur_uv = t->d_uv; t->cur_start = t->d_start;
     t->n_obs = n_obs; t->n_pts = n_pts;
+    t->out_owned = false;   // results of an earlier problem are not this problem's
     return PCS_OK;
 }
 
@@ -278,6 +342,7 @@ int pcs_tri_set_observations_device(pcs_triangulator *t, int64_t n_obs, const in
     if (!t || n_obs < 0 || n_pts < 0 || !d_start_inds || (n_obs > 0 && (!d_cam || !d_uv))) return fail(PCS_ERR_ARG, "pcs_tri_set_observations_device: bad arguments");
     t->cur_cam = d_cam; t->cur_uv = d_uv; t->cur_start = d_start_inds;   // caller-owned, not range-checked (stay on the device)
     t->n_obs = n_obs; t->n_pts = n_pts;
+    t->out_owned = false;
     return PCS_OK;
 }
 
@@ -288,11 +353,17 @@ int pcs_tri_run(pcs_triangulator *t, double *d_pts, void *stream) {
     if (t->n_pts == 0) return PCS_OK;
     HIPCHK(hipSetDevice(t->device));
     hipStream_t s = stream ? (hipStream_t)stream : t->stream;
+    const bool grows = t->n_obs > t->scr_capacity || t->n_obs > t->scl_capacity || (!d_pts && t->n_pts > t->out_capacity);
+    if (t->have_done) {   // scratch and output are shared between runs: the previous one finishes first
+        if (grows || s == hipStreamLegacy || t->done_stream == hipStreamLegacy) HIPCHK(hipEventSynchronize(t->done));   // frees need the host to wait
+        else if (s != t->done_stream) HIPCHK(hipStreamWaitEvent(s, t->done, 0));
+    }
     int rc = tri_grow(&t->d_scr, &t->scr_capacity, std::max<int64_t>(1, t->n_obs), 4 * sizeof(double));   // Householder row r_i per observation
     if (rc) return rc;
     rc = tri_grow(&t->d_scl, &t->scl_capacity, std::max<int64_t>(1, t->n_obs), 2 * sizeof(double));   // (1 / E_i, lambda_i)
     if (rc) return rc;
-    if (!d_pts) {
+    const bool owned = !d_pts;
+    if (owned) {
         rc = tri_grow((void **)&t->d_pts, &t->out_capacity, t->n_pts, 3 * sizeof(double));
         if (rc) return rc;
         d_pts = t->d_pts;
@@ -310,13 +381,19 @@ int pcs_tri_run(pcs_triangulator *t, double *d_pts, void *stream) {
 #undef PCS_TRI_LAUNCH
     HIPCHK(hipGetLastError());
     t->timed = true;
+    t->out_owned = owned;
+    t->have_done = true;
+    t->done_stream = s;   // compared only, never used as a handle again
+    HIPCHK(hipEventRecord(t->done, s));
     return PCS_OK;
 }
 
 int pcs_tri_points(pcs_triangulator *t, double *pts) {
     if (!t || !pts) return fail(PCS_ERR_ARG, "pcs_tri_points: bad arguments");
-    if (t->n_pts < 0 || !t->d_pts || t->out_capacity < t->n_pts) return fail(PCS_ERR_STATE, "pcs_tri_points: no handle-owned result (run with d_pts = NULL first)");
+    if (t->n_pts < 0 || (t->n_pts > 0 && (!t->out_owned || !t->d_pts || t->out_capacity < t->n_pts)))
+        return fail(PCS_ERR_STATE, "pcs_tri_points: the last run left no handle-owned result (run with d_pts = NULL first)");
     HIPCHK(hipSetDevice(t->device));
+    HIPCHK(tri_wait_done_host(t));   // the run may have been queued on a caller stream
     if (t->n_pts) HIPCHK(hipMemcpyAsync(pts, t->d_pts, sizeof(double) * 3 * t->n_pts, hipMemcpyDeviceToHost, t->stream));
     HIPCHK(hipStreamSynchronize(t->stream));
     return PCS_OK;
@@ -477,7 +554,8 @@ int pcs_create(pcs_engine **out, int chain, int dtype, int64_t n_cams, int64_t n
                    : prop.sharedMemPerBlock > 0            ? prop.sharedMemPerBlock
                                                            : 64 * 1024;
     CREATE_CHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-    h->ev.assign(3, nullptr);
+    h->ev.assign(4, nullptr);
+    h->ev_has_prep.assign(1, 0);
     for (auto &e : h->ev) CREATE_CHK(hipEventCreate(&e));
     CREATE_CHK(hipEventCreateWithFlags(&h->done, hipEventDisableTiming));
     CREATE_CHK(hipMalloc(&h->d_param, sizeof(double) * h->n_params));
@@ -529,19 +607,23 @@ static int upload_detections(pcs_engine *h, std::vector<int32_t> &cam, std::vect
     h->h_cam.swap(cam); h->h_img.swap(img); h->h_key.swap(key);
     h->n = 0;  // stays 0 (= "no detections set") if an allocation or copy below fails
     {   // slab-read locality of the table, per 64-detection tile (drives the automatic variant choice)
-        int64_t tiles = 0, good = 0;
+        int64_t tiles = 0, good = 0, runs = 0;
+        const bool has_img = h->chain != PCS_CHAIN_FREE;
         for (int64_t t0 = 0; t0 < n; t0 += TILE, ++tiles) {
             const int64_t t1 = std::min<int64_t>(t0 + TILE, n);
-            int64_t p0 = -1, p1 = -1;
+            int64_t p0 = -1, p1 = -1, prev = -1;
             bool ok = true;
-            for (int64_t i = t0; i < t1 && ok; ++i) {
-                const int64_t pr = ((int64_t)h->h_cam[i] << 32) | (uint32_t)h->h_img[i];
+            for (int64_t i = t0; i < t1; ++i) {
+                const int64_t pr = ((int64_t)h->h_cam[i] << 32) | (has_img ? (uint32_t)h->h_img[i] : 0u);
+                runs += pr != prev;   // an upper bound of the distinct pairs of the tile; exact for run-ordered tables
+                prev = pr;
                 if (pr == p0 || pr == p1) continue;
                 if (p0 < 0) p0 = pr; else if (p1 < 0) p1 = pr; else ok = false;
             }
             good += ok;
         }
         h->tile_locality = tiles ? (double)good / (double)tiles : 1.0;
+        h->tile_segments = tiles ? (double)runs / (double)tiles : 1.0;
     }
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(wait_done_host(h));
@@ -651,6 +733,16 @@ int pcs_set_option(pcs_engine *h, const char *key, int64_t value) {
         if (value < 0 || value > 1000000) return fail(PCS_ERR_ARG, "timing_every must be in [0,1000000]");
         h->timing_every = value;
         h->eval_count = 0;
+    } else if (!strcmp(key, "fuse_prep")) {
+        if (value < -1 || value > 1) return fail(PCS_ERR_ARG, "fuse_prep must be -1 (automatic), 0 (slab_prep launch) or 1 (waves prepare their slabs)");
+        h->fuse_prep = (int)value;
+    } else if (!strcmp(key, "fuse_prep_max_n")) {
+        if (value < 0) return fail(PCS_ERR_ARG, "fuse_prep_max_n must be >= 0");
+        h->fuse_prep_max_n = value;
+    } else if (!strcmp(key, "lazy_done_event")) {
+        HIPCHK(hipSetDevice(h->device));
+        HIPCHK(flush_done(h));
+        h->lazy_done = value != 0;
     } else if (!strcmp(key, "xcd_remap")) {
         h->xcd_remap = value != 0;
     } else if (!strcmp(key, "waves_per_wg")) {
@@ -681,7 +773,8 @@ int pcs_set_option(pcs_engine *h, const char *key, int64_t value) {
         HIPCHK(wait_done_host(h));
         for (auto &e : h->ev)
             if (e) (void)hipEventDestroy(e);
-        h->ev.assign(3 * value, nullptr);
+        h->ev.assign(4 * value, nullptr);
+        h->ev_has_prep.assign(value, 0);
         for (auto &e : h->ev) HIPCHK(hipEventCreate(&e));
         h->ev_ring = value;
         h->ev_count = 0;
@@ -712,9 +805,9 @@ static DetTable det_table(const pcs_engine *h) {
     return t;
 }
 
-template <int CHAIN, int MODE, int VARIANT, typename TO>
+template <int CHAIN, int MODE, int VARIANT, typename TO, bool PREP = false>
 static hipError_t launch_eval_v(const EvalArgs &a, dim3 grid, int threads, size_t lds, hipStream_t s, EvPair ev) {
-    auto kern = ba_eval_kernel<CHAIN, MODE, VARIANT, TO>;
+    auto kern = ba_eval_kernel<CHAIN, MODE, VARIANT, TO, PREP>;
     // per device: largest dynamic-LDS size already enabled for this kernel.  Handles driven from different host threads
     // may get here together: the value is monotone and setting the attribute twice is harmless, so an atomic max is enough
     static std::atomic<size_t> configured[64];
@@ -732,7 +825,16 @@ static hipError_t launch_eval_v(const EvalArgs &a, dim3 grid, int threads, size_
 }
 
 template <int CHAIN, int MODE, typename TO>
-static hipError_t launch_eval_m(int variant, const EvalArgs &a, dim3 grid, int threads, size_t lds, hipStream_t s, EvPair ev) {
+static hipError_t launch_eval_m(int variant, bool prep, const EvalArgs &a, dim3 grid, int threads, size_t lds, hipStream_t s, EvPair ev) {
+    if (prep) {   // one-launch step: slabs through L1/L2 is the only form it replaces; transposed stores whenever there is a Jacobian
+        if constexpr (MODE == MODE_RESID) {
+            return (variant & VAR_NT) ? launch_eval_v<CHAIN, MODE, VAR_NT, TO, true>(a, grid, threads, lds, s, ev)
+                                      : launch_eval_v<CHAIN, MODE, 0, TO, true>(a, grid, threads, lds, s, ev);
+        } else {
+            return (variant & VAR_NT) ? launch_eval_v<CHAIN, MODE, VAR_TRANSPOSE | VAR_NT, TO, true>(a, grid, threads, lds, s, ev)
+                                      : launch_eval_v<CHAIN, MODE, VAR_TRANSPOSE, TO, true>(a, grid, threads, lds, s, ev);
+        }
+    }
     switch (variant) {
         case 0: return launch_eval_v<CHAIN, MODE, 0, TO>(a, grid, threads, lds, s, ev);
         case 1: return launch_eval_v<CHAIN, MODE, 1, TO>(a, grid, threads, lds, s, ev);
@@ -746,20 +848,20 @@ static hipError_t launch_eval_m(int variant, const EvalArgs &a, dim3 grid, int t
 }
 
 template <int CHAIN, typename TO>
-static hipError_t launch_eval_c(int mode, int variant, const EvalArgs &a, dim3 grid, int threads, size_t lds, hipStream_t s, EvPair ev) {
+static hipError_t launch_eval_c(int mode, int variant, bool prep, const EvalArgs &a, dim3 grid, int threads, size_t lds, hipStream_t s, EvPair ev) {
     switch (mode) {
-        case MODE_RESID: return launch_eval_m<CHAIN, MODE_RESID, TO>(variant & ~VAR_TRANSPOSE, a, grid, threads, lds, s, ev);
-        case MODE_JAC: return launch_eval_m<CHAIN, MODE_JAC, TO>(variant, a, grid, threads, lds, s, ev);
-        default: return launch_eval_m<CHAIN, MODE_RESID | MODE_JAC, TO>(variant, a, grid, threads, lds, s, ev);
+        case MODE_RESID: return launch_eval_m<CHAIN, MODE_RESID, TO>(variant & ~VAR_TRANSPOSE, prep, a, grid, threads, lds, s, ev);
+        case MODE_JAC: return launch_eval_m<CHAIN, MODE_JAC, TO>(variant, prep, a, grid, threads, lds, s, ev);
+        default: return launch_eval_m<CHAIN, MODE_RESID | MODE_JAC, TO>(variant, prep, a, grid, threads, lds, s, ev);
     }
 }
 
 template <typename TO>
-static hipError_t launch_eval_t(int chain, int mode, int variant, const EvalArgs &a, dim3 grid, int threads, size_t lds, hipStream_t s, EvPair ev) {
+static hipError_t launch_eval_t(int chain, int mode, int variant, bool prep, const EvalArgs &a, dim3 grid, int threads, size_t lds, hipStream_t s, EvPair ev) {
     switch (chain) {
-        case CHAIN_TEMPLATE: return launch_eval_c<CHAIN_TEMPLATE, TO>(mode, variant, a, grid, threads, lds, s, ev);
-        case CHAIN_SELF: return launch_eval_c<CHAIN_SELF, TO>(mode, variant, a, grid, threads, lds, s, ev);
-        default: return launch_eval_c<CHAIN_FREE, TO>(mode, variant, a, grid, threads, lds, s, ev);
+        case CHAIN_TEMPLATE: return launch_eval_c<CHAIN_TEMPLATE, TO>(mode, variant, prep, a, grid, threads, lds, s, ev);
+        case CHAIN_SELF: return launch_eval_c<CHAIN_SELF, TO>(mode, variant, prep, a, grid, threads, lds, s, ev);
+        default: return launch_eval_c<CHAIN_FREE, TO>(mode, variant, prep, a, grid, threads, lds, s, ev);
     }
 }
 
@@ -796,15 +898,14 @@ static hipError_t launch_compact_t(int chain, int mode, const EvalArgs &a, dim3 
     }
 }
 
-static int launch_slab_prep(pcs_engine *h, const double *d_prm, hipStream_t s, hipEvent_t start = nullptr) {
+static int launch_slab_prep(pcs_engine *h, const double *d_prm, hipStream_t s, hipEvent_t start = nullptr, hipEvent_t stop = nullptr) {
     HIPCHK(order_after_done(h, s));   // the slabs are shared: an evaluation still reading them on another stream goes first
     const int has_pose = h->chain != PCS_CHAIN_FREE;
     const int copy_points = h->chain != PCS_CHAIN_TEMPLATE;
-    const int64_t ents = h->n_cams + (has_pose ? h->n_imgs : 0);
-    int64_t threads = ents;
+    int64_t threads = slab_prep_threads(h->n_cams, h->n_imgs, has_pose);   // one per slab element
     if (copy_points) threads = std::max<int64_t>(threads, std::min<int64_t>(3 * h->n_keys, 1 << 16));
     const dim3 grid((unsigned)((threads + 63) / 64));
-    hipExtLaunchKernelGGL(slab_prep_kernel, grid, dim3(64), 0, s, start, nullptr, 0, d_prm, (double *)h->d_cam_slab,
+    hipExtLaunchKernelGGL(slab_prep_kernel, grid, dim3(64), 0, s, start, stop, 0, d_prm, (double *)h->d_cam_slab,
                           (double *)h->d_pose_slab, (double *)h->d_points, (int)h->n_cams, (int)h->n_imgs, (int)h->n_keys,
                           h->extr_off, h->pose_off, h->point_off, has_pose, copy_points);
     HIPCHK(hipGetLastError());
@@ -882,9 +983,31 @@ static hipError_t gather_rows(const int32_t *order, const void *src, void **dst,
 
 // (cam, key)- and (image, key)-sorted visiting orders for the point passes of the normal equations: built on the host
 // at the first normal-equations call of a self / free engine (two stable sorts, ~0.1 s at 1e6 detections)
+static int build_point_orders(pcs_engine *h);
+// all or nothing: a build that fails half-way (an allocation, a gather launch) leaves no sorted copy behind, so that the
+// next call starts again instead of pairing sorted index words with unsorted measurements
 static int ensure_point_orders(pcs_engine *h) {
     if (h->point_orders_tried) return PCS_OK;
-    h->point_orders_tried = true;
+    const int rc = build_point_orders(h);
+    if (rc == PCS_OK) {
+        h->point_orders_tried = true;
+        return PCS_OK;
+    }
+    const std::string keep = g_err;
+    (void)hipStreamSynchronize(h->stream);
+    for (int32_t **o : {&h->d_order_ck, &h->d_order_ik}) {
+        if (*o) (void)hipFree(*o);
+        *o = nullptr;
+    }
+    for (auto &t : h->d_sorted)
+        for (void *&b : t) {
+            if (b) (void)hipFree(b);
+            b = nullptr;
+        }
+    g_err = keep;
+    return rc;
+}
+static int build_point_orders(pcs_engine *h) {
     const int64_t n = h->n;
     if (n <= 0) return PCS_OK;
     if (h->chain != PCS_CHAIN_TEMPLATE) {
@@ -927,14 +1050,14 @@ static int enqueue_normal(pcs_engine *h, const double *d_prm, double *d_H, doubl
     if (h->n > INT32_MAX) return fail(PCS_ERR_ARG, "normal equations: tables beyond 2^31 rows are not supported (visiting orders are int32)");
     if (h->chain == PCS_CHAIN_TEMPLATE && !h->have_template) return fail(PCS_ERR_STATE, "template points not set");
     // the flush addresses H with 32-bit byte offsets: 8 n^2 < 2^32 (a 4.3 GB matrix)
-    if (h->n_params > 23170) return fail(PCS_ERR_ARG, "normal equations: more than 23170 parameters (dense H beyond 4 GiB) is not supported");
+    if (h->n_params > PCS_NORMAL_MAX_PARAMS) return fail(PCS_ERR_ARG, "normal equations: more than %d parameters (dense H beyond 4 GiB) is not supported", PCS_NORMAL_MAX_PARAMS);
     HIPCHK(hipSetDevice(h->device));
     int rc0 = ensure_point_orders(h);
     if (rc0) return rc0;
     if (reinterpret_cast<uintptr_t>(d_H) % 16 == 0) {   // slab_prep and the zeroing of the outputs in one launch
         HIPCHK(order_after_done(h, s));
         const int has_pose = h->chain != PCS_CHAIN_FREE, copy_points = h->chain != PCS_CHAIN_TEMPLATE;
-        int64_t threads = h->n_cams + (has_pose ? h->n_imgs : 0);
+        int64_t threads = slab_prep_threads(h->n_cams, h->n_imgs, has_pose);
         if (copy_points) threads = std::max<int64_t>(threads, std::min<int64_t>(3 * h->n_keys, 1 << 16));
         const int prep_blocks = (int)((threads + 63) / 64);
         const int64_t n_h = h->n_params * h->n_params;
@@ -968,9 +1091,8 @@ static int enqueue_normal(pcs_engine *h, const double *d_prm, double *d_H, doubl
         a.tiles_per_wave = (int32_t)tpw;
         return dim3((unsigned)((a.n_tiles + tpw - 1) / tpw));
     };
-    hipEvent_t *ev = h->ev.data() + 3 * (h->ev_count % h->ev_ring);
-    HIPCHK(hipEventRecord(ev[0], s));
-    HIPCHK(hipEventRecord(ev[1], s));
+    hipEvent_t *ev = ring_slot(h, false);
+    HIPCHK(hipEventRecord(ev[2], s));
     const int n_pass = h->chain == PCS_CHAIN_TEMPLATE ? 1 : h->chain == PCS_CHAIN_SELF ? 3 : 2;
     for (int pass = 0; pass < n_pass; ++pass) {
         if (h->normal_debug & (256 << pass)) continue;   // profiling: time the passes one by one
@@ -979,7 +1101,7 @@ static int enqueue_normal(pcs_engine *h, const double *d_prm, double *d_H, doubl
         a.tab = det_table(h);
         if (a.order && h->sort_tables) {   // the pass's own copy of the table, already in visiting order
             void *const *t = h->d_sorted[pass];
-            if (t[0] || t[1]) {
+            if ((t[0] || t[1]) && (t[4] || pass == PASS_IMGKEY)) {   // index words AND measurements, or neither
                 a.tab.packed = static_cast<const uint32_t *>(t[0]);
                 a.tab.cam = static_cast<const int32_t *>(t[1]); a.tab.img = static_cast<const int32_t *>(t[2]); a.tab.key = static_cast<const int32_t *>(t[3]);
                 if (t[4]) a.tab.uv = t[4];
@@ -1002,7 +1124,7 @@ static int enqueue_normal(pcs_engine *h, const double *d_prm, double *d_H, doubl
         }
         if (e != hipSuccess) return fail(PCS_ERR_HIP, "normal-equations kernel launch failed: %s", hipGetErrorString(e));
     }
-    HIPCHK(hipEventRecord(ev[2], s));
+    HIPCHK(hipEventRecord(ev[3], s));
     ++h->ev_count;
     h->events_valid = true;
     HIPCHK(mark_done(h, s));
@@ -1016,14 +1138,22 @@ static int enqueue_eval(pcs_engine *h, const double *d_prm, void *d_resid, void 
     const int mode = (d_resid ? MODE_RESID : 0) | (d_out ? MODE_JAC : 0);
     if (!mode) return PCS_OK;
     HIPCHK(hipSetDevice(h->device));
-    hipEvent_t no_ev[3] = {nullptr, nullptr, nullptr};
+    // One launch per step for small, run-ordered tables (see pcs_engine::fuse_prep): the waves prepare their own slabs.
+    const bool slab_lds_forced = h->variant >= 0 && (h->variant & VAR_SLAB_LDS);
+    const bool prep = !compact && !slab_lds_forced && !(h->variant >= 0 && (mode & MODE_JAC) && !(h->variant & VAR_TRANSPOSE)) &&
+                      (h->fuse_prep > 0 || (h->fuse_prep < 0 && h->tile_locality >= 0.5 && h->tile_segments <= 2.5 && h->n <= h->fuse_prep_max_n));
+    hipEvent_t no_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     const bool timed = h->timing_every > 0 && (h->eval_count++ % h->timing_every) == 0;
-    hipEvent_t *ev = timed ? h->ev.data() + 3 * (h->ev_count % h->ev_ring) : no_ev;
-    {
-        int rc0 = launch_slab_prep(h, d_prm, s, ev[0]);  // ev[0] = start of slab_prep
+    hipEvent_t *ev = timed ? ring_slot(h, !prep) : no_ev;
+    if (!prep) {
+        int rc0 = launch_slab_prep(h, d_prm, s, ev[0], ev[1]);
         if (rc0) return rc0;
+    } else {
+        HIPCHK(order_after_done(h, s));   // keeps `done` meaning "everything queued so far", whatever stream it was on
+        h->linearized = false;   // the global slabs are not refreshed: the matrix-free operators need pcs_linearize
     }
     EvalArgs a{};
+    a.prm = d_prm; a.extr_off = h->extr_off; a.pose_off = h->pose_off; a.point_off = h->point_off;
     a.tab = det_table(h);
     a.cam_slab = h->d_cam_slab; a.pose_slab = h->d_pose_slab; a.points = h->d_points;
     a.resid = d_resid; a.jac = d_out; a.sink = h->d_sink;
@@ -1032,7 +1162,7 @@ static int enqueue_eval(pcs_engine *h, const double *d_prm, void *d_resid, void 
     a.n_tiles = (h->n + TILE - 1) / TILE;
     if (compact) {
         a.keep = h->d_keep; a.row_off = h->d_row_off;
-        if (timed) HIPCHK(hipEventRecord(ev[1], s));
+        if (timed) HIPCHK(hipEventRecord(ev[2], s));
         hipError_t e;
         if (h->compact_variant == 0 && h->dtype == PCS_F64) {  // per-lane stores (first version, kept for A/B)
             const int64_t blocks = std::min<int64_t>((h->n + WG_THREADS - 1) / WG_THREADS, (int64_t)h->n_cu * 8);
@@ -1051,10 +1181,10 @@ static int enqueue_eval(pcs_engine *h, const double *d_prm, void *d_resid, void 
                               : launch_compact_tile_t<float>(h->chain, mode, a, dim3((unsigned)grid), lds, s);
         }
         if (e != hipSuccess) return fail(PCS_ERR_HIP, "compact kernel launch failed: %s", hipGetErrorString(e));
-        if (timed) HIPCHK(hipEventRecord(ev[2], s));
+        if (timed) HIPCHK(hipEventRecord(ev[3], s));
     } else {
         const bool local = h->tile_locality >= 0.5;
-        int variant = h->variant >= 0 ? h->variant : (VAR_TRANSPOSE | VAR_NT | (local ? 0 : VAR_SLAB_LDS));
+        int variant = h->variant >= 0 ? h->variant : (VAR_TRANSPOSE | VAR_NT | (local || prep ? 0 : VAR_SLAB_LDS));
         if (!(mode & MODE_JAC)) variant &= ~VAR_TRANSPOSE;
         // waves per workgroup: 4 for large tables; a small table (config 2: 1 600 tiles on 256 CUs) is cut into
         // one-wave workgroups so that every CU gets several and the tail of the grid stays short
@@ -1064,7 +1194,7 @@ static int enqueue_eval(pcs_engine *h, const double *d_prm, void *d_resid, void 
         const size_t slab_bytes = sizeof(double) * (size_t)(h->n_cams * CAM_STRIDE + h->n_imgs * POSE_STRIDE + padded_points(h->n_keys));
         const size_t tr_bytes = (variant & VAR_TRANSPOSE) ? h->osize * (size_t)waves * HALF * lds_row_stride(2 * h->P, (int)h->osize) : 0;
         if ((variant & VAR_SLAB_LDS) && slab_bytes + tr_bytes > h->lds_limit) variant &= ~VAR_SLAB_LDS;  // read slabs through L1/L2
-        const size_t lds = ((variant & VAR_SLAB_LDS) ? slab_bytes : 0) + tr_bytes;
+        const size_t lds = ((variant & VAR_SLAB_LDS) ? slab_bytes : 0) + (prep ? sizeof(double) * (size_t)waves * PAIR_SLAB : 0) + tr_bytes;
         int64_t tpw = h->tiles_per_wg;
         if (tpw <= 0 && h->wgs_per_cu <= 0 && !(variant & VAR_SLAB_LDS)) {
             // slabs through L1/L2: one tile per wave, as many workgroups as that takes.  Up to 1e6 detections this
@@ -1078,9 +1208,9 @@ static int enqueue_eval(pcs_engine *h, const double *d_prm, void *d_resid, void 
         }
         a.tiles_per_wg = (int32_t)tpw;
         const int64_t grid = (a.n_tiles + tpw - 1) / tpw;
-        const EvPair evp{ev[1], ev[2]};  // start / stop of the evaluation kernel itself
-        hipError_t e = h->osize == 8 ? launch_eval_t<double>(h->chain, mode, variant, a, dim3((unsigned)grid), 64 * waves, lds, s, evp)
-                                     : launch_eval_t<float>(h->chain, mode, variant, a, dim3((unsigned)grid), 64 * waves, lds, s, evp);
+        const EvPair evp{ev[2], ev[3]};  // start / stop of the evaluation kernel itself
+        hipError_t e = h->osize == 8 ? launch_eval_t<double>(h->chain, mode, variant, prep, a, dim3((unsigned)grid), 64 * waves, lds, s, evp)
+                                     : launch_eval_t<float>(h->chain, mode, variant, prep, a, dim3((unsigned)grid), 64 * waves, lds, s, evp);
         if (e != hipSuccess) return fail(PCS_ERR_HIP, "eval kernel launch failed: %s", hipGetErrorString(e));
     }
     if (timed) {
@@ -1326,9 +1456,8 @@ int pcs_legacy_cost(pcs_engine *h, const double *im_points, const double *proj, 
     HIPCHK(hipStreamSynchronize(s));   // `tab` is a local
     const int64_t n_tiles = (h->n + 63) / 64;
     const dim3 grid((unsigned)std::min<int64_t>((n_tiles + 3) / 4, (int64_t)h->n_cu * 16));
-    hipEvent_t *ev = h->ev.data() + 3 * (h->ev_count % h->ev_ring);
-    HIPCHK(hipEventRecord(ev[0], s));  // keeps (ev0, ev1) a valid pair for pcs_last_kernel_ms
-    hipExtLaunchKernelGGL(legacy_cost_kernel, grid, dim3(256), 0, s, ev[1], ev[2], 0, det_table(h), (const double *)h->d_im_points,
+    hipEvent_t *ev = ring_slot(h, false);
+    hipExtLaunchKernelGGL(legacy_cost_kernel, grid, dim3(256), 0, s, ev[2], ev[3], 0, det_table(h), (const double *)h->d_im_points,
                           (const double *)h->d_cam_tab, (double *)h->d_resid, h->n, h->n_keys, h->d_sink);
     HIPCHK(hipGetLastError());
     ++h->ev_count;
@@ -1391,12 +1520,11 @@ int pcs_matfree(pcs_engine *h, int op, const double *in, double *out, double *co
     tpw = std::max<int64_t>(WAVES_PER_WG, (tpw + WAVES_PER_WG - 1) / WAVES_PER_WG * WAVES_PER_WG);
     a.tiles_per_wg = (int32_t)tpw;
     const dim3 grid((unsigned)((a.n_tiles + tpw - 1) / tpw));
-    hipEvent_t *ev = h->ev.data() + 3 * (h->ev_count % h->ev_ring);
-    HIPCHK(hipEventRecord(ev[0], s));
-    HIPCHK(hipEventRecord(ev[1], s));
+    hipEvent_t *ev = ring_slot(h, false);
+    HIPCHK(hipEventRecord(ev[2], s));
     hipError_t e = launch_matfree_t(h->chain, op, lds_acc, a, grid, lds, s);
     if (e != hipSuccess) return fail(PCS_ERR_HIP, "matfree kernel launch failed: %s", hipGetErrorString(e));
-    HIPCHK(hipEventRecord(ev[2], s));
+    HIPCHK(hipEventRecord(ev[3], s));
     ++h->ev_count;
     h->events_valid = true;
     HIPCHK(mark_done(h, s));
@@ -1418,9 +1546,9 @@ int pcs_normal_equations_device(pcs_engine *h, const double *param_str, double *
 int pcs_normal_equations(pcs_engine *h, const double *param_str, double *H, double *g, double *cost) {
     if (!h || !param_str || !H || !g || !cost) return fail(PCS_ERR_ARG, "pcs_normal_equations: bad arguments");
     if (h->n <= 0) return fail(PCS_ERR_STATE, "no detections set");
-    if (h->n_params > 32768)  // 8.6 GB of H: beyond this the matrix-free products (pcs_matfree) are the tool
-        return fail(PCS_ERR_ARG, "pcs_normal_equations: %lld parameters make a dense J^T J of %.1f GB; use pcs_matfree",
-                    (long long)h->n_params, (double)h->n_params * (double)h->n_params * 8e-9);
+    if (h->n_params > PCS_NORMAL_MAX_PARAMS)  // the same limit as enqueue_normal, checked BEFORE the scratch allocation
+        return fail(PCS_ERR_ARG, "pcs_normal_equations: %lld parameters make a dense J^T J of %.1f GB (limit %d parameters: 32-bit byte offsets); use pcs_matfree",
+                    (long long)h->n_params, (double)h->n_params * (double)h->n_params * 8e-9, PCS_NORMAL_MAX_PARAMS);
     HIPCHK(hipSetDevice(h->device));
     const int64_t need = h->n_params * h->n_params + h->n_params + 1;  // H | g | cost in one scratch buffer
     if (h->H_capacity < need) {
@@ -1450,11 +1578,9 @@ int pcs_synchronize(pcs_engine *h, void *stream) {
 int pcs_last_kernel_ms(pcs_engine *h, float *slab_prep_ms, float *eval_ms) {
     if (!h) return fail(PCS_ERR_ARG, "pcs_last_kernel_ms: bad arguments");
     if (!h->events_valid) return fail(PCS_ERR_STATE, "no evaluation has been queued yet");
-    hipEvent_t *ev = h->ev.data() + 3 * ((h->ev_count - 1) % h->ev_ring);
-    HIPCHK(hipEventSynchronize(ev[2]));
     float a = 0, b = 0;
-    HIPCHK(hipEventElapsedTime(&a, ev[0], ev[1]));
-    HIPCHK(hipEventElapsedTime(&b, ev[1], ev[2]));
+    int rc = ring_read(h, (h->ev_count - 1) % h->ev_ring, &a, &b);
+    if (rc) return rc;
     if (slab_prep_ms) *slab_prep_ms = a;
     if (eval_ms) *eval_ms = b;
     return PCS_OK;
@@ -1466,11 +1592,9 @@ int pcs_kernel_ms_mean(pcs_engine *h, int64_t *count, float *slab_prep_ms, float
     const int64_t n = std::min<int64_t>(h->ev_count, h->ev_ring);
     double sa = 0, sb = 0;
     for (int64_t i = 0; i < n; ++i) {
-        hipEvent_t *ev = h->ev.data() + 3 * i;
-        HIPCHK(hipEventSynchronize(ev[2]));
         float a = 0, b = 0;
-        HIPCHK(hipEventElapsedTime(&a, ev[0], ev[1]));
-        HIPCHK(hipEventElapsedTime(&b, ev[1], ev[2]));
+        int rc = ring_read(h, i, &a, &b);
+        if (rc) return rc;
         sa += a;
         sb += b;
     }
@@ -1486,10 +1610,8 @@ int pcs_kernel_ms_samples(pcs_engine *h, int64_t capacity, float *slab_prep_ms, 
     const int64_t have = std::min<int64_t>(h->ev_count, h->ev_ring), n = std::min<int64_t>(have, capacity);
     const int64_t first = h->ev_count - n;   // the n most recent evaluations, oldest first
     for (int64_t i = 0; i < n; ++i) {
-        hipEvent_t *ev = h->ev.data() + 3 * ((first + i) % h->ev_ring);
-        HIPCHK(hipEventSynchronize(ev[2]));
-        HIPCHK(hipEventElapsedTime(slab_prep_ms + i, ev[0], ev[1]));
-        HIPCHK(hipEventElapsedTime(eval_ms + i, ev[1], ev[2]));
+        int rc = ring_read(h, (first + i) % h->ev_ring, slab_prep_ms + i, eval_ms + i);
+        if (rc) return rc;
     }
     *count = n;
     return PCS_OK;

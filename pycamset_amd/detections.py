@@ -37,12 +37,17 @@ class TargetDetection:
         (td:333-351)."""
         if self._data.shape[1] == 5:  # already flat (td:342-343)
             return self
-        data = self._data.copy()
-        padded_prod = np.append(np.asarray(keydims)[1:], 1)
-        prods = np.cumprod(padded_prod[::-1])[::-1]
-        dim_1_keys = np.sum(data[:, 2:-2] * prods, axis=1).reshape((-1, 1))
-        new_data = np.concatenate([data[:, :2], dim_1_keys, data[:, -2:]], axis=1)
-        return TargetDetection(self.cam_names, new_data, self.max_ims)
+        # row-major strides of the key grid: the last key dimension is contiguous, as in point_data.reshape(-1, 3)
+        dims = [int(d) for d in keydims]
+        strides = np.ones(len(dims))
+        for axis in range(len(dims) - 2, -1, -1):
+            strides[axis] = strides[axis + 1] * dims[axis + 1]
+        table = self._data
+        flat = np.empty((table.shape[0], 5))
+        flat[:, :2] = table[:, :2]
+        flat[:, 2] = table[:, 2:-2] @ strides
+        flat[:, 3:] = table[:, -2:]
+        return TargetDetection(self.cam_names, flat, self.max_ims)
 
     def delete_row(self, im_num=None) -> "TargetDetection":
         """Drop all rows of the given image numbers (used by get_detection_data, th:399-403)."""

@@ -7,6 +7,7 @@ All arithmetic happens in the HIP kernels behind the C ABI; nothing here compute
 from __future__ import annotations
 
 import ctypes
+import sys
 from ctypes import POINTER, byref, c_double, c_float, c_int32, c_int64, c_uint8, c_void_p
 
 import numpy as np
@@ -49,6 +50,25 @@ def pinned_empty(shape, dtype=np.float64) -> np.ndarray:
     buf = (ctypes.c_char * nbytes).from_address(block.ptr.value)
     buf._pcs_owner = block  # ctypes object keeps the owner; the ndarray keeps the ctypes object
     return np.frombuffer(buf, dtype=dtype, count=n).reshape(shape)
+
+
+def _ring_counts(bufs: list, idx: int) -> tuple[int, int]:
+    """Reference counts of ring buffer ``bufs[idx]`` and of the array its views hang on.  Views of a buffer
+    (``a.reshape(-1)``, a ``csr_array`` built on one) do not reference the buffer itself but the array NumPy collapses
+    their ``base`` chain to — ``a.base``, the ``frombuffer`` array of ``pinned_empty`` — so both are counted.  The buffer
+    is fetched from the list in here, so the numbers do not depend on the caller's frames."""
+    a = bufs[idx]
+    base = a.base
+    return sys.getrefcount(a), (sys.getrefcount(base) if base is not None else 0)
+
+
+_IDLE_COUNTS = _ring_counts([np.frombuffer(bytearray(16), dtype=np.float64).reshape(1, 2)], 0)   # a buffer nobody else holds
+
+
+def _still_held(bufs: list, idx: int) -> bool:
+    """True when something besides the ring references ring buffer ``bufs[idx]`` or any view of it."""
+    n_a, n_base = _ring_counts(bufs, idx)
+    return n_a > _IDLE_COUNTS[0] or n_base > _IDLE_COUNTS[1]
 
 
 def _stream_arg(stream):
@@ -138,8 +158,9 @@ class Engine:
         return p
 
     def _out(self, name: str, shape, pinned_ring: int):
-        """Output array: fresh pageable memory (reference semantics), or the next buffer of a ring of
-        ``pinned_ring`` page-locked buffers (valid until ``pinned_ring`` further calls)."""
+        """Output array: fresh pageable memory, or the next buffer of a ring of ``pinned_ring`` page-locked
+        buffers.  A ring buffer is only reused once nobody else references it, so every array handed out stays
+        valid for as long as it is held — reference semantics either way."""
         if pinned_ring <= 0:
             return np.empty(shape)
         ring = self._rings.setdefault((name, tuple(shape), pinned_ring), {"bufs": [], "count": 0})
@@ -147,6 +168,12 @@ class Engine:
         ring["count"] += 1
         if idx >= len(ring["bufs"]):
             ring["bufs"].append(pinned_empty(shape))
+        elif _still_held(ring["bufs"], idx):
+            # Somebody still holds this buffer (or a view of it: `j.reshape(-1)`, a csr_array wrapping it — every view
+            # keeps its base alive, so the base's reference count says so): the reference hands out a fresh array per
+            # call (afb:561) and a kept Jacobian must never change under its owner.  The slot gets a new page-locked
+            # buffer; the old one lives on with its holder and is freed with it.
+            ring["bufs"][idx] = pinned_empty(shape)
         return ring["bufs"][idx]
 
     def eval(self, param_str, want_resid: bool = True, want_jac: bool = True, pinned_ring: int = 0):

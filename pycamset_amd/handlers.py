@@ -34,7 +34,6 @@ Differences from the reference, on purpose:
 from __future__ import annotations
 
 from copy import deepcopy
-from itertools import combinations
 
 import numpy as np
 from scipy.sparse import csr_array
@@ -66,13 +65,18 @@ def fill_flat(src: np.ndarray, dst: np.ndarray, dst_unfixed: np.ndarray) -> None
     dst[np.asarray(dst_unfixed, dtype=bool)] = src
 
 
-def _list_dict_to_np_array(d):  # utils/general_utils.py:21-30
-    if isinstance(d, dict):
-        for key, val in d.items():
-            if isinstance(val, dict):
-                _list_dict_to_np_array(val)
-            elif isinstance(val, list):
-                d[key] = np.array(val)
+def _list_dict_to_np_array(d):
+    """Lists inside a (nested) ``fixed_params`` dict become arrays, in place — the normalisation the reference applies to
+    the dict before reading 'int' / 'ext' entries out of it (utils/general_utils.py:21-30)."""
+    pending = [d] if isinstance(d, dict) else []
+    while pending:
+        level = pending.pop()
+        for name in list(level):
+            entry = level[name]
+            if isinstance(entry, list):
+                level[name] = np.asarray(entry)
+            elif isinstance(entry, dict):
+                pending.append(entry)
     return d
 
 
@@ -137,11 +141,16 @@ def FreePointPrimitive(bundle_points, extr, intr, bundle_points_unfixed=None, ex
                            {"intr": intr_unfixed, "extr": extr_unfixed, "bdpt": bundle_points_unfixed})
 
 
-def find_not_colinear_pts(points):  # sbh:30-44
-    ind0 = 0
-    for ind1, ind2 in combinations(np.arange(1, points.shape[0]), 2):
-        if np.linalg.norm(np.cross(points[ind0] - points[ind1], points[ind0] - points[ind2])) > 1e-8:
-            return ind0, ind1, ind2
+def find_not_colinear_pts(points):
+    """Indices of three points that span a plane: point 0 and the first pair (i, j), 1 <= i < j in lexicographic order,
+    whose triangle with it has a cross product longer than 1e-8 (the gauge points of sbh:30-44, same search order)."""
+    pts = np.asarray(points, dtype=np.float64)
+    legs = pts[1:] - pts[0]
+    for i in range(legs.shape[0]):
+        areas = np.linalg.norm(np.cross(legs[i], legs[i + 1:]), axis=-1)
+        hit = np.nonzero(areas > 1e-8)[0]
+        if hit.size:
+            return 0, i + 1, i + 2 + int(hit[0])
     raise ValueError("No set of values that were not colinear were found in the provided data.")
 
 

@@ -398,16 +398,132 @@ def round2_vectors(mods):
         print("block", chain, "large nnz", res["data_all_t5"].shape)
 
 
+EDGE_RVECS = np.array([
+    # the rotation vectors of unit_vectors(): every branch and every ill-conditioned region of ch:197-286
+    [0.0, 0.0, 0.0], [1e-11, 0.0, 0.0], [3e-11, -4e-11, 1e-11], [1e-9, 2e-9, -1e-9], [1e-5, -2e-5, 3e-5],
+    [np.pi, 0.0, 0.0], [0.0, np.pi - 1e-9, 0.0], [1.2, -2.0, 2.1], [0.0, 0.0, 1.0],
+    # beyond pi, and the decades between the theta < 1e-10 branch and well-conditioned angles
+    [2.5, -2.5, 1.0], [1e-7, -1e-7, 2e-7], [3e-4, 1e-4, -2e-4],
+])
+
+
+def edge_rotation_rig(seed=31):
+    """Every camera extrinsic AND every target pose takes one of EDGE_RVECS as its rotation: 12 cameras x 12 images x
+    6 points, all visible (N = 864).  Translations keep the camera-frame depth in [0.4, 0.8] whatever the rotation."""
+    rng = np.random.default_rng(seed)
+    n = EDGE_RVECS.shape[0]
+    intr = np.empty((n, 9))
+    intr[:, 0], intr[:, 2] = rng.uniform(900, 1100, n), rng.uniform(900, 1100, n)
+    intr[:, 1], intr[:, 3] = rng.uniform(480, 520, n), rng.uniform(480, 520, n)
+    intr[:, 4], intr[:, 5] = rng.normal(0, 0.05, n), rng.normal(0, 0.01, n)
+    intr[:, 6:8], intr[:, 8] = rng.normal(0, 1e-3, (n, 2)), rng.normal(0, 1e-3, n)
+    extr = np.concatenate([EDGE_RVECS, np.stack([rng.normal(0, 0.02, n), rng.normal(0, 0.02, n), rng.uniform(0.55, 0.65, n)], 1)], axis=1)
+    poses = np.concatenate([EDGE_RVECS[::-1], rng.normal(0, 0.02, (n, 3))], axis=1)   # another pairing than cam i <-> image i
+    points = rng.uniform(-0.05, 0.05, (6, 3))
+    cam, im, key = np.meshgrid(np.arange(n), np.arange(n), np.arange(6), indexing="ij")
+    det = np.stack([cam.ravel(), im.ravel(), key.ravel()], 1).astype(np.float64)
+    det = np.concatenate([det, 500.0 + rng.normal(0, 60.0, (det.shape[0], 2))], axis=1)
+    return synthetic.SyntheticRig("edge-rot", det, intr, extr, poses, points)
+
+
+def nonfinite_focal_rig(seed=32):
+    """fbi:32-35 multiplies by fx and divides by it again: a focal length of 0, NaN or inf poisons BOTH residual rows
+    and every non-constant Jacobian entry of the camera's detections.  Cameras: fx = 0 | fy = NaN | fx = inf | fy = 0 | fine."""
+    rig = synthetic.tiny_rig(seed=seed, n_cams=5, n_imgs=3, n_keys=7, visibility=1.0)
+    rig.intr[0, 0] = 0.0
+    rig.intr[1, 2] = np.nan
+    rig.intr[2, 0] = np.inf
+    rig.intr[3, 2] = 0.0
+    return rig
+
+
+def generic_chain(fb, names):
+    op = getattr(fb, names[0])()
+    for n in names[1:]:
+        op = op + getattr(fb, n)()
+    return op
+
+
+GENERIC_CHAINS = {
+    # chains that are NOT one of the three the reference's handlers build (afb:735-748 composes any of them); the slab a
+    # block reads is named by its link type (afb:42-46) and its place among the blocks of that link type
+    "proj_rigid_free": ("projection", "rigidTform3d", "free_point"),                       # one camera at the origin, moving scene
+    "proj_extr_rigid_template": ("projection", "extrinsic3D", "rigidTform3d", "template_points"),   # two per-image transforms
+    "proj_template": ("projection", "template_points"),                                    # a single fixed camera
+    "proj_rigid_extr_free": ("projection", "rigidTform3d", "extrinsic3D", "free_point"),   # per-image BEFORE per-camera
+}
+
+
+def generic_block_level(fb, rig, names, seed=5):
+    """The reference's code generator on a chain none of its handlers builds: residual, Jacobian (all columns and
+    masked), structure, block_param_inds; the slabs each block consumes are stored in block order."""
+    rng = np.random.default_rng(seed)
+    op = generic_chain(fb, names)
+    slabs = []
+    seen_img = 0
+    for n in names:
+        if n == "projection":
+            slabs.append(rig.intr)
+        elif n == "extrinsic3D":
+            slabs.append(rig.extr)
+        elif n in ("rigidTform3d", "template_points"):
+            # a second per-image group gets its own, different 6-vectors
+            slabs.append(rig.poses if seen_img == 0 else np.concatenate([rig.poses[::-1, :3] * 0.5, rig.poses[:, 3:] * -0.3], axis=1))
+            seen_img += 1
+        elif n == "free_point":
+            slabs.append(rig.points)
+    template = rig.points if names[-1] == "template_points" else None
+    param_str = op.build_param_list(*slabs)
+    unfixed = rng.random(param_str.shape[0]) > 0.3
+    call = (lambda f: f(param_str, template)) if template is not None else (lambda f: f(param_str))
+    out = dict(detections=rig.detections, param_str=param_str, points=rig.points, blocks=np.array(names), unfixed=unfixed)
+    for i, sl in enumerate(slabs):
+        out[f"slab_{i}"] = np.array(sl)
+    out["resid"] = np.array(call(op.make_full_loss_fn(rig.detections, 2)))
+    d, c, rp = call(op.make_jacobean(rig.detections, 2))
+    out["data_all"], out["indices_all"], out["indptr_all"] = np.array(d), np.array(c), np.array(rp)
+    d, c, rp = call(op.make_jacobean(rig.detections, 2, unfixed_params=unfixed))
+    out["data_masked"], out["indices_masked"], out["indptr_masked"] = np.array(d), np.array(c), np.array(rp)
+    out["block_param_inds"] = np.array(op.get_block_param_inds(rig.detections, 1, unthreaded=True)).astype(np.int64)
+    return out
+
+
+def round3_vectors(mods):
+    """Fixtures asked for by the round-2 review: the edge rotations of unit_vectors() as the poses AND extrinsics of a
+    block-level problem per chain (so that they go through the HIP slab code, not only the oracle's), non-finite / zero
+    focal lengths, and chains that are not one of the handlers' three (for the chain compiler)."""
+    edge = edge_rotation_rig()
+    for chain in ("template", "self", "free"):
+        res = block_level(mods.fb, edge, chain, threads_list=(2,))
+        np.savez_compressed(HERE / f"block_{chain}_edge_rot.npz", **res)
+        print("block", chain, "edge_rot N", edge.n_det, "nnz", res["data_all_t2"].shape)
+    bad = nonfinite_focal_rig()
+    for chain in ("template", "self", "free"):
+        with np.errstate(all="ignore"):
+            res = block_level(mods.fb, bad, chain, threads_list=(1,))
+        np.savez_compressed(HERE / f"block_{chain}_focal_nonfinite.npz", **res)
+        print("block", chain, "focal_nonfinite: NaN residuals", int(np.isnan(res["resid_t1"]).sum()), "of", res["resid_t1"].size)
+    small = synthetic.tiny_rig(seed=33, n_cams=3, n_imgs=5, n_keys=8, visibility=0.85)
+    for tag, names in GENERIC_CHAINS.items():
+        res = generic_block_level(mods.fb, small, names)
+        np.savez_compressed(HERE / f"generic_{tag}.npz", **res)
+        print("generic", tag, "P", res["block_param_inds"].shape[1], "nnz", res["data_all"].shape)
+
+
 def main():
     import argparse
 
     import _refload
 
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", choices=["round1", "round2"], default=None, help="regenerate one group of fixtures only")
+    ap.add_argument("--only", choices=["round1", "round2", "round3"], default=None, help="regenerate one group of fixtures only")
     args = ap.parse_args()
     with _refload.reference_modules() as mods:
         ch, fb, th, sbh, fph, TargetDetection = mods.ch, mods.fb, mods.th, mods.sbh, mods.fph, mods.TargetDetection
+        if args.only in (None, "round3"):
+            round3_vectors(mods)
+        if args.only == "round3":
+            return
         if args.only in (None, "round2"):
             round2_vectors(mods)
         if args.only == "round2":

@@ -70,6 +70,113 @@ def test_hip_against_reference_goldens(Engine, golden_dir, chain, tag):
     e.close()
 
 
+# ---- round 3: the reference's edge rotations THROUGH the HIP slab code ---------------------------------
+def _unfloored(j, ref):
+    """(worst plain relative error over entries the row floor does not cover, fraction of entries under the floor,
+    worst plain relative error over ALL non-zero entries)."""
+    rows = np.max(np.abs(ref), axis=1, keepdims=True)
+    nz = ref != 0
+    under = nz & (np.abs(ref) < H.ROW_FLOOR * rows)
+    rel = np.zeros_like(ref)
+    rel[nz] = np.abs(j - ref)[nz] / np.abs(ref)[nz]
+    above = nz & ~under
+    return (float(rel[above].max()) if above.any() else 0.0, float(under.sum() / max(1, nz.sum())), float(rel[nz].max()) if nz.any() else 0.0)
+
+
+@pytest.mark.parametrize("chain", CHAINS)
+@pytest.mark.parametrize("fuse_prep", [0, 1])
+def test_edge_rotations_through_the_hip_slab_code(Engine, golden_dir, chain, fuse_prep, capsys):
+    """block_*_edge_rot.npz: every camera extrinsic and every target pose of the problem is one of the edge rotation
+    vectors of unit_vectors.npz (theta = 0, 1e-11, 5e-11, 2e-9, 4e-5, pi, pi - 1e-9, ~pi, > pi, 2e-7, 4e-4), evaluated by the
+    reference's make_full_loss_fn / make_jacobean (afb:656-667).  Both forms of the step — slab_prep launch (0) and the
+    waves preparing their own slabs (1) — must match at the product tolerance."""
+    g = np.load(golden_dir / f"block_{chain}_edge_rot.npz")
+    det, ps = g["detections"], g["param_str"]
+    C, I, K = orc.counts_from_detections(det)
+    e = Engine(chain, C, I, K)
+    e.set_detections_table(det)
+    if chain == "template":
+        e.set_template(g["points"])
+    e.set_option("fuse_prep", fuse_prep)
+    r, j = e.eval(ps)
+    ref_j = g["data_all_t2"].reshape(j.shape)
+    H.assert_resid_close(r, g["resid_t2"], det[:, 3:])
+    H.assert_jac_close(j, ref_j)
+    worst_above, frac_under, worst_all = _unfloored(j, ref_j)
+    with capsys.disabled():
+        print(f"\n[edge rotations, chain {chain}, fuse_prep {fuse_prep}] floored err {H.jac_rel_err(j, ref_j):.2e}; plain relative error: "
+              f"{worst_above:.2e} over entries above the 1e-6 row floor, {worst_all:.2e} over all non-zero entries; "
+              f"{100 * frac_under:.3f} % of the non-zero entries sit under the floor")
+    assert worst_above <= H.JAC_RTOL
+    # masked (device compaction) against the reference's masked data
+    unfixed = g["unfixed"]
+    assert e.set_unfixed(unfixed) == g["data_masked_t2"].shape[0]
+    _, data = e.eval_compact(ps)
+    _, _, m = orc.csr_structure(chain, det, unfixed)
+    rows = np.broadcast_to(np.max(np.abs(ref_j), axis=1, keepdims=True), ref_j.shape)[m]
+    assert np.max(np.abs(data - g["data_masked_t2"]) / np.maximum(np.abs(g["data_masked_t2"]), H.ROW_FLOOR * rows)) <= H.JAC_RTOL
+    e.close()
+
+
+@pytest.mark.parametrize("chain", CHAINS)
+@pytest.mark.parametrize("fuse_prep", [0, 1])
+def test_nonfinite_focal_lengths_poison_both_residual_rows_like_the_reference(Engine, golden_dir, chain, fuse_prep):
+    """fbi:32-35 (u = (fx x + px z) / z, x_n = (u - px) / fx): fx or fy in {0, NaN, inf} makes BOTH residual rows of the
+    camera's detections non-finite in the reference; its Jacobian formulas never form that quotient.  Pinned behaviour of the
+    engine: the same rows are non-finite (the slab's principal point is NaN for such a camera, ba_device.hpp), every other
+    residual and every Jacobian entry the reference leaves finite agrees at the product tolerance."""
+    g = np.load(golden_dir / f"block_{chain}_focal_nonfinite.npz")
+    det, ps = g["detections"], g["param_str"]
+    C, I, K = orc.counts_from_detections(det)
+    e = Engine(chain, C, I, K)
+    e.set_detections_table(det)
+    if chain == "template":
+        e.set_template(g["points"])
+    e.set_option("fuse_prep", fuse_prep)
+    r, j = e.eval(ps)
+    e.close()
+    ref_r, ref_j = g["resid_t1"].reshape(r.shape), g["data_all_t1"].reshape(j.shape)
+    assert np.array_equal(np.isfinite(r), np.isfinite(ref_r))
+    assert not np.isfinite(r[det[:, 0] < 4]).any() and np.isfinite(r[det[:, 0] == 4]).all()
+    ok = np.isfinite(ref_r).all(axis=1)
+    H.assert_resid_close(r[ok], ref_r[ok], det[ok, 3:])
+    # Jacobian: rows of cameras with a ZERO focal length are finite in the reference and must agree; where the reference is
+    # non-finite (fx = inf / NaN enter its products) the engine must be non-finite too
+    fin = np.isfinite(ref_j)
+    assert np.array_equal(np.isfinite(j), fin)
+    rows = np.max(np.abs(np.where(fin, ref_j, 0.0)), axis=1, keepdims=True)
+    err = np.abs(np.where(fin, j - ref_j, 0.0)) / np.maximum(np.abs(np.where(fin, ref_j, 0.0)), np.maximum(H.ROW_FLOOR * rows, 1e-300))
+    assert err.max() <= H.JAC_RTOL
+
+
+@pytest.mark.parametrize("chain", CHAINS)
+@pytest.mark.parametrize("dtype", ["f64", "mixed"])
+def test_one_launch_step_is_bit_identical_to_slab_prep_plus_evaluation(Engine, chain, dtype):
+    """fuse_prep = 1: every wave prepares the slab of each (camera, image) pair of its tile itself (rot_terms + rot_element,
+    the functions slab_prep_kernel is made of) — residual, Jacobian and residual-only mode must not differ in one bit from
+    the two-launch step, on a run-ordered table (tiles inside one run and tiles straddling a boundary) and on a shuffled
+    one (many pairs per tile)."""
+    rig = synthetic.config_rig(1)
+    ps = orc.build_param_list(*H.chain_slabs(rig, chain))
+    rng = np.random.default_rng(5)
+    for det in (rig.detections, rig.detections[rng.permutation(rig.n_det)][:1500]):
+        e = make_engine(Engine, rig, chain, dtype=dtype, det=det)
+        outs = {}
+        for f in (0, 1):
+            e.set_option("fuse_prep", f)
+            outs[f] = e.eval(ps) + (e.eval(ps, want_jac=False)[0],)
+        for a, b in zip(outs[0], outs[1]):
+            assert np.array_equal(a, b)
+        # a second parameter string: the one-launch step must not see anything of the first (no stale slabs)
+        ps2 = ps * (1.0 + 1e-3 * rng.standard_normal(ps.shape[0]))
+        e.set_option("fuse_prep", 1)
+        r1, j1 = e.eval(ps2)
+        e.set_option("fuse_prep", 0)
+        r0, j0 = e.eval(ps2)
+        assert np.array_equal(r0, r1) and np.array_equal(j0, j1) and not np.array_equal(j0, outs[0][1])
+        e.close()
+
+
 # ---- oracle on seeded synthetic rigs: every chain, every kernel variant ------------------------
 @pytest.mark.parametrize("chain", CHAINS)
 def test_all_kernel_variants_agree_with_oracle(Engine, chain):
@@ -367,16 +474,41 @@ def test_pinned_output_ring(Engine):
     ps = orc.build_param_list(rig.intr, rig.extr, rig.poses)
     e = make_engine(Engine, rig, "template")
     r0, j0 = e.eval(ps)
+    # reference semantics (afb:561: a fresh array per call): an array that is still held is never handed out again ...
     outs = [e.eval(ps, pinned_ring=2) for _ in range(4)]
-    assert outs[0][1] is outs[2][1] and outs[1][1] is outs[3][1] and outs[0][1] is not outs[1][1]
+    addrs = {o[1].ctypes.data for o in outs}
+    assert len(addrs) == 4
     for r, j in outs:
         assert np.array_equal(r, r0) and np.array_equal(j, j0)
-    e.set_unfixed(np.arange(ps.shape[0]) % 3 != 0)
+    kept = outs[0][1]
+    view = outs[1][1].reshape(-1)[:100]      # a VIEW keeps its buffer out of circulation too (csr_array holds one)
+    kept_addr, view_addr = kept.ctypes.data, outs[1][1].ctypes.data
+    snapshot = kept.copy()
+    del outs, r, j
+    later = []
+    for _ in range(6):
+        jn = e.eval(ps * 1.001, pinned_ring=2)[1]
+        later.append(jn.ctypes.data)
+        del jn
+    assert kept_addr not in later and view_addr not in later
+    assert np.array_equal(kept, snapshot) and np.array_equal(view, snapshot.reshape(-1)[:100])
+    # ... and a buffer nobody holds any more is: a loop that drops each Jacobian before asking for the next one (scipy's
+    # least_squares) cycles through the ring's two page-locked buffers
+    assert len(set(later[2:])) <= 2
+    del kept, view
+    again = []
+    for _ in range(6):
+        jn = e.eval(ps, pinned_ring=2)[1]
+        again.append(jn.ctypes.data)
+        del jn
+    assert len(set(again[2:])) <= 2
+    # the compacted data array goes through the same ring
+    nnz = e.set_unfixed(np.arange(ps.shape[0]) % 3 != 0)
     _, d0 = e.eval_compact(ps)
-    _, d1 = e.eval_compact(ps, pinned_ring=3)
-    assert np.array_equal(d0, d1)
+    ds = [e.eval_compact(ps, pinned_ring=3)[1] for _ in range(3)]
+    assert all(d.shape == (nnz,) and np.array_equal(d, d0) for d in ds) and len({d.ctypes.data for d in ds}) == 3
     e.close()
-    assert np.array_equal(outs[0][1], j0)  # views outlive the engine
+    assert np.array_equal(ds[0], d0)  # page-locked outputs outlive the engine
 
 
 def test_slabs_too_large_for_lds_fall_back_to_l2(Engine):

@@ -66,12 +66,14 @@ def test_projection_fun_and_jac(unit):
 
 
 @pytest.mark.parametrize("chain", ["template", "self", "free"])
-@pytest.mark.parametrize("tag", ["tiny", "medium", "large"])
+@pytest.mark.parametrize("tag", ["tiny", "medium", "large", "edge_rot"])
 def test_block_level_chain(golden_dir, chain, tag):
     g = np.load(golden_dir / f"block_{chain}_{tag}.npz")
     det, ps = g["detections"], g["param_str"]
     tmpl = g["points"] if chain == "template" else None
-    threads = {"tiny": [1, 3], "medium": [4], "large": [5]}[tag]   # large: N ~ 3000 (4 cams, 20 images, 486 keys)
+    # large: N ~ 3000 (4 cams, 20 images, 486 keys); edge_rot: every extrinsic and pose rotation is one of the edge vectors of
+    # unit_vectors.npz (theta = 0, 1e-11 ... 1e-4, pi, > pi; make_golden.py EDGE_RVECS)
+    threads = {"tiny": [1, 3], "medium": [4], "large": [5], "edge_rot": [2]}[tag]
     P = orc.CHAIN_P[chain]
     # layout + structure are integer work: exact
     assert np.array_equal(orc.block_param_inds(chain, det), g["block_param_inds"])
@@ -96,6 +98,29 @@ def test_block_level_chain(golden_dir, chain, tag):
     d = dense.reshape(-1, 2, P)
     assert np.all(d[:, 0, 1] == 1) and np.all(d[:, 1, 3] == 1)
     assert np.all(d[:, 0, 2] == 0) and np.all(d[:, 0, 3] == 0) and np.all(d[:, 1, 0] == 0) and np.all(d[:, 1, 1] == 0)
+
+
+@pytest.mark.parametrize("chain", ["template", "self", "free"])
+def test_nonfinite_focal_lengths_follow_the_reference(golden_dir, chain):
+    """fbi:32-35 multiplies by fx and divides by it again: fx or fy in {0, NaN, inf} makes both residual rows of that
+    camera's detections non-finite, while the Jacobian formulas (fbi:62-134) never form the quotient.  The fixture was
+    made by the reference's blocks on cameras with fx = 0 | fy = NaN | fx = inf | fy = 0 | finite."""
+    g = np.load(golden_dir / f"block_{chain}_focal_nonfinite.npz")
+    det, ps = g["detections"], g["param_str"]
+    tmpl = g["points"] if chain == "template" else None
+    with np.errstate(all="ignore"):
+        res = orc.full_loss(chain, det, ps, tmpl)
+        dense = orc.full_jac_dense(chain, det, ps, tmpl)
+    ref_r, ref_j = g["resid_t1"], g["data_all_t1"].reshape(dense.shape)
+    bad_cam = det[:, 0] < 4
+    assert not np.isfinite(ref_r[bad_cam]).any() and np.isfinite(ref_r[~bad_cam]).all()
+    assert np.array_equal(np.isnan(res), np.isnan(ref_r)) and np.array_equal(np.isposinf(res), np.isposinf(ref_r))
+    fin = np.isfinite(ref_r)
+    assert np.max(np.abs(res[fin] - ref_r[fin])) <= 1e-10
+    assert np.array_equal(np.isfinite(dense), np.isfinite(ref_j))
+    fj = np.isfinite(ref_j)
+    rows = np.max(np.abs(np.where(fj, ref_j, 0.0)), axis=1, keepdims=True)
+    assert_close(np.where(fj, dense, 0.0), np.where(fj, ref_j, 0.0), rows=rows)
 
 
 def test_oracle_fast_build_agrees(golden_dir):
