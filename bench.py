@@ -448,9 +448,12 @@ def main():
     # what a solver needs instead of the gathered J — the block-reduced normal equations per rank and
     # ONE all-reduce of the packed [J^T J, J^T r, cost]
     normal_info = None
-    if not args.no_normal_probe and eng.n_params <= 8192:
+    from pycamset_amd.device_solver import blocked_fits
+
+    if not args.no_normal_probe and blocked_fits(eng):
         try:
             npar = eng.n_params
+            lay = eng.normal_layout()
             # the reduction must count every row of the rig ONCE: the last ranks' shards are padded by cyclic repeats
             # (sharding.padded_shard), so the probe runs on the rank's REAL rows (possibly none: zeros enter the all-reduce)
             eng_n, n_rows_n = eng, N
@@ -462,13 +465,13 @@ def main():
                     eng_n.set_detections_table(det[:n_rows_n])
                     if chain == "template":
                         eng_n.set_template(rig.points)
-            packed = torch.empty(npar * npar + npar + 1, dtype=torch.float64, device=dev)
-            pH, pg, pc = packed.data_ptr(), packed.data_ptr() + 8 * npar * npar, packed.data_ptr() + 8 * (npar * npar + npar)
+            # blocked form [A | B | C | g | cost] (include/pcs_hip.h): leading x leading, leading x trailing, block-diagonal trailing group
+            packed = torch.empty(lay["packed_len"], dtype=torch.float64, device=dev)
             def build():
                 if eng_n is None:
                     packed.zero_()
                 else:
-                    eng_n.normal_equations_device(ps, pH, pg, pc, stream)
+                    eng_n.normal_blocks_device(d_p.data_ptr(), packed.data_ptr(), stream)
 
             k_ms = [0.0]
             if eng_n is not None:
@@ -495,7 +498,9 @@ def main():
 
             normal_info = {"n_params": npar, "kernel_ms": float(np.median(k_ms)), "build_call_ms": timed(build, 5) * 1e3,
                            "bytes": packed.numel() * 8, "rows_this_rank": 2 * n_rows_n,
-                           "note": "ba_normal_kernel (+ point passes for the self / free chains): H = J^T J (upper triangle), g, cost; J never written"}
+                           "layout": {k: lay[k] for k in ("n_lead", "n_trail", "tb")},
+                           "note": "ba_normal_mfma_kernel (+ point passes for the self / free chains): J^T J in blocked form [A | B | C], g, cost; "
+                                   "J never written; parameter string resident in HBM"}
             if world > 1:
                 for _ in range(2):
                     build_reduce()

@@ -175,6 +175,32 @@ int pcs_matfree(pcs_engine *h, int op, const double *in, double *out, double *co
 int pcs_normal_equations(pcs_engine *h, const double *param_str, double *H, double *g, double *cost);
 int pcs_normal_equations_device(pcs_engine *h, const double *param_str, double *d_H, double *d_g, double *d_cost, void *stream);
 
+/* The same normal equations in BLOCKED form, for a solver that stays on the device (round 3): the parameter string splits
+ * into a leading part (cameras; + poses for the self chain) and the trailing group whose entities never share a detection
+ * (poses of the template chain — 6 columns each —, points of the self / free chains — 3 each), and only what is structurally
+ * non-zero is stored:
+ *     d_packed = [ A (n_lead x n_lead, upper triangle) | B (n_lead x n_trail) | C (n_trail / tb blocks of tb x tb, upper
+ *                  triangle) | g (n_params) | cost (1) ]     float64, 16-byte aligned, zeroed by the call.
+ * pcs_normal_layout: out5 = {n_lead, n_trail, tb, length of d_packed in doubles, n_params}.  The parameter string is read
+ * from DEVICE memory (d_param_str), so an LM loop never stages it through the host.  Limits: each region below 4 GiB.
+ * Observation shards: all-reduce d_packed.  Consumer: pycamset_amd/device_solver.py (reference consumer of J:
+ * optimisation_handling.py:88-98). */
+int pcs_normal_layout(const pcs_engine *h, int64_t *out5);
+int pcs_normal_blocks_device(pcs_engine *h, const double *d_param_str, double *d_packed, void *stream);
+/* The block-shaped parts of one damped step (H + lambda diag(H)) x = -g on the packed form (csrc/ba_schur.hpp; all pointers
+ * are device memory, lambda included):
+ *   pcs_schur_prepare  per trailing entity C_e + lambda D_e = L L' -> d_linvt (n_ent x tb x tb: L^-T), d_u (n_trail: L^-1 g_e);
+ *                      d_V (n_lead x n_trail) = B L^-T;  d_S (n_lead x n_lead) = sym(A) + lambda D;  d_rhs = -g_lead;
+ *                      d_dvec (n_params) = D;  d_gm (n_params) = g.  Parameters with d_fixed[i] != 0 (n_params bytes) get identity
+ *                      rows / columns and a zero gradient (B is masked in place).  *d_status |= 1 when a trailing block is
+ *                      not positive definite.  The caller then forms S -= V V', rhs += V u, solves S x_l = rhs (library
+ *                      GEMM / Cholesky) and w = V' x_l, and
+ *   pcs_schur_finish   writes the step in parameter-string order: d_delta (n_params) = [x_l | -L^-T (u + w)], 0 where fixed. */
+int pcs_schur_prepare(pcs_engine *h, double *d_packed, const uint8_t *d_fixed, const double *d_lambda, double *d_linvt, double *d_u,
+                      double *d_V, double *d_S, double *d_rhs, double *d_dvec, double *d_gm, int32_t *d_status, void *stream);
+int pcs_schur_finish(pcs_engine *h, const double *d_linvt, const double *d_u, const double *d_w, const double *d_xlead, const uint8_t *d_fixed,
+                     double *d_delta, void *stream);
+
 /* Which entry of H / g / cost every accumulator register of the normal-equations kernel stands for (host function, no
  * GPU needed): out[m][lane][r][2], m < 2 MFMAs, lane < 64, r < 4 registers = the two local column ids (index into
  * a J row, 30 = the residual column) of D_m[(lane >> 4) + 4 r][lane & 15], or -1, -1 where the register is not owned.
@@ -213,8 +239,10 @@ int pcs_kernel_ms_mean(pcs_engine *h, int64_t *count, float *slab_prep_ms, float
 int pcs_kernel_ms_samples(pcs_engine *h, int64_t capacity, float *slab_prep_ms, float *eval_ms, int64_t *count);
 /* Tuning knobs ("variant", "wgs_per_cu", "tiles_per_wg", "event_ring", "timing_every", "compact_variant",
  * "fuse_prep" (-1 automatic / 0 / 1: one launch per step — every wave of the evaluation kernel prepares the R, t, dR/dr
- * slabs of its own tile instead of a slab_prep launch in front; automatic = tables of at most "fuse_prep_max_n" detections
- * in the reference's run order; same slab element functions, same bits; the matrix-free operators then need pcs_linearize),
+ * slabs of its own tile instead of a slab_prep launch in front; automatic = tables in the reference's run order, FP64 outputs
+ * at any size, float outputs up to "fuse_prep_max_n" detections; same slab element functions, same bits; the matrix-free
+ * operators then need pcs_linearize), "lazy_done_event" (1: the engine's ordering event is recorded when somebody waits for
+ * it, not after every step),
  * "matfree_lds", "xcd_remap", "waves_per_wg", "pack_indices", "normal_rows", "normal_imgkey_product",
  * "normal_imgkey_wgs_per_cu", "normal_sort_tables"; "normal_debug" is a bit mask of profiling switches of pcs_normal_equations — phases
  * or whole passes are skipped and the results are wrong while it is non-zero); see DESIGN.md.

@@ -46,6 +46,10 @@ SYMBOLS = {
     "pcs_matfree": (c_int, [_P, c_int, POINTER(c_double), POINTER(c_double), POINTER(c_double)]),
     "pcs_normal_equations": (c_int, [_P, POINTER(c_double), POINTER(c_double), POINTER(c_double), POINTER(c_double)]),
     "pcs_normal_equations_device": (c_int, [_P, POINTER(c_double), c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pcs_normal_layout": (c_int, [_P, POINTER(c_int64)]),
+    "pcs_normal_blocks_device": (c_int, [_P, _P, _P, _P]),
+    "pcs_schur_prepare": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "pcs_schur_finish": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
     "pcs_synchronize": (c_int, [_P, _P]),
     "pcs_last_kernel_ms": (c_int, [_P, POINTER(c_float), POINTER(c_float)]),
     "pcs_kernel_ms_mean": (c_int, [_P, POINTER(c_int64), POINTER(c_float), POINTER(c_float)]),

@@ -52,9 +52,23 @@ struct NormalArgs {
     DetTable tab;
     const int32_t *order;  // visit the detections in this order (a sorted permutation), or NULL = table order
     const void *cam_slab, *pose_slab, *points;
-    double *H;      // n_params x n_params, zeroed by the host; upper triangle written
-    double *g;      // n_params, zeroed by the host
-    double *cost;   // 1, zeroed by the host
+    // Output, zeroed by the prologue launch.  Two layouts of J^T J (round 3):
+    //   dense    H = n_params x n_params, upper triangle written (ldA = n_params, trail_group = -1);
+    //   blocked  the parameter string is split at trail_off into a LEADING part (cameras; + poses for the self chain) and
+    //            the TRAILING group whose entities never share a detection (poses of the template chain, points of the
+    //            self / free chains; `tb` = 6 or 3 columns each):
+    //                H  = A  n_lead x n_lead, upper triangle           (leading x leading, ld = ldA = n_lead)
+    //                HB = B  n_lead x n_trail                          (leading x trailing, ld = ldB = n_trail)
+    //                HC = C  (n_trail / tb) blocks of tb x tb, upper   (trailing x trailing: block diagonal)
+    //            — what a Schur-complement LM step consumes (ba_schur.hpp), and all that is stored: rig-32-self 42 MB
+    //            instead of 79 MB, the free chain with 2e4 points 0.23 GB instead of 29 GB.
+    double *H;
+    double *HB, *HC;
+    double *g;      // n_params (parameter-string order in both layouts)
+    double *cost;   // 1
+    int32_t ldA, ldB, tb;
+    int32_t trail_group;   // 2 = pose, 3 = point, -1 = dense layout
+    int64_t trail_off;     // first parameter-string column of the trailing group
     int64_t n, n_tiles;
     int64_t extr_off, pose_off, point_off;
     int64_t n_params;
@@ -158,18 +172,28 @@ __global__ __launch_bounds__(64, 2) void ba_normal_mfma_kernel(const NormalArgs 
     // D layout of v_mfma_f64_16x16x4_f64: register r of lane l = D[(l >> 4) + 4 r][l & 15].
     // Where a finished register goes.  Its two columns are (group, offset) pairs — groups in parameter-string order:
     // 0 intrinsics, 1 extrinsics, 2 pose, 3 point, 4 = the residual column — and the destination is
-    //     H + 8 ((base[gR] + oR) n_params + base[gC] + oC)    (gR, oR) <= (gC, oC)
+    //     region + 8 (row(gR) + oR ld + col(gC) + oC)          (gR, oR) <= (gC, oC); region / ld by the layout (NormalArgs)
     //     g + 8 (base[g] + o)                                  one of the two is the residual
     //     cost                                                 both are
-    // with base[] the first global column of each group for the current run.  Everything static is folded into one
-    // descriptor per register, K = oR n_params + oC | row selector | column selector | pointer selector | owned | pose,
-    // and the run-dependent part is looked up across lanes (ds_bpermute) in a table the flush refreshes with eight
-    // v_writelane: lanes 0-3 hold 8 n_params base[g], lanes 8-11 hold 8 base[g], lanes 4 and 12 stay zero.  No selects:
-    // hipcc turned the select chains of the first version into ~10 exec-mask branches per register (800 instructions and
-    // 80 branches per flush, 12 us of the 92 at N = 1e6).
+    // with base[] the first parameter-string column of each group for the current run.  Everything static is folded into one
+    // descriptor per register (offsets | which table rows to read | owned | pose) and the run-dependent part is looked up
+    // across lanes (ds_bpermute) in a table the flush refreshes with v_writelane.  No selects: hipcc turned the select
+    // chains of the first version into ~10 exec-mask branches per register (800 instructions and 80 branches per flush,
+    // 12 us of the 92 at N = 1e6).
     constexpr int NS = normal_shared_cols(CHAIN);
     auto col_group = [](const int lc) -> int { return lc == NORMAL_R ? 4 : lc < 9 ? 0 : lc < 15 ? 1 : (HAS_POSE && lc < NS) ? 2 : 3; };
     auto col_offset = [](const int lc) -> int { return lc == NORMAL_R ? 0 : lc < 9 ? lc : lc < 15 ? lc - 9 : (HAS_POSE && lc < NS) ? lc - 15 : lc - NS; };
+    // Descriptor of a register: oR | oC << 4 | row entry << 8 | column entry << 13 | ld entry << 18 | pointer entry << 23 |
+    // owned << 27 | pose << 28, the "entries" being lanes of the look-up table the flush refreshes:
+    //   lanes  0- 3  8 ldA base[g]            row offset of a leading group inside A
+    //   lanes  4- 7  8 ldB base[g]            row offset of a leading group inside B
+    //   lane   8     8 tb tb entity           the run's trailing block inside C        lane 9: zero
+    //   lanes 16-19  8 (base[g] - (g == trail_group ? trail_off : 0))   column offset: leading columns keep their
+    //                parameter-string index, trailing ones are local to the trailing part
+    //   lanes 24-27  8 base[g]                index into g (parameter-string order)
+    //   lanes 32-35  ldA, ldB, tb, 0          row lengths
+    // (everything in bytes except the row lengths; A and B are addressed with 32-bit byte offsets: the host checks the sizes)
+    const int tg = a.trail_group;
     int ent[NM][4];
 #pragma unroll
     for (int m = 0; m < NM; ++m)
@@ -181,16 +205,18 @@ __global__ __launch_bounds__(64, 2) void ba_normal_mfma_kernel(const NormalArgs 
             int gR = col_group(la), oR = col_offset(la), gC = col_group(lb), oC = col_offset(lb);
             const bool pose = PASS == PASS_SHARED && (gR == 2 || gC == 2);
             if (gR > gC || (gR == gC && oR > oC)) { int t = gR; gR = gC; gC = t; t = oR; oR = oC; oC = t; }   // row <= column; the residual (4) ends up as the column
-            int K, selR, selC, selP;
-            if (gR == 4) { K = 0; selR = 4; selC = 4; selP = 2; }                       // r . r
-            else if (gC == 4) { K = oR; selR = 4; selC = gR; selP = 1; }                // J^T r
-            else { K = oR * (int)a.n_params + oC; selR = gR; selC = gC; selP = 0; }
-            ent[m][r] = K | (selR << 19) | (selC << 22) | (selP << 25) | (keep ? 1 << 27 : 0) | (pose ? 1 << 28 : 0);
+            int eRow, eCol, eLd, ePtr;
+            if (gR == 4) { oR = 0; oC = 0; eRow = 9; eCol = 9; eLd = 35; ePtr = 4; }                       // r . r -> cost
+            else if (gC == 4) { oC = oR; oR = 0; eRow = 9; eCol = 24 + gR; eLd = 35; ePtr = 3; }           // J^T r -> g
+            else if (gR == tg) { eRow = 8; eCol = 9; eLd = 34; ePtr = 2; }                                 // trailing x trailing -> C
+            else if (gC == tg) { eRow = 4 + gR; eCol = 16 + gC; eLd = 33; ePtr = 1; }                      // leading x trailing -> B
+            else { eRow = gR; eCol = 16 + gC; eLd = 32; ePtr = 0; }                                        // leading x leading -> A
+            ent[m][r] = oR | (oC << 4) | (eRow << 8) | (eCol << 13) | (eLd << 18) | (ePtr << 23) | (keep ? 1 << 27 : 0) | (pose ? 1 << 28 : 0);
         }
-    // lanes 16, 17, 18: the three output pointers
-    const uint64_t out_ptr = lane == 17 ? (uint64_t)a.g : lane == 18 ? (uint64_t)a.cost : (uint64_t)a.H;
+    // lanes 0-4: the five output pointers (A, B, C, g, cost)
+    const uint64_t out_ptr = lane == 1 ? (uint64_t)a.HB : lane == 2 ? (uint64_t)a.HC : lane == 3 ? (uint64_t)a.g : lane == 4 ? (uint64_t)a.cost : (uint64_t)a.H;
     const int ptr_lo = (int)(uint32_t)out_ptr, ptr_hi = (int)(uint32_t)(out_ptr >> 32);
-    int base_tab = 0;
+    int base_tab = lane == 32 ? a.ldA : lane == 33 ? a.ldB : lane == 34 ? a.tb : 0;
     d4v acc[NM];
 #pragma unroll
     for (int m = 0; m < NM; ++m) acc[m] = d4v{0.0, 0.0, 0.0, 0.0};
@@ -212,16 +238,24 @@ __global__ __launch_bounds__(64, 2) void ba_normal_mfma_kernel(const NormalArgs 
         const int cam = PASS == PASS_IMGKEY ? 0 : run_a;
         const int img = PASS == PASS_SHARED ? run_b : run_a;     // only used where pose columns occur
         const int key = run_b;                                   // only used in the point passes
-        // first global column of each group for this run (wave-uniform)
+        // first parameter-string column of each group for this run (wave-uniform) -> the table rows described above
         const int base[4] = {9 * cam, (int)a.extr_off + 6 * cam, (int)a.pose_off + 6 * img, (int)a.point_off + 3 * key};
-        const int n8 = 8 * (int)a.n_params;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const int row8 = __builtin_amdgcn_readfirstlane(n8 * base[g]), col8 = __builtin_amdgcn_readfirstlane(8 * base[g]);
-            asm("v_writelane_b32 %0, %1, %2" : "+v"(base_tab) : "s"(row8), "n"(g));
-            asm("v_writelane_b32 %0, %1, %2" : "+v"(base_tab) : "s"(col8), "n"(8 + g));
+            const int b = __builtin_amdgcn_readfirstlane(base[g]);
+            const int rowA = 8 * a.ldA * b, rowB = 8 * a.ldB * b;
+            const int col = 8 * (b - (g == tg ? (int)a.trail_off : 0)), gi = 8 * b;
+            asm("v_writelane_b32 %0, %1, %2" : "+v"(base_tab) : "s"(rowA), "n"(g));
+            asm("v_writelane_b32 %0, %1, %2" : "+v"(base_tab) : "s"(rowB), "n"(4 + g));
+            asm("v_writelane_b32 %0, %1, %2" : "+v"(base_tab) : "s"(col), "n"(16 + g));
+            asm("v_writelane_b32 %0, %1, %2" : "+v"(base_tab) : "s"(gi), "n"(24 + g));
         }
-        // all destinations first (4 lane look-ups per register, no branch in between, so their latencies overlap) ...
+        {
+            const int ent_idx = tg == 2 ? img : key;   // entity of the trailing group in this run
+            const int rowC = __builtin_amdgcn_readfirstlane(8 * a.tb * a.tb * ent_idx);
+            asm("v_writelane_b32 %0, %1, %2" : "+v"(base_tab) : "s"(rowC), "n"(8));
+        }
+        // all destinations first (5 lane look-ups per register, no branch in between, so their latencies overlap) ...
         uint64_t dst[NM][4];
         int dsc[NM][4];
 #pragma unroll
@@ -230,9 +264,11 @@ __global__ __launch_bounds__(64, 2) void ba_normal_mfma_kernel(const NormalArgs 
             for (int r = 0; r < 4; ++r) {
                 int d = ent[m][r];
                 asm volatile("" : "+v"(d));   // opaque: nothing of the address arithmetic is to be hoisted out of the tile loop
-                const uint32_t off = (uint32_t)__builtin_amdgcn_ds_bpermute((d >> 17) & (7 << 2), base_tab) +
-                                     (uint32_t)__builtin_amdgcn_ds_bpermute(32 + ((d >> 20) & (7 << 2)), base_tab) + 8u * (uint32_t)(d & 0x7ffff);
-                const int psel = 64 + ((d >> 23) & (3 << 2));
+                const uint32_t ld = (uint32_t)__builtin_amdgcn_ds_bpermute((d >> 16) & (31 << 2), base_tab);
+                const uint32_t off = (uint32_t)__builtin_amdgcn_ds_bpermute((d >> 6) & (31 << 2), base_tab) +
+                                     (uint32_t)__builtin_amdgcn_ds_bpermute((d >> 11) & (31 << 2), base_tab) +
+                                     8u * ((uint32_t)(d & 15) * ld + (uint32_t)((d >> 4) & 15));
+                const int psel = (d >> 21) & (7 << 2);
                 const uint64_t pb = ((uint64_t)(uint32_t)__builtin_amdgcn_ds_bpermute(psel, ptr_hi) << 32) | (uint32_t)__builtin_amdgcn_ds_bpermute(psel, ptr_lo);
                 dst[m][r] = pb + off;
                 dsc[m][r] = d;
@@ -595,7 +631,10 @@ __global__ __launch_bounds__(64, 3) void ba_normal_imgkey_kernel(const NormalArg
 #pragma unroll
                 for (int x = 0; x < 3; ++x) GR[cc][x] = G[cc][0] * Rp[x] + G[cc][1] * Rp[3 + x] + G[cc][2] * Rp[6 + x];
             const bool live = owner && !(a.debug & 2);
-            double *Hrow = a.H + ((int64_t)a.pose_off + 6 * mine.y) * a.n_params + a.point_off + 3 * mine.z;
+            // pose rows x point columns: inside B when the points are the trailing group (blocked layout), else inside the dense H
+            const bool in_b = a.trail_group == 3;
+            const int64_t ldh = in_b ? (int64_t)a.ldB : a.n_params;
+            double *Hrow = (in_b ? a.HB : a.H) + ((int64_t)a.pose_off + 6 * mine.y) * ldh + (in_b ? 0 : a.point_off) + 3 * mine.z;
             auto emit = [&](double *ptr, const double val) {
                 if (live && val != 0.0) unsafeAtomicAdd(ptr, val);
             };
@@ -603,11 +642,11 @@ __global__ __launch_bounds__(64, 3) void ba_normal_imgkey_kernel(const NormalArg
             for (int aa = 0; aa < 3; ++aa)
 #pragma unroll
                 for (int x = 0; x < 3; ++x)
-                    emit(Hrow + (int64_t)aa * a.n_params + x, Qr[aa] * GR[0][x] + Qr[3 + aa] * GR[1][x] + Qr[6 + aa] * GR[2][x]);
+                    emit(Hrow + (int64_t)aa * ldh + x, Qr[aa] * GR[0][x] + Qr[3 + aa] * GR[1][x] + Qr[6 + aa] * GR[2][x]);
 #pragma unroll
             for (int cc = 0; cc < 3; ++cc)
 #pragma unroll
-                for (int x = 0; x < 3; ++x) emit(Hrow + (int64_t)(3 + cc) * a.n_params + x, GR[cc][x]);
+                for (int x = 0; x < 3; ++x) emit(Hrow + (int64_t)(3 + cc) * ldh + x, GR[cc][x]);
         };
         if (img_uni) finish(lp);
         else finish(pose_slab + mine.y * POSE_STRIDE);

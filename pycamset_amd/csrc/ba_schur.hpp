@@ -1,0 +1,193 @@
+// ba_schur.hpp — the block parts of a Levenberg-Marquardt step on the blocked normal equations.
+//
+// The reference hands J to scipy (optimisation_handling.py:88-98) and lets trf / lsmr work out the step on the host.
+// Here J^T J arrives from ba_normal.hpp already split as
+//     [ A  B ] [x_l]     [g_l]        A  n_lead x n_lead   leading parameters (cameras; + poses for the self chain)
+//     [ B' C ] [x_t] = - [g_t]        C  block diagonal    trailing entities (poses of the template chain, points of the
+//                                                          self / free chains) never share a detection
+// and the damped system (H + lambda D) x = -g, D = diag(H) (Marquardt), is reduced by the Schur complement of C:
+//     C_e + lambda D_e = L_e L_e'                       per trailing entity, tb = 6 or 3, in registers      schur_trail_kernel
+//     V = B L^-T   (V_e = B_e L_e^-T)                   one tb-chunk of one row per lane                   schur_v_kernel
+//     S = A + lambda D_l - V V',  rhs = -g_l + V u      u_e = L_e^-1 g_e                                    schur_lead_kernel + GEMM
+//     S x_l = rhs                                       dense Cholesky of the LEADING size only
+//     x_e = -L_e^-T (u_e + V_e' x_l)                                                                       schur_back_kernel
+// The GEMM and the dense factorisation are plain library calls (rocBLAS / rocSOLVER through torch, device_solver.py); the
+// kernels here are everything that is block-shaped.  Fixed parameters (the handlers' masks: th:177-183, sbh:211-218) are not
+// squeezed out of the system: their rows and columns are replaced by the identity and their gradient by zero, so their step
+// is exactly zero and the block structure survives gauge points with single fixed coordinates (sbh:153-158) unpermuted.
+// Everything — lambda included — is read from device memory: the LM driver never has to wait for the host to form a step.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace pcs {
+
+struct SchurArgs {
+    double *A, *B;              // regions of the packed normal equations (B is masked in place: rows / columns of fixed parameters -> 0)
+    const double *C, *g;
+    const uint8_t *fixed;       // n_params: 1 = the parameter does not move
+    const double *lambda;       // device scalar
+    double *linvt;              // n_ent x tb x tb: L_e^-T (upper triangular, row-major)
+    double *u;                  // n_trail: L_e^-1 g_e
+    double *V;                  // n_lead x n_trail
+    double *S;                  // n_lead x n_lead (full symmetric, before the - V V' update)
+    double *rhs;                // n_lead: -g_l (the GEMV adds V u)
+    double *dvec;               // n_params: the damping diagonal D (0 for fixed parameters)
+    double *gm;                 // n_params: g with the fixed entries zeroed
+    int32_t *status;            // bit 0: a trailing block was not positive definite
+    int64_t n_lead, n_trail, n_ent, trail_off;
+};
+
+// One lane = one trailing entity.
+template <int TB>
+__global__ __launch_bounds__(256) void schur_trail_kernel(const SchurArgs a) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= a.n_ent) return;
+    const double lam = *a.lambda;
+    const double *Ce = a.C + e * TB * TB;
+    const int64_t col0 = a.trail_off + e * TB;
+    double M[TB][TB], gv[TB];
+    bool fx[TB];
+#pragma unroll
+    for (int i = 0; i < TB; ++i) {
+        fx[i] = a.fixed[col0 + i] != 0;
+        gv[i] = fx[i] ? 0.0 : a.g[col0 + i];
+    }
+#pragma unroll
+    for (int i = 0; i < TB; ++i)
+#pragma unroll
+        for (int j = i; j < TB; ++j) {   // the build writes the upper triangle
+            double v = Ce[i * TB + j];
+            if (fx[i] || fx[j]) v = (i == j) ? 1.0 : 0.0;
+            M[i][j] = v;
+            M[j][i] = v;
+        }
+#pragma unroll
+    for (int i = 0; i < TB; ++i) {
+        const double d = fx[i] ? 0.0 : fmax(M[i][i], 1e-300);
+        a.dvec[col0 + i] = d;
+        a.gm[col0 + i] = gv[i];
+        M[i][i] += lam * d;
+    }
+    // Cholesky M = L L' (lower triangle of M becomes L)
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < TB; ++j) {
+        double s = M[j][j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) s -= M[j][k] * M[j][k];
+        ok = ok && (s > 0.0);
+        const double l = sqrt(s), il = 1.0 / l;
+        M[j][j] = l;
+#pragma unroll
+        for (int i = j + 1; i < TB; ++i) {
+            double t = M[i][j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) t -= M[i][k] * M[j][k];
+            M[i][j] = t * il;
+        }
+    }
+    if (!ok) atomicOr(a.status, 1);
+    // Linv = L^-1 (lower), column by column; u = Linv g
+    double Li[TB][TB];
+#pragma unroll
+    for (int c = 0; c < TB; ++c)
+#pragma unroll
+        for (int i = 0; i < TB; ++i) {
+            if (i < c) { Li[i][c] = 0.0; continue; }
+            double t = (i == c) ? 1.0 : 0.0;
+#pragma unroll
+            for (int k = c; k < i; ++k) t -= M[i][k] * Li[k][c];
+            Li[i][c] = t / M[i][i];
+        }
+#pragma unroll
+    for (int i = 0; i < TB; ++i) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k <= i; ++k) t += Li[i][k] * gv[k];
+        a.u[e * TB + i] = t;
+    }
+    double *out = a.linvt + e * TB * TB;   // L^-T[i][j] = Linv[j][i]
+#pragma unroll
+    for (int i = 0; i < TB; ++i)
+#pragma unroll
+        for (int j = 0; j < TB; ++j) out[i * TB + j] = Li[j][i];
+}
+
+// One lane = one tb-chunk of one leading row: V[r, e, :] = b L_e^-T with b = the masked B[r, e, :].
+template <int TB>
+__global__ __launch_bounds__(256) void schur_v_kernel(const SchurArgs a) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= a.n_lead * a.n_ent) return;
+    const int64_t r = t / a.n_ent, e = t - r * a.n_ent;
+    double *Bp = a.B + r * a.n_trail + e * TB;
+    double b[TB];
+    bool touched = false;
+    const bool row_fixed = a.fixed[r] != 0;
+#pragma unroll
+    for (int j = 0; j < TB; ++j) {
+        b[j] = Bp[j];
+        if ((row_fixed || a.fixed[a.trail_off + e * TB + j]) && b[j] != 0.0) { b[j] = 0.0; touched = true; }
+    }
+    if (touched) {
+#pragma unroll
+        for (int j = 0; j < TB; ++j) Bp[j] = b[j];
+    }
+    const double *Lt = a.linvt + e * TB * TB;
+    double *Vp = a.V + r * a.n_trail + e * TB;
+#pragma unroll
+    for (int j = 0; j < TB; ++j) {
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i <= j; ++i) s += b[i] * Lt[i * TB + j];
+        Vp[j] = s;
+    }
+}
+
+// One lane = one entry of the leading block: S = sym(A) with fixed rows / columns -> identity and the damped diagonal.
+__global__ __launch_bounds__(256) void schur_lead_kernel(const SchurArgs a) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= a.n_lead * a.n_lead) return;
+    const int64_t r = t / a.n_lead, c = t - r * a.n_lead;
+    const bool fr = a.fixed[r] != 0, fc = a.fixed[c] != 0;
+    double v = r <= c ? a.A[r * a.n_lead + c] : a.A[c * a.n_lead + r];   // the build writes the upper triangle
+    if (fr || fc) v = (r == c) ? 1.0 : 0.0;
+    if (r == c) {
+        const double d = fr ? 0.0 : fmax(v, 1e-300);
+        a.dvec[r] = d;
+        const double gr = fr ? 0.0 : a.g[r];
+        a.gm[r] = gr;
+        a.rhs[r] = -gr;
+        v += *a.lambda * d;
+    }
+    a.S[t] = v;
+}
+
+struct SchurBackArgs {
+    const double *linvt, *u, *w, *xl;   // w = V' x_l (n_trail)
+    const uint8_t *fixed;
+    double *delta;                      // n_params, parameter-string order
+    int64_t n_lead, n_ent, trail_off;
+};
+
+template <int TB>
+__global__ __launch_bounds__(256) void schur_back_kernel(const SchurBackArgs a) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < a.n_lead) a.delta[t] = a.fixed[t] ? 0.0 : a.xl[t];
+    if (t >= a.n_ent) return;
+    const double *Lt = a.linvt + t * TB * TB;
+    double s[TB];
+#pragma unroll
+    for (int i = 0; i < TB; ++i) s[i] = a.u[t * TB + i] + a.w[t * TB + i];
+#pragma unroll
+    for (int i = 0; i < TB; ++i) {   // x = -L^-T s: L^-T is upper triangular
+        double x = 0.0;
+#pragma unroll
+        for (int j = i; j < TB; ++j) x += Lt[i * TB + j] * s[j];
+        const int64_t col = a.trail_off + t * TB + i;
+        a.delta[col] = a.fixed[col] ? 0.0 : -x;
+    }
+}
+
+}  // namespace pcs

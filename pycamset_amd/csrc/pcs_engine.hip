@@ -26,6 +26,7 @@
 #include "ba_kernels.hpp"
 #include "ba_matfree.hpp"
 #include "ba_normal.hpp"
+#include "ba_schur.hpp"
 #include "ba_triangulate.hpp"
 
 // ---------------------------------------------------------------------------------------------
@@ -139,9 +140,12 @@ struct pcs_engine {
     double tile_locality = 1.0;  // fraction of 64-detection tiles touching <= 2 distinct (cam, image) pairs
     double tile_segments = 1.0;  // mean number of (cam, image) runs per 64-detection tile (1.0 = every tile inside one run)
     // One-launch step: the evaluation kernel prepares the slabs of its tile per wave instead of a slab_prep launch in front
-    // (ba_eval_kernel<..., PREP>).  -1 = automatic: tables of at most fuse_prep_max_n detections whose tiles hold few runs.
+    // (ba_eval_kernel<..., PREP>).  -1 = automatic: run-ordered tables (few (camera, image) runs per tile); FP64 outputs at
+    // any size (measured on MI355X, profiles/r03: rig-32 71.2 -> 65.0 us per step, rig-32-self 82.0 -> 78.7, free 60.1 -> 57.4,
+    // an 8-way shard 14.2 -> 12.3, ring-8 12.3 -> 10.3), float outputs only up to fuse_prep_max_n detections (the float
+    // kernels are issue-bound at large N: rig-32 mixed 35.3 -> 53.4 us, rig-128 f32 294 -> 500 us with it).
     int fuse_prep = -1;
-    int64_t fuse_prep_max_n = 400000;
+    int64_t fuse_prep_max_n = 250000;
     int64_t tiles_per_wg = 0;  // 0 = derive from wgs_per_cu
     size_t lds_limit = 160 * 1024;
 };
@@ -1044,13 +1048,39 @@ static int build_point_orders(pcs_engine *h) {
     return PCS_OK;
 }
 
+// The blocked layout of J^T J (NormalArgs, ba_normal.hpp): where the parameter string splits into leading part and trailing group.
+struct BlockLayout {
+    int64_t n_lead, n_trail, n_ent, trail_off;
+    int tb, tg;
+    int64_t a_len() const { return n_lead * n_lead; }
+    int64_t b_len() const { return n_lead * n_trail; }
+    int64_t c_len() const { return n_ent * tb * tb; }
+};
+static BlockLayout block_layout(const pcs_engine *h) {
+    BlockLayout L{};
+    if (h->chain == PCS_CHAIN_TEMPLATE) { L.tg = 2; L.tb = 6; L.trail_off = h->pose_off; L.n_ent = h->n_imgs; }
+    else { L.tg = 3; L.tb = 3; L.trail_off = h->point_off; L.n_ent = h->n_keys; }
+    L.n_lead = L.trail_off;
+    L.n_trail = L.n_ent * L.tb;
+    return L;
+}
+
 // slab_prep + the normal-equations passes on `s`; d_prm holds the parameter string; outputs are zeroed here.
-static int enqueue_normal(pcs_engine *h, const double *d_prm, double *d_H, double *d_g, double *d_cost, hipStream_t s) {
+// blocked: d_H points at the packed [A | B | C] (contiguous), see pcs_normal_blocks_device.
+static int enqueue_normal(pcs_engine *h, const double *d_prm, double *d_H, double *d_g, double *d_cost, hipStream_t s, bool blocked = false) {
     if (h->n <= 0) return fail(PCS_ERR_STATE, "no detections set");
     if (h->n > INT32_MAX) return fail(PCS_ERR_ARG, "normal equations: tables beyond 2^31 rows are not supported (visiting orders are int32)");
     if (h->chain == PCS_CHAIN_TEMPLATE && !h->have_template) return fail(PCS_ERR_STATE, "template points not set");
-    // the flush addresses H with 32-bit byte offsets: 8 n^2 < 2^32 (a 4.3 GB matrix)
-    if (h->n_params > PCS_NORMAL_MAX_PARAMS) return fail(PCS_ERR_ARG, "normal equations: more than %d parameters (dense H beyond 4 GiB) is not supported", PCS_NORMAL_MAX_PARAMS);
+    const BlockLayout L = block_layout(h);
+    if (!blocked) {
+        // the flush addresses H with 32-bit byte offsets: 8 n^2 < 2^32 (a 4.3 GB matrix)
+        if (h->n_params > PCS_NORMAL_MAX_PARAMS) return fail(PCS_ERR_ARG, "normal equations: more than %d parameters (dense H beyond 4 GiB) is not supported", PCS_NORMAL_MAX_PARAMS);
+    } else {
+        const int64_t lim = (int64_t)1 << 29;   // doubles per region: 32-bit byte offsets
+        if (L.a_len() >= lim || L.b_len() >= lim || L.c_len() >= lim)
+            return fail(PCS_ERR_ARG, "blocked normal equations: a region beyond 4 GiB (leading %lld, trailing %lld columns) is not supported; use pcs_matfree",
+                        (long long)L.n_lead, (long long)L.n_trail);
+    }
     HIPCHK(hipSetDevice(h->device));
     int rc0 = ensure_point_orders(h);
     if (rc0) return rc0;
@@ -1060,7 +1090,7 @@ static int enqueue_normal(pcs_engine *h, const double *d_prm, double *d_H, doubl
         int64_t threads = slab_prep_threads(h->n_cams, h->n_imgs, has_pose);
         if (copy_points) threads = std::max<int64_t>(threads, std::min<int64_t>(3 * h->n_keys, 1 << 16));
         const int prep_blocks = (int)((threads + 63) / 64);
-        const int64_t n_h = h->n_params * h->n_params;
+        const int64_t n_h = blocked ? L.a_len() + L.b_len() + L.c_len() : h->n_params * h->n_params;
         const int zero_blocks = (int)std::min<int64_t>((n_h / 2 + 63) / 64 + 1, (int64_t)h->n_cu * 32);
         hipLaunchKernelGGL(normal_prologue_kernel, dim3((unsigned)(prep_blocks + zero_blocks)), dim3(64), 0, s, d_prm, (double *)h->d_cam_slab,
                            (double *)h->d_pose_slab, (double *)h->d_points, (int)h->n_cams, (int)h->n_imgs, (int)h->n_keys, h->extr_off,
@@ -1068,7 +1098,7 @@ static int enqueue_normal(pcs_engine *h, const double *d_prm, double *d_H, doubl
         HIPCHK(hipGetLastError());
         h->linearized = true;
     } else {
-        HIPCHK(hipMemsetAsync(d_H, 0, sizeof(double) * h->n_params * h->n_params, s));
+        HIPCHK(hipMemsetAsync(d_H, 0, sizeof(double) * (blocked ? L.a_len() + L.b_len() + L.c_len() : h->n_params * h->n_params), s));
         HIPCHK(hipMemsetAsync(d_g, 0, sizeof(double) * h->n_params, s));
         HIPCHK(hipMemsetAsync(d_cost, 0, sizeof(double), s));
         int rc = launch_slab_prep(h, d_prm, s);
@@ -1078,6 +1108,13 @@ static int enqueue_normal(pcs_engine *h, const double *d_prm, double *d_H, doubl
     a.tab = det_table(h);
     a.cam_slab = h->d_cam_slab; a.pose_slab = h->d_pose_slab; a.points = h->d_points;
     a.H = d_H; a.g = d_g; a.cost = d_cost;
+    if (blocked) {
+        a.HB = d_H + L.a_len(); a.HC = a.HB + L.b_len();
+        a.ldA = (int32_t)L.n_lead; a.ldB = (int32_t)L.n_trail; a.tb = L.tb; a.trail_group = L.tg; a.trail_off = L.trail_off;
+    } else {
+        a.HB = a.HC = d_H;
+        a.ldA = (int32_t)h->n_params; a.ldB = 0; a.tb = 0; a.trail_group = -1; a.trail_off = 0;
+    }
     a.n = h->n; a.n_tiles = (h->n + TILE - 1) / TILE;
     a.extr_off = h->extr_off; a.pose_off = h->pose_off; a.point_off = h->point_off;
     a.n_params = h->n_params;
@@ -1141,7 +1178,7 @@ static int enqueue_eval(pcs_engine *h, const double *d_prm, void *d_resid, void 
     // One launch per step for small, run-ordered tables (see pcs_engine::fuse_prep): the waves prepare their own slabs.
     const bool slab_lds_forced = h->variant >= 0 && (h->variant & VAR_SLAB_LDS);
     const bool prep = !compact && !slab_lds_forced && !(h->variant >= 0 && (mode & MODE_JAC) && !(h->variant & VAR_TRANSPOSE)) &&
-                      (h->fuse_prep > 0 || (h->fuse_prep < 0 && h->tile_locality >= 0.5 && h->tile_segments <= 2.5 && h->n <= h->fuse_prep_max_n));
+                      (h->fuse_prep > 0 || (h->fuse_prep < 0 && h->tile_locality >= 0.5 && h->tile_segments <= 2.5 && (h->osize == 8 || h->n <= h->fuse_prep_max_n)));
     hipEvent_t no_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     const bool timed = h->timing_every > 0 && (h->eval_count++ % h->timing_every) == 0;
     hipEvent_t *ev = timed ? ring_slot(h, !prep) : no_ev;
@@ -1541,6 +1578,71 @@ int pcs_normal_equations_device(pcs_engine *h, const double *param_str, double *
     int rc = stage_params(h, param_str, s);
     if (rc) return rc;
     return enqueue_normal(h, h->d_param, d_H, d_g, d_cost, s);
+}
+
+int pcs_normal_layout(const pcs_engine *h, int64_t *out5) {
+    if (!h || !out5) return fail(PCS_ERR_ARG, "pcs_normal_layout: bad arguments");
+    const BlockLayout L = block_layout(h);
+    out5[0] = L.n_lead; out5[1] = L.n_trail; out5[2] = L.tb;
+    out5[3] = L.a_len() + L.b_len() + L.c_len() + h->n_params + 1;
+    out5[4] = h->n_params;
+    return PCS_OK;
+}
+
+int pcs_normal_blocks_device(pcs_engine *h, const double *d_param_str, double *d_packed, void *stream) {
+    if (!h || !d_param_str || !d_packed) return fail(PCS_ERR_ARG, "pcs_normal_blocks_device: bad arguments");
+    if (reinterpret_cast<uintptr_t>(d_packed) % 16) return fail(PCS_ERR_ARG, "pcs_normal_blocks_device: the packed buffer must be 16-byte aligned");
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    const BlockLayout L = block_layout(h);
+    double *d_g = d_packed + L.a_len() + L.b_len() + L.c_len();
+    return enqueue_normal(h, d_param_str, d_packed, d_g, d_g + h->n_params, s, true);
+}
+
+int pcs_schur_prepare(pcs_engine *h, double *d_packed, const uint8_t *d_fixed, const double *d_lambda, double *d_linvt, double *d_u,
+                      double *d_V, double *d_S, double *d_rhs, double *d_dvec, double *d_gm, int32_t *d_status, void *stream) {
+    if (!h || !d_packed || !d_fixed || !d_lambda || !d_linvt || !d_u || !d_V || !d_S || !d_rhs || !d_dvec || !d_gm || !d_status)
+        return fail(PCS_ERR_ARG, "pcs_schur_prepare: bad arguments");
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    const BlockLayout L = block_layout(h);
+    SchurArgs a{};
+    a.A = d_packed; a.B = d_packed + L.a_len(); a.C = a.B + L.b_len(); a.g = a.C + L.c_len();
+    a.fixed = d_fixed; a.lambda = d_lambda;
+    a.linvt = d_linvt; a.u = d_u; a.V = d_V; a.S = d_S; a.rhs = d_rhs; a.dvec = d_dvec; a.gm = d_gm; a.status = d_status;
+    a.n_lead = L.n_lead; a.n_trail = L.n_trail; a.n_ent = L.n_ent; a.trail_off = L.trail_off;
+    auto blocks = [](int64_t n) { return dim3((unsigned)((n + 255) / 256)); };
+    if (L.n_ent > 0) {
+        if (L.tb == 6) hipLaunchKernelGGL(schur_trail_kernel<6>, blocks(L.n_ent), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(schur_trail_kernel<3>, blocks(L.n_ent), dim3(256), 0, s, a);
+        HIPCHK(hipGetLastError());
+        if (L.n_lead > 0) {
+            if (L.tb == 6) hipLaunchKernelGGL(schur_v_kernel<6>, blocks(L.n_lead * L.n_ent), dim3(256), 0, s, a);
+            else hipLaunchKernelGGL(schur_v_kernel<3>, blocks(L.n_lead * L.n_ent), dim3(256), 0, s, a);
+            HIPCHK(hipGetLastError());
+        }
+    }
+    if (L.n_lead > 0) {
+        hipLaunchKernelGGL(schur_lead_kernel, blocks(L.n_lead * L.n_lead), dim3(256), 0, s, a);
+        HIPCHK(hipGetLastError());
+    }
+    return PCS_OK;
+}
+
+int pcs_schur_finish(pcs_engine *h, const double *d_linvt, const double *d_u, const double *d_w, const double *d_xlead, const uint8_t *d_fixed,
+                     double *d_delta, void *stream) {
+    if (!h || !d_linvt || !d_u || !d_w || !d_xlead || !d_fixed || !d_delta) return fail(PCS_ERR_ARG, "pcs_schur_finish: bad arguments");
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    const BlockLayout L = block_layout(h);
+    SchurBackArgs a{};
+    a.linvt = d_linvt; a.u = d_u; a.w = d_w; a.xl = d_xlead; a.fixed = d_fixed; a.delta = d_delta;
+    a.n_lead = L.n_lead; a.n_ent = L.n_ent; a.trail_off = L.trail_off;
+    const int64_t n = std::max(L.n_lead, L.n_ent);
+    const dim3 grid((unsigned)((n + 255) / 256));
+    if (L.tb == 6) hipLaunchKernelGGL(schur_back_kernel<6>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(schur_back_kernel<3>, grid, dim3(256), 0, s, a);
+    HIPCHK(hipGetLastError());
+    return PCS_OK;
 }
 
 int pcs_normal_equations(pcs_engine *h, const double *param_str, double *H, double *g, double *cost) {

@@ -13,8 +13,12 @@ all-reduce J^T J v, diag(J^T J) and J^T r (a few KB).
 
 Two ways to get the LM step from the GPU: ``"pcg"`` — Jacobi-preconditioned CG on matrix-free
 J^T (J v) products (~150 passes over the detections per step, parameter-sized traffic only); and
-``"cholesky"`` — one pass of csrc/ba_normal.hpp builds H = J^T J, g = J^T r and the cost, and the damped
-system is factorised (rocSOLVER through torch on the GPU; the sharded form all-reduces H, g, cost).
+``"cholesky"`` — one pass of csrc/ba_normal.hpp builds J^T J, J^T r and the cost in BLOCKED form
+([A | B | C]: leading x leading, leading x trailing, block-diagonal trailing group) and the damped system is
+reduced by the Schur complement of the trailing group (csrc/ba_schur.hpp + one library GEMM + a dense Cholesky
+of the leading size).  That loop is device-resident (round 3): parameter string, step, damping, gain ratio and
+the accept / reject decision live in HBM, and the host reads ONE small vector per trial step to steer the loop.
+The sharded form all-reduces the packed [A | B | C | g | cost].
 
 ``as_linear_operator()`` exposes J as a scipy LinearOperator (matvec / rmatvec) for callers that
 want scipy's own solvers without materialising J.
@@ -113,7 +117,14 @@ def pcg(apply_a, b, m_inv, tol: float, max_iter: int):
     return x, it
 
 
-DENSE_LIMIT = 8192   # parameters up to which lm_solve(linear_solver="auto") forms the dense J^T J
+LEAD_LIMIT = 16384          # leading parameters up to which lm_solve(linear_solver="auto") takes the Schur / Cholesky step (S: 2 GB)
+BLOCKED_BYTES_LIMIT = 16e9  # and total bytes of the two packed buffers + V
+
+
+def blocked_fits(engine) -> bool:
+    lay = engine.normal_layout()
+    return lay["n_lead"] <= LEAD_LIMIT and 8.0 * (2 * lay["packed_len"] + lay["n_lead"] * lay["n_trail"] + lay["n_lead"] ** 2) <= BLOCKED_BYTES_LIMIT
+
 
 
 class NormalEquations:
@@ -174,6 +185,152 @@ class NormalEquations:
         p = self._perm
         delta = schur_cholesky_step(Hs[p][:, p], g[p], lam, d[p], n_lead, block)
         return None if delta is None else delta[self._inv_perm]
+
+
+class BlockedNormalEquations:
+    """J^T J in blocked form + the Schur-complement step, all on the device (engine.normal_blocks_device,
+    engine.schur_prepare / schur_finish; include/pcs_hip.h).  Two packed buffers (current state, trial state) so that an
+    accepted trial becomes the current state by swapping indices."""
+
+    def __init__(self, engine, unfixed=None, reduce_fn=None):
+        import torch
+
+        self.torch, self.eng, self.reduce_fn = torch, engine, reduce_fn
+        lay = engine.normal_layout()
+        self.n_lead, self.n_trail, self.tb, self.n_params = lay["n_lead"], lay["n_trail"], lay["tb"], lay["n_params"]
+        self.n_ent = self.n_trail // self.tb
+        mask = np.ones(self.n_params, dtype=bool) if unfixed is None else np.asarray(unfixed, dtype=bool)
+        if mask.shape[0] != self.n_params:
+            raise ValueError("mask must have one entry per parameter")
+        self.free = np.flatnonzero(mask)
+        self.n_free = self.free.shape[0]
+        dev = self.dev = torch.device("cuda", engine.device)
+        f64 = dict(dtype=torch.float64, device=dev)
+        self.packed = [torch.empty(lay["packed_len"], **f64) for _ in range(2)]
+        self.fixed = torch.from_numpy((~mask).astype(np.uint8)).to(dev)
+        self.free_idx = torch.from_numpy(self.free).to(dev)
+        self.linvt = torch.empty(max(1, self.n_ent * self.tb * self.tb), **f64)
+        self.u = torch.empty(max(1, self.n_trail), **f64)
+        self.V = torch.empty((self.n_lead, max(1, self.n_trail)), **f64)
+        self.S = torch.empty((self.n_lead, self.n_lead), **f64)
+        self.rhs = torch.empty(self.n_lead, **f64)
+        self.dvec = torch.empty(self.n_params, **f64)
+        self.gm = torch.empty(self.n_params, **f64)
+        self.delta = torch.empty(self.n_params, **f64)
+        self.status = torch.zeros(1, dtype=torch.int32, device=dev)
+
+    def cost(self, slot):
+        return self.packed[slot][-1]
+
+    def build(self, ps, slot: int):
+        """packed[slot] <- [A | B | C | g | cost] at the device parameter string ``ps`` (+ the sum over the ranks)."""
+        torch = self.torch
+        buf = self.packed[slot]
+        if self.eng.n == 0:   # empty shard: zeros, but the all-reduce below still happens (see JacobianOperator)
+            buf.zero_()
+        else:
+            self.eng.normal_blocks_device(ps.data_ptr(), buf.data_ptr(), torch.cuda.current_stream(self.dev).cuda_stream)
+        if self.reduce_fn is not None:
+            if getattr(self.reduce_fn, "on_device", False):
+                self.reduce_fn(buf)
+            else:
+                buf.copy_(torch.from_numpy(self.reduce_fn(buf.cpu().numpy())))
+
+    def solve(self, slot: int, lam):
+        """(delta (n_params, parameter-string order, 0 where fixed), predicted reduction, ok) of
+        (H + lam diag(H)) delta = -g for the state in packed[slot]; tensors on the device, nothing is read back."""
+        torch = self.torch
+        stream = torch.cuda.current_stream(self.dev).cuda_stream
+        self.status.zero_()
+        self.eng.schur_prepare(self.packed[slot].data_ptr(), self.fixed.data_ptr(), lam.data_ptr(), self.linvt.data_ptr(), self.u.data_ptr(),
+                               self.V.data_ptr(), self.S.data_ptr(), self.rhs.data_ptr(), self.dvec.data_ptr(), self.gm.data_ptr(),
+                               self.status.data_ptr(), stream)
+        if self.n_trail:
+            V = self.V[:, : self.n_trail]
+            self.S.addmm_(V, V.T, alpha=-1.0)            # S = A + lam D - V V'          (rocBLAS)
+            self.rhs.addmv_(V, self.u[: self.n_trail])   # rhs = -g_l + V u
+        L, info = torch.linalg.cholesky_ex(self.S)       # rocSOLVER; `info` stays on the device
+        xl = torch.cholesky_solve(self.rhs.unsqueeze(1), L).squeeze(1)
+        w = torch.mv(self.V[:, : self.n_trail].T, xl) if self.n_trail else self.u
+        self.eng.schur_finish(self.linvt.data_ptr(), self.u.data_ptr(), w.data_ptr(), xl.data_ptr(), self.fixed.data_ptr(),
+                              self.delta.data_ptr(), stream)
+        pred = 0.5 * (lam[0] * torch.dot(self.dvec, self.delta * self.delta) - torch.dot(self.gm, self.delta))
+        ok = (info == 0) & (self.status[0] == 0) & torch.isfinite(pred)
+        return self.delta, pred, ok
+
+    def gradient(self, slot: int, lam):
+        """masked J^T r of the state in packed[slot] (free entries), as NumPy — one read-back, used once at the end."""
+        self.solve(slot, lam)
+        return self.gm[self.free_idx].cpu().numpy()
+
+
+def _lm_solve_blocked(ne: BlockedNormalEquations, ps0: np.ndarray, *, max_iter, ftol, xtol, gtol, lam0, verbose):
+    """The device-resident loop behind ``lm_solve(..., linear_solver='cholesky')``.  Per trial step the host enqueues
+    solve -> parameter update -> build -> decision and then reads ONE 8-vector
+        [accepted, max |g| before the step, relative cost drop, |step|, |x|, new sum r^2, old sum r^2, lambda used]
+    to steer the loop; x, lambda, the gain ratio and both states stay in HBM."""
+    torch = ne.torch
+    dev = ne.dev
+    with torch.cuda.device(dev):
+        ps = torch.from_numpy(np.ascontiguousarray(ps0, dtype=np.float64)).to(dev)
+        ps_new = torch.empty_like(ps)
+        lam = torch.full((1,), float(lam0), dtype=torch.float64, device=dev)
+        cur, new = 0, 1
+        ne.build(ps, cur)
+        sumsq = float(ne.cost(cur).item())
+        history = [0.5 * sumsq]
+        nfev, n_lin = 1, 0
+        status, message = 0, "maximum number of iterations reached"
+        it = 0
+        third, one, two = (torch.tensor(v, dtype=torch.float64, device=dev) for v in (1.0 / 3.0, 1.0, 2.0))
+        for it in range(1, max_iter + 1):
+            accepted = False
+            stop = False
+            for _retry in range(12):   # damping retries
+                delta, pred, ok = ne.solve(cur, lam)
+                n_lin += 1
+                torch.add(ps, delta, out=ps_new)
+                ne.build(ps_new, new)
+                nfev += 1
+                c_old, c_new = ne.cost(cur), ne.cost(new)
+                actual = 0.5 * (c_old - c_new)
+                rho = torch.where(pred > 0, actual / pred, -one)
+                acc = ok & torch.isfinite(c_new) & (actual > 0)
+                factor = torch.where(rho > 0.75, third, torch.where(rho > 0.25, one, two))
+                lam_used = lam.clone()
+                lam = torch.where(acc, torch.clamp(lam * factor, min=1e-12), lam * 4.0)
+                x = ps[ne.free_idx]
+                stats = torch.stack([acc.to(torch.float64), ne.gm.abs().max(), actual / (0.5 * c_old), torch.linalg.vector_norm(delta),
+                                     torch.linalg.vector_norm(x), c_new, c_old, lam_used[0]]).cpu().numpy()   # the ONE read-back
+                gmax = float(stats[1])
+                if verbose:
+                    print(f"  it {it}: lam {stats[7]:.2e} cost {0.5 * stats[6]:.6e} -> {0.5 * stats[5]:.6e} accepted {bool(stats[0])}")
+                if gmax <= gtol:   # the state BEFORE this step was already stationary: the step is dropped
+                    status, message, stop = 1, "gtol reached", True
+                    break
+                if stats[0] > 0:
+                    accepted = True
+                    ps, ps_new = ps_new, ps
+                    cur, new = new, cur
+                    history.append(0.5 * float(stats[5]))
+                    rel_drop, step_norm, x_norm = float(stats[2]), float(stats[3]), float(stats[4])
+                    break
+            if stop:
+                break
+            if not accepted:
+                status, message = 2, "no further decrease (damping exhausted)"
+                break
+            if rel_drop <= ftol:
+                status, message = 3, "ftol reached"
+                break
+            if step_norm <= xtol * (xtol + x_norm):
+                status, message = 4, "xtol reached"
+                break
+        g = ne.gradient(cur, lam)
+        x = ps[ne.free_idx].cpu().numpy()
+        cost = 0.5 * float(ne.cost(cur).item())
+    return DeviceLMResult(x=x, cost=cost, grad=g, optimality=float(np.max(np.abs(g))) if g.size else 0.0, nit=it, nfev=nfev,
+                          n_jtjv=n_lin, status=status, message=message, history=history)
 
 
 def reduce_normal_equations(U, g, c, reduce_fn):
@@ -346,9 +503,13 @@ def lm_solve(handler, x0, *, max_iter: int = 50, ftol: float = 1e-8, xtol: float
         dd = handler._flat_detections()
         eng = op_fun._engine_for(dd)
         op_fun._bind_template(eng, handler._template_arg())
-        if linear_solver == "auto":   # a dense J^T J up to 8 192 parameters (0.5 GB); beyond that matrix-free CG
-            linear_solver = "cholesky" if eng.n_params <= DENSE_LIMIT else "pcg"
-        operator = (JacobianOperator if linear_solver == "pcg" else NormalEquations)(eng, handler._jac_mask(), reduce_fn=reduce_fn)
+        if linear_solver == "auto":   # blocked J^T J while its regions fit comfortably; beyond that matrix-free CG
+            linear_solver = "cholesky" if blocked_fits(eng) else "pcg"
+        if linear_solver == "cholesky":
+            ne = BlockedNormalEquations(eng, handler._jac_mask(), reduce_fn=reduce_fn)
+            ps0 = op_fun.build_param_list(*handler.get_bundle_adjustment_inputs(np.array(x0, dtype=np.float64)))
+            return _lm_solve_blocked(ne, ps0, max_iter=max_iter, ftol=ftol, xtol=xtol, gtol=gtol, lam0=lam0, verbose=verbose)
+        operator = JacobianOperator(eng, handler._jac_mask(), reduce_fn=reduce_fn)
     elif linear_solver == "auto":
         linear_solver = "cholesky" if hasattr(operator, "build") else "pcg"
     step = _PcgStep(operator, cg_tol, cg_max_iter) if linear_solver == "pcg" else _CholeskyStep(operator)

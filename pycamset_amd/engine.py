@@ -271,6 +271,24 @@ class Engine:
         p = self._check_params(param_str)
         check(lib().pcs_normal_equations_device(self._h, _dp(p), c_void_p(d_H), c_void_p(d_g), c_void_p(d_cost), _stream_arg(stream)))
 
+    # -- blocked normal equations + the block parts of a damped step (device pointers only) -------------
+    def normal_layout(self) -> dict:
+        """{n_lead, n_trail, tb, packed_len, n_params}: see ``pcs_normal_blocks_device`` (include/pcs_hip.h)."""
+        out = (c_int64 * 5)()
+        check(lib().pcs_normal_layout(self._h, out))
+        return dict(n_lead=int(out[0]), n_trail=int(out[1]), tb=int(out[2]), packed_len=int(out[3]), n_params=int(out[4]))
+
+    def normal_blocks_device(self, d_param_str: int, d_packed: int, stream: int | None = None):
+        """[A | B | C | g | cost] at the DEVICE-resident parameter string; asynchronous, zeroes the buffer first."""
+        check(lib().pcs_normal_blocks_device(self._h, c_void_p(d_param_str), c_void_p(d_packed), _stream_arg(stream)))
+
+    def schur_prepare(self, d_packed, d_fixed, d_lambda, d_linvt, d_u, d_V, d_S, d_rhs, d_dvec, d_gm, d_status, stream=None):
+        check(lib().pcs_schur_prepare(self._h, *(c_void_p(p) for p in (d_packed, d_fixed, d_lambda, d_linvt, d_u, d_V, d_S, d_rhs, d_dvec, d_gm, d_status)),
+                                      _stream_arg(stream)))
+
+    def schur_finish(self, d_linvt, d_u, d_w, d_xlead, d_fixed, d_delta, stream=None):
+        check(lib().pcs_schur_finish(self._h, *(c_void_p(p) for p in (d_linvt, d_u, d_w, d_xlead, d_fixed, d_delta)), _stream_arg(stream)))
+
     # -- evaluation: device buffers -----------------------------------------------------------
     def eval_device(self, param_str, d_resid: int | None, d_jac: int | None, stream: int | None = None):
         """Asynchronous; ``d_resid`` / ``d_jac`` are raw device addresses in the engine dtype."""

@@ -800,7 +800,14 @@ def test_soa_upload_engine_buffers_and_timing_options(Engine):
         e.eval_device(ps, d_r, d_j)
     e.synchronize()
     cnt, prep_ms, eval_ms = e.kernel_ms_mean()
+    assert cnt == 4 and 0 < eval_ms < 5 and prep_ms == 0.0        # a small table: ONE launch per step, no slab_prep kernel
+    e.set_option("fuse_prep", 0)                                  # slab_prep + evaluation: both kernels carry their own events
+    for _ in range(4):
+        e.eval_device(ps, d_r, d_j)
+    e.synchronize()
+    cnt, prep_ms, eval_ms = e.kernel_ms_mean()
     assert cnt == 4 and 0 < eval_ms < 5 and 0 < prep_ms < 5
+    e.set_option("fuse_prep", -1)
     e.set_option("event_ring", 8)
     e.set_option("timing_every", 3)
     for _ in range(7):                            # evaluations 0, 3, 6 are timed

@@ -1,6 +1,11 @@
-"""Two ranks sharing the one GPU of the test box (gloo for the control plane; RCCL needs one GPU per
-rank): the real engine evaluates each rank's shard; gathered blocks and all-reduced normal-equation
-products must equal the single-process results, and the sharded device LM must land on the same cost."""
+"""Sharded evaluation on the real engine, one process per rank: gathered blocks and all-reduced normal-equation
+products must equal the single-process results, and the sharded device LM must land on the same cost.
+
+Two launches of the SAME worker:
+  * gloo, both ranks on the one GPU of the test box (control plane through the host) — always runs;
+  * nccl (= RCCL over xGMI), one GPU per rank, blocks gathered and products reduced on the device — runs wherever
+    ``torch.cuda.device_count() >= 2`` (auto-skipped on a one-GPU box), so the first multi-GPU test box proves that RCCL
+    has seen N ranks without anybody editing this file."""
 import os
 import socket
 import sys
@@ -38,10 +43,17 @@ class _Target:
         self.point_data = np.asarray(pts)[None]
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, backend="gloo"):
     sys.path.insert(0, str(REPO))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver only supports dmabuf IPC (RCCL needs it)
+    rccl = backend == "nccl"
+    device = rank if rccl else 0                 # RCCL: one GPU per rank; gloo: the ranks share GPU 0
+    torch.cuda.set_device(device)
+    if rccl:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from pycamset_amd import handlers, sharding, synthetic
         from pycamset_amd.detections import TargetDetection
@@ -54,30 +66,32 @@ def _worker(rank, world, port, out_dir):
         ps = np.concatenate([rig.intr.ravel(), rig.extr.ravel(), rig.poses.ravel()])
 
         # (1) sharded evaluation + gather (blocks moved to the host for gloo)
-        local = sharding.make_engine_eval("template", det, counts, rig.points, rank=rank, world=world)
+        local = sharding.make_engine_eval("template", det, counts, rig.points, rank=rank, world=world, device=device)
 
         def local_cpu(p, want_resid=True, want_jac=True):
             r, j = local(p, want_resid, want_jac)
             torch.cuda.synchronize()
             return (r.cpu() if r is not None else None), (j.cpu() if j is not None else None)
 
-        ev = sharding.ShardedEvaluator(det.shape[0], 21, local_cpu)
+        # RCCL: the blocks stay on the GPUs and all_gather_into_tensor moves them over xGMI; gloo: through the host
+        ev = sharding.ShardedEvaluator(det.shape[0], 21, local if rccl else local_cpu)
         r, j = ev.eval_gathered(ps)
-        full = Engine("template", *counts)
+        full = Engine("template", *counts, device=device)
         full.set_detections_table(det)
         full.set_template(rig.points)
         r0, j0 = full.eval(ps)
-        assert np.array_equal(r.numpy(), r0) and np.array_equal(j.numpy(), j0)
+        assert np.array_equal(r.cpu().numpy(), r0) and np.array_equal(j.cpu().numpy(), j0)
+        vec_reduce = sharding.allreduce_sum_fn(device=torch.device("cuda", device) if rccl else None)
 
         # (2) all-reduced matrix-free products on unpadded shards == single-process products
         per = sharding.shard_rows(det.shape[0], world)
         mine = det[rank * per:(rank + 1) * per]
-        eng = Engine("template", *counts)
+        eng = Engine("template", *counts, device=device)
         eng.set_detections_table(mine)
         eng.set_template(rig.points)
         mask = np.ones(ps.shape[0], bool)
         mask[15 * rig.n_cams: 15 * rig.n_cams + 6] = False
-        op = JacobianOperator(eng, mask, reduce_fn=sharding.allreduce_sum_fn())
+        op = JacobianOperator(eng, mask, reduce_fn=vec_reduce)
         ref = JacobianOperator(full, mask)
         op.linearize(ps)
         ref.linearize(ps)
@@ -92,19 +106,21 @@ def _worker(rank, world, port, out_dir):
             return handlers.TemplateBundleHandler(_Camset(rig.n_cams), _Target(rig.points),
                                                   TargetDetection(names, rows, max_ims=rig.n_imgs),
                                                   fixed_params={"cam_0": {"ext": rig.extr_true[0].copy()}},
-                                                  options={"verbosity": 0}, counts=counts)
+                                                  options={"verbosity": 0}, counts=counts, device=device)
 
         h_shard, h_full = handler(mine), handler(det)
         bp = h_full.bundlePrimitive
         x0 = np.concatenate([rig.intr[bp.intr_unfixed].ravel(), rig.extr[bp.extr_unfixed].ravel(), rig.poses[bp.poses_unfixed].ravel()])
-        res = lm_solve(h_shard, x0.copy(), max_iter=20, reduce_fn=sharding.allreduce_sum_fn(), linear_solver="pcg")
+        res = lm_solve(h_shard, x0.copy(), max_iter=20, reduce_fn=vec_reduce, linear_solver="pcg")
         one = lm_solve(h_full, x0.copy(), max_iter=20, linear_solver="pcg")
         assert abs(res.cost - one.cost) <= 1e-5 * one.cost and res.cost < 0.01 * res.history[0], (res.cost, one.cost, res.history[0])
         gathered = [None] * world
         dist.all_gather_object(gathered, res.x)
         assert all(np.array_equal(gathered[0], g) for g in gathered)      # every rank walked the same path
         # the same with the block-reduced normal equations: ranks all-reduce [J^T J, J^T r, cost]
-        chol = lm_solve(h_shard, x0.copy(), max_iter=20, reduce_fn=sharding.allreduce_sum_fn(), linear_solver="cholesky")
+        # RCCL: the packed [J^T J, J^T r, cost] tensor is all-reduced in place on the device
+        mat_reduce = sharding.allreduce_sum_tensor_fn() if rccl else sharding.allreduce_sum_fn()
+        chol = lm_solve(h_shard, x0.copy(), max_iter=20, reduce_fn=mat_reduce, linear_solver="cholesky")
         assert abs(chol.cost - one.cost) <= 1e-5 * one.cost, (chol.cost, one.cost)
         dist.all_gather_object(gathered, chol.x)
         assert all(np.array_equal(gathered[0], g) for g in gathered)
@@ -116,18 +132,18 @@ def _worker(rank, world, port, out_dir):
             return handlers.SelfBundleHandler(_Camset(rig.n_cams), _Target(rig.points),
                                               TargetDetection(names, rows, max_ims=rig.n_imgs),
                                               fixed_params={"cam_0": {"ext": rig.extr_true[0].copy()}},
-                                              options={"verbosity": 0}, counts=counts, visible_feature_mask=vis)
+                                              options={"verbosity": 0}, counts=counts, visible_feature_mask=vis, device=device)
 
         s_shard, s_full = self_handler(mine), self_handler(det)
         assert np.array_equal(s_shard._jac_mask(), s_full._jac_mask())
         bs = s_full.bundlePrimitive
         xs = np.concatenate([rig.intr[bs.intr_unfixed].ravel(), rig.extr[bs.extr_unfixed].ravel(),
                              rig.poses[bs.poses_unfixed].ravel(), rig.points.ravel()[bs.bdpt_unfixed]])
-        rs = lm_solve(s_shard, xs.copy(), max_iter=15, reduce_fn=sharding.allreduce_sum_fn(), linear_solver="pcg")
+        rs = lm_solve(s_shard, xs.copy(), max_iter=15, reduce_fn=vec_reduce, linear_solver="pcg")
         r1 = lm_solve(s_full, xs.copy(), max_iter=15, linear_solver="pcg")
         # default ("auto" = block-reduced normal equations + Schur step; the gauge-fixed point coordinates are permuted
         # into the leading group): exact steps end at least as low as the inexact CG steps
-        ra = lm_solve(s_shard, xs.copy(), max_iter=15, reduce_fn=sharding.allreduce_sum_fn())
+        ra = lm_solve(s_shard, xs.copy(), max_iter=15, reduce_fn=mat_reduce)
         assert ra.cost <= r1.cost * (1 + 1e-3), (ra.cost, r1.cost)
         # self-calibration has a flat valley (gauge + point/pose trade-offs) and the J^T products sum with
         # f64 atomics in arrival order, so after 15 iterations the two runs agree in cost, not bit for bit
@@ -139,5 +155,13 @@ def _worker(rank, world, port, out_dir):
 
 def test_two_ranks_on_one_gpu(tmp_path):
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), "gloo"), nprocs=world, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(world))
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank: this box has fewer than two")
+def test_ranks_on_their_own_gpus_over_rccl(tmp_path):
+    """The same assertions with backend nccl (RCCL over xGMI), one device per rank, at most 4 ranks."""
+    world = min(4, torch.cuda.device_count())
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), "nccl"), nprocs=world, join=True)
     assert all((tmp_path / f"ok{r}").exists() for r in range(world))
