@@ -360,29 +360,16 @@ def main():
 
     use_gather_in_step = args.collective == "allgather" and world > 1
 
-    host_ring = None
+    streamer = None
     if args.stream_to_host:
-        # two device buffers + two pinned host buffers: the copy of step i overlaps the kernel of step i+1
-        copy_stream = torch.cuda.Stream(dev)
-        dev_bufs = [d_j, torch.empty_like(d_j)]
-        host_ring = [torch.empty(d_j.shape, dtype=tdt, pin_memory=True) for _ in range(2)]
-        ev_done = [torch.cuda.Event() for _ in range(2)]   # kernel finished writing dev_bufs[b]
-        ev_free = [torch.cuda.Event() for _ in range(2)]   # copy out of dev_bufs[b] finished
-        for e_ in ev_free:
-            e_.record(copy_stream)
-        step_no = [0]
+        # two device buffers + two page-locked host buffers: the copy of step i overlaps the kernel of step i + 1
+        from pycamset_amd.host_stream import JacobianHostStreamer
+
+        streamer = JacobianHostStreamer(eng, N, device=local_rank, first_device_buffer=d_j)
 
     def step():
-        if host_ring is not None:
-            b = step_no[0] & 1
-            step_no[0] += 1
-            torch.cuda.current_stream(dev).wait_event(ev_free[b])
-            eng.eval_device_resident(d_p.data_ptr(), d_r.data_ptr(), dev_bufs[b].data_ptr(), stream)
-            ev_done[b].record(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(copy_stream):
-                copy_stream.wait_event(ev_done[b])
-                host_ring[b].copy_(dev_bufs[b], non_blocking=True)
-                ev_free[b].record(copy_stream)
+        if streamer is not None:
+            streamer.step(d_p.data_ptr(), d_r.data_ptr())
             return
         eng.eval_device_resident(d_p.data_ptr(), d_r.data_ptr(), d_j.data_ptr(), stream)
         if use_gather_in_step:

@@ -210,6 +210,40 @@ int pcs_schur_finish(pcs_engine *h, const double *d_linvt, const double *d_u, co
  * belongs to local run (l >> 4) + 4 r.
  * Diagnostic aid: tests/test_host_logic.py checks that every needed column pair is owned exactly once. */
 int pcs_normal_entry_map(int chain, int pass, int32_t *out);
+/* The packed destination descriptor of every accumulator register of ba_normal_mfma_kernel (passes 0 and 1; host function, no
+ * GPU needed): out[m][lane][r], layout documented at entry_descriptor (csrc/ba_normal.hpp).  trail_group = 2 (pose) / 3 (point)
+ * for the blocked layout, -1 for the dense one.  tests/test_host_logic.py decodes them for sample runs exactly like the
+ * kernel's flush does and checks every owned entry's address against the column pair pcs_normal_entry_map reports. */
+int pcs_normal_descriptors(int chain, int pass, int trail_group, int32_t *out);
+
+/*
+ * Generated chains (round 3).  The reference composes ANY list of function blocks (afb:735-748) and code-generates the loss /
+ * Jacobian / chain rule for it (afb:290-419, afb:492-652, mm:147-263).  pycamset_amd/chain_compiler.py emits a ChainSpec for a
+ * composition  projection + T_1 + ... + T_M + source  (T_i in {rigidTform3d, extrinsic3D}, source in {template_points,
+ * free_point}), has hipcc compile csrc/ba_generic.hpp for it (gfx950 code object) and hands the file to pcs_genchain_create.
+ *   code_object_path   .hsaco with the entry points pcs_genchain_prep / pcs_genchain_eval_{1,2,3} / pcs_genchain_gather
+ *   n_transforms = M,  src_kind 0 template_points / 1 free_point;  row length P = 9 + 6 M + (6 | 3)
+ *   rigid parameter groups (one Rodrigues slab each): first parameter-string column and entity count per group; which group
+ *   and which index (camera / image) each block reads is compiled into the code object
+ *   intr_off / point_off: first column of the projection and of the free_point group
+ * Outputs and layouts as pcs_eval: resid (N, 2), jac (2N, P) dense block rows, u row then v row.  pcs_genchain_set_gather +
+ * pcs_genchain_eval_compact replace `data[:n][good_mask]` (afb:644-651) by a static gather on the device.
+ */
+typedef struct pcs_genchain pcs_genchain;
+int pcs_genchain_create(pcs_genchain **out, const char *code_object_path, int n_transforms, int src_kind, int n_groups, const int64_t *group_off,
+                     const int32_t *group_count, int64_t intr_off, int64_t point_off, int64_t n_params, int64_t n_cams, int64_t n_imgs,
+                     int64_t n_keys, int device);
+int pcs_genchain_destroy(pcs_genchain *h);
+int pcs_genchain_row_len(const pcs_genchain *h);
+int pcs_genchain_set_detections_table(pcs_genchain *h, const double *det5, int64_t n);
+int pcs_genchain_set_template(pcs_genchain *h, const double *points);
+int pcs_genchain_eval(pcs_genchain *h, const double *param_str, double *resid, double *jac);
+int pcs_genchain_eval_device(pcs_genchain *h, const double *d_param_str, double *d_resid, double *d_jac, void *stream);
+int pcs_genchain_set_gather(pcs_genchain *h, const int64_t *src, int64_t nnz);
+int pcs_genchain_eval_compact(pcs_genchain *h, const double *param_str, double *resid, double *data);
+int pcs_genchain_device_buffers(pcs_genchain *h, void **d_resid, void **d_jac);
+int pcs_genchain_synchronize(pcs_genchain *h, void *stream);
+int pcs_genchain_last_kernel_ms(pcs_genchain *h, float *slab_prep_ms, float *eval_ms);
 
 /*
  * Legacy residual-only cost.

@@ -50,6 +50,20 @@ SYMBOLS = {
     "pcs_normal_blocks_device": (c_int, [_P, _P, _P, _P]),
     "pcs_schur_prepare": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pcs_schur_finish": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
+    "pcs_normal_descriptors": (c_int, [c_int, c_int, c_int, POINTER(c_int32)]),
+    "pcs_genchain_create": (c_int, [POINTER(_P), c_char_p, c_int, c_int, c_int, POINTER(c_int64), POINTER(c_int32), c_int64, c_int64, c_int64,
+                                 c_int64, c_int64, c_int64, c_int]),
+    "pcs_genchain_destroy": (c_int, [_P]),
+    "pcs_genchain_row_len": (c_int, [_P]),
+    "pcs_genchain_set_detections_table": (c_int, [_P, POINTER(c_double), c_int64]),
+    "pcs_genchain_set_template": (c_int, [_P, POINTER(c_double)]),
+    "pcs_genchain_eval": (c_int, [_P, POINTER(c_double), POINTER(c_double), POINTER(c_double)]),
+    "pcs_genchain_eval_device": (c_int, [_P, _P, _P, _P, _P]),
+    "pcs_genchain_set_gather": (c_int, [_P, POINTER(c_int64), c_int64]),
+    "pcs_genchain_eval_compact": (c_int, [_P, POINTER(c_double), POINTER(c_double), POINTER(c_double)]),
+    "pcs_genchain_device_buffers": (c_int, [_P, POINTER(_P), POINTER(_P)]),
+    "pcs_genchain_synchronize": (c_int, [_P, _P]),
+    "pcs_genchain_last_kernel_ms": (c_int, [_P, POINTER(c_float), POINTER(c_float)]),
     "pcs_synchronize": (c_int, [_P, _P]),
     "pcs_last_kernel_ms": (c_int, [_P, POINTER(c_float), POINTER(c_float)]),
     "pcs_kernel_ms_mean": (c_int, [_P, POINTER(c_int64), POINTER(c_float), POINTER(c_float)]),

@@ -176,6 +176,97 @@ __global__ void normal_prologue_kernel(const double *__restrict__ prm, T *__rest
     if (t == 0) *cost = 0.0;
 }
 
+// The coalesced store phase of a 64-detection tile (VAR_TRANSPOSE): every lane holds the 2P values of its detection in J;
+// the wave streams the tile out as 16-byte units at consecutive addresses through its private LDS region `tr`.  Shared by
+// ba_eval_kernel and the generated chain kernels (ba_generic.hpp), which therefore write with the same instruction stream.
+template <int P, typename TO, bool NT>
+__device__ __forceinline__ void store_jac_tile(const T (&J)[2 * P], TO *tr, TO *jac, const int64_t tile, const int lane, const int64_t total_jac) {
+    constexpr int P2 = 2 * P;
+    constexpr int LROW = lds_row_stride(P2, (int)sizeof(TO));
+    using O2 = typename Vec2<TO>::type;
+    // Two passes of 32 detections: the active half writes its 2P values row-major into
+    // the wave-private LDS region, then all 64 lanes stream the region out in 16-byte
+    // units at consecutive addresses.  Same-wave LDS ops execute in order; the
+    // wavefront-scope fences only stop the compiler from reordering across them.
+    constexpr int VS = 16 / sizeof(TO);  // scalars per 16-byte unit
+    using V16 = __attribute__((ext_vector_type(VS))) TO;
+    constexpr int UNITS = HALF * P2 / VS;
+    static_assert((HALF * P2) % VS == 0, "half tile must be a whole number of 16-byte units");
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        if ((lane >> 5) == h) {
+            O2 *dst = reinterpret_cast<O2 *>(tr + (lane & 31) * LROW);
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+                O2 w;
+                w.x = (TO)J[2 * j];
+                w.y = (TO)J[2 * j + 1];
+                dst[j] = w;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int64_t base = (tile * TILE + h * HALF) * (int64_t)P2;  // scalar offset, multiple of VS
+        // The padded-row index maths is tile-invariant; left alone, hipcc hoists all of it out of
+        // the tile loop and the kernel grows from 164 to 244 VGPRs.  An opaque copy of the lane
+        // id keeps it inside (148 VGPRs for the self chain).
+        int lane_v = lane;
+        if constexpr (LROW != P2) asm volatile("" : "+v"(lane_v));
+        auto lds_unit = [&](const int q) {  // unit index inside the (possibly padded) LDS image
+            if constexpr (LROW != P2) {
+                static_assert(P2 % VS == 0 && LROW % VS == 0, "padded rows must hold whole 16-byte units");
+                const int row = q / (P2 / VS);
+                return row * (LROW / VS) + (q - row * (P2 / VS));
+            } else {
+                return q;
+            }
+        };
+        if (base + (int64_t)HALF * P2 <= total_jac) {
+            // whole half tile inside the array (every tile but the last): no per-unit range checks, and
+            // the LDS read of unit u + 1 is issued before unit u is stored (left alone hipcc pairs every
+            // ds_read_b128 with an s_waitcnt 0 right before its store)
+            constexpr int NU = (UNITS + 63) / 64;
+            V16 w[2];
+            w[0] = reinterpret_cast<const V16 *>(tr)[lds_unit(lane_v)];
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int qn = (u + 1) * 64 + lane_v;
+                if (u + 1 < NU) {
+                    if ((u + 2) * 64 <= UNITS || qn < UNITS) w[(u + 1) & 1] = reinterpret_cast<const V16 *>(tr)[lds_unit(qn)];
+                }
+                asm volatile("" ::: "memory");
+                const int q = u * 64 + lane_v;
+                if ((u + 1) * 64 <= UNITS || q < UNITS) {
+                    V16 *dst = reinterpret_cast<V16 *>(jac + base + (int64_t)q * VS);
+                    if constexpr (NT) __builtin_nontemporal_store(w[u & 1], dst);
+                    else *dst = w[u & 1];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int q0 = 0; q0 < UNITS; q0 += 64) {
+                const int q = q0 + lane_v;
+                if (q < UNITS) {
+                    const int64_t e = base + (int64_t)q * VS;
+                    const int lq = lds_unit(q);
+                    if (e + VS <= total_jac) {
+                        const V16 w = reinterpret_cast<const V16 *>(tr)[lq];
+                        if constexpr (NT) __builtin_nontemporal_store(w, reinterpret_cast<V16 *>(jac + e));
+                        else *reinterpret_cast<V16 *>(jac + e) = w;
+                    } else {
+                        for (int s = 0; s < VS; ++s)
+                            if (e + s < total_jac) jac[e + s] = tr[lq * VS + s];
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // K1-K4  fused residual + Jacobian
 // ---------------------------------------------------------------------------------------------
@@ -347,87 +438,7 @@ __global__ __launch_bounds__(WG_THREADS, (sizeof(TO) == 4 && (MODE & MODE_JAC) &
                     }
                 }
             } else {
-                // Two passes of 32 detections: the active half writes its 2P values row-major into
-                // the wave-private LDS region, then all 64 lanes stream the region out in 16-byte
-                // units at consecutive addresses.  Same-wave LDS ops execute in order; the
-                // wavefront-scope fences only stop the compiler from reordering across them.
-                constexpr int VS = 16 / sizeof(TO);  // scalars per 16-byte unit
-                using V16 = __attribute__((ext_vector_type(VS))) TO;
-                constexpr int UNITS = HALF * P2 / VS;
-                static_assert((HALF * P2) % VS == 0, "half tile must be a whole number of 16-byte units");
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    if ((lane >> 5) == h) {
-                        O2 *dst = reinterpret_cast<O2 *>(tr + (lane & 31) * LROW);
-#pragma unroll
-                        for (int j = 0; j < P; ++j) {
-                            O2 w;
-                            w.x = (TO)J[2 * j];
-                            w.y = (TO)J[2 * j + 1];
-                            dst[j] = w;
-                        }
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    const int64_t base = (tile * TILE + h * HALF) * (int64_t)P2;  // scalar offset, multiple of VS
-                    // The padded-row index maths is tile-invariant; left alone, hipcc hoists all of it out of
-                    // the tile loop and the kernel grows from 164 to 244 VGPRs.  An opaque copy of the lane
-                    // id keeps it inside (148 VGPRs for the self chain).
-                    int lane_v = lane;
-                    if constexpr (LROW != P2) asm volatile("" : "+v"(lane_v));
-                    auto lds_unit = [&](const int q) {  // unit index inside the (possibly padded) LDS image
-                        if constexpr (LROW != P2) {
-                            static_assert(P2 % VS == 0 && LROW % VS == 0, "padded rows must hold whole 16-byte units");
-                            const int row = q / (P2 / VS);
-                            return row * (LROW / VS) + (q - row * (P2 / VS));
-                        } else {
-                            return q;
-                        }
-                    };
-                    if (base + (int64_t)HALF * P2 <= total_jac) {
-                        // whole half tile inside the array (every tile but the last): no per-unit range checks, and
-                        // the LDS read of unit u + 1 is issued before unit u is stored (left alone hipcc pairs every
-                        // ds_read_b128 with an s_waitcnt 0 right before its store)
-                        constexpr int NU = (UNITS + 63) / 64;
-                        V16 w[2];
-                        w[0] = reinterpret_cast<const V16 *>(tr)[lds_unit(lane_v)];
-#pragma unroll
-                        for (int u = 0; u < NU; ++u) {
-                            const int qn = (u + 1) * 64 + lane_v;
-                            if (u + 1 < NU) {
-                                if ((u + 2) * 64 <= UNITS || qn < UNITS) w[(u + 1) & 1] = reinterpret_cast<const V16 *>(tr)[lds_unit(qn)];
-                            }
-                            asm volatile("" ::: "memory");
-                            const int q = u * 64 + lane_v;
-                            if ((u + 1) * 64 <= UNITS || q < UNITS) {
-                                V16 *dst = reinterpret_cast<V16 *>(jac + base + (int64_t)q * VS);
-                                if constexpr (NT) __builtin_nontemporal_store(w[u & 1], dst);
-                                else *dst = w[u & 1];
-                            }
-                        }
-                    } else {
-#pragma unroll
-                        for (int q0 = 0; q0 < UNITS; q0 += 64) {
-                            const int q = q0 + lane_v;
-                            if (q < UNITS) {
-                                const int64_t e = base + (int64_t)q * VS;
-                                const int lq = lds_unit(q);
-                                if (e + VS <= total_jac) {
-                                    const V16 w = reinterpret_cast<const V16 *>(tr)[lq];
-                                    if constexpr (NT) __builtin_nontemporal_store(w, reinterpret_cast<V16 *>(jac + e));
-                                    else *reinterpret_cast<V16 *>(jac + e) = w;
-                                } else {
-                                    for (int s = 0; s < VS; ++s)
-                                        if (e + s < total_jac) jac[e + s] = tr[lq * VS + s];
-                                }
-                            }
-                        }
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                }
+                store_jac_tile<P, TO, NT>(J, tr, jac, tile, lane, total_jac);
             }
         }
     }

@@ -138,6 +138,40 @@ __host__ __device__ __forceinline__ bool entry_kept(int m, int i, int j, int &sa
     return true;                                      // pose x pt
 }
 
+// Descriptor of accumulator register r of lane `lane` of MFMA m (see the flush of ba_normal_mfma_kernel): where the entry goes.
+//   oR | oC << 4 | row entry << 8 | column entry << 13 | ld entry << 18 | pointer entry << 23 | owned << 27 | pose << 28
+// the "entries" being lanes of the look-up table the flush refreshes per run:
+//   lanes  0- 3  8 ldA base[g]            row offset of a leading group inside A
+//   lanes  4- 7  8 ldB base[g]            row offset of a leading group inside B
+//   lane   8     8 tb tb entity           the run's trailing block inside C        lanes 9, 15: zero
+//   lanes 12-14  ldA, ldB, tb             row lengths
+//   lanes 16-19  8 (base[g] - (g == trail_group ? trail_off : 0))   column offset: leading columns keep their
+//                parameter-string index, trailing ones are local to the trailing part
+//   lanes 24-27  8 base[g]                index into g (parameter-string order)
+// (bytes except the row lengths; every entry number fits its 5-bit field).  Pointer entries: 0 A, 1 B, 2 C, 3 g, 4 cost.
+// Host-callable: tests/test_host_logic.py decodes these descriptors for sample runs and checks every owned entry against the
+// column pair pcs_normal_entry_map reports for it (pcs_normal_descriptors).
+template <int CHAIN, int PASS>
+__host__ __device__ __forceinline__ int entry_descriptor(const int m, const int lane, const int r, const int tg) {
+    constexpr bool HAS_POSE = CHAIN != CHAIN_FREE;
+    constexpr int NS = normal_shared_cols(CHAIN);
+    auto col_group = [](const int lc) -> int { return lc == NORMAL_R ? 4 : lc < 9 ? 0 : lc < 15 ? 1 : (HAS_POSE && lc < NS) ? 2 : 3; };
+    auto col_offset = [](const int lc) -> int { return lc == NORMAL_R ? 0 : lc < 9 ? lc : lc < 15 ? lc - 9 : (HAS_POSE && lc < NS) ? lc - 15 : lc - NS; };
+    int sa, sb;
+    const bool keep = entry_kept<CHAIN, PASS>(m, (lane >> 4) + 4 * r, lane & 15, sa, sb);
+    const int la = slot_col<CHAIN, PASS>(keep ? sa : 0), lb = slot_col<CHAIN, PASS>(keep ? sb : 0);
+    int gR = col_group(la), oR = col_offset(la), gC = col_group(lb), oC = col_offset(lb);
+    const bool pose = PASS == PASS_SHARED && (gR == 2 || gC == 2);
+    if (gR > gC || (gR == gC && oR > oC)) { int t = gR; gR = gC; gC = t; t = oR; oR = oC; oC = t; }   // row <= column; the residual (4) ends up as the column
+    int eRow, eCol, eLd, ePtr;
+    if (gR == 4) { oR = 0; oC = 0; eRow = 9; eCol = 9; eLd = 15; ePtr = 4; }                       // r . r -> cost
+    else if (gC == 4) { oC = oR; oR = 0; eRow = 9; eCol = 24 + gR; eLd = 15; ePtr = 3; }           // J^T r -> g
+    else if (gR == tg) { eRow = 8; eCol = 9; eLd = 14; ePtr = 2; }                                 // trailing x trailing -> C
+    else if (gC == tg) { eRow = 4 + gR; eCol = 16 + gC; eLd = 13; ePtr = 1; }                      // leading x trailing -> B
+    else { eRow = gR; eCol = 16 + gC; eLd = 12; ePtr = 0; }                                        // leading x leading -> A
+    return oR | (oC << 4) | (eRow << 8) | (eCol << 13) | (eLd << 18) | (ePtr << 23) | (keep ? 1 << 27 : 0) | (pose ? 1 << 28 : 0);
+}
+
 using d4v = __attribute__((ext_vector_type(4))) double;
 
 template <int CHAIN, int PASS, int ROWS>
@@ -180,43 +214,17 @@ __global__ __launch_bounds__(64, 2) void ba_normal_mfma_kernel(const NormalArgs 
     // across lanes (ds_bpermute) in a table the flush refreshes with v_writelane.  No selects: hipcc turned the select
     // chains of the first version into ~10 exec-mask branches per register (800 instructions and 80 branches per flush,
     // 12 us of the 92 at N = 1e6).
-    constexpr int NS = normal_shared_cols(CHAIN);
-    auto col_group = [](const int lc) -> int { return lc == NORMAL_R ? 4 : lc < 9 ? 0 : lc < 15 ? 1 : (HAS_POSE && lc < NS) ? 2 : 3; };
-    auto col_offset = [](const int lc) -> int { return lc == NORMAL_R ? 0 : lc < 9 ? lc : lc < 15 ? lc - 9 : (HAS_POSE && lc < NS) ? lc - 15 : lc - NS; };
-    // Descriptor of a register: oR | oC << 4 | row entry << 8 | column entry << 13 | ld entry << 18 | pointer entry << 23 |
-    // owned << 27 | pose << 28, the "entries" being lanes of the look-up table the flush refreshes:
-    //   lanes  0- 3  8 ldA base[g]            row offset of a leading group inside A
-    //   lanes  4- 7  8 ldB base[g]            row offset of a leading group inside B
-    //   lane   8     8 tb tb entity           the run's trailing block inside C        lane 9: zero
-    //   lanes 16-19  8 (base[g] - (g == trail_group ? trail_off : 0))   column offset: leading columns keep their
-    //                parameter-string index, trailing ones are local to the trailing part
-    //   lanes 24-27  8 base[g]                index into g (parameter-string order)
-    //   lanes 32-35  ldA, ldB, tb, 0          row lengths
-    // (everything in bytes except the row lengths; A and B are addressed with 32-bit byte offsets: the host checks the sizes)
+    // (entry_descriptor above; A and B are addressed with 32-bit byte offsets: the host checks the sizes)
     const int tg = a.trail_group;
     int ent[NM][4];
 #pragma unroll
     for (int m = 0; m < NM; ++m)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            int sa, sb;
-            const bool keep = entry_kept<CHAIN, PASS>(m, (lane >> 4) + 4 * r, lane & 15, sa, sb);
-            const int la = slot_col<CHAIN, PASS>(keep ? sa : 0), lb = slot_col<CHAIN, PASS>(keep ? sb : 0);
-            int gR = col_group(la), oR = col_offset(la), gC = col_group(lb), oC = col_offset(lb);
-            const bool pose = PASS == PASS_SHARED && (gR == 2 || gC == 2);
-            if (gR > gC || (gR == gC && oR > oC)) { int t = gR; gR = gC; gC = t; t = oR; oR = oC; oC = t; }   // row <= column; the residual (4) ends up as the column
-            int eRow, eCol, eLd, ePtr;
-            if (gR == 4) { oR = 0; oC = 0; eRow = 9; eCol = 9; eLd = 35; ePtr = 4; }                       // r . r -> cost
-            else if (gC == 4) { oC = oR; oR = 0; eRow = 9; eCol = 24 + gR; eLd = 35; ePtr = 3; }           // J^T r -> g
-            else if (gR == tg) { eRow = 8; eCol = 9; eLd = 34; ePtr = 2; }                                 // trailing x trailing -> C
-            else if (gC == tg) { eRow = 4 + gR; eCol = 16 + gC; eLd = 33; ePtr = 1; }                      // leading x trailing -> B
-            else { eRow = gR; eCol = 16 + gC; eLd = 32; ePtr = 0; }                                        // leading x leading -> A
-            ent[m][r] = oR | (oC << 4) | (eRow << 8) | (eCol << 13) | (eLd << 18) | (ePtr << 23) | (keep ? 1 << 27 : 0) | (pose ? 1 << 28 : 0);
-        }
+        for (int r = 0; r < 4; ++r) ent[m][r] = entry_descriptor<CHAIN, PASS>(m, lane, r, tg);
     // lanes 0-4: the five output pointers (A, B, C, g, cost)
     const uint64_t out_ptr = lane == 1 ? (uint64_t)a.HB : lane == 2 ? (uint64_t)a.HC : lane == 3 ? (uint64_t)a.g : lane == 4 ? (uint64_t)a.cost : (uint64_t)a.H;
     const int ptr_lo = (int)(uint32_t)out_ptr, ptr_hi = (int)(uint32_t)(out_ptr >> 32);
-    int base_tab = lane == 32 ? a.ldA : lane == 33 ? a.ldB : lane == 34 ? a.tb : 0;
+    int base_tab = lane == 12 ? a.ldA : lane == 13 ? a.ldB : lane == 14 ? a.tb : 0;
     d4v acc[NM];
 #pragma unroll
     for (int m = 0; m < NM; ++m) acc[m] = d4v{0.0, 0.0, 0.0, 0.0};

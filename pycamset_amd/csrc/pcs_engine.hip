@@ -1259,6 +1259,13 @@ static int enqueue_eval(pcs_engine *h, const double *d_prm, void *d_resid, void 
 }
 
 template <int CHAIN, int PASS>
+static void fill_descriptors(int tg, int32_t *out) {
+    for (int m = 0; m < 2; ++m)
+        for (int lane = 0; lane < 64; ++lane)
+            for (int r = 0; r < 4; ++r) out[(m * 64 + lane) * 4 + r] = m < normal_mfmas(CHAIN, PASS) ? entry_descriptor<CHAIN, PASS>(m, lane, r, tg) : 0;
+}
+
+template <int CHAIN, int PASS>
 static void fill_entry_map(int32_t *out) {
     for (int m = 0; m < 2; ++m)
         for (int lane = 0; lane < 64; ++lane)
@@ -1719,6 +1726,20 @@ int pcs_kernel_ms_samples(pcs_engine *h, int64_t capacity, float *slab_prep_ms, 
     return PCS_OK;
 }
 
+int pcs_normal_descriptors(int chain, int pass, int trail_group, int32_t *out) {
+    if (!out || chain < 0 || chain > 2 || pass < 0 || pass > 1 || (pass == PASS_CAMKEY && chain == CHAIN_TEMPLATE))
+        return fail(PCS_ERR_ARG, "pcs_normal_descriptors: bad arguments (passes 0 and 1 of ba_normal_mfma_kernel only)");
+    if (pass == PASS_SHARED) {
+        if (chain == CHAIN_TEMPLATE) fill_descriptors<CHAIN_TEMPLATE, PASS_SHARED>(trail_group, out);
+        else if (chain == CHAIN_SELF) fill_descriptors<CHAIN_SELF, PASS_SHARED>(trail_group, out);
+        else fill_descriptors<CHAIN_FREE, PASS_SHARED>(trail_group, out);
+    } else {
+        if (chain == CHAIN_SELF) fill_descriptors<CHAIN_SELF, PASS_CAMKEY>(trail_group, out);
+        else fill_descriptors<CHAIN_FREE, PASS_CAMKEY>(trail_group, out);
+    }
+    return PCS_OK;
+}
+
 int pcs_normal_entry_map(int chain, int pass, int32_t *out) {
     if (!out || chain < 0 || chain > 2 || pass < 0 || pass > 2) return fail(PCS_ERR_ARG, "pcs_normal_entry_map: bad arguments");
     if ((pass != PASS_SHARED && chain == CHAIN_TEMPLATE) || (pass == PASS_IMGKEY && chain != CHAIN_SELF))
@@ -1747,3 +1768,5 @@ int pcs_normal_entry_map(int chain, int pass, int32_t *out) {
 }
 
 }  // extern "C"
+
+#include "pcs_genchain.inc"

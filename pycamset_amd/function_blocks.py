@@ -13,9 +13,12 @@ Same names, argument meaning and return layouts as
     jac(param_str, template)  -> (data, indices, indptr)
 
 The blocks here are *declarations*: the arithmetic of every block (and the chain rule the
-reference code-generates with matmul_map.py) lives in the fused HIP kernels behind the C ABI
-(csrc/ba_device.hpp).  Only the three chains the reference's handlers build are available; any
-other combination raises, loudly — there is no interpreter fallback.
+reference code-generates with matmul_map.py) lives in the fused HIP kernels behind the C ABI.  The three
+chains the reference's handlers build run on hand-fused kernels (csrc/ba_kernels.hpp); every other valid
+composition ``projection + {rigidTform3d | extrinsic3D}* + (template_points | free_point)`` is compiled on first
+use into a fused kernel of its own (pycamset_amd/chain_compiler.py -> csrc/ba_generic.hpp, hipcc --genco) — the
+counterpart of the reference's code generator (afb:424-463, afb:492-652, mm:147-263).  Anything outside that family
+raises, loudly: there is no interpreter fallback.
 """
 from __future__ import annotations
 
@@ -134,16 +137,16 @@ class optimisation_function:  # afb:111-685
 
     @property
     def chain(self) -> str:
-        """Which fused kernel family evaluates this chain.  `a + b + c` builds intermediate
-        partial chains (afb:735-748), so the check happens on use, not on construction."""
+        """Which fused kernel evaluates this chain: 'template' / 'self' / 'free' (hand-fused) or 'generated'.
+        `a + b + c` builds intermediate partial chains (afb:735-748), so validity is checked on use, not on construction
+        (an invalid composition raises NotImplementedError from the chain compiler)."""
         kinds = tuple(type(b) for b in self.function_blocks)
-        if kinds not in _CHAINS:
-            names = " + ".join(k.__name__ for k in kinds)
-            raise NotImplementedError(
-                f"chain '{names}' has no fused HIP kernel; supported: "
-                + "; ".join(" + ".join(k.__name__ for k in c) for c in _CHAINS)
-            )
-        return _CHAINS[kinds]
+        if kinds in _CHAINS:
+            return _CHAINS[kinds]
+        from .chain_compiler import ChainSpec
+
+        ChainSpec.from_blocks(self.function_blocks)   # raises for compositions outside the compilable family
+        return "generated"
 
     # -- engine sharing between the loss and the Jacobian closures ---------------------------
     def _engine_for(self, detections: np.ndarray) -> Engine:
@@ -158,13 +161,20 @@ class optimisation_function:  # afb:111-685
                 C, I, K = _counts(det)
                 if self.counts is not None:
                     C, I, K = (max(a, b) for a, b in zip(self.counts, (C, I, K)))
-            eng = Engine(self.chain, C, I, K, dtype=self.dtype, device=self.device)
+            if self.chain == "generated":
+                if self.dtype != "f64":
+                    raise NotImplementedError("generated chains write FP64 outputs; the float engines exist for the three hand-fused chains")
+                from .chain_compiler import ChainEngine
+
+                eng = ChainEngine(self.function_blocks, C, I, K, device=self.device)
+            else:
+                eng = Engine(self.chain, C, I, K, dtype=self.dtype, device=self.device)
             eng.set_detections_table(det)
             self._engine, self._engine_key = eng, key
         return self._engine
 
     def _bind_template(self, eng: Engine, template) -> None:
-        if self.chain != "template":
+        if not self.templated:
             return
         if template is None:
             raise ValueError("the template chain needs the template points (target.point_data.reshape(-1, 3))")

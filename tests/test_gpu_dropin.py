@@ -488,6 +488,84 @@ def test_device_lm_reaches_the_scipy_solution(chain):
     assert L.shape == Jc.shape and np.max(np.abs(L @ v - Jc @ v)) <= 1e-9 * np.max(np.abs(Jc @ v))
 
 
+# ---- round 3: chains as data (pycamset_amd/chain_compiler.py + csrc/ba_generic.hpp) -------------------------------------
+@pytest.mark.parametrize("tag", ["proj_rigid_free", "proj_extr_rigid_template", "proj_template", "proj_rigid_extr_free"])
+def test_generated_chains_match_the_reference_code_generator(golden_dir, tag):
+    """Compositions that are NOT one of the handlers' three chains (make_golden.py GENERIC_CHAINS: a single camera at the origin
+    with a moving scene; two per-image transforms; a bare projection of a posed template; per-image BEFORE per-camera), evaluated
+    by the reference's own generated loss / Jacobian (afb:290-419, afb:492-652, mm:147-263).  Through the operator API: the
+    chain is compiled into a fused kernel on first use; residual, dense data, masked data and both CSR structures must match."""
+    from pycamset_amd import function_blocks as fb
+    g = np.load(golden_dir / f"generic_{tag}.npz")
+    names = [str(n) for n in g["blocks"]]
+    op = getattr(fb, names[0])()
+    for n in names[1:]:
+        op = op + getattr(fb, n)()
+    assert op.chain == "generated"
+    det, ps = g["detections"], g["param_str"]
+    tm = (g["points"],) if names[-1] == "template_points" else ()
+    slabs = [g[f"slab_{i}"] for i in range(len(names))]          # one slab per block, in block order
+    assert np.array_equal(op.build_param_list(*slabs), ps)
+    r = op.make_full_loss_fn(det, 2)(ps, *tm)
+    H.assert_resid_close(r, g["resid"].reshape(r.shape), det[:, 3:])
+    data, idx, ptr = op.make_jacobean(det, 2)(ps, *tm)
+    P = g["block_param_inds"].shape[1]
+    ref = g["data_all"].reshape(-1, P)
+    H.assert_jac_close(data.reshape(-1, P), ref)
+    assert np.array_equal(idx, g["indices_all"]) and np.array_equal(ptr, g["indptr_all"])
+    assert np.array_equal(op.get_block_param_inds(det, 1), g["block_param_inds"])
+    dm, idx, ptr = op.make_jacobean(det, 2, unfixed_params=g["unfixed"])(ps, *tm)
+    assert np.array_equal(idx, g["indices_masked"]) and np.array_equal(ptr, g["indptr_masked"])
+    keep = np.repeat(g["unfixed"][g["block_param_inds"]], 2, axis=0)
+    rows = np.broadcast_to(np.max(np.abs(ref), axis=1, keepdims=True), ref.shape)[keep]
+    assert np.max(np.abs(dm - g["data_masked"]) / np.maximum(np.abs(g["data_masked"]), H.ROW_FLOOR * rows)) <= H.JAC_RTOL
+    assert np.array_equal(dm, data.reshape(-1, P)[keep])          # the device gather moves values, it does not recompute them
+    # explicit structural entries stay stored, like the reference's CSR (mm:231, mm:237-242)
+    d = data.reshape(-1, 2, P)
+    assert np.all(d[:, 0, 1] == 1) and np.all(d[:, 1, 3] == 1) and np.all(d[:, 0, 2] == 0) and np.all(d[:, 1, 0] == 0)
+
+
+def test_generated_kernel_for_the_template_chain_against_the_hand_fused_one(capsys):
+    """The chain compiler applied to `projection + extrinsic3D + template_points` itself (bypassing the hand-fused fast path):
+    same function as ba_eval_kernel on the headline rig (N = 1e6) — values to 1e-12 of the row scale, golden parity on the
+    reference fixture — and a kernel time within 1.2 x of the hand-fused kernel's."""
+    import torch
+    from pycamset_amd import function_blocks as fb
+    from pycamset_amd.chain_compiler import ChainEngine
+    from pycamset_amd.engine import Engine
+    rig = synthetic.config_rig(3)
+    ps = orc.build_param_list(rig.intr, rig.extr, rig.poses)
+    N = rig.n_det
+    gen = ChainEngine([fb.projection(), fb.extrinsic3D(), fb.template_points()], rig.n_cams, rig.n_imgs, rig.n_keys)
+    gen.set_detections_table(rig.detections)
+    gen.set_template(rig.points)
+    hand = Engine("template", rig.n_cams, rig.n_imgs, rig.n_keys)
+    hand.set_detections_table(rig.detections)
+    hand.set_template(rig.points)
+    assert gen.n_params == hand.n_params and gen.P == hand.P
+    d_p = torch.from_numpy(ps).cuda()
+    bufs = [(torch.empty((N, 2), dtype=torch.float64, device="cuda"), torch.empty((2 * N, 21), dtype=torch.float64, device="cuda")) for _ in range(2)]
+    stream = torch.cuda.current_stream().cuda_stream
+    t_gen, t_hand = [], []
+    for _ in range(12):   # interleaved
+        gen.eval_device(d_p.data_ptr(), bufs[0][0].data_ptr(), bufs[0][1].data_ptr(), stream)
+        hand.eval_device_resident(d_p.data_ptr(), bufs[1][0].data_ptr(), bufs[1][1].data_ptr(), stream)
+        torch.cuda.synchronize()
+        t_gen.append(gen.last_kernel_ms()[1])
+        t_hand.append(hand.last_kernel_ms()[1])
+    rg, jg = bufs[0][0].cpu().numpy(), bufs[0][1].cpu().numpy()
+    rh, jh = bufs[1][0].cpu().numpy(), bufs[1][1].cpu().numpy()
+    rows = np.max(np.abs(jh), axis=1, keepdims=True)
+    assert np.max(np.abs(jg - jh) / np.maximum(np.abs(jh), H.ROW_FLOOR * rows)) <= 1e-11
+    assert np.max(np.abs(rg - rh)) <= 1e-9
+    ratio = float(np.median(t_gen[2:]) / np.median(t_hand[2:]))
+    with capsys.disabled():
+        print(f"\n[generated vs hand-fused, chain T, N = {N}] generated {np.median(t_gen[2:]) * 1e3:.1f} us, hand-fused {np.median(t_hand[2:]) * 1e3:.1f} us, ratio {ratio:.3f}")
+    assert ratio <= 1.2
+    gen.close()
+    hand.close()
+
+
 def test_free_point_chain_with_2e4_points_solves_through_the_schur_path():
     """Classic free-point bundle adjustment (fph:143) beyond the dense-H limits of round 2 (23 170 parameters in the kernel,
     8 192 before lm_solve fell back to CG): 12 cameras x 2e4 points = 60 180 parameters.  The blocked normal equations store

@@ -824,6 +824,47 @@ def test_soa_upload_engine_buffers_and_timing_options(Engine):
     e.close()
 
 
+def test_config5_jacobian_streamed_to_host(Engine):
+    """BASELINE config 5's mode ("block-sparse Jacobian streamed to host"): pycamset_amd.host_stream.JacobianHostStreamer, the
+    class behind bench.py --stream-to-host.  Three consecutive steps with three different parameter strings, TWO device
+    buffers and THREE page-locked host buffers, no host synchronisation in between: every host buffer must hold exactly
+    the Jacobian of its own step — in particular the first one, whose device buffer the third step reuses while copy 1
+    (~1 ms) may still be reading it: the step has to wait for that copy (`free` event), not overwrite it."""
+    import torch
+    from pycamset_amd.host_stream import JacobianHostStreamer
+    rig = synthetic.config_rig(5, scale=0.02)
+    assert rig.n_det > 1e5
+    e = make_engine(Engine, rig, "template", dtype="f32")
+    ps = orc.build_param_list(rig.intr, rig.extr, rig.poses)
+    rng = np.random.default_rng(8)
+    strings = [ps * (1.0 + 1e-3 * rng.standard_normal(ps.shape[0])) for _ in range(3)]
+    d_ps = [torch.from_numpy(p).cuda() for p in strings]
+    N = rig.n_det
+    d_r = torch.empty((N, 2), dtype=torch.float32, device="cuda")
+    # reference Jacobians, one at a time, each into its own device buffer
+    refs = []
+    for dp in d_ps:
+        dj = torch.empty((2 * N, e.P), dtype=torch.float32, device="cuda")
+        e.eval_device_resident(dp.data_ptr(), d_r.data_ptr(), dj.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        refs.append(dj.cpu().numpy())
+    assert not np.array_equal(refs[0], refs[1]) and not np.array_equal(refs[0], refs[2])
+    st = JacobianHostStreamer(e, N, n_device_buffers=2, n_host_buffers=3)
+    for h in st.host:
+        h.fill_(-7.0)
+    slots = [st.step(dp.data_ptr(), d_r.data_ptr()) for dp in d_ps]          # queued back to back
+    assert slots == [0, 1, 2]
+    for k, ref in zip(slots, refs):
+        got = st.wait(k).numpy()
+        assert np.array_equal(got, ref), f"host buffer {k} does not hold its step's Jacobian"
+    # a second round through the same ring: host buffers are reused once their consumer is done with them
+    slots2 = [st.step(dp.data_ptr(), d_r.data_ptr()) for dp in reversed(d_ps)]
+    for k, ref in zip(slots2, reversed(refs)):
+        assert np.array_equal(st.wait(k).numpy(), ref)
+    torch.cuda.synchronize()
+    e.close()
+
+
 @pytest.mark.parametrize("dtype", ["f32", "mixed"])
 def test_config5_at_full_size(Engine, dtype):
     """BASELINE config 5 at its stated size (128 cameras x 500 poses x 486 keys, ~1e7 detections, FP32 bytes) — outputs stay

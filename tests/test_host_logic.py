@@ -228,10 +228,48 @@ def test_return_flattened_keys_matches_row_major_reshape():
 
 
 def test_unsupported_chain_raises():
+    """Compositions outside `projection + {rigidTform3d | extrinsic3D}* + (template_points | free_point)` have no kernel and
+    no interpreter: they raise when used (a + b + c builds partial chains first, afb:735-748, so not at construction)."""
     from pycamset_amd import function_blocks as fb
-    op = fb.projection() + fb.rigidTform3d()
-    with pytest.raises(NotImplementedError):
-        op.make_full_loss_fn(np.zeros((1, 5)), 1)
+    for op in (fb.projection() + fb.rigidTform3d(),                                   # no point source
+               fb.rigidTform3d() + fb.free_point(),                                   # no projection
+               fb.projection() + fb.free_point() + fb.rigidTform3d(),                 # source not last
+               fb.projection() + fb.projection() + fb.free_point()):                  # a 3 -> 2 block in the middle
+        with pytest.raises(NotImplementedError):
+            op.make_full_loss_fn(np.zeros((1, 5)), 1)
+    assert (fb.projection() + fb.extrinsic3D() + fb.template_points()).chain == "template"
+    assert (fb.projection() + fb.rigidTform3d() + fb.free_point()).chain == "generated"
+
+
+@pytest.mark.parametrize("tag", ["proj_rigid_free", "proj_extr_rigid_template", "proj_template", "proj_rigid_extr_free"])
+def test_chain_compiler_layout_and_structure_match_the_reference_generator(golden_dir, tag):
+    """Chains that are NOT one of the handlers' three, run through the reference's own code generator (make_golden.py
+    generic_block_level): the parameter-string layout (make_param_struct, afb:777-820), get_block_param_inds (afb:192-233)
+    and the CSR structure (afb:465-489) of pycamset_amd.chain_compiler must reproduce them bit for bit — integer work, no GPU.
+    The emitted translation unit must also compile for gfx950 (hipcc cross-compiles here)."""
+    from pycamset_amd import function_blocks as fb
+    from pycamset_amd import chain_compiler as cc
+    g = np.load(golden_dir / f"generic_{tag}.npz")
+    names = [str(n) for n in g["blocks"]]
+    spec = cc.ChainSpec.from_blocks([getattr(fb, n)() for n in names])
+    det = g["detections"]
+    C, I, K = (int(det[:, j].max()) + 1 for j in range(3))
+    lay = spec.layout(C, I, K)
+    assert lay["n_params"] == g["param_str"].shape[0]
+    cols = cc.block_param_inds(spec, lay, det[:, :3].astype(np.int64))
+    assert cols.shape[1] == spec.P and np.array_equal(cols, g["block_param_inds"])
+    idx, ptr, _ = cc.csr_structure_of(cols, lay["n_params"], None)
+    assert np.array_equal(idx, g["indices_all"]) and np.array_equal(ptr, g["indptr_all"])
+    idx, ptr, src = cc.csr_structure_of(cols, lay["n_params"], g["unfixed"])
+    assert np.array_equal(idx, g["indices_masked"]) and np.array_equal(ptr, g["indptr_masked"])
+    assert np.array_equal(g["data_all"][src], g["data_masked"])      # the gather list IS data[:n][good_mask] (afb:644-651)
+    src_text = cc.emit_source(spec)
+    assert f"M = {len(names) - 2}" in src_text and "PCS_GENCHAIN_ENTRY_POINTS" in src_text
+    obj = cc.compile_chain(spec)
+    assert obj.exists() and obj.stat().st_size > 10_000
+    # blocks of one class share ONE parameter group, like the reference's object-identity rule (afb:160-163)
+    twice = cc.ChainSpec.from_blocks([fb.projection(), fb.rigidTform3d(), fb.rigidTform3d(), fb.free_point()])
+    assert twice.n_rigid_groups == 1 and twice.block_group == (0, 0) and twice.layout(2, 3, 4)["n_params"] == 18 + 18 + 12
 
 
 def test_initial_params_must_be_supplied():
@@ -418,3 +456,89 @@ def test_normal_equation_entry_maps_own_every_pair_exactly_once():
         assert sorted(pairs) == upper([18, 19, 20])
     for chain, p in (("template", 1), ("template", 2), ("free", 2)):
         assert lib.pcs_normal_entry_map(_capi.CHAIN_IDS[chain], p, np.zeros(1024, np.int32).ctypes.data_as(POINTER(c_int32))) == _capi.PCS_ERR_ARG
+
+
+def test_normal_equation_flush_descriptors_address_the_right_entries():
+    """Round 3: the flush of ba_normal_mfma_kernel finds every destination from a packed per-register descriptor and a
+    64-lane table it refreshes per run (entry_descriptor, csrc/ba_normal.hpp) — for the dense layout and for the blocked
+    one ([A | B | C]: leading x leading, leading x trailing, block-diagonal trailing group).  Both are host functions here:
+    the test rebuilds the table for sample runs, decodes the descriptors exactly like the kernel does (two row / column
+    look-ups, the row length, the pointer entry) and checks every owned register against the column pair
+    pcs_normal_entry_map reports for it — inside its region, at the right offset."""
+    from ctypes import POINTER, c_int32
+    from pycamset_amd import _capi
+    lib = _capi.lib()
+    R = 30
+    C, I, K = 5, 7, 11
+    for chain in ("template", "self", "free"):
+        has_pose = chain != "free"
+        n_shared = 21 if has_pose else 15
+        extr_off, pose_off = 9 * C, 15 * C
+        point_off = 15 * C + 6 * I if chain == "self" else 15 * C
+        n_params = 15 * C + (6 * I if has_pose else 0) + (0 if chain == "template" else 3 * K)
+        for p in ((0,) if chain == "template" else (0, 1)):
+            emap = np.full((2, 64, 4, 2), -7, dtype=np.int32)
+            _capi.check(lib.pcs_normal_entry_map(_capi.CHAIN_IDS[chain], p, emap.ctypes.data_as(POINTER(c_int32))))
+            for blocked in (False, True):
+                tg = (2 if chain == "template" else 3) if blocked else -1
+                trail_off = (pose_off if chain == "template" else point_off) if blocked else 0
+                tb = (6 if chain == "template" else 3) if blocked else 0
+                n_lead = trail_off if blocked else n_params
+                n_trail = n_params - n_lead
+                ldA, ldB = n_lead, n_trail
+                desc = np.zeros((2, 64, 4), dtype=np.int32)
+                _capi.check(lib.pcs_normal_descriptors(_capi.CHAIN_IDS[chain], p, tg, desc.ctypes.data_as(POINTER(c_int32))))
+                for cam, img, key in ((0, 0, 0), (C - 1, I - 1, K - 1), (2, 3, 4)):
+                    base = [9 * cam, extr_off + 6 * cam, pose_off + 6 * img, point_off + 3 * key]
+                    tab = np.zeros(64, dtype=np.int64)
+                    tab[12], tab[13], tab[14] = ldA, ldB, tb
+                    for g in range(4):
+                        tab[g] = 8 * ldA * base[g]
+                        tab[4 + g] = 8 * ldB * base[g]
+                        tab[16 + g] = 8 * (base[g] - (trail_off if g == tg else 0))
+                        tab[24 + g] = 8 * base[g]
+                    tab[8] = 8 * tb * tb * (img if tg == 2 else key)
+
+                    def glob(lc):
+                        if lc < 9:
+                            return base[0] + lc
+                        if lc < 15:
+                            return base[1] + lc - 9
+                        if has_pose and lc < n_shared:
+                            return base[2] + lc - 15
+                        return base[3] + lc - n_shared
+
+                    seen = set()
+                    for m in range(2):
+                        for lane in range(64):
+                            for r in range(4):
+                                la, lb = (int(v) for v in emap[m, lane, r])
+                                d = int(desc[m, lane, r])
+                                assert ((d >> 27) & 1) == (la >= 0)
+                                if la < 0:
+                                    continue
+                                o_r, o_c = d & 15, (d >> 4) & 15
+                                e_row, e_col, e_ld, e_ptr = (d >> 8) & 31, (d >> 13) & 31, (d >> 18) & 31, (d >> 23) & 7
+                                off = (tab[e_row] + tab[e_col]) // 8 + o_r * tab[e_ld] + o_c
+                                if la == R and lb == R:
+                                    want = (4, 0)
+                                elif R in (la, lb):
+                                    want = (3, glob(lb if la == R else la))
+                                else:
+                                    ga, gb = sorted((glob(la), glob(lb)))
+                                    if gb < n_lead:
+                                        want = (0, ga * ldA + gb)
+                                    elif ga < n_lead:
+                                        want = (1, ga * ldB + gb - n_lead)
+                                    else:
+                                        e = (ga - n_lead) // tb
+                                        assert (gb - n_lead) // tb == e
+                                        want = (2, e * tb * tb + ((ga - n_lead) % tb) * tb + (gb - n_lead) % tb)
+                                assert (e_ptr, off) == want, (chain, p, blocked, (cam, img, key), m, lane, r, (la, lb), (e_ptr, off), want)
+                                limit = [n_lead * n_lead, n_lead * n_trail, (n_trail // tb) * tb * tb if tb else 0, n_params, 1][e_ptr]
+                                assert 0 <= off < limit
+                                assert (e_ptr, off) not in seen
+                                seen.add((e_ptr, off))
+                                # entries that involve a pose column are the ones flushed when only the image changes
+                                if p == 0:
+                                    assert ((d >> 28) & 1) == int(has_pose and any(15 <= x < n_shared for x in (la, lb)))
