@@ -201,6 +201,15 @@ int pcs_schur_prepare(pcs_engine *h, double *d_packed, const uint8_t *d_fixed, c
 int pcs_schur_finish(pcs_engine *h, const double *d_linvt, const double *d_u, const double *d_w, const double *d_xlead, const uint8_t *d_fixed,
                      double *d_delta, void *stream);
 
+/* S x = rhs for a dense symmetric positive definite S (float64, n x n row-major with row stride ld, LOWER triangle read and
+ * overwritten by its Cholesky factor): the reduced system of the Schur step above.  Blocked right-looking factorisation (32 x 32
+ * tiles, two launches per block column) + both substitutions in one workgroup (csrc/ba_dense_chol.hpp) — at n = 480 / 1 680
+ * several times faster than rocSOLVER's potrf + potrs, whose dependent chain is what an LM iteration waits for.  All pointers are
+ * device memory; d_work holds pcs_dense_spd_work_len(n) doubles; *d_status |= 2 when a pivot is not positive; queued on `stream`
+ * (NULL = the default stream), n <= 32768. */
+int64_t pcs_dense_spd_work_len(int64_t n);
+int pcs_dense_spd_solve(int device, int64_t n, double *d_S, int64_t ld, const double *d_rhs, double *d_x, double *d_work, int32_t *d_status, void *stream);
+
 /* Which entry of H / g / cost every accumulator register of the normal-equations kernel stands for (host function, no
  * GPU needed): out[m][lane][r][2], m < 2 MFMAs, lane < 64, r < 4 registers = the two local column ids (index into
  * a J row, 30 = the residual column) of D_m[(lane >> 4) + 4 r][lane & 15], or -1, -1 where the register is not owned.

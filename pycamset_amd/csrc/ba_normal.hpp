@@ -327,10 +327,12 @@ __global__ __launch_bounds__(64, 2) void ba_normal_mfma_kernel(const NormalArgs 
         asm volatile("" ::: "memory");   // keep the requests up here
         T u, v;
         T J[P2];
-        if (a.debug & 16) {   // profiling: no evaluation
+        if (a.debug & 16) {   // profiling: no evaluation.  The stand-in values hang on THIS tile's measurement: loop-invariant ones
+            // ((double)(lane + j), round 2) were hoisted out of the tile loop by hipcc and kept 84 VGPRs alive across it —
+            // the reason the kernel sat at 255 VGPRs + scratch
             u = m.x; v = m.y;
 #pragma unroll
-            for (int j = 0; j < P2; ++j) J[j] = (double)(lane + j);
+            for (int j = 0; j < P2; ++j) J[j] = m.x + (double)j;
         } else {
             // Slabs: when the whole tile refers to one camera (image) its slab is fetched with ONE coalesced load and read
             // through v_readlane (LaneSlab) instead of 48 (39) per-lane loads of the same address — with one-wave
@@ -550,7 +552,7 @@ __global__ __launch_bounds__(64, 3) void ba_normal_imgkey_kernel(const NormalArg
         const LaneSlab lp{pose_slab[im0 * POSE_STRIDE + min(lane, POSE_STRIDE - 1)]};
         if (a.debug & 16) {
 #pragma unroll
-            for (int j = 0; j < 3; ++j) { Su[j] = (double)(lane + j); Sv[j] = (double)(lane - j); }
+            for (int j = 0; j < 3; ++j) { Su[j] = X0 + (double)j; Sv[j] = X1 - (double)j; }
         } else {
             T u, v;
             T J[P2];

@@ -27,6 +27,7 @@
 #include "ba_matfree.hpp"
 #include "ba_normal.hpp"
 #include "ba_schur.hpp"
+#include "ba_dense_chol.hpp"
 #include "ba_triangulate.hpp"
 
 // ---------------------------------------------------------------------------------------------
@@ -1648,6 +1649,31 @@ int pcs_schur_finish(pcs_engine *h, const double *d_linvt, const double *d_u, co
     const dim3 grid((unsigned)((n + 255) / 256));
     if (L.tb == 6) hipLaunchKernelGGL(schur_back_kernel<6>, grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(schur_back_kernel<3>, grid, dim3(256), 0, s, a);
+    HIPCHK(hipGetLastError());
+    return PCS_OK;
+}
+
+int64_t pcs_dense_spd_work_len(int64_t n) { return n > 0 ? ((n + 31) / 32) * 32 * 32 : -1; }
+
+int pcs_dense_spd_solve(int device, int64_t n, double *d_S, int64_t ld, const double *d_rhs, double *d_x, double *d_work, int32_t *d_status, void *stream) {
+    constexpr int NB = 32;
+    if (n <= 0 || n > (1 << 15) || ld < n || !d_S || !d_rhs || !d_x || !d_work || !d_status) return fail(PCS_ERR_ARG, "pcs_dense_spd_solve: bad arguments");
+    if (device < 0 || device >= pcs_device_count()) return fail(PCS_ERR_NODEVICE, "pcs_dense_spd_solve: device %d not available", device);
+    HIPCHK(hipSetDevice(device));
+    hipStream_t s = (hipStream_t)stream;   // NULL = the default stream
+    const int nblk = (int)((n + NB - 1) / NB);
+    CholArgs a{d_S, d_work, d_status, (int32_t)n, (int32_t)ld, 0};
+    for (int k = 0; k < nblk; ++k) {
+        a.k = k;
+        hipLaunchKernelGGL(chol_panel_kernel<NB>, dim3((unsigned)(nblk - k)), dim3(256), 0, s, a);
+        const int m = nblk - k - 1;
+        if (m > 0) hipLaunchKernelGGL(chol_update_kernel<NB>, dim3((unsigned)(m * (m + 1) / 2)), dim3(256), 0, s, a);
+    }
+    HIPCHK(hipGetLastError());
+    const size_t lds = sizeof(double) * ((size_t)nblk * NB + 1024);
+    if (lds > 48 * 1024) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(chol_solve_kernel<NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CholSolveArgs b{d_S, d_work, d_rhs, d_x, (int32_t)n, (int32_t)ld};
+    hipLaunchKernelGGL(chol_solve_kernel<NB>, dim3(1), dim3(1024), lds, s, b);
     HIPCHK(hipGetLastError());
     return PCS_OK;
 }

@@ -351,5 +351,16 @@ class Engine:
         return out
 
 
+def dense_spd_solve(device: int, n: int, d_S: int, ld: int, d_rhs: int, d_x: int, d_work: int, d_status: int, stream: int | None = None):
+    """S x = rhs on the device (csrc/ba_dense_chol.hpp; raw float64 device addresses, the lower triangle of S becomes its
+    Cholesky factor).  ``d_work``: ``dense_spd_work_len(n)`` doubles.  ``stream=None`` queues on the default stream."""
+    s = c_void_p(0) if stream is None else _stream_arg(stream)
+    check(lib().pcs_dense_spd_solve(int(device), int(n), c_void_p(d_S), int(ld), c_void_p(d_rhs), c_void_p(d_x), c_void_p(d_work), c_void_p(d_status), s))
+
+
+def dense_spd_work_len(n: int) -> int:
+    return int(lib().pcs_dense_spd_work_len(int(n)))
+
+
 def device_count() -> int:
     return int(lib().pcs_device_count())

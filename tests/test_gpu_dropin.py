@@ -566,6 +566,40 @@ def test_generated_kernel_for_the_template_chain_against_the_hand_fused_one(caps
     hand.close()
 
 
+@pytest.mark.parametrize("n", [1, 31, 32, 33, 97, 480, 1003])
+def test_dense_spd_solve_against_numpy(n):
+    """csrc/ba_dense_chol.hpp (the reduced system of the Schur step): blocked Cholesky + both substitutions on the device
+    against numpy.linalg.solve, ragged sizes included; only the lower triangle may be read; a non-positive pivot is flagged."""
+    import torch
+    from pycamset_amd.engine import dense_spd_solve, dense_spd_work_len
+    rng = np.random.default_rng(n)
+    G = rng.standard_normal((n, n + 5))
+    S = G @ G.T + 1e-3 * np.eye(n)
+    S *= np.outer(10.0 ** rng.uniform(-2, 2, n), np.ones(n))          # badly scaled rows ...
+    S = 0.5 * (S + S.T) + np.diag(np.abs(S).sum(axis=1))                  # ... kept positive definite by diagonal dominance
+    rhs = rng.standard_normal(n)
+    x_ref = np.linalg.solve(S, rhs)
+    dS = torch.from_numpy(np.tril(S) + np.triu(np.full((n, n), np.nan), 1)).cuda()     # the upper triangle must not be touched
+    d_rhs, d_x = torch.from_numpy(rhs).cuda(), torch.empty(n, dtype=torch.float64, device="cuda")
+    work = torch.empty(dense_spd_work_len(n), dtype=torch.float64, device="cuda")
+    status = torch.zeros(1, dtype=torch.int32, device="cuda")
+    dense_spd_solve(0, n, dS.data_ptr(), n, d_rhs.data_ptr(), d_x.data_ptr(), work.data_ptr(), status.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert int(status.item()) == 0
+    x = d_x.cpu().numpy()
+    assert np.max(np.abs(x - x_ref)) <= 1e-9 * np.max(np.abs(x_ref)), np.max(np.abs(x - x_ref)) / np.max(np.abs(x_ref))
+    L = np.tril(dS.cpu().numpy())
+    assert np.max(np.abs(L @ L.T - S)) <= 1e-11 * np.max(np.abs(S))
+    assert np.all(np.isnan(dS.cpu().numpy()[np.triu_indices(n, 1)]))
+    if n > 1:   # an indefinite matrix: flagged, never an exception or a hang
+        bad = S.copy()
+        bad[n // 2, n // 2] = -1.0
+        dB = torch.from_numpy(bad).cuda()
+        dense_spd_solve(0, n, dB.data_ptr(), n, d_rhs.data_ptr(), d_x.data_ptr(), work.data_ptr(), status.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert int(status.item()) & 2
+
+
 def test_free_point_chain_with_2e4_points_solves_through_the_schur_path():
     """Classic free-point bundle adjustment (fph:143) beyond the dense-H limits of round 2 (23 170 parameters in the kernel,
     8 192 before lm_solve fell back to CG): 12 cameras x 2e4 points = 60 180 parameters.  The blocked normal equations store

@@ -21,7 +21,7 @@ dbgs = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0]
 for dbg in dbgs:
   e.set_option("normal_debug", dbg)
   print("normal_debug", dbg)
-  for rows in (64,):
+  for rows in ([int(x) for x in sys.argv[4].split(",")] if len(sys.argv) > 4 else (64,)):
     for wpc in [int(x) for x in (sys.argv[3].split(',') if len(sys.argv) > 3 else ['7', '14'])]:
         e.set_option("normal_rows", rows); e.set_option("wgs_per_cu", wpc)
         ks = []
