@@ -195,11 +195,18 @@ int pcs_normal_blocks_device(pcs_engine *h, const double *d_param_str, double *d
  *                      rows / columns and a zero gradient (B is masked in place).  *d_status |= 1 when a trailing block is
  *                      not positive definite.  The caller then forms S -= V V', rhs += V u, solves S x_l = rhs (library
  *                      GEMM / Cholesky) and w = V' x_l, and
- *   pcs_schur_finish   writes the step in parameter-string order: d_delta (n_params) = [x_l | -L^-T (u + w)], 0 where fixed. */
+ *   pcs_schur_finish   writes the step in parameter-string order: d_delta (n_params) = [x_l | -L^-T (u + w)], 0 where fixed; with
+ *                      d_ps_in / d_ps_out (both or neither) also the trial parameter string d_ps_out = d_ps_in + d_delta.
+ *   pcs_lm_decide      the accept / reject decision of the trial on the device: predicted reduction 0.5 (lambda d'D d - g'd), actual
+ *                      reduction 0.5 (cost_old - cost_new), gain ratio, *d_lambda <- the next damping (x 1/3 | 1 | 2 by the ratio, x 4
+ *                      on a rejected or failed step), *d_status <- 0, and d_stats[8] = {accepted, max |g|, relative cost drop, |step|,
+ *                      |x| over the free parameters, new sum r^2, old sum r^2, lambda used} — the one vector the host reads per trial. */
 int pcs_schur_prepare(pcs_engine *h, double *d_packed, const uint8_t *d_fixed, const double *d_lambda, double *d_linvt, double *d_u,
                       double *d_V, double *d_S, double *d_rhs, double *d_dvec, double *d_gm, int32_t *d_status, void *stream);
 int pcs_schur_finish(pcs_engine *h, const double *d_linvt, const double *d_u, const double *d_w, const double *d_xlead, const uint8_t *d_fixed,
-                     double *d_delta, void *stream);
+                     double *d_delta, const double *d_ps_in, double *d_ps_out, void *stream);
+int pcs_lm_decide(pcs_engine *h, const double *d_cost_old, const double *d_cost_new, const double *d_dvec, const double *d_gm, const double *d_delta,
+                  const double *d_ps, const uint8_t *d_fixed, int32_t *d_status, double *d_lambda, double *d_stats, void *stream);
 
 /* S x = rhs for a dense symmetric positive definite S (float64, n x n row-major with row stride ld, LOWER triangle read and
  * overwritten by its Cholesky factor): the reduced system of the Schur step above.  Blocked right-looking factorisation (32 x 32

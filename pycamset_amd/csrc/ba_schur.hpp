@@ -168,13 +168,19 @@ struct SchurBackArgs {
     const double *linvt, *u, *w, *xl;   // w = V' x_l (n_trail)
     const uint8_t *fixed;
     double *delta;                      // n_params, parameter-string order
+    const double *ps_in;                // optional: the current parameter string ...
+    double *ps_out;                     // ... and where the trial string ps_in + delta goes
     int64_t n_lead, n_ent, trail_off;
 };
 
 template <int TB>
 __global__ __launch_bounds__(256) void schur_back_kernel(const SchurBackArgs a) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < a.n_lead) a.delta[t] = a.fixed[t] ? 0.0 : a.xl[t];
+    if (t < a.n_lead) {
+        const double d = a.fixed[t] ? 0.0 : a.xl[t];
+        a.delta[t] = d;
+        if (a.ps_out) a.ps_out[t] = a.ps_in[t] + d;
+    }
     if (t >= a.n_ent) return;
     const double *Lt = a.linvt + t * TB * TB;
     double s[TB];
@@ -186,7 +192,76 @@ __global__ __launch_bounds__(256) void schur_back_kernel(const SchurBackArgs a) 
 #pragma unroll
         for (int j = i; j < TB; ++j) x += Lt[i * TB + j] * s[j];
         const int64_t col = a.trail_off + t * TB + i;
-        a.delta[col] = a.fixed[col] ? 0.0 : -x;
+        const double d = a.fixed[col] ? 0.0 : -x;
+        a.delta[col] = d;
+        if (a.ps_out) a.ps_out[col] = a.ps_in[col] + d;
+    }
+}
+
+// The accept / reject decision of one LM trial, on the device (one workgroup): predicted reduction of the damped model,
+// actual reduction, gain ratio, the next damping parameter (Nielsen-free classic schedule: x 1/3 above 0.75, x 1 above 0.25,
+// x 2 below, x 4 on a rejected or failed step — device_solver.lm_solve's host rule), and the eight numbers the host reads to
+// steer the loop.  Nothing else of an iteration ever reaches the host.
+struct LmDecideArgs {
+    const double *cost_old, *cost_new;     // sum r^2 of the current state and of the trial state
+    const double *dvec, *gm, *delta, *ps;  // n_params each: damping diagonal, masked gradient, step, CURRENT parameter string
+    const uint8_t *fixed;
+    int32_t *status;                        // != 0: the step is invalid (a factorisation failed); cleared here for the next solve
+    double *lambda;                         // in: the damping the step was computed with; out: the next one
+    double *stats;                          // out[8]: accepted, max |g|, relative cost drop, |step|, |x|, new sum r^2, old sum r^2, lambda used
+    int64_t n_params;
+};
+
+__global__ __launch_bounds__(1024) void lm_decide_kernel(const LmDecideArgs a) {
+    __shared__ double red[4][1024];
+    const int tid = threadIdx.x;
+    double gd = 0.0, dd = 0.0, gmax = 0.0, xx = 0.0, ss = 0.0;
+    for (int64_t i = tid; i < a.n_params; i += 1024) {
+        const double d = a.delta[i], g = a.gm[i];
+        gd += g * d;
+        dd += a.dvec[i] * d * d;
+        gmax = fmax(gmax, fabs(g));
+        ss += d * d;
+        if (!a.fixed[i]) xx += a.ps[i] * a.ps[i];
+    }
+    // five reductions through LDS (sum, sum, max, sum, sum): four arrays, the fifth reuses the first after a barrier
+    red[0][tid] = gd; red[1][tid] = dd; red[2][tid] = gmax; red[3][tid] = xx;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if (tid < s) {
+            red[0][tid] += red[0][tid + s];
+            red[1][tid] += red[1][tid + s];
+            red[2][tid] = fmax(red[2][tid], red[2][tid + s]);
+            red[3][tid] += red[3][tid + s];
+        }
+        __syncthreads();
+    }
+    const double s_gd = red[0][0], s_dd = red[1][0], s_gmax = red[2][0], s_xx = red[3][0];
+    __syncthreads();
+    red[0][tid] = ss;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if (tid < s) red[0][tid] += red[0][tid + s];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const double lam = *a.lambda, c_old = *a.cost_old, c_new = *a.cost_new;
+        const double pred = 0.5 * (lam * s_dd - s_gd);
+        const double actual = 0.5 * (c_old - c_new);
+        const bool ok = *a.status == 0 && pred == pred && fabs(pred) < 1.0e300;
+        const double rho = pred > 0.0 ? actual / pred : -1.0;
+        const bool acc = ok && c_new == c_new && fabs(c_new) < 1.0e300 && actual > 0.0;
+        const double factor = rho > 0.75 ? 1.0 / 3.0 : rho > 0.25 ? 1.0 : 2.0;
+        *a.lambda = acc ? fmax(lam * factor, 1e-12) : lam * 4.0;
+        *a.status = 0;
+        a.stats[0] = acc ? 1.0 : 0.0;
+        a.stats[1] = s_gmax;
+        a.stats[2] = actual / (0.5 * c_old);
+        a.stats[3] = sqrt(red[0][0]);
+        a.stats[4] = sqrt(s_xx);
+        a.stats[5] = c_new;
+        a.stats[6] = c_old;
+        a.stats[7] = lam;
     }
 }
 

@@ -1636,14 +1636,28 @@ int pcs_schur_prepare(pcs_engine *h, double *d_packed, const uint8_t *d_fixed, c
     return PCS_OK;
 }
 
+int pcs_lm_decide(pcs_engine *h, const double *d_cost_old, const double *d_cost_new, const double *d_dvec, const double *d_gm, const double *d_delta,
+                  const double *d_ps, const uint8_t *d_fixed, int32_t *d_status, double *d_lambda, double *d_stats, void *stream) {
+    if (!h || !d_cost_old || !d_cost_new || !d_dvec || !d_gm || !d_delta || !d_ps || !d_fixed || !d_status || !d_lambda || !d_stats)
+        return fail(PCS_ERR_ARG, "pcs_lm_decide: bad arguments");
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    LmDecideArgs a{d_cost_old, d_cost_new, d_dvec, d_gm, d_delta, d_ps, d_fixed, d_status, d_lambda, d_stats, h->n_params};
+    hipLaunchKernelGGL(lm_decide_kernel, dim3(1), dim3(1024), 0, s, a);
+    HIPCHK(hipGetLastError());
+    return PCS_OK;
+}
+
 int pcs_schur_finish(pcs_engine *h, const double *d_linvt, const double *d_u, const double *d_w, const double *d_xlead, const uint8_t *d_fixed,
-                     double *d_delta, void *stream) {
-    if (!h || !d_linvt || !d_u || !d_w || !d_xlead || !d_fixed || !d_delta) return fail(PCS_ERR_ARG, "pcs_schur_finish: bad arguments");
+                     double *d_delta, const double *d_ps_in, double *d_ps_out, void *stream) {
+    if (!h || !d_linvt || !d_u || !d_w || !d_xlead || !d_fixed || !d_delta || ((d_ps_in == nullptr) != (d_ps_out == nullptr)))
+        return fail(PCS_ERR_ARG, "pcs_schur_finish: bad arguments");
     HIPCHK(hipSetDevice(h->device));
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
     const BlockLayout L = block_layout(h);
     SchurBackArgs a{};
     a.linvt = d_linvt; a.u = d_u; a.w = d_w; a.xl = d_xlead; a.fixed = d_fixed; a.delta = d_delta;
+    a.ps_in = d_ps_in; a.ps_out = d_ps_out;
     a.n_lead = L.n_lead; a.n_ent = L.n_ent; a.trail_off = L.trail_off;
     const int64_t n = std::max(L.n_lead, L.n_ent);
     const dim3 grid((unsigned)((n + 255) / 256));

@@ -244,12 +244,12 @@ class BlockedNormalEquations:
             else:
                 buf.copy_(torch.from_numpy(self.reduce_fn(buf.cpu().numpy())))
 
-    def solve(self, slot: int, lam):
-        """(delta (n_params, parameter-string order, 0 where fixed), predicted reduction, ok) of
-        (H + lam diag(H)) delta = -g for the state in packed[slot]; tensors on the device, nothing is read back."""
+    def solve(self, slot: int, lam, ps=None, ps_out=None):
+        """Enqueue the damped step (H + lam diag(H)) delta = -g for the state in packed[slot]: ``self.delta`` (n_params,
+        parameter-string order, 0 where fixed) and — given the current parameter string ``ps`` — the trial string
+        ``ps_out = ps + delta``.  Device work only; ``self.status`` becomes non-zero when a factorisation fails."""
         torch = self.torch
         stream = torch.cuda.current_stream(self.dev).cuda_stream
-        self.status.zero_()
         self.eng.schur_prepare(self.packed[slot].data_ptr(), self.fixed.data_ptr(), lam.data_ptr(), self.linvt.data_ptr(), self.u.data_ptr(),
                                self.V.data_ptr(), self.S.data_ptr(), self.rhs.data_ptr(), self.dvec.data_ptr(), self.gm.data_ptr(),
                                self.status.data_ptr(), stream)
@@ -263,27 +263,39 @@ class BlockedNormalEquations:
             xl = self.xl
             dense_spd_solve(self.eng.device, self.n_lead, self.S.data_ptr(), self.n_lead, self.rhs.data_ptr(), xl.data_ptr(),
                             self.chol_work.data_ptr(), self.status.data_ptr(), stream)
-            info_ok = True
         else:
             L, info = torch.linalg.cholesky_ex(self.S)   # rocSOLVER; `info` stays on the device
             xl = torch.cholesky_solve(self.rhs.unsqueeze(1), L).squeeze(1)
-            info_ok = info == 0
+            self.status.bitwise_or_((info != 0).to(torch.int32) * 2)
         w = torch.mv(self.V[:, : self.n_trail].T, xl) if self.n_trail else self.u
-        self.eng.schur_finish(self.linvt.data_ptr(), self.u.data_ptr(), w.data_ptr(), xl.data_ptr(), self.fixed.data_ptr(),
-                              self.delta.data_ptr(), stream)
+        self.eng.schur_finish(self.linvt.data_ptr(), self.u.data_ptr(), w.data_ptr(), xl.data_ptr(), self.fixed.data_ptr(), self.delta.data_ptr(),
+                              ps.data_ptr() if ps is not None else 0, ps_out.data_ptr() if ps is not None else 0, stream)
+        return self.delta
+
+    def decide(self, cur: int, new: int, ps, lam, stats):
+        """The accept / reject decision of the trial state packed[new] against packed[cur] on the device (pcs_lm_decide):
+        updates ``lam`` in place, clears ``status`` and fills ``stats`` (8 doubles) — what the host reads once per trial."""
+        last = 8 * (self.packed[0].numel() - 1)
+        self.eng.lm_decide(self.packed[cur].data_ptr() + last, self.packed[new].data_ptr() + last, self.dvec.data_ptr(), self.gm.data_ptr(),
+                           self.delta.data_ptr(), ps.data_ptr(), self.fixed.data_ptr(), self.status.data_ptr(), lam.data_ptr(), stats.data_ptr(),
+                           self.torch.cuda.current_stream(self.dev).cuda_stream)
+
+    def predicted_reduction(self, lam):
+        """(0.5 (lam d'D d - g'd), step is valid) of the last ``solve`` as device tensors (tests; the loop uses ``decide``)."""
+        torch = self.torch
         pred = 0.5 * (lam[0] * torch.dot(self.dvec, self.delta * self.delta) - torch.dot(self.gm, self.delta))
-        ok = (self.status[0] == 0) & torch.isfinite(pred) & info_ok
-        return self.delta, pred, ok
+        return pred, (self.status[0] == 0) & torch.isfinite(pred)
 
     def gradient(self, slot: int, lam):
         """masked J^T r of the state in packed[slot] (free entries), as NumPy — one read-back, used once at the end."""
         self.solve(slot, lam)
+        self.status.zero_()
         return self.gm[self.free_idx].cpu().numpy()
 
 
 def _lm_solve_blocked(ne: BlockedNormalEquations, ps0: np.ndarray, *, max_iter, ftol, xtol, gtol, lam0, verbose):
     """The device-resident loop behind ``lm_solve(..., linear_solver='cholesky')``.  Per trial step the host enqueues
-    solve -> parameter update -> build -> decision and then reads ONE 8-vector
+    solve (+ trial parameter string) -> build -> decision and then reads ONE 8-vector
         [accepted, max |g| before the step, relative cost drop, |step|, |x|, new sum r^2, old sum r^2, lambda used]
     to steer the loop; x, lambda, the gain ratio and both states stay in HBM."""
     torch = ne.torch
@@ -292,6 +304,7 @@ def _lm_solve_blocked(ne: BlockedNormalEquations, ps0: np.ndarray, *, max_iter, 
         ps = torch.from_numpy(np.ascontiguousarray(ps0, dtype=np.float64)).to(dev)
         ps_new = torch.empty_like(ps)
         lam = torch.full((1,), float(lam0), dtype=torch.float64, device=dev)
+        stats_dev = torch.zeros(8, dtype=torch.float64, device=dev)
         cur, new = 0, 1
         ne.build(ps, cur)
         sumsq = float(ne.cost(cur).item())
@@ -299,26 +312,16 @@ def _lm_solve_blocked(ne: BlockedNormalEquations, ps0: np.ndarray, *, max_iter, 
         nfev, n_lin = 1, 0
         status, message = 0, "maximum number of iterations reached"
         it = 0
-        third, one, two = (torch.tensor(v, dtype=torch.float64, device=dev) for v in (1.0 / 3.0, 1.0, 2.0))
         for it in range(1, max_iter + 1):
             accepted = False
             stop = False
             for _retry in range(12):   # damping retries
-                delta, pred, ok = ne.solve(cur, lam)
+                ne.solve(cur, lam, ps, ps_new)
                 n_lin += 1
-                torch.add(ps, delta, out=ps_new)
                 ne.build(ps_new, new)
                 nfev += 1
-                c_old, c_new = ne.cost(cur), ne.cost(new)
-                actual = 0.5 * (c_old - c_new)
-                rho = torch.where(pred > 0, actual / pred, -one)
-                acc = ok & torch.isfinite(c_new) & (actual > 0)
-                factor = torch.where(rho > 0.75, third, torch.where(rho > 0.25, one, two))
-                lam_used = lam.clone()
-                lam = torch.where(acc, torch.clamp(lam * factor, min=1e-12), lam * 4.0)
-                x = ps[ne.free_idx]
-                stats = torch.stack([acc.to(torch.float64), ne.gm.abs().max(), actual / (0.5 * c_old), torch.linalg.vector_norm(delta),
-                                     torch.linalg.vector_norm(x), c_new, c_old, lam_used[0]]).cpu().numpy()   # the ONE read-back
+                ne.decide(cur, new, ps, lam, stats_dev)
+                stats = stats_dev.cpu().numpy()        # the ONE read-back of the trial
                 gmax = float(stats[1])
                 if verbose:
                     print(f"  it {it}: lam {stats[7]:.2e} cost {0.5 * stats[6]:.6e} -> {0.5 * stats[5]:.6e} accepted {bool(stats[0])}")

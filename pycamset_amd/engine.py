@@ -286,8 +286,12 @@ class Engine:
         check(lib().pcs_schur_prepare(self._h, *(c_void_p(p) for p in (d_packed, d_fixed, d_lambda, d_linvt, d_u, d_V, d_S, d_rhs, d_dvec, d_gm, d_status)),
                                       _stream_arg(stream)))
 
-    def schur_finish(self, d_linvt, d_u, d_w, d_xlead, d_fixed, d_delta, stream=None):
-        check(lib().pcs_schur_finish(self._h, *(c_void_p(p) for p in (d_linvt, d_u, d_w, d_xlead, d_fixed, d_delta)), _stream_arg(stream)))
+    def schur_finish(self, d_linvt, d_u, d_w, d_xlead, d_fixed, d_delta, d_ps_in=0, d_ps_out=0, stream=None):
+        check(lib().pcs_schur_finish(self._h, *(c_void_p(p) for p in (d_linvt, d_u, d_w, d_xlead, d_fixed, d_delta, d_ps_in, d_ps_out)), _stream_arg(stream)))
+
+    def lm_decide(self, d_cost_old, d_cost_new, d_dvec, d_gm, d_delta, d_ps, d_fixed, d_status, d_lambda, d_stats, stream=None):
+        check(lib().pcs_lm_decide(self._h, *(c_void_p(p) for p in (d_cost_old, d_cost_new, d_dvec, d_gm, d_delta, d_ps, d_fixed, d_status, d_lambda, d_stats)),
+                                  _stream_arg(stream)))
 
     # -- evaluation: device buffers -----------------------------------------------------------
     def eval_device(self, param_str, d_resid: int | None, d_jac: int | None, stream: int | None = None):

@@ -125,20 +125,14 @@ def main():
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / reps * 1e6
     ps_new = torch.empty_like(ps)
-    one = torch.tensor(1.0, dtype=torch.float64, device="cuda")
-    def decide():
-        delta, pred, ok = ne.delta, one, ne.status[0] == 0
-        c_old, c_new = ne.cost(0), ne.cost(1)
-        actual = 0.5 * (c_old - c_new)
-        rho = torch.where(pred > 0, actual / pred, -one)
-        acc = ok & torch.isfinite(c_new) & (actual > 0)
-        factor = torch.where(rho > 0.75, one / 3, torch.where(rho > 0.25, one, 2 * one))
-        lam2 = torch.where(acc, torch.clamp(lam * factor, min=1e-12), lam * 4.0)
-        x = ps[ne.free_idx]
-        return torch.stack([acc.to(torch.float64), ne.gm.abs().max(), actual / (0.5 * c_old), torch.linalg.vector_norm(delta),
-                            torch.linalg.vector_norm(x), c_new, c_old, lam2[0]]).cpu().numpy()
+    stats = torch.zeros(8, dtype=torch.float64, device="cuda")
     ne.build(ps, 1)
-    print(f"  loop sections (host wall us): solve {wall(lambda: ne.solve(0, lam)):.0f}, update+build {wall(lambda: (torch.add(ps, ne.delta, out=ps_new), ne.build(ps_new, 1))):.0f}, "
+
+    def decide():
+        ne.decide(0, 1, ps, lam.clone(), stats)
+        return stats.cpu().numpy()
+
+    print(f"  loop sections (host wall us): solve + trial string {wall(lambda: ne.solve(0, lam, ps, ps_new)):.0f}, build {wall(lambda: ne.build(ps_new, 1)):.0f}, "
           f"decision + read-back {wall(decide):.0f}")
     for it in (30,):
         torch.cuda.synchronize()
