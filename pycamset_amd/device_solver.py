@@ -25,6 +25,7 @@ want scipy's own solvers without materialising J.
 """
 from __future__ import annotations
 
+import contextlib
 from dataclasses import dataclass, field
 
 import numpy as np
@@ -222,6 +223,7 @@ class BlockedNormalEquations:
         self.gm = torch.empty(self.n_params, **f64)
         self.delta = torch.empty(self.n_params, **f64)
         self.status = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.stream = torch.cuda.Stream(device=dev)
         from .engine import dense_spd_work_len
 
         self.xl = torch.empty(self.n_lead, **f64)
@@ -230,55 +232,74 @@ class BlockedNormalEquations:
     def cost(self, slot):
         return self.packed[slot][-1]
 
+    @contextlib.contextmanager
+    def on_stream(self):
+        """The solver mixes torch operations (GEMM, GEMV) with kernels launched through the C ABI; both must land on ONE
+        stream handle.  torch's default stream is the NULL handle, which the C ABI can only name as ``hipStreamLegacy`` — two
+        spellings the runtime is not guaranteed to order against each other in both directions.  So whenever the caller is on
+        the default stream the work moves to a stream of this object (ordered after what the caller queued, and the caller's
+        later work after ours); a caller that already runs on a real stream keeps it."""
+        torch = self.torch
+        cur = torch.cuda.current_stream(self.dev)
+        if cur.cuda_stream != 0:
+            yield cur.cuda_stream
+            return
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            yield self.stream.cuda_stream
+        cur.wait_stream(self.stream)
+
     def build(self, ps, slot: int):
         """packed[slot] <- [A | B | C | g | cost] at the device parameter string ``ps`` (+ the sum over the ranks)."""
         torch = self.torch
         buf = self.packed[slot]
-        if self.eng.n == 0:   # empty shard: zeros, but the all-reduce below still happens (see JacobianOperator)
-            buf.zero_()
-        else:
-            self.eng.normal_blocks_device(ps.data_ptr(), buf.data_ptr(), torch.cuda.current_stream(self.dev).cuda_stream)
-        if self.reduce_fn is not None:
-            if getattr(self.reduce_fn, "on_device", False):
-                self.reduce_fn(buf)
+        with self.on_stream() as stream:
+            if self.eng.n == 0:   # empty shard: zeros, but the all-reduce below still happens (see JacobianOperator)
+                buf.zero_()
             else:
-                buf.copy_(torch.from_numpy(self.reduce_fn(buf.cpu().numpy())))
+                self.eng.normal_blocks_device(ps.data_ptr(), buf.data_ptr(), stream)
+            if self.reduce_fn is not None:
+                if getattr(self.reduce_fn, "on_device", False):
+                    self.reduce_fn(buf)
+                else:
+                    buf.copy_(torch.from_numpy(self.reduce_fn(buf.cpu().numpy())))
 
     def solve(self, slot: int, lam, ps=None, ps_out=None):
         """Enqueue the damped step (H + lam diag(H)) delta = -g for the state in packed[slot]: ``self.delta`` (n_params,
         parameter-string order, 0 where fixed) and — given the current parameter string ``ps`` — the trial string
         ``ps_out = ps + delta``.  Device work only; ``self.status`` becomes non-zero when a factorisation fails."""
         torch = self.torch
-        stream = torch.cuda.current_stream(self.dev).cuda_stream
-        self.eng.schur_prepare(self.packed[slot].data_ptr(), self.fixed.data_ptr(), lam.data_ptr(), self.linvt.data_ptr(), self.u.data_ptr(),
-                               self.V.data_ptr(), self.S.data_ptr(), self.rhs.data_ptr(), self.dvec.data_ptr(), self.gm.data_ptr(),
-                               self.status.data_ptr(), stream)
-        if self.n_trail:
-            V = self.V[:, : self.n_trail]
-            self.S.addmm_(V, V.T, alpha=-1.0)            # S = A + lam D - V V'          (rocBLAS)
-            self.rhs.addmv_(V, self.u[: self.n_trail])   # rhs = -g_l + V u
-        if self.dense_solver == "hip":                   # S x_l = rhs: blocked Cholesky + substitutions (csrc/ba_dense_chol.hpp)
-            from .engine import dense_spd_solve
+        with self.on_stream() as stream:
+            self.eng.schur_prepare(self.packed[slot].data_ptr(), self.fixed.data_ptr(), lam.data_ptr(), self.linvt.data_ptr(), self.u.data_ptr(),
+                                   self.V.data_ptr(), self.S.data_ptr(), self.rhs.data_ptr(), self.dvec.data_ptr(), self.gm.data_ptr(),
+                                   self.status.data_ptr(), stream)
+            if self.n_trail:
+                V = self.V[:, : self.n_trail]
+                self.S.addmm_(V, V.T, alpha=-1.0)            # S = A + lam D - V V'          (rocBLAS)
+                self.rhs.addmv_(V, self.u[: self.n_trail])   # rhs = -g_l + V u
+            if self.dense_solver == "hip":                   # S x_l = rhs: blocked Cholesky + substitutions (csrc/ba_dense_chol.hpp)
+                from .engine import dense_spd_solve
 
-            xl = self.xl
-            dense_spd_solve(self.eng.device, self.n_lead, self.S.data_ptr(), self.n_lead, self.rhs.data_ptr(), xl.data_ptr(),
-                            self.chol_work.data_ptr(), self.status.data_ptr(), stream)
-        else:
-            L, info = torch.linalg.cholesky_ex(self.S)   # rocSOLVER; `info` stays on the device
-            xl = torch.cholesky_solve(self.rhs.unsqueeze(1), L).squeeze(1)
-            self.status.bitwise_or_((info != 0).to(torch.int32) * 2)
-        w = torch.mv(self.V[:, : self.n_trail].T, xl) if self.n_trail else self.u
-        self.eng.schur_finish(self.linvt.data_ptr(), self.u.data_ptr(), w.data_ptr(), xl.data_ptr(), self.fixed.data_ptr(), self.delta.data_ptr(),
-                              ps.data_ptr() if ps is not None else 0, ps_out.data_ptr() if ps is not None else 0, stream)
+                xl = self.xl
+                dense_spd_solve(self.eng.device, self.n_lead, self.S.data_ptr(), self.n_lead, self.rhs.data_ptr(), xl.data_ptr(),
+                                self.chol_work.data_ptr(), self.status.data_ptr(), stream)
+            else:
+                L, info = torch.linalg.cholesky_ex(self.S)   # rocSOLVER; `info` stays on the device
+                xl = torch.cholesky_solve(self.rhs.unsqueeze(1), L).squeeze(1)
+                self.status.bitwise_or_((info != 0).to(torch.int32) * 2)
+            w = torch.mv(self.V[:, : self.n_trail].T, xl) if self.n_trail else self.u
+            self.eng.schur_finish(self.linvt.data_ptr(), self.u.data_ptr(), w.data_ptr(), xl.data_ptr(), self.fixed.data_ptr(), self.delta.data_ptr(),
+                                  ps.data_ptr() if ps is not None else 0, ps_out.data_ptr() if ps is not None else 0, stream)
         return self.delta
 
     def decide(self, cur: int, new: int, ps, lam, stats):
         """The accept / reject decision of the trial state packed[new] against packed[cur] on the device (pcs_lm_decide):
         updates ``lam`` in place, clears ``status`` and fills ``stats`` (8 doubles) — what the host reads once per trial."""
         last = 8 * (self.packed[0].numel() - 1)
-        self.eng.lm_decide(self.packed[cur].data_ptr() + last, self.packed[new].data_ptr() + last, self.dvec.data_ptr(), self.gm.data_ptr(),
-                           self.delta.data_ptr(), ps.data_ptr(), self.fixed.data_ptr(), self.status.data_ptr(), lam.data_ptr(), stats.data_ptr(),
-                           self.torch.cuda.current_stream(self.dev).cuda_stream)
+        with self.on_stream() as stream:
+            self.eng.lm_decide(self.packed[cur].data_ptr() + last, self.packed[new].data_ptr() + last, self.dvec.data_ptr(), self.gm.data_ptr(),
+                               self.delta.data_ptr(), ps.data_ptr(), self.fixed.data_ptr(), self.status.data_ptr(), lam.data_ptr(), stats.data_ptr(),
+                               stream)
 
     def predicted_reduction(self, lam):
         """(0.5 (lam d'D d - g'd), step is valid) of the last ``solve`` as device tensors (tests; the loop uses ``decide``)."""
@@ -300,7 +321,7 @@ def _lm_solve_blocked(ne: BlockedNormalEquations, ps0: np.ndarray, *, max_iter, 
     to steer the loop; x, lambda, the gain ratio and both states stay in HBM."""
     torch = ne.torch
     dev = ne.dev
-    with torch.cuda.device(dev):
+    with torch.cuda.device(dev), torch.cuda.stream(ne.stream):     # one real stream for torch operations and C-ABI kernels alike
         ps = torch.from_numpy(np.ascontiguousarray(ps0, dtype=np.float64)).to(dev)
         ps_new = torch.empty_like(ps)
         lam = torch.full((1,), float(lam0), dtype=torch.float64, device=dev)

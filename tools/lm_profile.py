@@ -55,6 +55,7 @@ def main():
     lm_solve(h, x0.copy(), max_iter=2)     # warm-up (rocSOLVER / rocBLAS start-up)
     eng = h.op_fun.engine
     ne = BlockedNormalEquations(eng, h._jac_mask())
+    torch.cuda.set_stream(ne.stream)       # one real stream for torch operations and C-ABI kernels (BlockedNormalEquations.on_stream)
     ps = torch.from_numpy(h.op_fun.build_param_list(*h.get_bundle_adjustment_inputs(x0))).cuda()
     lam = torch.full((1,), 1e-3, dtype=torch.float64, device="cuda")
     ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
