@@ -48,32 +48,44 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(const CholArgs a) {
         D[r][c] = c <= r ? chol_load<NB>(a, k, k, r, c) : 0.0;
     }
     __syncthreads();
-    // right-looking factorisation of the tile: column j is scaled, then the trailing part of the tile is updated
+    // Right-looking factorisation of the tile, two barriers per column: (1) column j below the diagonal is scaled by 1 / l —
+    // every thread reads the pivot, nobody writes it in this phase —, (2) the trailing part is updated and the pivot's owner
+    // stores l.  Every thread owns the same NB * NB / 256 elements throughout; their (row, column) are compile-time shifts.
+    constexpr int EPT = NB * NB / 256;
     bool ok = true;
     for (int j = 0; j < NB; ++j) {
         const double p = D[j][j];
         ok = ok && (p > 0.0);
         const double l = sqrt(p), il = 1.0 / l;
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) {
+            const int e = tid + 256 * q, r = e / NB, c = e % NB;
+            if (c == j && r > j) D[r][c] *= il;
+        }
         __syncthreads();
-        if (tid == 0) D[j][j] = l;
-        for (int r = j + 1 + tid; r < NB; r += 256) D[r][j] *= il;
-        __syncthreads();
-        const int m = NB - 1 - j;                  // trailing size
-        for (int e = tid; e < m * m; e += 256) {
-            const int r = j + 1 + e / m, c = j + 1 + e % m;
-            if (c <= r) D[r][c] -= D[r][j] * D[c][j];
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) {
+            const int e = tid + 256 * q, r = e / NB, c = e % NB;
+            if (c > j && r >= c) D[r][c] -= D[r][j] * D[c][j];
+            else if (r == j && c == j) D[r][c] = l;
         }
         __syncthreads();
     }
     if (!ok && blockIdx.x == 0 && tid == 0) atomicOr(a.status, 2);
-    // inverse of the lower-triangular tile: thread c solves column c by forward substitution
+    // Inverse of the lower-triangular tile: thread c solves column c by forward substitution, the column in REGISTERS (a first
+    // version kept it in LDS: every step waited for its own previous LDS write, 28 us per tile — half of the whole factorisation)
     if (tid < NB) {
         const int c = tid;
+        double col[NB];
+#pragma unroll
         for (int r = 0; r < NB; ++r) {
             double t = (r == c) ? 1.0 : 0.0;
-            for (int m = c; m < r; ++m) t -= D[r][m] * Li[m][c];
-            Li[r][c] = r < c ? 0.0 : t / D[r][r];
+#pragma unroll
+            for (int m = 0; m < r; ++m) t -= D[r][m] * col[m];     // col[m] = 0 for m < c
+            col[r] = r < c ? 0.0 : t / D[r][r];
         }
+#pragma unroll
+        for (int r = 0; r < NB; ++r) Li[r][c] = col[r];
     }
     __syncthreads();
     if (blockIdx.x == 0) {

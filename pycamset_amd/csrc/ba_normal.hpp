@@ -174,6 +174,9 @@ __host__ __device__ __forceinline__ int entry_descriptor(const int m, const int 
 
 using d4v = __attribute__((ext_vector_type(4))) double;
 
+// Two waves per SIMD: the 22.9 KB image (ROWS = 64) allows 7 one-wave workgroups per CU anyway; the half-tile form (ROWS = 32,
+// 11.4 KB) keeps J live across its first MFMA walk and needs 232 VGPRs — held to 168 for a third wave it spills 256 B
+// (measured in round 2 with the same outcome: 99 us against 92).  Zero scratch in every instantiation as it stands.
 template <int CHAIN, int PASS, int ROWS>
 __global__ __launch_bounds__(64, 2) void ba_normal_mfma_kernel(const NormalArgs a) {
     static_assert(ROWS == 64 || ROWS == 32, "image holds a whole or half a tile");
