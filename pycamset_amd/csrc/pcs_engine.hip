@@ -1684,10 +1684,10 @@ int pcs_dense_spd_solve(int device, int64_t n, double *d_S, int64_t ld, const do
         if (m > 0) hipLaunchKernelGGL(chol_update_kernel<NB>, dim3((unsigned)(m * (m + 1) / 2)), dim3(256), 0, s, a);
     }
     HIPCHK(hipGetLastError());
-    const size_t lds = sizeof(double) * ((size_t)nblk * NB + 1024);
+    const size_t lds = sizeof(double) * ((size_t)nblk * NB + NB);
     if (lds > 48 * 1024) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(chol_solve_kernel<NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     CholSolveArgs b{d_S, d_work, d_rhs, d_x, (int32_t)n, (int32_t)ld};
-    hipLaunchKernelGGL(chol_solve_kernel<NB>, dim3(1), dim3(1024), lds, s, b);
+    hipLaunchKernelGGL(chol_solve_kernel<NB>, dim3(1), dim3(512), lds, s, b);
     HIPCHK(hipGetLastError());
     return PCS_OK;
 }
