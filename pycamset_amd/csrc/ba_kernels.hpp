@@ -270,6 +270,8 @@ __device__ __forceinline__ void store_jac_tile(const T (&J)[2 * P], TO *tr, TO *
 // ---------------------------------------------------------------------------------------------
 // K1-K4  fused residual + Jacobian
 // ---------------------------------------------------------------------------------------------
+// (The float-output kernels are held to 168 VGPRs = three waves per SIMD, which their halved store stream can use — except for
+// the self chain, whose 24 columns spilled 36-84 B under that limit: it keeps its registers and runs two waves per SIMD.)
 // TO = type of the residual and Jacobian written out.  The workgroup has blockDim.x / 64 waves (4 for large tables,
 // fewer for small ones so that the grid still covers every CU several times); wave w takes tiles w, w + waves, ...
 // of the workgroup's run of tiles.
@@ -278,7 +280,7 @@ __device__ __forceinline__ void store_jac_tile(const T (&J)[2 * P], TO *tr, TO *
 // iteration for a tile inside a run of the reference's table order, two for a tile that straddles a run boundary.  Points
 // of chains SELF / FREE come straight from the parameter string.
 template <int CHAIN, int MODE, int VARIANT, typename TO, bool PREP = false>
-__global__ __launch_bounds__(WG_THREADS, (sizeof(TO) == 4 && (MODE & MODE_JAC) && !PREP) ? 3 : 1) void ba_eval_kernel(const EvalArgs a) {
+__global__ __launch_bounds__(WG_THREADS, (sizeof(TO) == 4 && (MODE & MODE_JAC) && !PREP && CHAIN != CHAIN_SELF) ? 3 : 1) void ba_eval_kernel(const EvalArgs a) {
     constexpr int P = chain_P(CHAIN);
     constexpr int P2 = 2 * P;
     constexpr bool SLAB_LDS = (VARIANT & VAR_SLAB_LDS) != 0;
