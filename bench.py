@@ -267,6 +267,8 @@ def main():
     ap.add_argument("--variant", type=int, default=None)
     ap.add_argument("--wgs-per-cu", type=int, default=None)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--device-warmup-ms", type=float, default=400.0,
+                    help="plain streaming fills before the W warm-up steps, so that the timed region sees the GPU's steady-state clocks (0 = off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-allgather-probe", action="store_true")
     ap.add_argument("--no-normal-probe", action="store_true")
@@ -390,6 +392,19 @@ def main():
         if world > 1:
             dist.barrier()
         return reduce_scalar(time.perf_counter() - t0, dist.ReduceOp.MAX) / reps
+
+    # ---- device warm-up (not steps): a fresh process finds the GPU in its idle power state, and the W warm-up steps of a
+    # 65 us kernel (a millisecond or two) are over long before its memory and fabric clocks have ramped — measured on MI355X:
+    # the same step 75 us right after start-up, 65 us 20 ms later, 63.5 us in a process that has been busy for seconds
+    # (profiles/r03/README.md).  A fixed stretch of plain non-temporal fills brings the part to its steady state first.
+    if args.device_warmup_ms > 0:
+        from pycamset_amd import _capi
+        import ctypes
+
+        ms = ctypes.c_float()
+        t_w = time.perf_counter()
+        while (time.perf_counter() - t_w) * 1e3 < args.device_warmup_ms:
+            _capi.check(_capi.lib().pcs_membench(local_rank, 1, 256 << 20, 200, 8, ctypes.byref(ms)))
 
     # ---- the timed region: K steps, no HIP events attached to the launches ---------------------------------------
     eng.set_option("timing_every", 0)
@@ -529,6 +544,7 @@ def main():
                 "rows_per_step": 2.0 * n_total,
                 "row_len_P": P,
                 "collective_in_step": args.collective if world > 1 else "none",
+                "device_warmup_ms": args.device_warmup_ms,
                 "jacobian_streamed_to_host": bool(args.stream_to_host),
                 "parallelism": f"obs-shard x{world}",
                 **({"emulated_world": args.emulate_world} if args.emulate_world > 1 and world == 1 else {}),

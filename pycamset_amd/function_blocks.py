@@ -111,14 +111,14 @@ class optimisation_function:  # afb:111-685
     DEFAULT_PINNED_RING = 2
 
     def __init__(self, function_blocks, *, dtype: str = "f64", device: int = 0, pinned_ring: int | None = None, counts=None) -> None:
-        """``pinned_ring`` = R > 0 returns the Jacobian ``data`` array from a ring of R page-locked
-        host buffers (PCIe-rate device -> host copy, wrapped by ``csr_array`` without a copy); the array
-        handed out by one Jacobian call is overwritten by the R-th call after it.  The default (None) is
-        R = 2: scipy's ``least_squares`` drops the previous Jacobian before it asks for the next one
-        (optimisation_handling.py:88-98 -> scipy trf / lm), so the current and the previous one are always
-        intact, and a 335 MB Jacobian arrives in ~10 ms instead of ~34 ms (pageable memory).
-        0 = a fresh pageable NumPy array per call, exactly like the reference (afb:561) — for callers that
-        keep Jacobians of older parameter vectors around."""
+        """``pinned_ring`` = R > 0 returns the Jacobian ``data`` array from a ring of R page-locked host buffers
+        (PCIe-rate device -> host copy, wrapped by ``csr_array`` without a copy: a 335 MB Jacobian arrives in ~10 ms instead of
+        ~34 ms into pageable memory).  A ring buffer is handed out again only once nobody references it or any view
+        of it any more (``Engine._out``): an array — or a ``csr_array`` built on it — that the caller keeps stays intact for as
+        long as it is kept, exactly like the fresh array the reference returns per call (afb:561); the slot simply gets a new
+        page-locked buffer.  A loop that drops each Jacobian before asking for the next (scipy's ``least_squares``,
+        optimisation_handling.py:88-98) cycles through R buffers without allocating.  The default (None) is R = 2;
+        0 = always a fresh pageable NumPy array."""
         self.pinned_ring = self.DEFAULT_PINNED_RING if pinned_ring is None else int(pinned_ring)
         # (n_cams, n_imgs, n_keys): slab sizes of the parameter string.  None = the reference's own rule, max
         # index + 1 of the detection table (afb:793-795).  The handlers pass their slab sizes (a trailing camera /
