@@ -143,8 +143,9 @@ struct pcs_engine {
     // One-launch step: the evaluation kernel prepares the slabs of its tile per wave instead of a slab_prep launch in front
     // (ba_eval_kernel<..., PREP>).  -1 = automatic: run-ordered tables (few (camera, image) runs per tile); FP64 outputs at
     // any size (measured on MI355X, profiles/r03: rig-32 71.2 -> 65.0 us per step, rig-32-self 82.0 -> 78.7, free 60.1 -> 57.4,
-    // an 8-way shard 14.2 -> 12.3, ring-8 12.3 -> 10.3), float outputs only up to fuse_prep_max_n detections (the float
-    // kernels are issue-bound at large N: rig-32 mixed 35.3 -> 53.4 us, rig-128 f32 294 -> 500 us with it).
+    // an 8-way shard 14.2 -> 12.3, ring-8 12.3 -> 10.3), float outputs and residual-only evaluations only up to
+    // fuse_prep_max_n detections (those kernels are issue-bound at large N: rig-32 mixed 35.3 -> 53.4 us, rig-128 f32 294 -> 500 us,
+    // residual only at N = 1e6 9 + 4.4 -> 24.6 us with it).
     int fuse_prep = -1;
     int64_t fuse_prep_max_n = 250000;
     int64_t tiles_per_wg = 0;  // 0 = derive from wgs_per_cu
@@ -1179,7 +1180,8 @@ static int enqueue_eval(pcs_engine *h, const double *d_prm, void *d_resid, void 
     // One launch per step for small, run-ordered tables (see pcs_engine::fuse_prep): the waves prepare their own slabs.
     const bool slab_lds_forced = h->variant >= 0 && (h->variant & VAR_SLAB_LDS);
     const bool prep = !compact && !slab_lds_forced && !(h->variant >= 0 && (mode & MODE_JAC) && !(h->variant & VAR_TRANSPOSE)) &&
-                      (h->fuse_prep > 0 || (h->fuse_prep < 0 && h->tile_locality >= 0.5 && h->tile_segments <= 2.5 && (h->osize == 8 || h->n <= h->fuse_prep_max_n)));
+                      (h->fuse_prep > 0 || (h->fuse_prep < 0 && h->tile_locality >= 0.5 && h->tile_segments <= 2.5 &&
+                                            ((h->osize == 8 && (mode & MODE_JAC)) || h->n <= h->fuse_prep_max_n)));
     hipEvent_t no_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     const bool timed = h->timing_every > 0 && (h->eval_count++ % h->timing_every) == 0;
     hipEvent_t *ev = timed ? ring_slot(h, !prep) : no_ev;
