@@ -151,3 +151,39 @@ def test_triangulator_handle_resident_inputs_and_repeated_calls():
     with pytest.raises(ValueError):
         tri.set_cameras(P[:-1], K[:-1], D[:-1])
     tri.close()
+
+
+def test_triangulator_orders_runs_across_streams():
+    """Round 3 (advisor finding): the handle records an event after every run.  A run queued on a CALLER stream with the
+    handle-owned output followed by points() — which copies on the handle's stream — must return that run's points; points()
+    after a run that wrote to a caller buffer must refuse (PCS_ERR_STATE) instead of returning an older result; setters called
+    while a run may still be in flight on another stream wait for it."""
+    import torch
+    rig = synthetic.make_rig("tri-s", 12, 30, synthetic.ccube_points(), seed=9, visibility=0.4, n_rings=2)
+    rec, start, P, K, D, _ = rig_inputs(rig)
+    ref = hip_ch.nb_triangulate_full(rec, P, start, K, D)
+    cam = rec[:, 0].astype(np.int32)
+    tri = hip_ch.Triangulator(rig.n_cams)
+    tri.set_cameras(P, K, D)
+    tri.set_observations(cam, rec[:, -2:], start)
+    side = torch.cuda.Stream()
+    for _ in range(5):
+        tri.run(None, side.cuda_stream)                 # handle-owned output, caller stream, no synchronisation by the caller
+        assert np.array_equal(tri.points(), ref)
+    d_pts = torch.zeros((len(start) - 1, 3), dtype=torch.float64, device="cuda")
+    tri.run(d_pts.data_ptr(), side.cuda_stream)         # the result goes to the caller's buffer ...
+    with pytest.raises(_capi.PcsError) as ex:
+        tri.points()                                    # ... so there is no handle-owned result of THIS run
+    assert ex.value.code == _capi.PCS_ERR_STATE
+    side.synchronize()
+    assert np.array_equal(d_pts.cpu().numpy(), ref)
+    # a new problem right behind a run on the side stream: the setter waits for that run before it overwrites the inputs
+    half = len(start) // 2
+    tri.run(None, side.cuda_stream)
+    tri.set_observations(cam[: start[half]], rec[: start[half], -2:], start[: half + 1])
+    with pytest.raises(_capi.PcsError):
+        tri.points()                                    # results of the earlier problem are not this problem's
+    tri.run(None, side.cuda_stream)
+    assert np.array_equal(tri.points(), ref[:half])
+    tri.close()
+
