@@ -3,13 +3,14 @@
 //
 // Why not the library: rocSOLVER's potrf takes 1.15 ms for n = 480 and 4.6 ms for n = 1 680 on MI355X, its potrs another
 // 0.45 / 0.6 ms (profiles/r03/lm_profile_*.log) — ten times everything else in the iteration together.  The matrix is small:
-// what counts is the length of the dependent chain, not FLOPs.  Blocked right-looking factorisation, NB x NB tiles, two
-// launches per block column k:
-//   chol_panel_kernel   every workgroup factors the (already updated) diagonal tile A_kk in LDS and inverts the factor
-//                       — redundantly: 10 k FMAs are cheaper than a hand-off between workgroups —; workgroup 0 stores
-//                       L_kk and L_kk^-1, workgroup i > 0 turns its tile of the panel into L_ik = A_ik L_kk^-T with the inverse
-//                       (a small GEMM, no sequential substitution);
-//   chol_update_kernel  one workgroup per tile (i, j), i >= j > k, of the trailing matrix: A_ij -= L_ik L_jk'.
+// what counts is the length of the dependent chain, not FLOPs.  Blocked right-looking factorisation, NB x NB tiles, ONE
+// launch per block column:
+//   chol_panel_kernel   (block column 0) every workgroup factors the diagonal tile and inverts the factor — redundantly: 10 k FMAs
+//                       are cheaper than a hand-off between workgroups —, workgroup i > 0 turns its tile of the panel into
+//                       L_i0 = A_i0 L_00^-T with the inverse (a small GEMM, no sequential substitution);
+//   chol_step_kernel    (k = 0, 1, ...) one workgroup per tile (i, j), i >= j > k, of the trailing matrix: A_ij -= L_ik L_jk';
+//                       the workgroups of column k + 1 go straight on with that column's panel step (they form the updated
+//                       diagonal tile themselves).
 // chol_solve_kernel then runs both substitutions in ONE workgroup with the stored inverses of the diagonal tiles: per block a
 // partial GEMV over the finished part and a small matrix-vector product — 2 n / NB dependent steps of a few hundred ns.
 // Only the lower triangle of S is read and written.  A non-positive pivot sets bit 1 of *status (the LM loop reads it on the
@@ -24,6 +25,8 @@ namespace pcs {
 struct CholArgs {
     double *A;          // n x n, row-major, ld; lower triangle in / L out
     double *linv;       // (n / NB rounded up) x NB x NB: inverses of the diagonal tiles of L (lower triangular, row-major)
+    double *ldiag;      // same shape: the diagonal tiles of L.  They are NOT written into A by the panel launch — its other
+                        // workgroups read A_kk in the same launch — but copied there by chol_solve_kernel, which runs alone
     int32_t *status;
     int32_t n, ld, k;   // k = block column of this launch
 };
@@ -51,33 +54,20 @@ __device__ __forceinline__ double lane_bcast(const double v, const int src) {   
     return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
 }
 
+// Factor the lower-triangular tile held in LDS `D` (upper part zero) in place and leave the inverse of the factor in `Li`.
+// Wave 0 only, the tile in REGISTERS (lane r = row r; no barriers, no LDS round trips): per column j the pivot and the column
+// entries are broadcast with v_readlane (compile-time lanes after unrolling); the inverse by forward substitution with a
+// register-resident column and the reciprocal pivots (no divisions).  Returns false (wave-uniform) for a non-positive pivot.
+// The caller puts a workgroup barrier before (D complete) and after (D, Li complete).
 template <int NB>
-__global__ __launch_bounds__(256) void chol_panel_kernel(const CholArgs a) {
+__device__ __forceinline__ bool factor_and_invert_tile(double (&D)[NB][NB + 1], double (&Li)[NB][NB + 1], const int tid) {
     static_assert(NB == 32, "one row per lane of half a wave");
-    __shared__ double D[NB][NB + 1];    // L_kk (lower)
-    __shared__ double Li[NB][NB + 1];   // L_kk^-1 (lower)
-    __shared__ double X[NB][NB + 1];    // this workgroup's panel tile
-    __shared__ int flag_bad;
-    const int tid = threadIdx.x;
-    const int k = a.k;
-    const int bi = k + blockIdx.x;      // blockIdx.x > 0: a tile below the diagonal
-    constexpr int EPT = NB * NB / 256;
-    // the panel tile is requested first: its latency hides behind the factorisation of the diagonal tile
-    double xin[EPT];
-#pragma unroll
-    for (int q = 0; q < EPT; ++q) {
-        const int e = tid + 256 * q;
-        xin[q] = blockIdx.x > 0 ? chol_load<NB>(a, bi, k, e / NB, e % NB) : 0.0;
-    }
-    if (tid == 0) flag_bad = 0;
-    // Wave 0 factors the diagonal tile IN REGISTERS, lane r = row r (no barriers, no LDS round trips): per column j the pivot
-    // and the column entries are broadcast with v_readlane (compile-time lanes after unrolling); lanes >= NB idle along.
+    bool ok = true;
     if (tid < 64) {
         const int r = tid & (NB - 1);
         double row[NB], ild[NB];
 #pragma unroll
-        for (int c = 0; c < NB; ++c) row[c] = (c <= r && tid < NB) ? chol_load<NB>(a, k, k, r, c) : (c == r ? 1.0 : 0.0);
-        bool ok = true;
+        for (int c = 0; c < NB; ++c) row[c] = tid < NB ? D[r][c] : (c == r ? 1.0 : 0.0);
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             const double p = lane_bcast(row[j], j);
@@ -88,7 +78,6 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(const CholArgs a) {
 #pragma unroll
             for (int c = j + 1; c < NB; ++c) row[c] -= row[j] * lane_bcast(row[j], c);   // (c, j) lives in lane c
         }
-        if (!ok && tid == 0) flag_bad = 1;
         if (tid < NB) {
 #pragma unroll
             for (int c = 0; c < NB; ++c) D[r][c] = c <= r ? row[c] : 0.0;
@@ -96,8 +85,6 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(const CholArgs a) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // inverse of the lower-triangular tile: lane c solves column c by forward substitution, the column in registers, the
-        // reciprocal pivots from above (no divisions)
         if (tid < NB) {
             const int c = tid;
             double col[NB];
@@ -106,31 +93,50 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(const CholArgs a) {
                 double t = (rr == c) ? 1.0 : 0.0;
 #pragma unroll
                 for (int m = 0; m < rr; ++m) t -= D[rr][m] * col[m];     // col[m] = 0 for m < c
-                col[rr] = rr < c ? 0.0 : t * lane_bcast(ild[rr], 0);     // ild is wave-uniform
+                col[rr] = rr < c ? 0.0 : t * ild[rr];
             }
 #pragma unroll
             for (int rr = 0; rr < NB; ++rr) Li[rr][c] = col[rr];
         }
     }
+    return ok;
+}
+
+// First block column: every workgroup factors the diagonal tile A_00 (redundantly: 10 k FMAs are cheaper than a hand-off
+// between workgroups); workgroup 0 stores L_00 (into `ldiag`) and its inverse, workgroup i > 0 turns its tile into
+// L_i0 = A_i0 L_00^-T (a small GEMM with the inverse, no sequential substitution).
+template <int NB>
+__global__ __launch_bounds__(256) void chol_panel_kernel(const CholArgs a) {
+    __shared__ double D[NB][NB + 1];    // diagonal tile -> L_kk (lower)
+    __shared__ double Li[NB][NB + 1];   // L_kk^-1 (lower)
+    __shared__ double X[NB][NB + 1];    // this workgroup's panel tile
+    __shared__ int flag_bad;
+    const int tid = threadIdx.x;
+    const int k = a.k;
+    const int bi = k + blockIdx.x;      // blockIdx.x > 0: a tile below the diagonal
+    constexpr int EPT = NB * NB / 256;
 #pragma unroll
     for (int q = 0; q < EPT; ++q) {
-        const int e = tid + 256 * q;
-        X[e / NB][e % NB] = xin[q];
+        const int e = tid + 256 * q, r = e / NB, c = e % NB;
+        D[r][c] = c <= r ? chol_load<NB>(a, k, k, r, c) : 0.0;
+        X[r][c] = blockIdx.x > 0 ? chol_load<NB>(a, bi, k, r, c) : 0.0;
     }
+    if (tid == 0) flag_bad = 0;
+    __syncthreads();
+    const bool ok = factor_and_invert_tile<NB>(D, Li, tid);
+    if (!ok && tid == 0) flag_bad = 1;
     __syncthreads();
     if (blockIdx.x == 0) {
         if (flag_bad && tid == 0) atomicOr(a.status, 2);
         for (int e = tid; e < NB * NB; e += 256) {
             const int r = e / NB, c = e % NB;
-            const int gr = k * NB + r, gc = k * NB + c;
-            if (gr < a.n && gc < a.n && c <= r) a.A[(int64_t)gr * a.ld + gc] = D[r][c];
+            a.ldiag[((int64_t)k * NB + r) * NB + c] = D[r][c];
             a.linv[((int64_t)k * NB + r) * NB + c] = Li[r][c];
         }
         return;
     }
-    // L_ik = A_ik L_kk^-T
 #pragma unroll
-    for (int q = 0; q < EPT; ++q) {
+    for (int q = 0; q < EPT; ++q) {   // L_ik = A_ik L_kk^-T
         const int e = tid + 256 * q, r = e / NB, c = e % NB;
         double s = 0.0;
         for (int m = 0; m <= c; ++m) s += X[r][m] * Li[c][m];   // (L^-T)[m][c] = Linv[c][m]
@@ -139,40 +145,94 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(const CholArgs a) {
     }
 }
 
-// trailing update: workgroup t handles tile (i, j), k < j <= i, enumerated row by row
+// One launch per further block column: the trailing update with block column k (workgroup t handles tile (i, j), k < j <= i,
+// enumerated row by row: A_ij -= L_ik L_jk') AND the panel step of column k + 1 by the workgroups of that column (j = k + 1):
+// each of them also forms the updated diagonal tile A_{k+1,k+1} - L_{k+1,k} L_{k+1,k}' (the one extra tile it needs is the
+// L_jk it has loaded anyway), factors and inverts it, and writes its own updated tile as L_{i,k+1} = (A_ij - L_ik L_jk') L^-T
+// straight away.  Half the launches of the update + panel pair and one global round trip less per block column.
 template <int NB>
-__global__ __launch_bounds__(256) void chol_update_kernel(const CholArgs a) {
-    __shared__ double Lik[NB][NB + 1];
+__global__ __launch_bounds__(256) void chol_step_kernel(const CholArgs a) {
+    __shared__ double Lik[NB][NB + 1];   // later: this workgroup's updated tile
     __shared__ double Ljk[NB][NB + 1];
+    __shared__ double D[NB][NB + 1];
+    __shared__ double Li[NB][NB + 1];
+    __shared__ int flag_bad;
     const int tid = threadIdx.x;
     const int k = a.k;
-    // t -> (di, dj) with 0 <= dj <= di: di = floor((sqrt(8 t + 1) - 1) / 2)
     const int t = blockIdx.x;
-    int di = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+    int di = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);   // t -> (di, dj), 0 <= dj <= di
     while ((di + 1) * (di + 2) / 2 <= t) ++di;
     while (di * (di + 1) / 2 > t) --di;
     const int dj = t - di * (di + 1) / 2;
     const int bi = k + 1 + di, bj = k + 1 + dj;
-    for (int e = tid; e < NB * NB; e += 256) {
-        const int r = e / NB, c = e % NB;
+    const bool first_col = dj == 0;
+    constexpr int EPT = NB * NB / 256;
+    double own[EPT], dg[EPT];
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {
+        const int e = tid + 256 * q, r = e / NB, c = e % NB;
         Lik[r][c] = chol_load<NB>(a, bi, k, r, c);
         Ljk[r][c] = chol_load<NB>(a, bj, k, r, c);
+        own[q] = chol_load<NB>(a, bi, bj, r, c);
+        dg[q] = (first_col && c <= r) ? chol_load<NB>(a, bj, bj, r, c) : 0.0;
+    }
+    if (tid == 0) flag_bad = 0;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {
+        const int e = tid + 256 * q, r = e / NB, c = e % NB;
+        double s = 0.0, sd = 0.0;
+#pragma unroll 8
+        for (int m = 0; m < NB; ++m) {
+            s += Lik[r][m] * Ljk[c][m];
+            sd += Ljk[r][m] * Ljk[c][m];
+        }
+        own[q] -= s;
+        dg[q] = c <= r ? dg[q] - sd : 0.0;
+    }
+    if (!first_col) {
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) {
+            const int e = tid + 256 * q, r = e / NB, c = e % NB;
+            const int gr = bi * NB + r, gc = bj * NB + c;
+            if (gr < a.n && gc < a.n && gc <= gr) a.A[(int64_t)gr * a.ld + gc] = own[q];
+        }
+        return;
+    }
+    __syncthreads();   // everybody is done reading Lik / Ljk
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {
+        const int e = tid + 256 * q, r = e / NB, c = e % NB;
+        D[r][c] = dg[q];
+        Lik[r][c] = own[q];
     }
     __syncthreads();
-    for (int e = tid; e < NB * NB; e += 256) {
-        const int r = e / NB, c = e % NB;
-        const int gr = bi * NB + r, gc = bj * NB + c;
-        if (gr >= a.n || gc >= a.n || gc > gr) continue;
+    const bool ok = factor_and_invert_tile<NB>(D, Li, tid);
+    if (!ok && tid == 0) flag_bad = 1;
+    __syncthreads();
+    if (di == 0) {   // the diagonal tile's own workgroup
+        if (flag_bad && tid == 0) atomicOr(a.status, 2);
+        for (int e = tid; e < NB * NB; e += 256) {
+            const int r = e / NB, c = e % NB;
+            a.ldiag[((int64_t)bj * NB + r) * NB + c] = D[r][c];
+            a.linv[((int64_t)bj * NB + r) * NB + c] = Li[r][c];
+        }
+        return;
+    }
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {   // L_{i,k+1} = (updated tile) L^-T
+        const int e = tid + 256 * q, r = e / NB, c = e % NB;
         double s = 0.0;
-#pragma unroll 8
-        for (int m = 0; m < NB; ++m) s += Lik[r][m] * Ljk[c][m];
-        a.A[(int64_t)gr * a.ld + gc] -= s;
+        for (int m = 0; m <= c; ++m) s += Lik[r][m] * Li[c][m];
+        const int gr = bi * NB + r, gc = bj * NB + c;
+        if (gr < a.n && gc < a.n) a.A[(int64_t)gr * a.ld + gc] = s;
     }
 }
 
 struct CholSolveArgs {
-    const double *L;      // factor (lower triangle of A)
+    double *L;            // factor (lower triangle of A; its diagonal tiles arrive from ldiag here)
     const double *linv;   // inverses of its diagonal tiles
+    const double *ldiag;  // the diagonal tiles themselves
     const double *rhs;
     double *x;            // n
     int32_t n, ld;
@@ -195,6 +255,11 @@ __global__ __launch_bounds__(512) void chol_solve_kernel(const CholSolveArgs a) 
     double *y = sm;            // running right-hand side -> solution (npad)
     double *blk = y + npad;    // the block solved in this step (NB)
     for (int i = tid; i < npad; i += T) y[i] = i < n ? a.rhs[i] : 0.0;
+    for (int e = tid; e < nblk * NB * NB; e += T) {   // complete the factor in place: diagonal tiles (the sweeps below never read them)
+        const int k = e / (NB * NB), r = (e / NB) % NB, c = e % NB;
+        const int gr = k * NB + r, gc = k * NB + c;
+        if (gr < n && c <= r) a.L[(int64_t)gr * a.ld + gc] = a.ldiag[e];
+    }
     double cur[NB], nxt[NB], lin[NB];
     // ---------------- forward: L y = rhs ----------------
     auto panel_row = [&](const int k, double (&dst)[NB]) {      // row (k + 1) NB + tid of block column k

@@ -528,6 +528,58 @@ def test_generated_chains_match_the_reference_code_generator(golden_dir, tag):
     assert np.all(d[:, 0, 1] == 1) and np.all(d[:, 1, 3] == 1) and np.all(d[:, 0, 2] == 0) and np.all(d[:, 1, 0] == 0)
 
 
+def test_generated_chain_options_counts_shared_groups_and_errors():
+    """The operator API around generated chains: explicit `counts` (slab sizes beyond max index + 1), two blocks of one class
+    sharing ONE parameter group (the reference tells groups apart by object identity, afb:160-163: `rigidTform3d + rigidTform3d`
+    applies the same pose twice), the float engines refused, and agreement of a generated chain with its own hand-fused twin
+    when the extra transform is the identity."""
+    from pycamset_amd import function_blocks as fb
+    rig = synthetic.tiny_rig(seed=50, n_cams=3, n_imgs=5, n_keys=8, visibility=0.9)
+    det = rig.detections
+    # (1) projection + rigidTform3d + rigidTform3d + free_point with ONE pose group: R_p (R_p X + t_p) + t_p
+    op = fb.projection() + fb.rigidTform3d() + fb.rigidTform3d() + fb.free_point()
+    assert op.chain == "generated"
+    ps = op.build_param_list(rig.intr, rig.poses, rig.points)
+    r = op.make_full_loss_fn(det, 1)(ps)
+    data, idx, ptr = op.make_jacobean(det, 1)(ps)
+    cols = op.get_block_param_inds(det, 1)
+    assert cols.shape == (det.shape[0], 9 + 6 + 6 + 3) and np.array_equal(cols[:, 9:15], cols[:, 15:21])      # the shared group, twice
+    # finite differences of the residual (central, per parameter of detection 0's row) against the analytic columns;
+    # the two copies of the shared group each hold the partial derivative through THEIR block, the total is their sum
+    J = data.reshape(-1, 2, 24)
+    d0 = 0
+    for col in (0, 4, 9, 12, 14, 21):
+        gi = cols[d0, col]
+        h = 1e-6 * max(1.0, abs(ps[gi]))
+        pp, pm = ps.copy(), ps.copy()
+        pp[gi] += h
+        pm[gi] -= h
+        fd = (op.make_full_loss_fn(det, 1)(pp)[d0] - op.make_full_loss_fn(det, 1)(pm)[d0]) / (2 * h)
+        analytic = J[d0, :, [c for c in range(24) if cols[d0, c] == gi]].sum(axis=0)
+        assert np.max(np.abs(fd - analytic)) <= 1e-5 * max(1.0, np.max(np.abs(analytic))), (col, fd, analytic)
+    # (2) explicit counts: a trailing image and key without detections still get their place in the string
+    op2 = fb.optimisation_function([fb.projection(), fb.rigidTform3d(), fb.free_point()], counts=(3, 7, 10))
+    eng = op2._engine_for(det)
+    assert eng.n_params == 27 + 42 + 30
+    ps2 = np.concatenate([rig.intr.ravel(), np.concatenate([rig.poses, np.zeros((2, 6))]).ravel(), np.concatenate([rig.points, np.zeros((2, 3))]).ravel()])
+    ps1 = op2.build_param_list(rig.intr, rig.poses, rig.points)
+    op1 = fb.projection() + fb.rigidTform3d() + fb.free_point()
+    assert np.array_equal(op2.make_full_loss_fn(det, 1)(ps2), op1.make_full_loss_fn(det, 1)(ps1))
+    # (3) float engines exist for the hand-fused chains only
+    with pytest.raises(NotImplementedError):
+        fb.optimisation_function([fb.projection(), fb.rigidTform3d(), fb.free_point()], dtype="f32").make_full_loss_fn(det, 1)
+    # (4) a generated chain with an identity extra transform = the hand-fused self chain on the same inputs
+    op3 = fb.projection() + fb.extrinsic3D() + fb.rigidTform3d() + fb.free_point()          # hand-fused "self"
+    ps3 = op3.build_param_list(rig.intr, rig.extr, rig.poses, rig.points)
+    r3 = op3.make_full_loss_fn(det, 1)(ps3)
+    # per-image BEFORE per-camera is a different function unless the per-image transform is the identity:
+    op4 = fb.projection() + fb.rigidTform3d() + fb.extrinsic3D() + fb.free_point()          # generated
+    ps4 = op4.build_param_list(rig.intr, np.zeros_like(rig.poses), rig.extr, rig.points)
+    ps5 = op3.build_param_list(rig.intr, rig.extr, np.zeros_like(rig.poses), rig.points)
+    assert np.max(np.abs(op4.make_full_loss_fn(det, 1)(ps4) - op3.make_full_loss_fn(det, 1)(ps5))) <= 1e-9
+    assert r3.shape == (det.shape[0], 2)
+
+
 def test_generated_kernel_for_the_template_chain_against_the_hand_fused_one(capsys):
     """The chain compiler applied to `projection + extrinsic3D + template_points` itself (bypassing the hand-fused fast path):
     same function as ba_eval_kernel on the headline rig (N = 1e6) — values to 1e-12 of the row scale, golden parity on the
