@@ -1563,7 +1563,7 @@ int pcs_matfree(pcs_engine *h, int op, const double *in, double *out, double *co
     const size_t lds = lds_acc ? lds_need : 0;
     const int64_t wpc = h->wgs_per_cu > 0 ? h->wgs_per_cu : (op == OP_JV ? 8 : 2);
     const int64_t target_wgs = (int64_t)h->n_cu * wpc;
-    int64_t tpw = (a.n_tiles + target_wgs - 1) / target_wgs;
+    int64_t tpw = h->tiles_per_wg > 0 ? h->tiles_per_wg : (a.n_tiles + target_wgs - 1) / target_wgs;   // option tiles_per_wg: tests of the tile pipeline
     tpw = std::max<int64_t>(WAVES_PER_WG, (tpw + WAVES_PER_WG - 1) / WAVES_PER_WG * WAVES_PER_WG);
     a.tiles_per_wg = (int32_t)tpw;
     const dim3 grid((unsigned)((a.n_tiles + tpw - 1) / tpw));

@@ -291,14 +291,17 @@ def test_matrix_free_products_match_sparse_products_of_the_oracle_jacobian(chain
             assert a.shape == b.shape
             assert np.max(np.abs(a - b)) <= 1e-10 * np.max(np.abs(b)), float(np.max(np.abs(a - b)) / np.max(np.abs(b)))
 
-        if Jo is not None:
-            close(e.jv(v), Jo @ v)
-            close(e.jtu(u), Jo.T @ u)
-        close(e.jtjv(v), J.T @ (J @ v))
-        close(e.jtj_diag(), np.asarray(J.multiply(J).sum(axis=0)).ravel())
-        g, cost = e.grad()
-        close(g, J.T @ r.reshape(-1))
-        assert abs(cost - float(np.sum(r * r))) <= 1e-10 * float(np.sum(r * r))
+        for tpw in (0, 12, 32):   # 1, 3 and up to 8 tiles per wave: the kernels' two-level tile pipeline (ragged last workgroup)
+            e.set_option("tiles_per_wg", tpw)
+            if Jo is not None:
+                close(e.jv(v), Jo @ v)
+                close(e.jtu(u), Jo.T @ u)
+            close(e.jtjv(v), J.T @ (J @ v))
+            close(e.jtj_diag(), np.asarray(J.multiply(J).sum(axis=0)).ravel())
+            g, cost = e.grad()
+            close(g, J.T @ r.reshape(-1))
+            assert abs(cost - float(np.sum(r * r))) <= 1e-10 * float(np.sum(r * r))
+        e.set_option("tiles_per_wg", 0)
         # an evaluation re-linearises too
         e.eval(ps * (1 + 1e-3), want_jac=False)
         e.linearize(ps)
