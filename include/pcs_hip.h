@@ -210,7 +210,7 @@ int pcs_lm_decide(pcs_engine *h, const double *d_cost_old, const double *d_cost_
 
 /* S x = rhs for a dense symmetric positive definite S (float64, n x n row-major with row stride ld, LOWER triangle read and
  * overwritten by its Cholesky factor): the reduced system of the Schur step above.  Blocked right-looking factorisation (32 x 32
- * tiles, two launches per block column) + both substitutions in one workgroup (csrc/ba_dense_chol.hpp) — at n = 480 / 1 680
+ * tiles, one launch per block column) + both substitutions in one workgroup (csrc/ba_dense_chol.hpp) — at n = 480 / 1 680
  * several times faster than rocSOLVER's potrf + potrs, whose dependent chain is what an LM iteration waits for.  All pointers are
  * device memory; d_work holds pcs_dense_spd_work_len(n) doubles; *d_status |= 2 when a pivot is not positive; queued on `stream`
  * (NULL = the default stream), n <= 32768. */

@@ -25,8 +25,8 @@ namespace pcs {
 struct CholArgs {
     double *A;          // n x n, row-major, ld; lower triangle in / L out
     double *linv;       // (n / NB rounded up) x NB x NB: inverses of the diagonal tiles of L (lower triangular, row-major)
-    double *ldiag;      // same shape: the diagonal tiles of L.  They are NOT written into A by the panel launch — its other
-                        // workgroups read A_kk in the same launch — but copied there by chol_solve_kernel, which runs alone
+    double *ldiag;      // same shape: the diagonal tiles of L.  A launch does NOT write the tile it factors into A — its other
+                        // workgroups read that tile of A in the same launch; the NEXT launch copies it there (the last one: chol_solve_kernel)
     int32_t *status;
     int32_t n, ld, k;   // k = block column of this launch
 };
@@ -217,6 +217,13 @@ __global__ __launch_bounds__(256) void chol_step_kernel(const CholArgs a) {
             a.ldiag[((int64_t)bj * NB + r) * NB + c] = D[r][c];
             a.linv[((int64_t)bj * NB + r) * NB + c] = Li[r][c];
         }
+        // complete the factor in place: the diagonal tile of column k (from `ldiag`, written by the previous launch) goes into A
+        // now — this launch reads column k only below the diagonal.  Off the critical path: this workgroup has no panel tile.
+        for (int e = tid; e < NB * NB; e += 256) {
+            const int r = e / NB, c = e % NB;
+            const int gr = k * NB + r, gc = k * NB + c;
+            if (gr < a.n && c <= r) a.A[(int64_t)gr * a.ld + gc] = a.ldiag[((int64_t)k * NB + r) * NB + c];
+        }
         return;
     }
 #pragma unroll
@@ -255,10 +262,10 @@ __global__ __launch_bounds__(512) void chol_solve_kernel(const CholSolveArgs a) 
     double *y = sm;            // running right-hand side -> solution (npad)
     double *blk = y + npad;    // the block solved in this step (NB)
     for (int i = tid; i < npad; i += T) y[i] = i < n ? a.rhs[i] : 0.0;
-    for (int e = tid; e < nblk * NB * NB; e += T) {   // complete the factor in place: diagonal tiles (the sweeps below never read them)
-        const int k = e / (NB * NB), r = (e / NB) % NB, c = e % NB;
+    for (int e = tid; e < NB * NB; e += T) {   // complete the factor in place: the LAST diagonal tile (the others: chol_step_kernel; the sweeps never read them)
+        const int k = nblk - 1, r = e / NB, c = e % NB;
         const int gr = k * NB + r, gc = k * NB + c;
-        if (gr < n && c <= r) a.L[(int64_t)gr * a.ld + gc] = a.ldiag[e];
+        if (gr < n && c <= r) a.L[(int64_t)gr * a.ld + gc] = a.ldiag[(int64_t)k * NB * NB + e];
     }
     double cur[NB], nxt[NB], lin[NB];
     // ---------------- forward: L y = rhs ----------------
