@@ -88,7 +88,7 @@ constexpr int normal_slots(int chain, int pass) {
 constexpr int normal_mfmas(int chain, int pass) { return (pass == PASS_SHARED && chain != CHAIN_FREE) ? 2 : 1; }
 // bytes between column slots: 2 * ROWS doubles + 16 -> slot s starts on bank (4 s) mod 64
 constexpr int normal_slot_stride(int rows) { return 2 * rows * 8 + 16; }
-constexpr int normal_lds_bytes(int chain, int pass, int rows) { return normal_slots(chain, pass) * normal_slot_stride(rows); }
+constexpr int normal_lds_bytes(int chain, int pass, int rows) { return normal_slots(chain, pass) * normal_slot_stride(rows) + 64; }   // + 64: the walk's look-ahead read past the last k-step
 
 // local column id (index into a J row; NORMAL_R = residual) stored in slot s of the image
 template <int CHAIN, int PASS>
@@ -409,11 +409,22 @@ __global__ __launch_bounds__(64, 2) void ba_normal_mfma_kernel(const NormalArgs 
             };
             // k-steps [s0, s1) of the image, all inside the current run: rolled loop, the operands of step s + 1 are
             // requested before the MFMAs of step s are issued (the MFMAs of one step take 64 cycles each — the LDS latency)
+            const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)lds_image;
             auto run_steps = [&](const int s0, const int s1) {
                 if (s0 >= s1) return;
                 double x[2][NW];
+                // one running byte address per operand window: the reads of a trip are `adr + 32` and `adr + 64` (immediate offsets)
+                // and the trip costs NW additions.  The first version rebuilt every address from the step number (9 v_add per trip
+                // + a clamp of the look-ahead step on the scalar side); the look-ahead past the image's last step now simply reads
+                // the next slot's first bytes / the 64-byte pad behind the image, and that value is never used.
+                using LdsD = const __attribute__((address_space(3))) double *;
+                uint32_t adr[NW];   // LDS byte addresses
 #pragma unroll
-                for (int w = 0; w < NW; ++w) x[0][w] = operand(w, s0);
+                for (int w = 0; w < NW; ++w) {
+                    adr[w] = lds_base + (uint32_t)rd_off[w] + (uint32_t)s0 * 32u;
+                    asm volatile("" : "+v"(adr[w]));   // one register per window (otherwise hipcc keeps base and offset apart: an add per read)
+                    x[0][w] = *(LdsD)(uintptr_t)adr[w];
+                }
                 int s = s0;
                 // Order per step: wait for THIS step's operands, request the next step's, issue the MFMAs.  hipcc places its
                 // s_waitcnt directly before the first use of a loaded register and — left alone — sinks the next step's
@@ -428,17 +439,19 @@ __global__ __launch_bounds__(64, 2) void ba_normal_mfma_kernel(const NormalArgs 
                     touch(x[0]);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int w = 0; w < NW; ++w) x[1][w] = operand(w, s + 1);
+                    for (int w = 0; w < NW; ++w) x[1][w] = *(LdsD)(uintptr_t)(adr[w] + 32u);
                     __builtin_amdgcn_sched_barrier(0);
                     run_mfmas(x[0]);
                     __builtin_amdgcn_sched_barrier(0);
                     touch(x[1]);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int w = 0; w < NW; ++w) x[0][w] = operand(w, min(s + 2, STEPS - 1));
+                    for (int w = 0; w < NW; ++w) x[0][w] = *(LdsD)(uintptr_t)(adr[w] + 64u);
                     __builtin_amdgcn_sched_barrier(0);
                     run_mfmas(x[1]);
                     __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) adr[w] += 64u;
                 }
                 if (s < s1) run_mfmas(x[0]);
             };
