@@ -159,11 +159,22 @@ __global__ __launch_bounds__(256) void chol_step_kernel(const CholArgs a) {
     __shared__ int flag_bad;
     const int tid = threadIdx.x;
     const int k = a.k;
-    const int t = blockIdx.x;
-    int di = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);   // t -> (di, dj), 0 <= dj <= di
-    while ((di + 1) * (di + 2) / 2 <= t) ++di;
-    while (di * (di + 1) / 2 > t) --di;
-    const int dj = t - di * (di + 1) / 2;
+    // workgroups 0 .. m - 1 (m = block rows of the trailing matrix): its first column, the launch's critical path — dispatched
+    // first, so that a trailing matrix of more tiles than the chip holds at once (n = 1 680: 1 378) does not leave panel
+    // tiles to the second round; the others enumerate the rest of the lower triangle row by row
+    const int m = (a.n + NB - 1) / NB - k - 1;
+    int di, dj;
+    if ((int)blockIdx.x < m) {
+        di = blockIdx.x;
+        dj = 0;
+    } else {
+        const int t = blockIdx.x - m;   // -> (di - 1, dj - 1), 0 <= dj - 1 <= di - 1
+        int ri = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+        while ((ri + 1) * (ri + 2) / 2 <= t) ++ri;
+        while (ri * (ri + 1) / 2 > t) --ri;
+        di = ri + 1;
+        dj = t - ri * (ri + 1) / 2 + 1;
+    }
     const int bi = k + 1 + di, bj = k + 1 + dj;
     const bool first_col = dj == 0;
     constexpr int EPT = NB * NB / 256;
