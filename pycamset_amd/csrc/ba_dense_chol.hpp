@@ -60,16 +60,22 @@ __device__ __forceinline__ double lane_bcast(const double v, const int src) {   
 // register-resident column and the reciprocal pivots (no divisions).  Returns false (wave-uniform) for a non-positive pivot.
 // The caller puts a workgroup barrier before (D complete) and after (D, Li complete).
 template <int NB>
-__device__ __forceinline__ bool factor_and_invert_tile(double (&D)[NB][NB + 1], double (&Li)[NB][NB + 1], const int tid) {
+__device__ __forceinline__ bool factor_and_invert_tile(double (&D)[NB][NB + 1], double (&Li)[NB][NB + 1], const int tid) {   // NB + 1 = CHOL_LDF
     static_assert(NB == 32, "one row per lane of half a wave");
     bool ok = true;
     if (tid < 64) {
         const int r = tid & (NB - 1);
         double row[NB], ild[NB];
+#if defined(PCS_CHOL_SKIP) && PCS_CHOL_SKIP
+        for (int c = 0; c < NB; ++c) ild[c] = 1.0;
+#endif
 #pragma unroll
         for (int c = 0; c < NB; ++c) row[c] = tid < NB ? D[r][c] : (c == r ? 1.0 : 0.0);
+#ifndef PCS_CHOL_SKIP
+#define PCS_CHOL_SKIP 0   // timing experiments only: 1 = no factorisation loop, 2 = no inversion loop
+#endif
 #pragma unroll
-        for (int j = 0; j < NB; ++j) {
+        for (int j = 0; j < ((PCS_CHOL_SKIP & 1) ? 0 : NB); ++j) {
             const double p = lane_bcast(row[j], j);
             ok = ok && (p > 0.0);
             const double il = rsqrt_nr(p);
@@ -86,32 +92,56 @@ __device__ __forceinline__ bool factor_and_invert_tile(double (&D)[NB][NB + 1], 
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (tid < NB) {
+            // column c of the inverse: L x = e_c, COLUMN-oriented — once x[m] is known every later equation gets its term, 31 - m
+            // independent FMAs.  (Row-oriented, the first version, each x[rr] was a chain of rr dependent FMAs on a SIMD this
+            // wave has to itself: 4.3 us per tile; skipping the loop in a timing build showed it.)
             const int c = tid;
-            double col[NB];
+            double t[NB];
 #pragma unroll
-            for (int rr = 0; rr < NB; ++rr) {
-                double t = (rr == c) ? 1.0 : 0.0;
+            for (int rr = 0; rr < NB; ++rr) t[rr] = (rr == c) ? 1.0 : 0.0;
 #pragma unroll
-                for (int m = 0; m < rr; ++m) t -= D[rr][m] * col[m];     // col[m] = 0 for m < c
-                col[rr] = rr < c ? 0.0 : t * ild[rr];
+            for (int m = 0; m < ((PCS_CHOL_SKIP & 2) ? 0 : NB); ++m) {
+                const double xm = t[m] * ild[m];   // 0 for m < c
+                Li[m][c] = xm;
+#pragma unroll
+                for (int rr = m + 1; rr < NB; ++rr) t[rr] -= D[rr][m] * xm;
             }
-#pragma unroll
-            for (int rr = 0; rr < NB; ++rr) Li[rr][c] = col[rr];
         }
     }
     return ok;
 }
 
+// ---- 32 x 32 x 32 products on the FP64 matrix cores ------------------------------------------------------------------------------
+// Wave w of the four owns the 16 x 16 quadrant (16 (w >> 1), 16 (w & 1)) of a tile; v_mfma_f64_16x16x4 computes
+// D[i][j] += sum_k A[k][i] B[k][j] with lane l supplying A[l >> 4][l & 15] and B[l >> 4][l & 15] per k-step of 4 and
+// holding D[(l >> 4) + 4 r][l & 15] in register r.  Here both operands are ROWS of row-major LDS tiles (X Y' products):
+// lane l reads P[i0 + (l & 15)][4 s + (l >> 4)] and Q[j0 + (l & 15)][4 s + (l >> 4)].  Eight k-steps, 8 MFMAs and 16
+// ds_read_b64 per product and wave — the first version's VALU form read 9 LDS operands per 8 FMAs, ~4 us of a 22 us launch.
+using chol_d4 = __attribute__((ext_vector_type(4))) double;
+constexpr int CHOL_LDP = 36;   // row stride (doubles) of MFMA operand tiles: lanes (row, k) -> banks 8 row + 2 k: two passes, the minimum
+constexpr int CHOL_LDF = 33;   // row stride of the tiles the factorisation walks row-per-lane (conflict-free)
+
+template <int LDP_, int LDQ_, int KSTEPS = 8>
+__device__ __forceinline__ chol_d4 chol_quadrant_xyT(const double *P, const double *Q, const int i0, const int j0, const int lane) {
+    chol_d4 acc = {0.0, 0.0, 0.0, 0.0};
+    const double *p = P + (i0 + (lane & 15)) * LDP_ + (lane >> 4);
+    const double *q = Q + (j0 + (lane & 15)) * LDQ_ + (lane >> 4);
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(p[4 * s], q[4 * s], acc, 0, 0, 0);
+    return acc;
+}
+
 // First block column: every workgroup factors the diagonal tile A_00 (redundantly: 10 k FMAs are cheaper than a hand-off
 // between workgroups); workgroup 0 stores L_00 (into `ldiag`) and its inverse, workgroup i > 0 turns its tile into
-// L_i0 = A_i0 L_00^-T (a small GEMM with the inverse, no sequential substitution).
+// L_i0 = A_i0 L_00^-T (a product with the inverse on the matrix cores, no sequential substitution).
 template <int NB>
 __global__ __launch_bounds__(256) void chol_panel_kernel(const CholArgs a) {
-    __shared__ double D[NB][NB + 1];    // diagonal tile -> L_kk (lower)
-    __shared__ double Li[NB][NB + 1];   // L_kk^-1 (lower)
-    __shared__ double X[NB][NB + 1];    // this workgroup's panel tile
+    static_assert(NB == 32, "four waves, one 16 x 16 quadrant each");
+    __shared__ double D[NB][CHOL_LDF];    // diagonal tile -> L_kk (lower)
+    __shared__ double Li[NB][CHOL_LDF];   // L_kk^-1 (lower)
+    __shared__ double X[NB][CHOL_LDP];    // this workgroup's panel tile
     __shared__ int flag_bad;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int k = a.k;
     const int bi = k + blockIdx.x;      // blockIdx.x > 0: a tile below the diagonal
     constexpr int EPT = NB * NB / 256;
@@ -135,29 +165,30 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(const CholArgs a) {
         }
         return;
     }
+    const int i0 = 16 * (wave >> 1), j0 = 16 * (wave & 1);
+    const chol_d4 l = chol_quadrant_xyT<CHOL_LDP, CHOL_LDF>(&X[0][0], &Li[0][0], i0, j0, lane);   // L_ik = A_ik L_kk^-T: (L^-T)[m][c] = Linv[c][m]
 #pragma unroll
-    for (int q = 0; q < EPT; ++q) {   // L_ik = A_ik L_kk^-T
-        const int e = tid + 256 * q, r = e / NB, c = e % NB;
-        double s = 0.0;
-        for (int m = 0; m <= c; ++m) s += X[r][m] * Li[c][m];   // (L^-T)[m][c] = Linv[c][m]
-        const int gr = bi * NB + r, gc = k * NB + c;
-        if (gr < a.n && gc < a.n) a.A[(int64_t)gr * a.ld + gc] = s;
+    for (int r = 0; r < 4; ++r) {
+        const int gr = bi * NB + i0 + (lane >> 4) + 4 * r, gc = k * NB + j0 + (lane & 15);
+        if (gr < a.n && gc < a.n) a.A[(int64_t)gr * a.ld + gc] = l[r];
     }
 }
 
-// One launch per further block column: the trailing update with block column k (workgroup t handles tile (i, j), k < j <= i,
-// enumerated row by row: A_ij -= L_ik L_jk') AND the panel step of column k + 1 by the workgroups of that column (j = k + 1):
+// One launch per further block column: the trailing update with block column k (one workgroup per tile (i, j), k < j <= i:
+// A_ij -= L_ik L_jk') AND the panel step of column k + 1 by the workgroups of that column (j = k + 1):
 // each of them also forms the updated diagonal tile A_{k+1,k+1} - L_{k+1,k} L_{k+1,k}' (the one extra tile it needs is the
 // L_jk it has loaded anyway), factors and inverts it, and writes its own updated tile as L_{i,k+1} = (A_ij - L_ik L_jk') L^-T
-// straight away.  Half the launches of the update + panel pair and one global round trip less per block column.
+// straight away.  Half the launches of the update + panel pair and one global round trip less per block column.  All three
+// products run on the matrix cores (chol_quadrant_xyT).
 template <int NB>
 __global__ __launch_bounds__(256) void chol_step_kernel(const CholArgs a) {
-    __shared__ double Lik[NB][NB + 1];   // later: this workgroup's updated tile
-    __shared__ double Ljk[NB][NB + 1];
-    __shared__ double D[NB][NB + 1];
-    __shared__ double Li[NB][NB + 1];
+    static_assert(NB == 32, "four waves, one 16 x 16 quadrant each");
+    __shared__ double Lik[NB][CHOL_LDP];   // later: this workgroup's updated tile
+    __shared__ double Ljk[NB][CHOL_LDP];
+    __shared__ double D[NB][CHOL_LDF];
+    __shared__ double Li[NB][CHOL_LDF];
     __shared__ int flag_bad;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int k = a.k;
     // workgroups 0 .. m - 1 (m = block rows of the trailing matrix): its first column, the launch's critical path — dispatched
     // first, so that a trailing matrix of more tiles than the chip holds at once (n = 1 680: 1 378) does not leave panel
@@ -178,44 +209,46 @@ __global__ __launch_bounds__(256) void chol_step_kernel(const CholArgs a) {
     const int bi = k + 1 + di, bj = k + 1 + dj;
     const bool first_col = dj == 0;
     constexpr int EPT = NB * NB / 256;
-    double own[EPT], dg[EPT];
+    const int i0 = 16 * (wave >> 1), j0 = 16 * (wave & 1);
+    // this lane's four entries of its quadrant (the MFMA result layout): rows i0 + (lane >> 4) + 4 r, column j0 + (lane & 15)
+    const int qr = i0 + (lane >> 4), qc = j0 + (lane & 15);
+    double own[4], dg[4];
 #pragma unroll
     for (int q = 0; q < EPT; ++q) {
         const int e = tid + 256 * q, r = e / NB, c = e % NB;
         Lik[r][c] = chol_load<NB>(a, bi, k, r, c);
         Ljk[r][c] = chol_load<NB>(a, bj, k, r, c);
-        own[q] = chol_load<NB>(a, bi, bj, r, c);
-        dg[q] = (first_col && c <= r) ? chol_load<NB>(a, bj, bj, r, c) : 0.0;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        own[r] = chol_load<NB>(a, bi, bj, qr + 4 * r, qc);
+        dg[r] = (first_col && qc <= qr + 4 * r) ? chol_load<NB>(a, bj, bj, qr + 4 * r, qc) : 0.0;
     }
     if (tid == 0) flag_bad = 0;
     __syncthreads();
+    {
+        const chol_d4 u = chol_quadrant_xyT<CHOL_LDP, CHOL_LDP>(&Lik[0][0], &Ljk[0][0], i0, j0, lane);
 #pragma unroll
-    for (int q = 0; q < EPT; ++q) {
-        const int e = tid + 256 * q, r = e / NB, c = e % NB;
-        double s = 0.0, sd = 0.0;
-#pragma unroll 8
-        for (int m = 0; m < NB; ++m) {
-            s += Lik[r][m] * Ljk[c][m];
-            sd += Ljk[r][m] * Ljk[c][m];
-        }
-        own[q] -= s;
-        dg[q] = c <= r ? dg[q] - sd : 0.0;
+        for (int r = 0; r < 4; ++r) own[r] -= u[r];
     }
     if (!first_col) {
 #pragma unroll
-        for (int q = 0; q < EPT; ++q) {
-            const int e = tid + 256 * q, r = e / NB, c = e % NB;
-            const int gr = bi * NB + r, gc = bj * NB + c;
-            if (gr < a.n && gc < a.n && gc <= gr) a.A[(int64_t)gr * a.ld + gc] = own[q];
+        for (int r = 0; r < 4; ++r) {
+            const int gr = bi * NB + qr + 4 * r, gc = bj * NB + qc;
+            if (gr < a.n && gc < a.n && gc <= gr) a.A[(int64_t)gr * a.ld + gc] = own[r];
         }
         return;
     }
+    {   // first column: bj = k + 1, Ljk = L_{k+1,k}; the updated diagonal tile (lower part)
+        const chol_d4 u = chol_quadrant_xyT<CHOL_LDP, CHOL_LDP>(&Ljk[0][0], &Ljk[0][0], i0, j0, lane);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dg[r] = qc <= qr + 4 * r ? dg[r] - u[r] : 0.0;
+    }
     __syncthreads();   // everybody is done reading Lik / Ljk
 #pragma unroll
-    for (int q = 0; q < EPT; ++q) {
-        const int e = tid + 256 * q, r = e / NB, c = e % NB;
-        D[r][c] = dg[q];
-        Lik[r][c] = own[q];
+    for (int r = 0; r < 4; ++r) {
+        D[qr + 4 * r][qc] = dg[r];
+        Lik[qr + 4 * r][qc] = own[r];
     }
     __syncthreads();
     const bool ok = factor_and_invert_tile<NB>(D, Li, tid);
@@ -237,13 +270,11 @@ __global__ __launch_bounds__(256) void chol_step_kernel(const CholArgs a) {
         }
         return;
     }
+    const chol_d4 l = chol_quadrant_xyT<CHOL_LDP, CHOL_LDF>(&Lik[0][0], &Li[0][0], i0, j0, lane);   // L_{i,k+1} = (updated tile) L^-T
 #pragma unroll
-    for (int q = 0; q < EPT; ++q) {   // L_{i,k+1} = (updated tile) L^-T
-        const int e = tid + 256 * q, r = e / NB, c = e % NB;
-        double s = 0.0;
-        for (int m = 0; m <= c; ++m) s += Lik[r][m] * Li[c][m];
-        const int gr = bi * NB + r, gc = bj * NB + c;
-        if (gr < a.n && gc < a.n) a.A[(int64_t)gr * a.ld + gc] = s;
+    for (int r = 0; r < 4; ++r) {
+        const int gr = bi * NB + qr + 4 * r, gc = bj * NB + qc;
+        if (gr < a.n && gc < a.n) a.A[(int64_t)gr * a.ld + gc] = l[r];
     }
 }
 
