@@ -382,13 +382,25 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    def timed(fn, reps):
-        """max-over-ranks seconds per call of `fn`, bracketed by barrier + synchronize on both sides"""
+    region_gpu_ms = [None]   # GPU time of the last timed(..., bracket=True) region per call: two events on the launch stream
+
+    def timed(fn, reps, bracket=False):
+        """max-over-ranks seconds per call of `fn`, bracketed by barrier + synchronize on both sides.  ``bracket``: also two HIP
+        events on the launch stream around the calls (this rank's GPU time per call, gaps between launches included)."""
         fence()
+        e0 = e1 = None
+        if bracket:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
+        if bracket:
+            e0.record()
         for _ in range(reps):
             fn()
+        if bracket:
+            e1.record()
         torch.cuda.synchronize(dev)
+        if bracket:
+            region_gpu_ms[0] = e0.elapsed_time(e1) / reps
         if world > 1:
             dist.barrier()
         return reduce_scalar(time.perf_counter() - t0, dist.ReduceOp.MAX) / reps
@@ -412,11 +424,27 @@ def main():
                 eng.eval_device_resident(d_p.data_ptr(), d_r.data_ptr(), None, stream)
             torch.cuda.synchronize(dev)
 
+    # the part's sustained write rate TODAY, in the fused kernel's store shape (non-temporal 16-byte stores, whole chunks per wave),
+    # back to back like the steps: boxes of this pool differ by 20 % in it (4.5-5.6 TB/s), and it is the bound of this path
+    nt_fill_GBps = None
+    try:
+        from pycamset_amd import _capi
+        import ctypes
+
+        ms_f = ctypes.c_float()
+        fill_bytes = max(1 << 20, (int(N) * int(2 * P + 2) * (8 if dtype == "f64" else 4)) // 4096 * 4096)
+        _capi.check(_capi.lib().pcs_membench(local_rank, 4, fill_bytes, 50, 8, ctypes.byref(ms_f)))
+        if ms_f.value > 0:
+            nt_fill_GBps = fill_bytes / (ms_f.value * 1e-3) / 1e9
+        torch.cuda.synchronize(dev)
+    except Exception as e:  # a probe: its failure must not cost the bench line
+        print(f"[bench] membench probe failed: {e}", file=sys.stderr)
+
     # ---- the timed region: K steps, no HIP events attached to the launches ---------------------------------------
     eng.set_option("timing_every", 0)
     for _ in range(args.warmup):
         step()
-    sec_per_step = timed(step, args.steps)
+    sec_per_step = timed(step, args.steps, bracket=True)
     elapsed = sec_per_step * args.steps
 
     # ---- kernel durations: >= 20 extra launches with start/stop events, outside the wall-clock region ------------
@@ -427,7 +455,14 @@ def main():
     torch.cuda.synchronize(dev)
     prep_s, eval_s = eng.kernel_ms_samples(KERNEL_SAMPLES)
     eng.set_option("timing_every", 0)
-    eval_ms, prep_ms = float(np.mean(eval_s)), float(np.mean(prep_s))
+    iso_ms, prep_ms = float(np.mean(eval_s)), float(np.mean(prep_s))
+    # The kernel's average duration OVER THE TIMED REGION: the GPU time between two events that bracket the K steps on the launch
+    # stream, per step, minus slab_prep's own duration where a step has that second launch.  It contains the ~1-3 us between
+    # consecutive launches — an upper bound of the kernel's duration, and the figure that agrees with `rocprofv3 --stats` of
+    # this command.  The launches that carry their own start / stop events (`kernel_ms_isolated*`, after the region) follow a
+    # timed dispatch's ~12 us gap, find the memory system drained and run 4-9 % faster: reported, not used for `frac`.
+    in_region = region_gpu_ms[0] is not None and streamer is None and not use_gather_in_step
+    eval_ms = max(region_gpu_ms[0] - prep_ms, 0.0) if in_region else iso_ms
 
     # ---- multi-GPU extras, outside the timed region --------------------------------------------------------------
     multi = None
@@ -565,15 +600,18 @@ def main():
                 "traffic_source": traffic_source,
                 "kernel": "ba_eval_kernel",
                 "kernel_ms": eval_ms,
-                "kernel_ms_median": float(np.median(eval_s)),
-                "kernel_ms_min": float(np.min(eval_s)),
+                "kernel_ms_isolated": iso_ms,
+                "kernel_ms_isolated_median": float(np.median(eval_s)),
+                "kernel_ms_isolated_min": float(np.min(eval_s)),
                 # each kernel's own start/stop events: the figures rocprofv3 reports.  0 = a one-launch step (the waves of the
                 # evaluation kernel prepare their own slabs; tables of <= 4e5 detections in run order, option "fuse_prep")
                 "slab_prep_ms": prep_ms,
                 "one_launch_step": bool(prep_ms == 0.0),
-                "step_kernel_sum_ms": eval_ms + prep_ms,    # <= ms_per_step; the difference is launch gaps + dispatch
+                "step_kernel_sum_ms": eval_ms + prep_ms,    # <= ms_per_step: GPU time per step of the region (the rest: first dispatch + final synchronisation)
                 "launches_timed": int(eval_s.shape[0]),
-                "timing": "HIP start/stop events of hipExtLaunchKernelGGL on the launch stream (every kernel its own pair), on extra launches after the wall-clock region",
+                "timing": ("kernel_ms: two HIP events on the launch stream around the K timed steps, per step" + (" minus slab_prep_ms" if prep_ms > 0 else "")
+                           + " (launch-to-launch gaps included: an upper bound)" if in_region else "kernel_ms = kernel_ms_isolated (the step of this mode contains copies / collectives)")
+                          + "; kernel_ms_isolated*, slab_prep_ms: start/stop events of hipExtLaunchKernelGGL, every kernel its own pair, on extra launches after the region",
                 "units_per_launch": N,
                 "algorithmic_bytes_per_detection": bpd,
                 "frac_of_measured_copy_peak_6290": achieved / 6290.0,
@@ -581,6 +619,10 @@ def main():
                 # (pcs_membench kind 4: 5.5-5.6 TB/s, profiles/r01/sweeps.md) — the write stream is the bound
                 "written_GBps": N * (bpd - in_bytes) / (eval_ms * 1e-3) / 1e9,
                 "frac_of_measured_nt_fill_5600": N * (bpd - in_bytes) / (eval_ms * 1e-3) / 1e9 / 5600.0,
+                # the same fill measured in THIS run on THIS box right before the timed region (50 back-to-back launches of the
+                # output's size): the ceiling the write stream of the step is held against
+                "nt_fill_GBps_this_run": nt_fill_GBps,
+                "frac_of_nt_fill_this_run": (N * (bpd - in_bytes) / (eval_ms * 1e-3) / 1e9 / nt_fill_GBps) if nt_fill_GBps else None,
             },
         }
         if args.stream_to_host:

@@ -73,7 +73,7 @@ timeout -k 10 300 python tools/lm_profile.py --config 4 --chain self --reps 5 2>
 timeout -k 10 300 python tools/lm_profile.py --config 2 2>&1 < /dev/null | grep -v amdgpu > $O/lm_profile_ring8.log
 fi
 if has gloo; then
-say "gloo rehearsal of bench.py --gpus N on one GPU (ranks share the card; the box admits at most 6 GPU processes)"
+say "gloo rehearsal of bench.py --gpus N on one GPU (ranks share the card; the box admits at most 6 GPU processes INCLUDING the launcher: a 6-rank rehearsal was killed by its process guard)"
 for n in 2 4; do
   PCS_BENCH_BACKEND=gloo timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port $((29510 + n)) bench.py --gpus $n --steps 50 --warmup 5 > $O/bench_N${n}_gloo_rehearsal_one_gpu.json 2> $O/bench_N${n}_gloo.err < /dev/null
 done
