@@ -110,69 +110,14 @@ struct ScalarSlab {
     __device__ __forceinline__ double operator[](const int j) const { return p[j]; }
 };
 
-// Rodrigues rotation and its derivative from a rotation vector, in double whatever the slab
-// dtype.  Same formulas and the same theta < 1e-10 branches as ch:205-234 and ch:244-286
-// (pose 0 is exactly zero by default, template_handler.py:134-137, so the branch is live).
-__device__ inline void rodrigues_and_jac(const double r0, const double r1, const double r2, double (&R)[9], double (&dR)[27]) {
-    const double theta = sqrt(r0 * r0 + r1 * r1 + r2 * r2);
-    if (theta < 1e-10) {
-#pragma unroll
-        for (int i = 0; i < 9; ++i) R[i] = 0.0;
-        R[0] = 1.0; R[4] = 1.0; R[8] = 1.0;
-#pragma unroll
-        for (int i = 0; i < 27; ++i) dR[i] = 0.0;
-        dR[5] = -1.0; dR[15] = -1.0; dR[19] = -1.0;
-        dR[7] = 1.0; dR[11] = 1.0; dR[21] = 1.0;
-        return;
-    }
-    const double it = 1.0 / theta;
-    double st, ct;
-    sincos(theta, &st, &ct);
-    const double r[3] = {r0, r1, r2};
-    {   // R = ct*I + (1-ct)/theta^2 * r r^T + st/theta * [r]x      (un-normalised r, ch:213-234)
-        const double f = (1.0 - ct) * (it * it);
-        const double s = st * it;
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) R[3 * i + j] = (r[i] * r[j]) * f;
-        R[0] += ct; R[4] += ct; R[8] += ct;
-        R[1] -= r2 * s; R[3] += r2 * s;
-        R[2] += r1 * s; R[6] -= r1 * s;
-        R[5] -= r0 * s; R[7] += r0 * s;
-    }
-    {   // dR/dr_a = a0*I + a1*rr^T + a2*d(rr^T)/dr_a + a3*[r]x + a4*d[r]x/dr_a on the unit axis (ch:256-286)
-        const double x = r0 * it, y = r1 * it, z = r2 * it;
-        const double ct_1 = 1.0 - ct;
-        const double rrt[9] = {x * x, x * y, x * z, x * y, y * y, y * z, x * z, y * z, z * z};
-        const double r_x[9] = {0, -z, y, z, 0, -x, -y, x, 0};
-        const double drrt[27] = {x + x, y, z, y, 0, 0, z, 0, 0, 0, x, 0, x, y + y, z, 0, z, 0, 0, 0, x, 0, 0, y, x, y, z + z};
-        const double drx[27] = {0, 0, 0, 0, 0, -1, 0, 1, 0, 0, 0, 1, 0, 0, 0, -1, 0, 0, 0, -1, 0, 1, 0, 0, 0, 0, 0};
-        const double ax[3] = {x, y, z};
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const double ri = ax[a];
-            const double a0 = -st * ri;
-            const double a1 = (st - 2 * ct_1 * it) * ri;
-            const double a2 = ct_1 * it;
-            const double a3 = (ct - st * it) * ri;
-            const double a4 = st * it;
-#pragma unroll
-            for (int k = 0; k < 9; ++k) {
-                const double eye = (k == 0 || k == 4 || k == 8) ? 1.0 : 0.0;
-                dR[a * 9 + k] = a0 * eye + a1 * rrt[k] + a2 * drrt[a * 9 + k] + a3 * r_x[k] + a4 * drx[a * 9 + k];
-            }
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
-// The same rotation slab, ONE ELEMENT PER LANE (round 3).  q in [0, 36): q < 9 -> R[q], else dR[q - 9]
+// Rodrigues rotation and its derivative from a rotation vector (in double whatever the slab dtype), ONE ELEMENT PER LANE
+// (round 3; rounds 1-2 computed all 36 in one thread).  q in [0, 36): q < 9 -> R[q], else dR[q - 9]
 // (dR[a*9 + row*3 + col] = d R[row][col] / d r_a).  Every operation is written out with explicit roundings
 // (no implicit contraction), so the element a lane computes does not depend on which kernel it was inlined
 // into: the stand-alone slab_prep_kernel and the evaluation kernels that prepare their own slabs per wave
 // (ba_eval_kernel<..., PREP = true>) produce the same bits.  Same formulas and the same theta < 1e-10 branches
-// as ch:205-234 / ch:244-286 (see rodrigues_and_jac above, which the host-visible maths was checked against).
+// as ch:205-234 / ch:244-286 (pose 0 is exactly zero by default, template_handler.py:134-137, so the branch is live).
 struct RotTerms {
     double r0, r1, r2;   // rotation vector
     double it, st, ct;   // 1 / theta, sin(theta), cos(theta)
