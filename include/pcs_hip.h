@@ -208,6 +208,17 @@ int pcs_schur_finish(pcs_engine *h, const double *d_linvt, const double *d_u, co
 int pcs_lm_decide(pcs_engine *h, const double *d_cost_old, const double *d_cost_new, const double *d_dvec, const double *d_gm, const double *d_delta,
                   const double *d_ps, const uint8_t *d_fixed, int32_t *d_status, double *d_lambda, double *d_stats, void *stream);
 
+/* The two products of the Schur step around the dense solve, on raw device pointers (float64, row-major):
+ *   pcs_schur_syrk   S -= V V' on the LOWER triangle of S (n_lead x n_lead, row stride lds; V n_lead x n_trail, row stride ldv) and,
+ *                    when d_u is given, rhs += V u — FP64 matrix cores, one workgroup per 32 x 32 tile and K split
+ *                    (csrc/ba_schur.hpp); the partial sums of a split meet in f64 atomics (last bits run-to-run dependent);
+ *   pcs_schur_vtx    w = V' x (n_trail outputs).
+ * They replace the rocBLAS GEMM / GEMV calls of the reference consumer's step (optimisation_handling.py:88-98) in the device LM
+ * loop; queued on `stream` (NULL = the default stream). */
+int pcs_schur_syrk(int device, int64_t n_lead, int64_t n_trail, const double *d_V, int64_t ldv, double *d_S, int64_t lds, const double *d_u,
+                   double *d_rhs, void *stream);
+int pcs_schur_vtx(int device, int64_t n_lead, int64_t n_trail, const double *d_V, int64_t ldv, const double *d_x, double *d_w, void *stream);
+
 /* S x = rhs for a dense symmetric positive definite S (float64, n x n row-major with row stride ld, LOWER triangle read and
  * overwritten by its Cholesky factor): the reduced system of the Schur step above.  Blocked right-looking factorisation (32 x 32
  * tiles, one launch per block column) + both substitutions in one workgroup (csrc/ba_dense_chol.hpp) — at n = 480 / 1 680

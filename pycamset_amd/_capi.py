@@ -51,6 +51,8 @@ SYMBOLS = {
     "pcs_schur_prepare": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pcs_schur_finish": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pcs_lm_decide": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "pcs_schur_syrk": (c_int, [c_int, c_int64, c_int64, _P, c_int64, _P, c_int64, _P, _P, _P]),
+    "pcs_schur_vtx": (c_int, [c_int, c_int64, c_int64, _P, c_int64, _P, _P, _P]),
     "pcs_dense_spd_work_len": (c_int64, [c_int64]),
     "pcs_dense_spd_solve": (c_int, [c_int, c_int64, _P, c_int64, _P, _P, _P, _P, _P]),
     "pcs_normal_descriptors": (c_int, [c_int, c_int, c_int, POINTER(c_int32)]),

@@ -8,11 +8,12 @@
 // and the damped system (H + lambda D) x = -g, D = diag(H) (Marquardt), is reduced by the Schur complement of C:
 //     C_e + lambda D_e = L_e L_e'                       per trailing entity, tb = 6 or 3, in registers      schur_trail_kernel
 //     V = B L^-T   (V_e = B_e L_e^-T)                   one tb-chunk of one row per lane                   schur_v_kernel
-//     S = A + lambda D_l - V V',  rhs = -g_l + V u      u_e = L_e^-1 g_e                                    schur_lead_kernel + GEMM
+//     S = A + lambda D_l - V V',  rhs = -g_l + V u      u_e = L_e^-1 g_e                                    schur_lead_kernel + schur_syrk_kernel
 //     S x_l = rhs                                       dense Cholesky of the LEADING size only
 //     x_e = -L_e^-T (u_e + V_e' x_l)                                                                       schur_back_kernel
-// The GEMM and the dense factorisation are plain library calls (rocBLAS / rocSOLVER through torch, device_solver.py); the
-// kernels here are everything that is block-shaped.  Fixed parameters (the handlers' masks: th:177-183, sbh:211-218) are not
+// Round 3 ends with no library call in the step: the two products around the dense solve are schur_syrk_kernel / schur_vtx_kernel
+// below (FP64 matrix cores), the factorisation is csrc/ba_dense_chol.hpp; rocBLAS / rocSOLVER through torch remain as the A/B path
+// of device_solver.py (dense_solver = 'rocsolver').  Fixed parameters (the handlers' masks: th:177-183, sbh:211-218) are not
 // squeezed out of the system: their rows and columns are replaced by the identity and their gradient by zero, so their step
 // is exactly zero and the block structure survives gauge points with single fixed coordinates (sbh:153-158) unpermuted.
 // Everything — lambda included — is read from device memory: the LM driver never has to wait for the host to form a step.
@@ -162,6 +163,124 @@ __global__ __launch_bounds__(256) void schur_lead_kernel(const SchurArgs a) {
         v += *a.lambda * d;
     }
     a.S[t] = v;
+}
+
+// ---- S -= V V' (lower tiles) and rhs += V u on the FP64 matrix cores ---------------------------------------------------------------
+// rocBLAS picks a 64 x 64 macro tile for the 480 x 480 x 1 200 product of rig-32: 64 workgroups on 256 CUs, 42 us (plus a GEMV
+// launch of 6 us).  Only the lower triangle of S is needed (pcs_dense_spd_solve reads nothing else), and a tile's two operands
+// are row blocks of the SAME matrix: one workgroup per 32 x 32 tile of the lower triangle (x a split of K when there are few
+// tiles: 180 leading x 60 000 trailing of the 2e4-point free chain), four waves = four 16 x 16 quadrants, both row blocks
+// staged through LDS 64 columns at a time (coalesced 512-byte row pieces; row stride 68 doubles = two LDS passes per operand
+// read), 16 v_mfma_f64_16x16x4 per staged chunk and wave, the next chunk in flight meanwhile.  The workgroups of the diagonal
+// tiles add their rows' share of V u.  K is split until ~512 workgroups exist (two per CU hide the chunk loads of each other: one
+// workgroup per tile and no split took 108 us on rig-32, twice the library call); partial sums meet in f64 atomics — like every
+// entry of J'J itself (ba_normal.hpp), so the step's last bits were run-to-run dependent before this kernel.
+struct SchurSyrkArgs {
+    const double *V;     // n_lead x n_trail, row stride ldv
+    double *S;           // n_lead x n_lead, row stride lds: lower triangle updated
+    const double *u;     // n_trail (may be null: no rhs update)
+    double *rhs;         // n_lead
+    int32_t n_lead, n_trail, ldv, lds, ksplit, kchunk;   // kchunk: columns per split (multiple of 64)
+};
+constexpr int SYRK_LD = 68;
+using schur_d4 = __attribute__((ext_vector_type(4))) double;
+
+__global__ __launch_bounds__(256) void schur_syrk_kernel(const SchurSyrkArgs a) {
+    __shared__ double P[32][SYRK_LD];
+    __shared__ double Q[32][SYRK_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int t = blockIdx.x / a.ksplit, kc = blockIdx.x % a.ksplit;
+    int bi = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);   // t -> (bi, bj), 0 <= bj <= bi
+    while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
+    while (bi * (bi + 1) / 2 > t) --bi;
+    const int bj = t - bi * (bi + 1) / 2;
+    const bool diag = bi == bj;
+    const int k_begin = kc * a.kchunk, k_end = min(a.n_trail, k_begin + a.kchunk);
+    const int i0 = 16 * (wave >> 1), j0 = 16 * (wave & 1);
+    schur_d4 acc = {0.0, 0.0, 0.0, 0.0};
+    const double *pq = diag ? &P[0][0] : &Q[0][0];
+    const double *pa = &P[0][0] + (i0 + (lane & 15)) * SYRK_LD + (lane >> 4);
+    const double *pb = pq + (j0 + (lane & 15)) * SYRK_LD + (lane >> 4);
+    double dot = 0.0;   // diagonal tiles: this thread's share of (V u)[row], row = tid / 8
+    // the next 64-column chunk travels from global memory into registers while the matrix cores work on the current one
+    double pn[8], qn[8];
+    auto fetch = [&](const int k0) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int e = tid + 256 * q, r = e >> 6, c = e & 63;
+            const int gk = k0 + c;
+            const int gi = bi * 32 + r, gj = bj * 32 + r;
+            pn[q] = (gi < a.n_lead && gk < k_end) ? a.V[(int64_t)gi * a.ldv + gk] : 0.0;
+            qn[q] = (!diag && gj < a.n_lead && gk < k_end) ? a.V[(int64_t)gj * a.ldv + gk] : 0.0;
+        }
+    };
+    if (k_begin < k_end) fetch(k_begin);
+    for (int k0 = k_begin; k0 < k_end; k0 += 64) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int e = tid + 256 * q, r = e >> 6, c = e & 63;
+            P[r][c] = pn[q];
+            if (!diag) Q[r][c] = qn[q];
+        }
+        __syncthreads();
+        if (k0 + 64 < k_end) fetch(k0 + 64);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[4 * s], pb[4 * s], acc, 0, 0, 0);
+        if (diag && a.u) {
+            const int r = tid >> 3, part = tid & 7;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int gk = k0 + part * 8 + c;
+                dot += P[r][part * 8 + c] * (gk < k_end ? a.u[gk] : 0.0);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int gi = bi * 32 + i0 + (lane >> 4) + 4 * r, gj = bj * 32 + j0 + (lane & 15);
+        if (gi < a.n_lead && gj <= gi) {
+            double *dst = a.S + (int64_t)gi * a.lds + gj;
+            if (a.ksplit == 1) *dst -= acc[r];
+            else unsafeAtomicAdd(dst, -acc[r]);
+        }
+    }
+    if (diag && a.u) {
+        dot += __shfl_xor(dot, 1);
+        dot += __shfl_xor(dot, 2);
+        dot += __shfl_xor(dot, 4);
+        const int gi = bi * 32 + (tid >> 3);
+        if ((tid & 7) == 0 && gi < a.n_lead) {
+            if (a.ksplit == 1) a.rhs[gi] += dot;
+            else unsafeAtomicAdd(a.rhs + gi, dot);
+        }
+    }
+}
+
+// w = V' x (n_trail outputs): 64 columns per workgroup, the reads of a row coalesced across a wave, sixteen waves share the rows
+// (four did at first: 19 workgroups x 4 waves x 120 dependent loads = 15 us for 4.6 MB)
+__global__ __launch_bounds__(1024) void schur_vtx_kernel(const double *__restrict__ V, const double *__restrict__ x, double *__restrict__ w,
+                                                         const int n_lead, const int n_trail, const int ldv) {
+    const int col = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + col;
+    __shared__ double red[16][64];
+    double s0 = 0.0, s1 = 0.0;
+    if (j < n_trail) {
+        int r = part;
+        for (; r + 16 < n_lead; r += 32) {   // two independent chains per thread
+            s0 += V[(int64_t)r * ldv + j] * x[r];
+            s1 += V[(int64_t)(r + 16) * ldv + j] * x[r + 16];
+        }
+        if (r < n_lead) s0 += V[(int64_t)r * ldv + j] * x[r];
+    }
+    red[part][col] = s0 + s1;
+    __syncthreads();
+    if (part == 0 && j < n_trail) {
+        double s = 0.0;
+#pragma unroll
+        for (int p = 0; p < 16; ++p) s += red[p][col];
+        w[j] = s;
+    }
 }
 
 struct SchurBackArgs {

@@ -1671,6 +1671,35 @@ int pcs_schur_finish(pcs_engine *h, const double *d_linvt, const double *d_u, co
 
 int64_t pcs_dense_spd_work_len(int64_t n) { return n > 0 ? 2 * ((n + 31) / 32) * 32 * 32 : -1; }
 
+int pcs_schur_syrk(int device, int64_t n_lead, int64_t n_trail, const double *d_V, int64_t ldv, double *d_S, int64_t lds, const double *d_u,
+                   double *d_rhs, void *stream) {
+    if (n_lead <= 0 || n_lead > (1 << 15) || n_trail < 0 || n_trail > (1ll << 30) || ldv < n_trail || lds < n_lead || !d_S || (n_trail && !d_V) || (d_u && !d_rhs))
+        return fail(PCS_ERR_ARG, "pcs_schur_syrk: bad arguments");
+    if (device < 0 || device >= pcs_device_count()) return fail(PCS_ERR_NODEVICE, "pcs_schur_syrk: device %d not available", device);
+    if (n_trail == 0) return PCS_OK;
+    HIPCHK(hipSetDevice(device));
+    const int64_t nb = (n_lead + 31) / 32, tiles = nb * (nb + 1) / 2;
+    // split K until ~512 workgroups exist (rig-32: 120 tiles x 5; the 2e4-point free chain: 21 tiles x 25 of 60 000 columns)
+    int64_t ksplit = std::min<int64_t>((512 + tiles - 1) / tiles, (n_trail + 127) / 128);
+    ksplit = std::max<int64_t>(1, ksplit);
+    int64_t kchunk = ((n_trail + ksplit - 1) / ksplit + 63) / 64 * 64;
+    ksplit = (n_trail + kchunk - 1) / kchunk;
+    SchurSyrkArgs a{d_V, d_S, d_u, d_rhs, (int32_t)n_lead, (int32_t)n_trail, (int32_t)ldv, (int32_t)lds, (int32_t)ksplit, (int32_t)kchunk};
+    hipLaunchKernelGGL(schur_syrk_kernel, dim3((unsigned)(tiles * ksplit)), dim3(256), 0, (hipStream_t)stream, a);
+    HIPCHK(hipGetLastError());
+    return PCS_OK;
+}
+
+int pcs_schur_vtx(int device, int64_t n_lead, int64_t n_trail, const double *d_V, int64_t ldv, const double *d_x, double *d_w, void *stream) {
+    if (n_lead <= 0 || n_trail < 0 || n_trail > (1ll << 30) || ldv < n_trail || (n_trail && (!d_V || !d_x || !d_w))) return fail(PCS_ERR_ARG, "pcs_schur_vtx: bad arguments");
+    if (device < 0 || device >= pcs_device_count()) return fail(PCS_ERR_NODEVICE, "pcs_schur_vtx: device %d not available", device);
+    if (n_trail == 0) return PCS_OK;
+    HIPCHK(hipSetDevice(device));
+    hipLaunchKernelGGL(schur_vtx_kernel, dim3((unsigned)((n_trail + 63) / 64)), dim3(1024), 0, (hipStream_t)stream, d_V, d_x, d_w, (int)n_lead, (int)n_trail, (int)ldv);
+    HIPCHK(hipGetLastError());
+    return PCS_OK;
+}
+
 int pcs_dense_spd_solve(int device, int64_t n, double *d_S, int64_t ld, const double *d_rhs, double *d_x, double *d_work, int32_t *d_status, void *stream) {
     constexpr int NB = 32;
     if (n <= 0 || n > (1 << 15) || ld < n || !d_S || !d_rhs || !d_x || !d_work || !d_status) return fail(PCS_ERR_ARG, "pcs_dense_spd_solve: bad arguments");

@@ -227,6 +227,7 @@ class BlockedNormalEquations:
         from .engine import dense_spd_work_len
 
         self.xl = torch.empty(self.n_lead, **f64)
+        self.w = torch.empty(max(1, self.n_trail), **f64)
         self.chol_work = torch.empty(dense_spd_work_len(self.n_lead), **f64)
 
     def cost(self, slot):
@@ -273,21 +274,32 @@ class BlockedNormalEquations:
             self.eng.schur_prepare(self.packed[slot].data_ptr(), self.fixed.data_ptr(), lam.data_ptr(), self.linvt.data_ptr(), self.u.data_ptr(),
                                    self.V.data_ptr(), self.S.data_ptr(), self.rhs.data_ptr(), self.dvec.data_ptr(), self.gm.data_ptr(),
                                    self.status.data_ptr(), stream)
-            if self.n_trail:
-                V = self.V[:, : self.n_trail]
-                self.S.addmm_(V, V.T, alpha=-1.0)            # S = A + lam D - V V'          (rocBLAS)
-                self.rhs.addmv_(V, self.u[: self.n_trail])   # rhs = -g_l + V u
-            if self.dense_solver == "hip":                   # S x_l = rhs: blocked Cholesky + substitutions (csrc/ba_dense_chol.hpp)
-                from .engine import dense_spd_solve
+            ldv = self.V.shape[1]
+            if self.dense_solver == "hip":
+                # S = A + lam D - V V' (lower triangle), rhs = -g_l + V u: MFMA kernel of csrc/ba_schur.hpp; S x_l = rhs: blocked
+                # Cholesky + substitutions (csrc/ba_dense_chol.hpp); w = V' x_l
+                from .engine import dense_spd_solve, schur_syrk, schur_vtx
 
                 xl = self.xl
+                if self.n_trail:
+                    schur_syrk(self.eng.device, self.n_lead, self.n_trail, self.V.data_ptr(), ldv, self.S.data_ptr(), self.n_lead,
+                               self.u.data_ptr(), self.rhs.data_ptr(), stream)
                 dense_spd_solve(self.eng.device, self.n_lead, self.S.data_ptr(), self.n_lead, self.rhs.data_ptr(), xl.data_ptr(),
                                 self.chol_work.data_ptr(), self.status.data_ptr(), stream)
-            else:
-                L, info = torch.linalg.cholesky_ex(self.S)   # rocSOLVER; `info` stays on the device
+                if self.n_trail:
+                    schur_vtx(self.eng.device, self.n_lead, self.n_trail, self.V.data_ptr(), ldv, xl.data_ptr(), self.w.data_ptr(), stream)
+                    w = self.w
+                else:
+                    w = self.u
+            else:                                            # the library path, kept for A/B: rocBLAS GEMM / GEMV + rocSOLVER through torch
+                if self.n_trail:
+                    V = self.V[:, : self.n_trail]
+                    self.S.addmm_(V, V.T, alpha=-1.0)
+                    self.rhs.addmv_(V, self.u[: self.n_trail])
+                L, info = torch.linalg.cholesky_ex(self.S)   # `info` stays on the device
                 xl = torch.cholesky_solve(self.rhs.unsqueeze(1), L).squeeze(1)
                 self.status.bitwise_or_((info != 0).to(torch.int32) * 2)
-            w = torch.mv(self.V[:, : self.n_trail].T, xl) if self.n_trail else self.u
+                w = torch.mv(self.V[:, : self.n_trail].T, xl) if self.n_trail else self.u
             self.eng.schur_finish(self.linvt.data_ptr(), self.u.data_ptr(), w.data_ptr(), xl.data_ptr(), self.fixed.data_ptr(), self.delta.data_ptr(),
                                   ps.data_ptr() if ps is not None else 0, ps_out.data_ptr() if ps is not None else 0, stream)
         return self.delta

@@ -362,6 +362,18 @@ def dense_spd_solve(device: int, n: int, d_S: int, ld: int, d_rhs: int, d_x: int
     check(lib().pcs_dense_spd_solve(int(device), int(n), c_void_p(d_S), int(ld), c_void_p(d_rhs), c_void_p(d_x), c_void_p(d_work), c_void_p(d_status), s))
 
 
+def schur_syrk(device: int, n_lead: int, n_trail: int, d_V: int, ldv: int, d_S: int, lds: int, d_u: int | None, d_rhs: int | None, stream: int | None = None):
+    """S -= V V' (lower triangle) and, with ``d_u``, rhs += V u on the device (csrc/ba_schur.hpp; raw float64 device addresses)."""
+    s = c_void_p(0) if stream is None else _stream_arg(stream)
+    check(lib().pcs_schur_syrk(int(device), int(n_lead), int(n_trail), c_void_p(d_V), int(ldv), c_void_p(d_S), int(lds), c_void_p(d_u or 0), c_void_p(d_rhs or 0), s))
+
+
+def schur_vtx(device: int, n_lead: int, n_trail: int, d_V: int, ldv: int, d_x: int, d_w: int, stream: int | None = None):
+    """w = V' x on the device (csrc/ba_schur.hpp)."""
+    s = c_void_p(0) if stream is None else _stream_arg(stream)
+    check(lib().pcs_schur_vtx(int(device), int(n_lead), int(n_trail), c_void_p(d_V), int(ldv), c_void_p(d_x), c_void_p(d_w), s))
+
+
 def dense_spd_work_len(n: int) -> int:
     return int(lib().pcs_dense_spd_work_len(int(n)))
 

@@ -662,6 +662,35 @@ def test_dense_spd_solve_against_numpy(n):
         assert int(status.item()) & 2
 
 
+@pytest.mark.parametrize("n_lead,n_trail", [(480, 1200), (45, 18), (100, 7), (180, 20001), (33, 64), (1, 3)])
+def test_schur_syrk_and_vtx_against_numpy(n_lead, n_trail):
+    """csrc/ba_schur.hpp: S -= V V' on the lower triangle (the upper one must stay as it was), rhs += V u and w = V' x against
+    NumPy — K split into 1 .. 25 parts (partial sums meet in atomics), ragged sizes, a row stride larger than the row."""
+    import torch
+    from pycamset_amd.engine import schur_syrk, schur_vtx
+    rng = np.random.default_rng(n_lead * 7 + n_trail)
+    ldv = n_trail + 3
+    V = rng.standard_normal((n_lead, ldv))
+    S0 = rng.standard_normal((n_lead, n_lead))
+    u, rhs0, x = rng.standard_normal(n_trail), rng.standard_normal(n_lead), rng.standard_normal(n_lead)
+    dV, dS, du, drhs, dx = (torch.from_numpy(a).cuda() for a in (V, S0.copy(), u, rhs0.copy(), x))
+    dw = torch.empty(n_trail, dtype=torch.float64, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    schur_syrk(0, n_lead, n_trail, dV.data_ptr(), ldv, dS.data_ptr(), n_lead, du.data_ptr(), drhs.data_ptr(), stream)
+    schur_vtx(0, n_lead, n_trail, dV.data_ptr(), ldv, dx.data_ptr(), dw.data_ptr(), stream)
+    torch.cuda.synchronize()
+    Vr = V[:, :n_trail]
+    ref = S0 - Vr @ Vr.T
+    got = dS.cpu().numpy()
+    scale = np.sqrt(np.outer(np.sum(Vr * Vr, axis=1), np.sum(Vr * Vr, axis=1))) + 1.0
+    lo = np.tril_indices(n_lead)
+    assert np.max(np.abs(got[lo] - ref[lo]) / scale[lo]) <= 1e-13
+    up = np.triu_indices(n_lead, 1)
+    assert np.array_equal(got[up], S0[up])
+    assert np.max(np.abs(drhs.cpu().numpy() - (rhs0 + Vr @ u))) <= 1e-12 * (1.0 + np.max(np.abs(Vr @ u)))
+    assert np.max(np.abs(dw.cpu().numpy() - Vr.T @ x)) <= 1e-12 * (1.0 + np.max(np.abs(Vr.T @ x)))
+
+
 def test_free_point_chain_with_2e4_points_solves_through_the_schur_path():
     """Classic free-point bundle adjustment (fph:143) beyond the dense-H limits of round 2 (23 170 parameters in the kernel,
     8 192 before lm_solve fell back to CG): 12 cameras x 2e4 points = 60 180 parameters.  The blocked normal equations store

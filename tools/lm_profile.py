@@ -15,6 +15,7 @@ import torch
 from pycamset_amd import handlers, synthetic
 from pycamset_amd.detections import TargetDetection
 from pycamset_amd.device_solver import BlockedNormalEquations, lm_solve
+from pycamset_amd.engine import schur_syrk, schur_vtx
 
 
 class _Camset:
@@ -82,6 +83,9 @@ def main():
                                                                  ne.status.data_ptr(), stream),
         "S -= V V' (addmm)": lambda: ne.S.addmm_(V, V.T, alpha=-1.0),
         "rhs += V u (addmv)": lambda: ne.rhs.addmv_(V, ne.u[: ne.n_trail]),
+        "pcs_schur_syrk (S -= V V', rhs += V u)": lambda: schur_syrk(0, ne.n_lead, ne.n_trail, ne.V.data_ptr(), ne.V.shape[1], ne.S.data_ptr(), ne.n_lead,
+                                                                    ne.u.data_ptr(), ne.rhs.data_ptr(), stream),
+        "pcs_schur_vtx (w = V' x)": lambda: schur_vtx(0, ne.n_lead, ne.n_trail, ne.V.data_ptr(), ne.V.shape[1], ne.xl.data_ptr(), ne.w.data_ptr(), stream),
     }
     for name, fn in phases.items():
         g, w = timed(fn)
