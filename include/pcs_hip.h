@@ -221,7 +221,7 @@ int pcs_schur_vtx(int device, int64_t n_lead, int64_t n_trail, const double *d_V
 
 /* S x = rhs for a dense symmetric positive definite S (float64, n x n row-major with row stride ld, LOWER triangle read and
  * overwritten by its Cholesky factor): the reduced system of the Schur step above.  Blocked right-looking factorisation (32 x 32
- * tiles, one launch per block column) + both substitutions in one workgroup (csrc/ba_dense_chol.hpp) — at n = 480 / 1 680
+ * tiles, one launch per block column, the forward substitution riding along; the backward one in one workgroup: csrc/ba_dense_chol.hpp) — at n = 480 / 1 680
  * several times faster than rocSOLVER's potrf + potrs, whose dependent chain is what an LM iteration waits for.  All pointers are
  * device memory; d_work holds pcs_dense_spd_work_len(n) doubles; *d_status |= 2 when a pivot is not positive; queued on `stream`
  * (NULL = the default stream), n <= 32768. */

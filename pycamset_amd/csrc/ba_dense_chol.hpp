@@ -29,6 +29,8 @@ struct CholArgs {
                         // workgroups read that tile of A in the same launch; the NEXT launch copies it there (the last one: chol_solve_kernel)
     int32_t *status;
     int32_t n, ld, k;   // k = block column of this launch
+    const double *rhs;  // the forward substitution L y = rhs rides along with the factorisation: the workgroup that owns a
+    double *y;          // diagonal tile forms its block of y as soon as the tile's inverse exists (rows of L left of it are final)
 };
 
 // tile element (r, c) of block (bi, bj), or the identity outside the matrix (a ragged last block is padded by the identity)
@@ -163,6 +165,11 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(const CholArgs a) {
             a.ldiag[((int64_t)k * NB + r) * NB + c] = D[r][c];
             a.linv[((int64_t)k * NB + r) * NB + c] = Li[r][c];
         }
+        if (tid < NB) {   // y_0 = L_00^-1 b_0
+            double t = 0.0;
+            for (int m = 0; m <= tid; ++m) t += Li[tid][m] * (k * NB + m < a.n ? a.rhs[k * NB + m] : 0.0);
+            a.y[k * NB + tid] = t;
+        }
         return;
     }
     const int i0 = 16 * (wave >> 1), j0 = 16 * (wave & 1);
@@ -213,6 +220,7 @@ __global__ __launch_bounds__(256) void chol_step_kernel(const CholArgs a) {
     // this lane's four entries of its quadrant (the MFMA result layout): rows i0 + (lane >> 4) + 4 r, column j0 + (lane & 15)
     const int qr = i0 + (lane >> 4), qc = j0 + (lane & 15);
     double own[4], dg[4];
+    __shared__ double tv[NB];   // di == 0: sum_j L_{bj,j} y_j over the finished block columns j <= k (forward substitution)
 #pragma unroll
     for (int q = 0; q < EPT; ++q) {
         const int e = tid + 256 * q, r = e / NB, c = e % NB;
@@ -251,6 +259,45 @@ __global__ __launch_bounds__(256) void chol_step_kernel(const CholArgs a) {
         Lik[qr + 4 * r][qc] = own[r];
     }
     __syncthreads();
+    if (di == 0 && tid >= 64 && tid < 192) {
+        // forward substitution, the part that needs no inverse: t = sum_{j <= k} L_{bj,j} y_j for the 32 rows of this block — by waves
+        // 1 and 2 WHILE wave 0 factors the tile (as the first thing of the workgroup it put 2.7 us on the launch's critical path)
+        const int r = (tid - 64) >> 2, part = tid & 3;
+        const int grow = bj * NB + r;
+        double t = 0.0;
+        if (grow < a.n) {
+            const double *Lr = a.A + (int64_t)grow * a.ld + part * 8, *yy = a.y + part * 8;
+            double acc[4] = {0, 0, 0, 0};
+            int j = 0;
+            for (; j + 4 <= k + 1; j += 4) {   // four block columns (4 x 64 bytes of the row) in flight at a time
+                double l[4][8], v[4][8];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) { l[q][c] = Lr[(j + q) * NB + c]; v[q][c] = yy[(j + q) * NB + c]; }
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) acc[q] += l[q][c] * v[q][c];
+            }
+            for (; j <= k; ++j)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) acc[j & 3] += Lr[j * NB + c] * yy[j * NB + c];
+            t = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        }
+        t += __shfl_xor(t, 1);
+        t += __shfl_xor(t, 2);
+        if (part == 0) tv[r] = (grow < a.n ? a.rhs[grow] : 0.0) - t;   // b - sum: what the inverse is applied to
+    }
+    if (di == 0 && tid >= 192) {
+        // wave 3, meanwhile: complete the factor in place — the diagonal tile of column k (from `ldiag`, written by the previous launch)
+        // goes into A now; this launch reads column k only below the diagonal
+        for (int e = tid - 192; e < NB * NB; e += 64) {
+            const int r = e / NB, c = e % NB;
+            const int gr = k * NB + r, gc = k * NB + c;
+            if (gr < a.n && c <= r) a.A[(int64_t)gr * a.ld + gc] = a.ldiag[((int64_t)k * NB + r) * NB + c];
+        }
+    }
     const bool ok = factor_and_invert_tile<NB>(D, Li, tid);
     if (!ok && tid == 0) flag_bad = 1;
     __syncthreads();
@@ -261,12 +308,11 @@ __global__ __launch_bounds__(256) void chol_step_kernel(const CholArgs a) {
             a.ldiag[((int64_t)bj * NB + r) * NB + c] = D[r][c];
             a.linv[((int64_t)bj * NB + r) * NB + c] = Li[r][c];
         }
-        // complete the factor in place: the diagonal tile of column k (from `ldiag`, written by the previous launch) goes into A
-        // now — this launch reads column k only below the diagonal.  Off the critical path: this workgroup has no panel tile.
-        for (int e = tid; e < NB * NB; e += 256) {
-            const int r = e / NB, c = e % NB;
-            const int gr = k * NB + r, gc = k * NB + c;
-            if (gr < a.n && c <= r) a.A[(int64_t)gr * a.ld + gc] = a.ldiag[((int64_t)k * NB + r) * NB + c];
+        if (tid < NB) {   // y_bj = L^-1 (b_bj - sum_j L_{bj,j} y_j)
+            double t = 0.0;
+#pragma unroll
+            for (int m = 0; m < NB; ++m) t += Li[tid][m] * tv[m];   // Li is lower triangular: zeros right of the diagonal
+            a.y[bj * NB + tid] = t;
         }
         return;
     }
@@ -282,17 +328,17 @@ struct CholSolveArgs {
     double *L;            // factor (lower triangle of A; its diagonal tiles arrive from ldiag here)
     const double *linv;   // inverses of its diagonal tiles
     const double *ldiag;  // the diagonal tiles themselves
-    const double *rhs;
+    const double *y;      // L y = rhs, padded to whole blocks: formed by the factorisation launches (CholArgs::y)
     double *x;            // n
     int32_t n, ld;
 };
 
-// L L' x = rhs in one workgroup of 512 threads, both sweeps COLUMN-oriented: once a block of the solution is known
-// (32 x 32 product with the stored inverse of the diagonal tile, 32 threads), every other thread subtracts that block's
-// contribution from the unknown it owns — a 32-term dot product with one panel row (forward) or one panel column
-// (backward), no cross-thread reduction.  Nothing that is loaded depends on the solution, so the panel values and the
-// inverse rows of step k + 1 are requested during step k (registers): the dependent chain per step is two barriers and ~100
-// FMAs instead of two global-memory round trips (the first version: 117 us at n = 480, 30 steps x ~4 us).
+// L' x = y in one workgroup of 512 threads, COLUMN-oriented: once a block of the solution is known (32 x 32 product with the
+// stored inverse of the diagonal tile, 32 threads), every other thread subtracts that block's contribution from the unknown it
+// owns — a 32-term dot product with one panel column, no cross-thread reduction.  Nothing that is loaded depends on the
+// solution, so the panel values and the inverse rows of step k - 1 are requested during step k (registers): the dependent chain
+// per step is two barriers and ~100 FMAs instead of two global-memory round trips.  (Until the forward sweep moved into the
+// factorisation launches this kernel ran both: 70 us at n = 480, 30 steps.)
 // Unknowns beyond the first 512 of a step are handled with plain loads (off the critical path except for n > 512 + 32 k).
 template <int NB>
 __global__ __launch_bounds__(512) void chol_solve_kernel(const CholSolveArgs a) {
@@ -303,60 +349,13 @@ __global__ __launch_bounds__(512) void chol_solve_kernel(const CholSolveArgs a) 
     const int nblk = (n + NB - 1) / NB, npad = nblk * NB;
     double *y = sm;            // running right-hand side -> solution (npad)
     double *blk = y + npad;    // the block solved in this step (NB)
-    for (int i = tid; i < npad; i += T) y[i] = i < n ? a.rhs[i] : 0.0;
+    for (int i = tid; i < npad; i += T) y[i] = a.y[i];
     for (int e = tid; e < NB * NB; e += T) {   // complete the factor in place: the LAST diagonal tile (the others: chol_step_kernel; the sweeps never read them)
         const int k = nblk - 1, r = e / NB, c = e % NB;
         const int gr = k * NB + r, gc = k * NB + c;
         if (gr < n && c <= r) a.L[(int64_t)gr * a.ld + gc] = a.ldiag[(int64_t)k * NB * NB + e];
     }
     double cur[NB], nxt[NB], lin[NB];
-    // ---------------- forward: L y = rhs ----------------
-    auto panel_row = [&](const int k, double (&dst)[NB]) {      // row (k + 1) NB + tid of block column k
-        const int i = (k + 1) * NB + tid;
-        if (i < n) {
-#pragma unroll
-            for (int c = 0; c < NB; ++c) dst[c] = a.L[(int64_t)i * a.ld + k * NB + c];
-        }
-    };
-    auto inv_row = [&](const int k) {                           // row tid of Linv_k (threads 0 .. NB-1)
-        if (tid < NB) {
-#pragma unroll
-            for (int m = 0; m < NB; ++m) lin[m] = a.linv[((int64_t)k * NB + tid) * NB + m];
-        }
-    };
-    inv_row(0);
-    panel_row(0, cur);
-    __syncthreads();
-    for (int k = 0; k < nblk; ++k) {
-        if (tid < NB) {
-            double t = 0.0;
-#pragma unroll
-            for (int m = 0; m < NB; ++m) t += (m <= tid ? lin[m] : 0.0) * y[k * NB + m];
-            blk[tid] = t;
-        }
-        __syncthreads();
-        if (tid < NB) y[k * NB + tid] = blk[tid];
-        if (k + 1 < nblk) { inv_row(k + 1); panel_row(k + 1, nxt); }      // requests for the next step: independent of y
-        {
-            const int i = (k + 1) * NB + tid;
-            if (i < n) {
-                double s = 0.0;
-#pragma unroll
-                for (int c = 0; c < NB; ++c) s += cur[c] * blk[c];
-                y[i] -= s;
-            }
-            for (int i2 = i + T; i2 < n; i2 += T) {
-                double s = 0.0;
-                const double *Lr = a.L + (int64_t)i2 * a.ld + k * NB;
-#pragma unroll 8
-                for (int c = 0; c < NB; ++c) s += Lr[c] * blk[c];
-                y[i2] -= s;
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int c = 0; c < NB; ++c) cur[c] = nxt[c];
-    }
     // ---------------- backward: L' x = y ----------------
     auto panel_col = [&](const int k, double (&dst)[NB]) {      // column tid (< k NB) of block row k
         if (tid < k * NB) {
@@ -375,6 +374,7 @@ __global__ __launch_bounds__(512) void chol_solve_kernel(const CholSolveArgs a) 
     };
     inv_col(nblk - 1);
     panel_col(nblk - 1, cur);
+    __syncthreads();
     for (int k = nblk - 1; k >= 0; --k) {
         if (tid < NB) {
             double t = 0.0;

@@ -1669,7 +1669,7 @@ int pcs_schur_finish(pcs_engine *h, const double *d_linvt, const double *d_u, co
     return PCS_OK;
 }
 
-int64_t pcs_dense_spd_work_len(int64_t n) { return n > 0 ? 2 * ((n + 31) / 32) * 32 * 32 : -1; }
+int64_t pcs_dense_spd_work_len(int64_t n) { return n > 0 ? 2 * ((n + 31) / 32) * 32 * 32 + ((n + 31) / 32) * 32 : -1; }   // inverses + diagonal tiles + y
 
 int pcs_schur_syrk(int device, int64_t n_lead, int64_t n_trail, const double *d_V, int64_t ldv, double *d_S, int64_t lds, const double *d_u,
                    double *d_rhs, void *stream) {
@@ -1708,7 +1708,8 @@ int pcs_dense_spd_solve(int device, int64_t n, double *d_S, int64_t ld, const do
     hipStream_t s = (hipStream_t)stream;   // NULL = the default stream
     const int nblk = (int)((n + NB - 1) / NB);
     double *d_ldiag = d_work + (int64_t)nblk * NB * NB;
-    CholArgs a{d_S, d_work, d_ldiag, d_status, (int32_t)n, (int32_t)ld, 0};
+    double *d_y = d_ldiag + (int64_t)nblk * NB * NB;
+    CholArgs a{d_S, d_work, d_ldiag, d_status, (int32_t)n, (int32_t)ld, 0, d_rhs, d_y};
     a.k = 0;
     hipLaunchKernelGGL(chol_panel_kernel<NB>, dim3((unsigned)nblk), dim3(256), 0, s, a);
     for (int k = 0; k + 1 < nblk; ++k) {   // trailing update with column k + panel step of column k + 1, one launch
@@ -1719,7 +1720,7 @@ int pcs_dense_spd_solve(int device, int64_t n, double *d_S, int64_t ld, const do
     HIPCHK(hipGetLastError());
     const size_t lds = sizeof(double) * ((size_t)nblk * NB + NB);
     if (lds > 48 * 1024) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(chol_solve_kernel<NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    CholSolveArgs b{d_S, d_work, d_ldiag, d_rhs, d_x, (int32_t)n, (int32_t)ld};
+    CholSolveArgs b{d_S, d_work, d_ldiag, d_y, d_x, (int32_t)n, (int32_t)ld};
     hipLaunchKernelGGL(chol_solve_kernel<NB>, dim3(1), dim3(512), lds, s, b);
     HIPCHK(hipGetLastError());
     return PCS_OK;
