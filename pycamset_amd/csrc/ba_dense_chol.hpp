@@ -328,41 +328,48 @@ struct CholSolveArgs {
     double *L;            // factor (lower triangle of A; its diagonal tiles arrive from ldiag here)
     const double *linv;   // inverses of its diagonal tiles
     const double *ldiag;  // the diagonal tiles themselves
-    const double *y;      // L y = rhs, padded to whole blocks: formed by the factorisation launches (CholArgs::y)
+    double *y;            // L y = rhs, padded to whole blocks: formed by the factorisation launches (CholArgs::y); the GEMV launches
+                          // between the pieces of the backward sweep update it in place
     double *x;            // n
     int32_t n, ld;
+    int32_t kb0, kb1;     // this launch solves the blocks kb1 - 1 down to kb0 (at most 16: one unknown per thread)
 };
 
-// L' x = y in one workgroup of 512 threads, COLUMN-oriented: once a block of the solution is known (32 x 32 product with the
-// stored inverse of the diagonal tile, 32 threads), every other thread subtracts that block's contribution from the unknown it
-// owns — a 32-term dot product with one panel column, no cross-thread reduction.  Nothing that is loaded depends on the
-// solution, so the panel values and the inverse rows of step k - 1 are requested during step k (registers): the dependent chain
-// per step is two barriers and ~100 FMAs instead of two global-memory round trips.  (Until the forward sweep moved into the
-// factorisation launches this kernel ran both: 70 us at n = 480, 30 steps.)
-// Unknowns beyond the first 512 of a step are handled with plain loads (off the critical path except for n > 512 + 32 k).
+// L' x = y for the block range [kb0, kb1) in ONE workgroup of 512 threads, COLUMN-oriented: once a block of the solution is
+// known (32 x 32 product with the stored inverse of the diagonal tile, 32 threads), every other thread subtracts that block's
+// contribution from the unknown it owns — a 32-term dot product with one panel column, no cross-thread reduction.  Nothing
+// that is loaded depends on the solution, so the panel values and the inverse rows of step k - 1 are requested during step k
+// (registers): the dependent chain per step is two barriers and ~100 FMAs instead of two global-memory round trips.
+// One workgroup has one CU's bandwidth: the whole sweep of n = 1 680 in it (11 MB of L, the first version) took 561 us of a
+// 1 566 us solve.  pcs_dense_spd_solve therefore halves the triangle recursively — lower-right half, then chol_gemv_t_kernel
+// (many workgroups) takes the solved half out of the rest of y, then the upper-left half — down to pieces of at most 16 blocks.
+// The forward sweep is not here at all: it rides along with the factorisation launches.
 template <int NB>
 __global__ __launch_bounds__(512) void chol_solve_kernel(const CholSolveArgs a) {
     extern __shared__ double sm[];
     constexpr int T = 512;
     const int tid = threadIdx.x;
     const int n = a.n;
-    const int nblk = (n + NB - 1) / NB, npad = nblk * NB;
-    double *y = sm;            // running right-hand side -> solution (npad)
-    double *blk = y + npad;    // the block solved in this step (NB)
-    for (int i = tid; i < npad; i += T) y[i] = a.y[i];
-    for (int e = tid; e < NB * NB; e += T) {   // complete the factor in place: the LAST diagonal tile (the others: chol_step_kernel; the sweeps never read them)
-        const int k = nblk - 1, r = e / NB, c = e % NB;
-        const int gr = k * NB + r, gc = k * NB + c;
-        if (gr < n && c <= r) a.L[(int64_t)gr * a.ld + gc] = a.ldiag[(int64_t)k * NB * NB + e];
+    const int nblk = (n + NB - 1) / NB;
+    const int c0 = a.kb0 * NB;                   // first unknown of the range
+    const int nloc = (a.kb1 - a.kb0) * NB;       // <= T
+    double *y = sm;            // running right-hand side -> solution of the range (nloc)
+    double *blk = y + nloc;    // the block solved in this step (NB)
+    for (int i = tid; i < nloc; i += T) y[i] = a.y[c0 + i];
+    if (a.kb1 == nblk) {
+        for (int e = tid; e < NB * NB; e += T) {   // complete the factor in place: the LAST diagonal tile (the others: chol_step_kernel; the sweep never reads them)
+            const int k = nblk - 1, r = e / NB, c = e % NB;
+            const int gr = k * NB + r, gc = k * NB + c;
+            if (gr < n && c <= r) a.L[(int64_t)gr * a.ld + gc] = a.ldiag[(int64_t)k * NB * NB + e];
+        }
     }
     double cur[NB], nxt[NB], lin[NB];
-    // ---------------- backward: L' x = y ----------------
-    auto panel_col = [&](const int k, double (&dst)[NB]) {      // column tid (< k NB) of block row k
-        if (tid < k * NB) {
+    auto panel_col = [&](const int k, double (&dst)[NB]) {      // column c0 + tid (< k NB) of block row k
+        if (c0 + tid < k * NB) {
 #pragma unroll
             for (int r = 0; r < NB; ++r) {
                 const int gr = k * NB + r;
-                dst[r] = gr < n ? a.L[(int64_t)gr * a.ld + tid] : 0.0;
+                dst[r] = gr < n ? a.L[(int64_t)gr * a.ld + c0 + tid] : 0.0;
             }
         }
     };
@@ -372,38 +379,59 @@ __global__ __launch_bounds__(512) void chol_solve_kernel(const CholSolveArgs a) 
             for (int m = 0; m < NB; ++m) lin[m] = a.linv[((int64_t)k * NB + m) * NB + tid];
         }
     };
-    inv_col(nblk - 1);
-    panel_col(nblk - 1, cur);
+    inv_col(a.kb1 - 1);
+    panel_col(a.kb1 - 1, cur);
     __syncthreads();
-    for (int k = nblk - 1; k >= 0; --k) {
+    for (int k = a.kb1 - 1; k >= a.kb0; --k) {
+        const int kl = (k - a.kb0) * NB;   // offset of block k inside the range
         if (tid < NB) {
             double t = 0.0;
 #pragma unroll
-            for (int m = 0; m < NB; ++m) t += (m >= tid ? lin[m] : 0.0) * y[k * NB + m];
+            for (int m = 0; m < NB; ++m) t += (m >= tid ? lin[m] : 0.0) * y[kl + m];
             blk[tid] = t;
         }
         __syncthreads();
-        if (tid < NB) y[k * NB + tid] = blk[tid];
-        if (k > 0) { inv_col(k - 1); panel_col(k - 1, nxt); }
-        if (tid < k * NB) {
+        if (tid < NB) y[kl + tid] = blk[tid];
+        if (k > a.kb0) { inv_col(k - 1); panel_col(k - 1, nxt); }
+        if (tid < kl) {   // unknown c0 + tid lies left of block k
             double s = 0.0;
 #pragma unroll
             for (int r = 0; r < NB; ++r) s += cur[r] * blk[r];
             y[tid] -= s;
         }
-        for (int j = tid + T; j < k * NB; j += T) {
-            double s = 0.0;
-            for (int r = 0; r < NB; ++r) {
-                const int gr = k * NB + r;
-                if (gr < n) s += a.L[(int64_t)gr * a.ld + j] * blk[r];
-            }
-            y[j] -= s;
-        }
         __syncthreads();
 #pragma unroll
         for (int c = 0; c < NB; ++c) cur[c] = nxt[c];
     }
-    for (int i = tid; i < n; i += T) a.x[i] = y[i];
+    for (int i = tid; i < nloc; i += T)
+        if (c0 + i < n) a.x[c0 + i] = y[i];
+}
+
+// y[c] -= sum_r L[r][c] x[r] for the columns [c0, c1) and the rows [r0, r1) of the factor (r0 >= c1: a rectangle below the
+// diagonal): a solved piece of the backward sweep leaves the rest of y.  64 columns per workgroup, sixteen waves share the rows,
+// one writer per entry (deterministic).
+__global__ __launch_bounds__(1024) void chol_gemv_t_kernel(const double *__restrict__ L, const int ld, const double *__restrict__ x, double *__restrict__ y,
+                                                           const int r0, const int r1, const int c0, const int c1) {
+    const int col = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int j = c0 + blockIdx.x * 64 + col;
+    __shared__ double red[16][64];
+    double s0 = 0.0, s1 = 0.0;
+    if (j < c1) {
+        int r = r0 + part;
+        for (; r + 16 < r1; r += 32) {   // two independent chains per thread
+            s0 += L[(int64_t)r * ld + j] * x[r];
+            s1 += L[(int64_t)(r + 16) * ld + j] * x[r + 16];
+        }
+        if (r < r1) s0 += L[(int64_t)r * ld + j] * x[r];
+    }
+    red[part][col] = s0 + s1;
+    __syncthreads();
+    if (part == 0 && j < c1) {
+        double s = 0.0;
+#pragma unroll
+        for (int p = 0; p < 16; ++p) s += red[p][col];
+        y[j] -= s;
+    }
 }
 
 }  // namespace pcs

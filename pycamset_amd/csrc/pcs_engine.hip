@@ -1718,10 +1718,28 @@ int pcs_dense_spd_solve(int device, int64_t n, double *d_S, int64_t ld, const do
         hipLaunchKernelGGL(chol_step_kernel<NB>, dim3((unsigned)(m * (m + 1) / 2)), dim3(256), 0, s, a);
     }
     HIPCHK(hipGetLastError());
-    const size_t lds = sizeof(double) * ((size_t)nblk * NB + NB);
-    if (lds > 48 * 1024) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(chol_solve_kernel<NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    CholSolveArgs b{d_S, d_work, d_ldiag, d_y, d_x, (int32_t)n, (int32_t)ld};
-    hipLaunchKernelGGL(chol_solve_kernel<NB>, dim3(1), dim3(512), lds, s, b);
+    // backward sweep L' x = y: pieces of at most 16 blocks in one workgroup each, lower-right first; between two pieces a GEMV over
+    // many workgroups takes the solved rows out of the rest of y (csrc/ba_dense_chol.hpp)
+    struct Rec {
+        static void run(hipStream_t s, const CholSolveArgs &base, int kb0, int kb1) {
+            constexpr int NBk = 32;
+            if (kb1 - kb0 <= 16) {
+                CholSolveArgs b = base;
+                b.kb0 = kb0; b.kb1 = kb1;
+                const size_t lds = sizeof(double) * ((size_t)(kb1 - kb0) * NBk + NBk);
+                hipLaunchKernelGGL(chol_solve_kernel<NBk>, dim3(1), dim3(512), lds, s, b);
+                return;
+            }
+            const int mid = kb0 + (kb1 - kb0 + 1) / 2;
+            run(s, base, mid, kb1);
+            const int r0 = mid * NBk, r1 = std::min<int>(kb1 * NBk, base.n), c0 = kb0 * NBk, c1 = mid * NBk;
+            hipLaunchKernelGGL(chol_gemv_t_kernel, dim3((unsigned)((c1 - c0 + 63) / 64)), dim3(1024), 0, s, (const double *)base.L, (int)base.ld, (const double *)base.x, base.y,
+                               r0, r1, c0, c1);
+            run(s, base, kb0, mid);
+        }
+    };
+    CholSolveArgs b{d_S, d_work, d_ldiag, d_y, d_x, (int32_t)n, (int32_t)ld, 0, nblk};
+    Rec::run(s, b, 0, nblk);
     HIPCHK(hipGetLastError());
     return PCS_OK;
 }
