@@ -303,7 +303,9 @@ int pcs_kernel_ms_samples(pcs_engine *h, int64_t capacity, float *slab_prep_ms, 
  * slabs of its own tile instead of a slab_prep launch in front; automatic = tables in the reference's run order, FP64 outputs
  * at any size, float outputs up to "fuse_prep_max_n" detections; same slab element functions, same bits; the matrix-free
  * operators then need pcs_linearize), "lazy_done_event" (1: the engine's ordering event is recorded when somebody waits for
- * it, not after every step),
+ * it, not after every step, for work on the engine's own or the default stream; 2: on caller streams too — the caller then keeps
+ * the stream alive until it resets the option, which records what is pending; 0: after every enqueue), "timing_every" (0: no start / stop
+ * events at all, neither around evaluations nor around normal-equations builds),
  * "matfree_lds", "xcd_remap", "waves_per_wg", "pack_indices", "normal_rows", "normal_imgkey_product",
  * "normal_imgkey_wgs_per_cu", "normal_sort_tables"; "normal_debug" is a bit mask of profiling switches of pcs_normal_equations — phases
  * or whole passes are skipped and the results are wrong while it is non-zero); see DESIGN.md.

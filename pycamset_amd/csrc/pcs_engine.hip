@@ -82,6 +82,7 @@ struct pcs_engine {
     bool have_done = false;
     bool done_pending = false;   // `done` still has to be recorded on done_stream (see flush_done)
     bool lazy_done = true;       // option "lazy_done_event" (A/B switch)
+    bool lazy_any_stream = false;   // "lazy_done_event" = 2: also on caller streams (the caller keeps the stream alive until it resets the option)
     // static inputs
     int32_t *d_cam = nullptr, *d_img = nullptr, *d_key = nullptr;  // split index arrays (only when the packed word does not fit)
     uint32_t *d_packed = nullptr;      // cam | image | key bit fields, one word per detection (DetTable, ba_device.hpp)
@@ -182,7 +183,7 @@ static hipError_t mark_done(pcs_engine *h, hipStream_t s) {
     // (every enqueue calls order_after_done(h, s) first, so work on an earlier stream is already ordered before `s`)
     h->have_done = true;
     h->done_stream = s;   // used as a handle again only when it is the engine's own stream or the default stream
-    if (h->lazy_done && (s == h->stream || s == hipStreamLegacy)) {
+    if (h->lazy_done && (h->lazy_any_stream || s == h->stream || s == hipStreamLegacy)) {
         h->done_pending = true;
         return hipSuccess;
     }
@@ -748,7 +749,9 @@ int pcs_set_option(pcs_engine *h, const char *key, int64_t value) {
     } else if (!strcmp(key, "lazy_done_event")) {
         HIPCHK(hipSetDevice(h->device));
         HIPCHK(flush_done(h));
+        if (value < 0 || value > 2) return fail(PCS_ERR_ARG, "lazy_done_event must be 0, 1 or 2");
         h->lazy_done = value != 0;
+        h->lazy_any_stream = value == 2;
     } else if (!strcmp(key, "xcd_remap")) {
         h->xcd_remap = value != 0;
     } else if (!strcmp(key, "waves_per_wg")) {
@@ -1130,8 +1133,11 @@ static int enqueue_normal(pcs_engine *h, const double *d_prm, double *d_H, doubl
         a.tiles_per_wave = (int32_t)tpw;
         return dim3((unsigned)((a.n_tiles + tpw - 1) / tpw));
     };
-    hipEvent_t *ev = ring_slot(h, false);
-    HIPCHK(hipEventRecord(ev[2], s));
+    // start / stop events of the passes (pcs_last_kernel_ms) unless timing is switched off: an event record is a packet of its own
+    // between two launches, ~5 us each on the stream (the device LM loop builds once per trial and switches them off)
+    const bool timed = h->timing_every > 0;
+    hipEvent_t *ev = timed ? ring_slot(h, false) : nullptr;
+    if (timed) HIPCHK(hipEventRecord(ev[2], s));
     const int n_pass = h->chain == PCS_CHAIN_TEMPLATE ? 1 : h->chain == PCS_CHAIN_SELF ? 3 : 2;
     for (int pass = 0; pass < n_pass; ++pass) {
         if (h->normal_debug & (256 << pass)) continue;   // profiling: time the passes one by one
@@ -1163,9 +1169,11 @@ static int enqueue_normal(pcs_engine *h, const double *d_prm, double *d_H, doubl
         }
         if (e != hipSuccess) return fail(PCS_ERR_HIP, "normal-equations kernel launch failed: %s", hipGetErrorString(e));
     }
-    HIPCHK(hipEventRecord(ev[3], s));
-    ++h->ev_count;
-    h->events_valid = true;
+    if (timed) {
+        HIPCHK(hipEventRecord(ev[3], s));
+        ++h->ev_count;
+        h->events_valid = true;
+    }
     HIPCHK(mark_done(h, s));
     return PCS_OK;
 }

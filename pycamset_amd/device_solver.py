@@ -333,11 +333,30 @@ def _lm_solve_blocked(ne: BlockedNormalEquations, ps0: np.ndarray, *, max_iter, 
     to steer the loop; x, lambda, the gain ratio and both states stay in HBM."""
     torch = ne.torch
     dev = ne.dev
+    # For the duration of the loop the engine records neither the start / stop events of every build (pcs_last_kernel_ms) nor its
+    # ordering event after every enqueue on this solver's stream (the stream lives as long as `ne`; "lazy_done_event" = 2 records
+    # when somebody waits): each record is a packet between two launches, three of them cost a trial ~17 us (rocprofv3 trace).
+    eng = ne.eng
+    saved = (eng.option("timing_every", 1), eng.option("lazy_done_event", 1))
+    eng.set_option("timing_every", 0)
+    eng.set_option("lazy_done_event", 2)
+    try:
+        return _lm_loop_blocked(ne, ps0, max_iter=max_iter, ftol=ftol, xtol=xtol, gtol=gtol, lam0=lam0, verbose=verbose)
+    finally:
+        eng.set_option("lazy_done_event", saved[1])   # flushes the pending record while the stream exists
+        eng.set_option("timing_every", saved[0])
+
+
+def _lm_loop_blocked(ne: BlockedNormalEquations, ps0: np.ndarray, *, max_iter, ftol, xtol, gtol, lam0, verbose):
+    torch = ne.torch
+    dev = ne.dev
     with torch.cuda.device(dev), torch.cuda.stream(ne.stream):     # one real stream for torch operations and C-ABI kernels alike
         ps = torch.from_numpy(np.ascontiguousarray(ps0, dtype=np.float64)).to(dev)
         ps_new = torch.empty_like(ps)
         lam = torch.full((1,), float(lam0), dtype=torch.float64, device=dev)
         stats_dev = torch.zeros(8, dtype=torch.float64, device=dev)
+        stats_host = torch.zeros(8, dtype=torch.float64).pin_memory()
+        verdict = torch.cuda.Event()
         cur, new = 0, 1
         ne.build(ps, cur)
         sumsq = float(ne.cost(cur).item())
@@ -354,7 +373,10 @@ def _lm_solve_blocked(ne: BlockedNormalEquations, ps0: np.ndarray, *, max_iter, 
                 ne.build(ps_new, new)
                 nfev += 1
                 ne.decide(cur, new, ps, lam, stats_dev)
-                stats = stats_dev.cpu().numpy()        # the ONE read-back of the trial
+                stats_host.copy_(stats_dev, non_blocking=True)   # the ONE read-back of the trial: 64 bytes into page-locked memory
+                verdict.record()
+                verdict.synchronize()
+                stats = stats_host.numpy().copy()
                 gmax = float(stats[1])
                 if verbose:
                     print(f"  it {it}: lam {stats[7]:.2e} cost {0.5 * stats[6]:.6e} -> {0.5 * stats[5]:.6e} accepted {bool(stats[0])}")

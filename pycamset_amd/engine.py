@@ -149,6 +149,11 @@ class Engine:
 
     def set_option(self, key: str, value: int):
         check(lib().pcs_set_option(self._h, key.encode(), int(value)))
+        self.__dict__.setdefault("_options", {})[key] = int(value)
+
+    def option(self, key: str, default: int) -> int:
+        """The value last given to ``set_option(key, ...)`` through this object, else ``default`` (the library's own default)."""
+        return self.__dict__.get("_options", {}).get(key, default)
 
     # -- evaluation: host buffers -------------------------------------------------------------
     def _check_params(self, param_str) -> np.ndarray:
