@@ -662,10 +662,11 @@ def test_dense_spd_solve_against_numpy(n):
         assert int(status.item()) & 2
 
 
-@pytest.mark.parametrize("n_lead,n_trail", [(480, 1200), (45, 18), (100, 7), (180, 20001), (33, 64), (1, 3)])
+@pytest.mark.parametrize("n_lead,n_trail", [(480, 1200), (45, 18), (100, 7), (180, 20001), (33, 64), (1, 3), (1100, 257), (1680, 1458)])
 def test_schur_syrk_and_vtx_against_numpy(n_lead, n_trail):
     """csrc/ba_schur.hpp: S -= V V' on the lower triangle (the upper one must stay as it was), rhs += V u and w = V' x against
-    NumPy — K split into 1 .. 25 parts (partial sums meet in atomics), ragged sizes, a row stride larger than the row."""
+    NumPy — K split into 1 .. 25 parts (partial sums meet in atomics), ragged sizes up to rig-32-self's 1 680 x 1 458, a row stride
+    larger than the row."""
     import torch
     from pycamset_amd.engine import schur_syrk, schur_vtx
     rng = np.random.default_rng(n_lead * 7 + n_trail)
