@@ -601,6 +601,7 @@ def main():
                 "kernel": "ba_eval_kernel",
                 "kernel_ms": eval_ms,
                 "kernel_ms_isolated": iso_ms,
+                "frac_isolated": N * bpd / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,   # what rounds 1-2 reported as `frac`
                 "kernel_ms_isolated_median": float(np.median(eval_s)),
                 "kernel_ms_isolated_min": float(np.min(eval_s)),
                 # each kernel's own start/stop events: the figures rocprofv3 reports.  0 = a one-launch step (the waves of the
