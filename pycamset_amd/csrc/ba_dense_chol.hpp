@@ -20,6 +20,12 @@
 
 #include <cstdint>
 
+// Timing builds only (hipcc -DPCS_CHOL_SKIP=1 / 2 / 3): leave out wave 0's factorisation loop / inversion loop of a tile, to see what
+// they cost inside a launch (5.2 / 3.4 us of 17, profiles/r03/README.md).  Results are wrong while it is non-zero.
+#ifndef PCS_CHOL_SKIP
+#define PCS_CHOL_SKIP 0
+#endif
+
 namespace pcs {
 
 struct CholArgs {
@@ -68,14 +74,11 @@ __device__ __forceinline__ bool factor_and_invert_tile(double (&D)[NB][NB + 1], 
     if (tid < 64) {
         const int r = tid & (NB - 1);
         double row[NB], ild[NB];
-#if defined(PCS_CHOL_SKIP) && PCS_CHOL_SKIP
+#if PCS_CHOL_SKIP
         for (int c = 0; c < NB; ++c) ild[c] = 1.0;
 #endif
 #pragma unroll
         for (int c = 0; c < NB; ++c) row[c] = tid < NB ? D[r][c] : (c == r ? 1.0 : 0.0);
-#ifndef PCS_CHOL_SKIP
-#define PCS_CHOL_SKIP 0   // timing experiments only: 1 = no factorisation loop, 2 = no inversion loop
-#endif
 #pragma unroll
         for (int j = 0; j < ((PCS_CHOL_SKIP & 1) ? 0 : NB); ++j) {
             const double p = lane_bcast(row[j], j);
