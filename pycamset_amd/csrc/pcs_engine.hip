@@ -1127,9 +1127,13 @@ static int enqueue_normal(pcs_engine *h, const double *d_prm, double *d_H, doubl
     // every wave walks a contiguous range of tiles, so its register accumulators survive across tiles.  One-wave
     // workgroups; the LDS image (22.9 KB for 22 columns x 64 rows) allows 7 per CU, and exactly one resident round of
     // waves is fastest (92 us against 105 us with two rounds on rig-32, profiles/r02/sweeps.md).
-    auto geometry = [&](const int64_t wpc) {
+    // Tables of 1 024 - 1 792 tiles: two tiles per wave instead of one.  A wave flushes everything it holds when it ends, and with
+    // one tile per wave every tile pays the camera-level flush into addresses that hundreds of waves share (ring-8, 1 600 tiles,
+    // 8 cameras: 35.0 us at one tile per wave, 27.7 at two, 28.4 at three).  Smaller tables keep one tile per wave: there the
+    // second tile's latency costs more than the flushes (110 tiles: 14.4 against 20.4 us).
+    auto geometry = [&](const int64_t wpc, const int64_t min_tiles = 1) {
         const int64_t target_waves = (int64_t)h->n_cu * wpc;
-        const int64_t tpw = std::max<int64_t>(1, (a.n_tiles + target_waves - 1) / target_waves);
+        const int64_t tpw = std::max<int64_t>(std::min<int64_t>(min_tiles, a.n_tiles), (a.n_tiles + target_waves - 1) / target_waves);
         a.tiles_per_wave = (int32_t)tpw;
         return dim3((unsigned)((a.n_tiles + tpw - 1) / tpw));
     };
@@ -1164,7 +1168,7 @@ static int enqueue_normal(pcs_engine *h, const double *d_prm, double *d_H, doubl
         } else {
             // the shared pass's image (22.9 KB) allows 7 waves per CU; the (cam, key) pass's (19.8 KB) allows 8 = two per SIMD,
             // 65.5 against 70.0 us on rig-32-self (profiles/r02/sweeps.md)
-            const dim3 grid = geometry(h->wgs_per_cu > 0 ? h->wgs_per_cu : pass == PASS_CAMKEY ? 8 : 7);
+            const dim3 grid = geometry(h->wgs_per_cu > 0 ? h->wgs_per_cu : pass == PASS_CAMKEY ? 8 : 7, (h->wgs_per_cu > 0 || a.n_tiles < 1024) ? 1 : 2);
             e = launch_normal(h->chain, pass, h->normal_rows, a, grid, s);
         }
         if (e != hipSuccess) return fail(PCS_ERR_HIP, "normal-equations kernel launch failed: %s", hipGetErrorString(e));

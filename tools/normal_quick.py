@@ -7,8 +7,10 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import torch
 from pycamset_amd import synthetic
 from pycamset_amd.engine import Engine
+CONFIG = None
+for arg in [x for x in sys.argv if x.startswith("--config=")]: sys.argv.remove(arg); CONFIG = int(arg[9:])
 chain = sys.argv[1] if len(sys.argv) > 1 else "template"
-rig = synthetic.config_rig(3 if chain == "template" else 4)
+rig = synthetic.config_rig(CONFIG if CONFIG else (3 if chain == "template" else 4))
 sl = {"template": [rig.intr, rig.extr, rig.poses], "self": [rig.intr, rig.extr, rig.poses, rig.points], "free": [rig.intr, rig.extr, rig.points]}[chain]
 ps = np.concatenate([a.ravel() for a in sl]); n = ps.shape[0]
 e = Engine(chain, rig.n_cams, rig.n_imgs, rig.n_keys); e.set_detections_table(rig.detections)
