@@ -3,16 +3,20 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A *step* is one LM-step evaluation of the hot path over the detection table: slab preparation (K0) + the
-fused residual/Jacobian kernel (K1) — ONE launch for tables of at most 4e5 detections in run order, where the
-waves of K1 prepare the slabs of their own tiles (the same functions K0 is made of) —, with the parameter string
-and the detection table already resident in HBM and the residual / dense Jacobian blocks left in HBM.
+A *step* is one LM-step evaluation of the hot path over the detection table, with the parameter string and the
+detection table already resident in HBM and the residual / dense Jacobian blocks left in HBM.  For FP64 outputs on a
+table in the reference's run order (every BASELINE config, the 1e6-detection headline included) that is ONE launch:
+the waves of the fused residual/Jacobian kernel (K1) prepare the slabs of their own tiles (the same element functions
+slab_prep, K0, is made of).  Float outputs above 2.5e5 detections and shuffled tables take K0 + K1 (two launches).
 
 Workload: BASELINE.json configs[2], "rig-32" — 32 cameras, Ccube target (486 keys), 200 poses, ~1.0e6
 detections, template chain, FP64; `--config 4 / 5` select the self-calibration and the
 1e7-detection FP32 rigs.
 
-N > 1 (one process per GPU, launched by torch.distributed.run, RCCL backend): `--scaling strong` (default) —
+N > 1 (one process per GPU, RCCL backend): either under a launcher (`python -m torch.distributed.run --nnodes=1
+--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...`) or plainly as `python bench.py
+--gpus N ...` — without WORLD_SIZE in the environment the process starts that launcher itself as a child
+(`self_launch`, before torch or HIP are touched) and relays rank 0's line.  `--scaling strong` (default) —
 every rank evaluates its contiguous ceil(N/G)-row shard of the ONE rig the config names (the reference's
 equal-chunk rule incl. cyclic padding, abstract_function_blocks.py:281-288; `pycamset_amd.sharding.padded_shard`),
 all ranks hold the same parameter string, and the timed region contains no collective: the path partitions by
@@ -248,6 +252,37 @@ def pmc_traffic(workload_key: str):
     return None, None
 
 
+def self_launch(n_ranks: int, argv, script=None, python=None, extra_env=None) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as CHILDREN
+    (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py argv`),
+    pass rank 0's JSON line (every stdout line that parses as a JSON object) through to this process's stdout, everything else
+    to stderr, and return the launcher's exit code (non-zero if any rank failed).  The parent never imports torch and never
+    touches HIP: the children are fresh processes, not a re-exec of one that has initialised the GPU."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver only supports dmabuf IPC (RCCL needs it)
+    env.update(extra_env or {})
+    cmd = [python or sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script or Path(__file__).resolve()), *argv]
+    print("[bench] self-launch: " + " ".join(cmd), file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    for raw in proc.stdout:
+        txt = raw.rstrip("\n")
+        is_line = False
+        if txt.startswith("{"):
+            try:
+                is_line = isinstance(json.loads(txt), dict)
+            except ValueError:
+                pass
+        print(txt, file=sys.stdout if is_line else sys.stderr, flush=True)
+    return proc.wait()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -287,10 +322,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit(f"--gpus {args.gpus} needs one process per GPU: launch with "
-                             f"python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} "
-                             f"--master-addr 127.0.0.1 --master-port P bench.py --gpus {args.gpus} ...")
+        if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+            # no launcher around us: become one (before torch / HIP are touched in this process)
+            raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
 
     import torch

@@ -229,6 +229,7 @@ class BlockedNormalEquations:
         self.xl = torch.empty(self.n_lead, **f64)
         self.w = torch.empty(max(1, self.n_trail), **f64)
         self.chol_work = torch.empty(dense_spd_work_len(self.n_lead), **f64)
+        self._cons = None   # sharded loop only: the ranks' consensus step (n_params + 1)
 
     def cost(self, slot):
         return self.packed[slot][-1]
@@ -302,7 +303,29 @@ class BlockedNormalEquations:
                 w = torch.mv(self.V[:, : self.n_trail].T, xl) if self.n_trail else self.u
             self.eng.schur_finish(self.linvt.data_ptr(), self.u.data_ptr(), w.data_ptr(), xl.data_ptr(), self.fixed.data_ptr(), self.delta.data_ptr(),
                                   ps.data_ptr() if ps is not None else 0, ps_out.data_ptr() if ps is not None else 0, stream)
+            if self.reduce_fn is not None and ps is not None:
+                self._consensus_step(ps, ps_out)
         return self.delta
+
+    def _consensus_step(self, ps, ps_out):
+        """Sharded loop: every rank has solved the SAME all-reduced system, but schur_syrk_kernel sums its K splits with f64
+        atomics in arrival order (csrc/ba_schur.hpp), so the steps agree to the last bits only — enough for one rank to meet
+        xtol, or to take the other branch of the gain-ratio rule, while its peers enter the next all-reduce (a hang).  The
+        ranks therefore adopt ONE step: the mean of theirs, from one more all-reduce of n_params + 1 doubles (the extra entry
+        counts the ranks; an all-reduce delivers the same bits to every rank).  From here on — trial string, build, all-reduced
+        blocks, decision, damping — every rank computes on identical inputs with order-deterministic kernels."""
+        torch = self.torch
+        if self._cons is None:
+            self._cons = torch.empty(self.n_params + 1, dtype=torch.float64, device=self.dev)
+        buf = self._cons
+        buf[:-1].copy_(self.delta)
+        buf[-1] = 1.0
+        if getattr(self.reduce_fn, "on_device", False):
+            self.reduce_fn(buf)
+        else:
+            buf.copy_(torch.from_numpy(np.asarray(self.reduce_fn(buf.cpu().numpy()), dtype=np.float64)))
+        torch.div(buf[:-1], buf[-1], out=self.delta)
+        torch.add(ps, self.delta, out=ps_out)
 
     def decide(self, cur: int, new: int, ps, lam, stats):
         """The accept / reject decision of the trial state packed[new] against packed[cur] on the device (pcs_lm_decide):

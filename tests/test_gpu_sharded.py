@@ -145,6 +145,12 @@ def _worker(rank, world, port, out_dir, backend="gloo"):
         # into the leading group): exact steps end at least as low as the inexact CG steps
         ra = lm_solve(s_shard, xs.copy(), max_iter=15, reduce_fn=mat_reduce)
         assert ra.cost <= r1.cost * (1 + 1e-3), (ra.cost, r1.cost)
+        # this system (192 leading x 192 trailing) makes schur_syrk_kernel split K (ksplit = 2: partial sums meet in atomics in
+        # arrival order); the ranks still walk ONE path because they adopt a consensus step (BlockedNormalEquations._consensus_step)
+        lay = s_shard.op_fun._engine_for(s_shard._flat_detections()).normal_layout()
+        assert lay["n_trail"] > 128, lay
+        dist.all_gather_object(gathered, (ra.x, ra.nit, ra.nfev, ra.status))
+        assert all(np.array_equal(gathered[0][0], g[0]) and gathered[0][1:] == g[1:] for g in gathered)
         # self-calibration has a flat valley (gauge + point/pose trade-offs) and the J^T products sum with
         # f64 atomics in arrival order, so after 15 iterations the two runs agree in cost, not bit for bit
         assert abs(rs.cost - r1.cost) <= 1e-3 * r1.cost and rs.cost < 0.01 * rs.history[0], (rs.cost, r1.cost, rs.history[0])
@@ -161,7 +167,7 @@ def test_two_ranks_on_one_gpu(tmp_path):
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank: this box has fewer than two")
 def test_ranks_on_their_own_gpus_over_rccl(tmp_path):
-    """The same assertions with backend nccl (RCCL over xGMI), one device per rank, at most 4 ranks."""
-    world = min(4, torch.cuda.device_count())
+    """The same assertions with backend nccl (RCCL over xGMI), one device per rank, every GPU of the box up to 8 ranks."""
+    world = min(8, torch.cuda.device_count())
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), "nccl"), nprocs=world, join=True)
     assert all((tmp_path / f"ok{r}").exists() for r in range(world))

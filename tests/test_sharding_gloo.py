@@ -236,3 +236,49 @@ def test_empty_shard_contributes_zeros_and_does_not_deadlock(tmp_path):
     world = 4
     mp.spawn(_worker_empty_shard, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     assert all((tmp_path / f"ok{r}").exists() for r in range(world))
+
+
+def _capture_self_launch(capfd, n, argv):
+    import bench
+
+    rc = bench.self_launch(n, argv, script=REPO / "tests" / "_bench_stub.py")
+    out, err = capfd.readouterr()
+    return rc, out, err
+
+
+def test_bench_launches_its_own_ranks(capfd):
+    """`python bench.py --gpus N` with no launcher around it: the parent starts N children through
+    torch.distributed.run, relays exactly ONE JSON line (rank 0's) on stdout and sends everything else to stderr.  Driven
+    here with a stub per-rank body (tests/_bench_stub.py: gloo rendezvous + all-reduce, no GPU)."""
+    import json
+
+    rc, out, err = _capture_self_launch(capfd, 3, ["--gpus", "3", "--steps", "5"])
+    assert rc == 0, err
+    lines = [ln for ln in out.splitlines() if ln.strip()]
+    assert len(lines) == 1, out
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 3 and line["sum"] == 6.0 and line["argv"] == ["--gpus", "3", "--steps", "5"]
+    assert "noise from rank 0" in err and "noise from rank 2" in err
+
+
+def test_bench_self_launch_reports_a_failed_rank(capfd):
+    rc, out, err = _capture_self_launch(capfd, 2, ["--fail-rank", "1"])
+    assert rc != 0
+
+
+def test_bench_main_becomes_the_launcher_only_without_world_size(monkeypatch):
+    """main(): --gpus N > 1 without WORLD_SIZE -> self_launch (and its exit code); with a WORLD_SIZE that disagrees -> an error,
+    never a second launcher."""
+    import bench
+
+    calls = []
+    monkeypatch.setattr(bench, "self_launch", lambda n, argv, **kw: calls.append((n, list(argv))) or 7)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7 and calls == [(4, ["--gpus", "4", "--steps", "3"])]
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert "WORLD_SIZE" in str(e.value.code) and len(calls) == 1
