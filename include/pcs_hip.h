@@ -199,7 +199,8 @@ int pcs_normal_blocks_device(pcs_engine *h, const double *d_param_str, double *d
  *                      d_ps_in / d_ps_out (both or neither) also the trial parameter string d_ps_out = d_ps_in + d_delta.
  *   pcs_lm_decide      the accept / reject decision of the trial on the device: predicted reduction 0.5 (lambda d'D d - g'd), actual
  *                      reduction 0.5 (cost_old - cost_new), gain ratio, *d_lambda <- the next damping (x 1/3 | 1 | 2 by the ratio, x 4
- *                      on a rejected or failed step), *d_status <- 0, and d_stats[8] = {accepted, max |g|, relative cost drop, |step|,
+ *                      on a rejected or failed step), *d_status <- 0, and d_stats[8] = {accepted (-1: bit 2 of *d_status was set — the dense solve
+ *                      did not complete, the trial is void), max |g|, relative cost drop, |step|,
  *                      |x| over the free parameters, new sum r^2, old sum r^2, lambda used} — the one vector the host reads per trial. */
 int pcs_schur_prepare(pcs_engine *h, double *d_packed, const uint8_t *d_fixed, const double *d_lambda, double *d_linvt, double *d_u,
                       double *d_V, double *d_S, double *d_rhs, double *d_dvec, double *d_gm, int32_t *d_status, void *stream);
@@ -220,12 +221,23 @@ int pcs_schur_syrk(int device, int64_t n_lead, int64_t n_trail, const double *d_
 int pcs_schur_vtx(int device, int64_t n_lead, int64_t n_trail, const double *d_V, int64_t ldv, const double *d_x, double *d_w, void *stream);
 
 /* S x = rhs for a dense symmetric positive definite S (float64, n x n row-major with row stride ld, LOWER triangle read and
- * overwritten by its Cholesky factor): the reduced system of the Schur step above.  Blocked right-looking factorisation (32 x 32
- * tiles, one launch per block column, the forward substitution riding along; the backward one in one workgroup: csrc/ba_dense_chol.hpp) — at n = 480 / 1 680
- * several times faster than rocSOLVER's potrf + potrs, whose dependent chain is what an LM iteration waits for.  All pointers are
- * device memory; d_work holds pcs_dense_spd_work_len(n) doubles; *d_status |= 2 when a pivot is not positive; queued on `stream`
- * (NULL = the default stream), n <= 32768. */
+ * overwritten by its Cholesky factor): the reduced system of the Schur step above — what optimisation_handling.py:88-98 leaves to
+ * scipy's trf / lsmr on the host.  Two forms of the same blocked factorisation (32 x 32 tiles):
+ *   PCS_SPD_ONE_LAUNCH  one persistent launch (csrc/ba_chol_persist.hpp): every tile lives in the LDS of one workgroup for the whole
+ *                       launch, block columns are handed over through HBM (write-through stores + one counter per column), the
+ *                       right-hand side rides along as one more block row, the backward substitution is a chain of 32-word hand-offs
+ *                       between the owners of the diagonal tiles.  n <= 1 984 on a 256-CU part (8 tiles per workgroup);
+ *   PCS_SPD_LAUNCHES    one launch per block column + substitution launches (csrc/ba_dense_chol.hpp): any n <= 32 768;
+ *   PCS_SPD_AUTO        the first where it fits (environment PCS_CHOL_LAUNCHES=1: always the second).
+ * All pointers are device memory; d_work holds pcs_dense_spd_work_len(n) doubles; *d_status |= 2 when a pivot is not positive,
+ * |= 4 when the one-launch form gave up waiting (another process holds the compute units: the results are not valid — solve
+ * again with PCS_SPD_LAUNCHES); queued on `stream` (NULL = the default stream). */
+#define PCS_SPD_AUTO 0
+#define PCS_SPD_LAUNCHES 1
+#define PCS_SPD_ONE_LAUNCH 2
 int64_t pcs_dense_spd_work_len(int64_t n);
+int pcs_dense_spd_solve_algo(int device, int64_t n, double *d_S, int64_t ld, const double *d_rhs, double *d_x, double *d_work, int32_t *d_status, void *stream,
+                             int algorithm);
 int pcs_dense_spd_solve(int device, int64_t n, double *d_S, int64_t ld, const double *d_rhs, double *d_x, double *d_work, int32_t *d_status, void *stream);
 
 /* Which entry of H / g / cost every accumulator register of the normal-equations kernel stands for (host function, no

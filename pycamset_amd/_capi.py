@@ -55,6 +55,7 @@ SYMBOLS = {
     "pcs_schur_vtx": (c_int, [c_int, c_int64, c_int64, _P, c_int64, _P, _P, _P]),
     "pcs_dense_spd_work_len": (c_int64, [c_int64]),
     "pcs_dense_spd_solve": (c_int, [c_int, c_int64, _P, c_int64, _P, _P, _P, _P, _P]),
+    "pcs_dense_spd_solve_algo": (c_int, [c_int, c_int64, _P, c_int64, _P, _P, _P, _P, _P, c_int]),
     "pcs_normal_descriptors": (c_int, [c_int, c_int, c_int, POINTER(c_int32)]),
     "pcs_genchain_create": (c_int, [POINTER(_P), c_char_p, c_int, c_int, c_int, POINTER(c_int64), POINTER(c_int32), c_int64, c_int64, c_int64,
                                  c_int64, c_int64, c_int64, c_int]),

@@ -327,7 +327,7 @@ struct LmDecideArgs {
     const uint8_t *fixed;
     int32_t *status;                        // != 0: the step is invalid (a factorisation failed); cleared here for the next solve
     double *lambda;                         // in: the damping the step was computed with; out: the next one
-    double *stats;                          // out[8]: accepted, max |g|, relative cost drop, |step|, |x|, new sum r^2, old sum r^2, lambda used
+    double *stats;                          // out[8]: accepted (-1: the trial is void, see below), max |g|, relative cost drop, |step|, |x|, new sum r^2, old sum r^2, lambda used
     int64_t n_params;
 };
 
@@ -367,13 +367,14 @@ __global__ __launch_bounds__(1024) void lm_decide_kernel(const LmDecideArgs a) {
         const double lam = *a.lambda, c_old = *a.cost_old, c_new = *a.cost_new;
         const double pred = 0.5 * (lam * s_dd - s_gd);
         const double actual = 0.5 * (c_old - c_new);
-        const bool ok = *a.status == 0 && pred == pred && fabs(pred) < 1.0e300;
+        const int st = *a.status;
+        const bool ok = st == 0 && pred == pred && fabs(pred) < 1.0e300;
         const double rho = pred > 0.0 ? actual / pred : -1.0;
         const bool acc = ok && c_new == c_new && fabs(c_new) < 1.0e300 && actual > 0.0;
         const double factor = rho > 0.75 ? 1.0 / 3.0 : rho > 0.25 ? 1.0 : 2.0;
         *a.lambda = acc ? fmax(lam * factor, 1e-12) : lam * 4.0;
         *a.status = 0;
-        a.stats[0] = acc ? 1.0 : 0.0;
+        a.stats[0] = (st & 4) ? -1.0 : acc ? 1.0 : 0.0;   // -1: the dense solve did not complete (ba_chol_persist.hpp's time limit): the host repeats the trial
         a.stats[1] = s_gmax;
         a.stats[2] = actual / (0.5 * c_old);
         a.stats[3] = sqrt(red[0][0]);

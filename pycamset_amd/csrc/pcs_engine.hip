@@ -28,6 +28,7 @@
 #include "ba_normal.hpp"
 #include "ba_schur.hpp"
 #include "ba_dense_chol.hpp"
+#include "ba_chol_persist.hpp"
 #include "ba_triangulate.hpp"
 
 // ---------------------------------------------------------------------------------------------
@@ -1681,7 +1682,11 @@ int pcs_schur_finish(pcs_engine *h, const double *d_linvt, const double *d_u, co
     return PCS_OK;
 }
 
-int64_t pcs_dense_spd_work_len(int64_t n) { return n > 0 ? 2 * ((n + 31) / 32) * 32 * 32 + ((n + 31) / 32) * 32 : -1; }   // inverses + diagonal tiles + y
+int64_t pcs_dense_spd_work_len(int64_t n) {   // launch-per-column form: inverses + diagonal tiles + y; one-launch form: flags + x + y
+    if (n <= 0) return -1;
+    const int64_t nb = (n + 31) / 32;
+    return std::max<int64_t>(2 * nb * 32 * 32 + nb * 32, cp_work_doubles(nb));
+}
 
 int pcs_schur_syrk(int device, int64_t n_lead, int64_t n_trail, const double *d_V, int64_t ldv, double *d_S, int64_t lds, const double *d_u,
                    double *d_rhs, void *stream) {
@@ -1712,11 +1717,38 @@ int pcs_schur_vtx(int device, int64_t n_lead, int64_t n_trail, const double *d_V
     return PCS_OK;
 }
 
+static int device_cu_count(int device) {
+    static std::atomic<int> cached[64];
+    if (device < 0 || device >= 64) return 0;
+    int v = cached[device].load();
+    if (v == 0) {
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) v = 0;
+        cached[device].store(v);
+    }
+    return v;
+}
+
 int pcs_dense_spd_solve(int device, int64_t n, double *d_S, int64_t ld, const double *d_rhs, double *d_x, double *d_work, int32_t *d_status, void *stream) {
+    return pcs_dense_spd_solve_algo(device, n, d_S, ld, d_rhs, d_x, d_work, d_status, stream, PCS_SPD_AUTO);
+}
+
+int pcs_dense_spd_solve_algo(int device, int64_t n, double *d_S, int64_t ld, const double *d_rhs, double *d_x, double *d_work, int32_t *d_status, void *stream,
+                             int algorithm) {
     constexpr int NB = 32;
     if (n <= 0 || n > (1 << 15) || ld < n || !d_S || !d_rhs || !d_x || !d_work || !d_status) return fail(PCS_ERR_ARG, "pcs_dense_spd_solve: bad arguments");
+    if (algorithm != PCS_SPD_AUTO && algorithm != PCS_SPD_LAUNCHES && algorithm != PCS_SPD_ONE_LAUNCH) return fail(PCS_ERR_ARG, "pcs_dense_spd_solve: unknown algorithm %d", algorithm);
     if (device < 0 || device >= pcs_device_count()) return fail(PCS_ERR_NODEVICE, "pcs_dense_spd_solve: device %d not available", device);
     HIPCHK(hipSetDevice(device));
+    {   // ONE persistent launch (csrc/ba_chol_persist.hpp) wherever its tiles fit the chip's LDS: n <= 1 984 on 256 CUs
+        static const bool env_launches = getenv("PCS_CHOL_LAUNCHES") != nullptr;   // A/B switch for whole runs
+        const int cus = device_cu_count(device);
+        const bool fits = cp_fits(n, cus);
+        if (algorithm == PCS_SPD_ONE_LAUNCH && !fits) return fail(PCS_ERR_ARG, "pcs_dense_spd_solve: n = %lld does not fit the one-launch form on %d compute units", (long long)n, cus);
+        if (fits && (algorithm == PCS_SPD_ONE_LAUNCH || (algorithm == PCS_SPD_AUTO && !env_launches))) {
+            HIPCHK(cp_launch(n, d_S, ld, d_rhs, d_x, d_work, d_status, cus, (hipStream_t)stream));
+            return PCS_OK;
+        }
+    }
     hipStream_t s = (hipStream_t)stream;   // NULL = the default stream
     const int nblk = (int)((n + NB - 1) / NB);
     double *d_ldiag = d_work + (int64_t)nblk * NB * NB;

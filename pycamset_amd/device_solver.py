@@ -230,6 +230,7 @@ class BlockedNormalEquations:
         self.w = torch.empty(max(1, self.n_trail), **f64)
         self.chol_work = torch.empty(dense_spd_work_len(self.n_lead), **f64)
         self._cons = None   # sharded loop only: the ranks' consensus step (n_params + 1)
+        self.spd_algorithm = "auto"   # 'launches' after a one-launch solve ran out of time (another process held the compute units)
 
     def cost(self, slot):
         return self.packed[slot][-1]
@@ -286,7 +287,7 @@ class BlockedNormalEquations:
                     schur_syrk(self.eng.device, self.n_lead, self.n_trail, self.V.data_ptr(), ldv, self.S.data_ptr(), self.n_lead,
                                self.u.data_ptr(), self.rhs.data_ptr(), stream)
                 dense_spd_solve(self.eng.device, self.n_lead, self.S.data_ptr(), self.n_lead, self.rhs.data_ptr(), xl.data_ptr(),
-                                self.chol_work.data_ptr(), self.status.data_ptr(), stream)
+                                self.chol_work.data_ptr(), self.status.data_ptr(), stream, algorithm=self.spd_algorithm)
                 if self.n_trail:
                     schur_vtx(self.eng.device, self.n_lead, self.n_trail, self.V.data_ptr(), ldv, xl.data_ptr(), self.w.data_ptr(), stream)
                     w = self.w
@@ -400,6 +401,10 @@ def _lm_loop_blocked(ne: BlockedNormalEquations, ps0: np.ndarray, *, max_iter, f
                 verdict.record()
                 verdict.synchronize()
                 stats = stats_host.numpy().copy()
+                if stats[0] < 0:   # the one-launch dense solve gave up waiting (status bit 2): nothing of this trial is valid —
+                    ne.spd_algorithm = "launches"   # repeat it with the launch-per-column form, at the damping it was meant to have
+                    lam.mul_(0.25)
+                    continue
                 gmax = float(stats[1])
                 if verbose:
                     print(f"  it {it}: lam {stats[7]:.2e} cost {0.5 * stats[6]:.6e} -> {0.5 * stats[5]:.6e} accepted {bool(stats[0])}")

@@ -360,11 +360,19 @@ class Engine:
         return out
 
 
-def dense_spd_solve(device: int, n: int, d_S: int, ld: int, d_rhs: int, d_x: int, d_work: int, d_status: int, stream: int | None = None):
-    """S x = rhs on the device (csrc/ba_dense_chol.hpp; raw float64 device addresses, the lower triangle of S becomes its
-    Cholesky factor).  ``d_work``: ``dense_spd_work_len(n)`` doubles.  ``stream=None`` queues on the default stream."""
+SPD_ALGORITHMS = {"auto": 0, "launches": 1, "one_launch": 2}   # include/pcs_hip.h PCS_SPD_*
+
+
+def dense_spd_solve(device: int, n: int, d_S: int, ld: int, d_rhs: int, d_x: int, d_work: int, d_status: int, stream: int | None = None,
+                    algorithm: str = "auto"):
+    """S x = rhs on the device (raw float64 device addresses, the lower triangle of S becomes its Cholesky factor).
+    ``algorithm``: 'one_launch' = the persistent kernel of csrc/ba_chol_persist.hpp, 'launches' = one launch per block column
+    (csrc/ba_dense_chol.hpp), 'auto' = the first where it fits.  ``d_work``: ``dense_spd_work_len(n)`` doubles; status bit 1
+    (value 2): a pivot was not positive, bit 2 (value 4): the one-launch form gave up waiting.  ``stream=None`` queues on the
+    default stream."""
     s = c_void_p(0) if stream is None else _stream_arg(stream)
-    check(lib().pcs_dense_spd_solve(int(device), int(n), c_void_p(d_S), int(ld), c_void_p(d_rhs), c_void_p(d_x), c_void_p(d_work), c_void_p(d_status), s))
+    check(lib().pcs_dense_spd_solve_algo(int(device), int(n), c_void_p(d_S), int(ld), c_void_p(d_rhs), c_void_p(d_x), c_void_p(d_work), c_void_p(d_status), s,
+                                         SPD_ALGORITHMS[algorithm]))
 
 
 def schur_syrk(device: int, n_lead: int, n_trail: int, d_V: int, ldv: int, d_S: int, lds: int, d_u: int | None, d_rhs: int | None, stream: int | None = None):

@@ -624,10 +624,12 @@ def test_generated_kernel_for_the_template_chain_against_the_hand_fused_one(caps
     hand.close()
 
 
-@pytest.mark.parametrize("n", [1, 31, 32, 33, 97, 480, 1003])
-def test_dense_spd_solve_against_numpy(n):
-    """csrc/ba_dense_chol.hpp (the reduced system of the Schur step): blocked Cholesky + both substitutions on the device
-    against numpy.linalg.solve, ragged sizes included; only the lower triangle may be read; a non-positive pivot is flagged."""
+@pytest.mark.parametrize("algorithm", ["one_launch", "launches"])
+@pytest.mark.parametrize("n", [1, 31, 32, 33, 97, 480, 1003, 1680])
+def test_dense_spd_solve_against_numpy(n, algorithm):
+    """The reduced system of the Schur step: blocked Cholesky + both substitutions on the device — as ONE persistent launch
+    (csrc/ba_chol_persist.hpp) and as one launch per block column (csrc/ba_dense_chol.hpp) — against numpy.linalg.solve, ragged
+    sizes included; only the lower triangle may be read; a non-positive pivot is flagged."""
     import torch
     from pycamset_amd.engine import dense_spd_solve, dense_spd_work_len
     rng = np.random.default_rng(n)
@@ -641,7 +643,8 @@ def test_dense_spd_solve_against_numpy(n):
     d_rhs, d_x = torch.from_numpy(rhs).cuda(), torch.empty(n, dtype=torch.float64, device="cuda")
     work = torch.empty(dense_spd_work_len(n), dtype=torch.float64, device="cuda")
     status = torch.zeros(1, dtype=torch.int32, device="cuda")
-    dense_spd_solve(0, n, dS.data_ptr(), n, d_rhs.data_ptr(), d_x.data_ptr(), work.data_ptr(), status.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    dense_spd_solve(0, n, dS.data_ptr(), n, d_rhs.data_ptr(), d_x.data_ptr(), work.data_ptr(), status.data_ptr(), torch.cuda.current_stream().cuda_stream,
+                    algorithm=algorithm)
     torch.cuda.synchronize()
     assert int(status.item()) == 0
     x = d_x.cpu().numpy()
@@ -657,9 +660,17 @@ def test_dense_spd_solve_against_numpy(n):
         bad = S.copy()
         bad[n // 2, n // 2] = -abs(S[n // 2, n // 2])
         dB = torch.from_numpy(bad).cuda()
-        dense_spd_solve(0, n, dB.data_ptr(), n, d_rhs.data_ptr(), d_x.data_ptr(), work.data_ptr(), status.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        dense_spd_solve(0, n, dB.data_ptr(), n, d_rhs.data_ptr(), d_x.data_ptr(), work.data_ptr(), status.data_ptr(), torch.cuda.current_stream().cuda_stream,
+                        algorithm=algorithm)
         torch.cuda.synchronize()
-        assert int(status.item()) & 2
+        assert int(status.item()) & 2 and not int(status.item()) & 4
+        # and the same buffers solve the good system again (the flags of a launch are reset by the next one)
+        status.zero_()
+        dS2 = torch.from_numpy(np.tril(S)).cuda()
+        dense_spd_solve(0, n, dS2.data_ptr(), n, d_rhs.data_ptr(), d_x.data_ptr(), work.data_ptr(), status.data_ptr(), torch.cuda.current_stream().cuda_stream,
+                        algorithm=algorithm)
+        torch.cuda.synchronize()
+        assert int(status.item()) == 0 and np.max(np.abs(d_x.cpu().numpy() - x_ref)) <= tol * np.max(np.abs(x_ref))
 
 
 @pytest.mark.parametrize("n_lead,n_trail", [(480, 1200), (45, 18), (100, 7), (180, 20001), (33, 64), (1, 3), (1100, 257), (1680, 1458)])
