@@ -29,7 +29,7 @@ def rodrigues(r: np.ndarray) -> np.ndarray:
     R[:, 0, 1] -= r[:, 2] * st; R[:, 1, 0] += r[:, 2] * st
     R[:, 0, 2] += r[:, 1] * st; R[:, 2, 0] -= r[:, 1] * st
     R[:, 1, 2] -= r[:, 0] * st; R[:, 2, 1] += r[:, 0] * st
-    R[small] = np.eye(3)
+    R[small] = np.eye(3, dtype=r.dtype)
     return R
 
 
@@ -44,12 +44,12 @@ def rodrigues_jac(r: np.ndarray) -> np.ndarray:
     ct_1 = 1 - ct
     ax = r * it[:, None]
     x, y, z = ax[:, 0], ax[:, 1], ax[:, 2]
-    zero = np.zeros(n)
+    zero = np.zeros(n, dtype=r.dtype)
     rrt = ax[:, :, None] * ax[:, None, :]
     r_x = np.stack([np.stack([zero, -z, y], 1), np.stack([z, zero, -x], 1), np.stack([-y, x, zero], 1)], 1)
-    eye = np.eye(3)[None]
+    eye = np.eye(3, dtype=r.dtype)[None]
     # d(rr^T)/d axis_a and d[r]x/d axis_a
-    drrt = np.zeros((n, 3, 3, 3))
+    drrt = np.zeros((n, 3, 3, 3), dtype=r.dtype)
     for a in range(3):
         drrt[:, a, a, :] += ax
         drrt[:, a, :, a] += ax
@@ -57,7 +57,7 @@ def rodrigues_jac(r: np.ndarray) -> np.ndarray:
     drx[0, 1, 2], drx[0, 2, 1] = -1, 1
     drx[1, 0, 2], drx[1, 2, 0] = 1, -1
     drx[2, 0, 1], drx[2, 1, 0] = -1, 1
-    out = np.empty((n, 3, 3, 3))
+    out = np.empty((n, 3, 3, 3), dtype=r.dtype)
     for a in range(3):
         ri = ax[:, a]
         a0 = -st * ri
@@ -111,10 +111,12 @@ def _projection(intr, X):
     return uv, A_p, A_x
 
 
-def evaluate(chain: str, det: np.ndarray, param_str: np.ndarray, template=None, counts=None, want_jac: bool = True):
+def evaluate(chain: str, det: np.ndarray, param_str: np.ndarray, template=None, counts=None, want_jac: bool = True, dtype=np.float64):
     """-> (resid (N,2), dense (2N,P) | None) with the layout of the generated full_loss / full_jac
-    (afb:350-387, afb:552-599 + afb:641)."""
+    (afb:350-387, afb:552-599 + afb:641).  ``dtype=np.longdouble`` evaluates the same formulas in x87 extended precision
+    (64-bit mantissa): the yardstick tests use to tell the kernel's rounding from the float64 oracle's own."""
     det = np.asarray(det, dtype=np.float64)
+    param_str = np.asarray(param_str, dtype=dtype)
     c, im, k = det[:, 0].astype(np.int64), det[:, 1].astype(np.int64), det[:, 2].astype(np.int64)
     C, I = counts[:2] if counts is not None else (int(c.max()) + 1, int(im.max()) + 1)
     intr = param_str[: 9 * C].reshape(C, 9)[c]
@@ -124,13 +126,13 @@ def evaluate(chain: str, det: np.ndarray, param_str: np.ndarray, template=None, 
         Xw = X
     else:
         pose = param_str[15 * C: 15 * C + 6 * I].reshape(I, 6)[im]
-        X = np.asarray(template, dtype=np.float64)[k] if chain == "template" else param_str[15 * C + 6 * I:].reshape(-1, 3)[k]
+        X = np.asarray(template, dtype=dtype)[k] if chain == "template" else param_str[15 * C + 6 * I:].reshape(-1, 3)[k]
         Rp = rodrigues(pose[:, :3])
         Xw = np.einsum("nij,nj->ni", Rp, X) + pose[:, 3:]          # fbi:150-155
     Re = rodrigues(extr[:, :3])
     Xc = np.einsum("nij,nj->ni", Re, Xw) + extr[:, 3:]
     uv, A_p, A_x = _projection(intr, Xc)
-    resid = uv - det[:, 3:]                                          # afb:384
+    resid = uv - det[:, 3:].astype(dtype)                                          # afb:384
     if not want_jac:
         return resid, None
     dRe = rodrigues_jac(extr[:, :3])

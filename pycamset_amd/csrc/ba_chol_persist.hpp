@@ -159,58 +159,68 @@ __device__ __forceinline__ void cp_apply(const double *P, const double *Q, doubl
     }
 }
 
-// One wave factors the 64 x 32 panel [D; X]: lanes 0-31 hold the rows of the (private copy of the) diagonal tile, lanes 32-63 the
-// rows of the tile below it; the elimination of D carries X along — X ends as X L^-T without any inverse.  Only X is written back.
-__device__ __forceinline__ bool cp_panel(const double *Td, double *Town, const int lane) {
+// The 64 x 32 panel [D; X] — D = the (private copy of the) diagonal tile, X = the tile below it — factored by the FOUR waves of the
+// workgroup: lane r of every wave is row r of the panel (lanes 0-31 D, lanes 32-63 X; the elimination of D carries X along, X ends as
+// X L^-T without any inverse), wave w holds the panel's columns 8 w .. 8 w + 7 in registers.  Block b of eight columns is factored by
+// wave b alone (pivot and column entries from lane j by v_readlane), parked in LDS as `Sp[jl][row]`, and the waves behind it
+// subtract its eight rank-1 terms from their own columns — row multiplier `Sp[jl][lane]`, column multiplier `Sp[jl][c]` as a
+// broadcast read.  Critical path: 4 sub-panels (8 pivots, 28 updates each) + 3 x (barrier + one block update) instead of one
+// wave's 32 pivots and 496 updates: 5.6 us -> ~2.6 us per block column, and 16 VGPRs of panel instead of 64.
+// `Sp`: 2 x 8 x 64 doubles.  D == X's tile for the diagonal owner (diag = true): lanes 32-63 shadow lanes 0-31, L goes back to the
+// tile with zeros above the diagonal, the reciprocal pivots to `ild` (32 doubles, for the inversion that follows later).
+// All four waves call it (it contains barriers); returns false in the wave that met a non-positive pivot.
+__device__ __forceinline__ bool cp_panel4(const double *Dt, double *Xt, const bool diag, double *ild, double *Sp, const int lane, const int wave) {
     const int r = lane & 31;
     const bool low = lane >= 32;
-    const double *src = (low ? Town : Td) + r * CP_LDT;
-    double row[32];
+    const double *src = ((low && !diag) ? Xt : Dt) + r * CP_LDT + 8 * wave;
+    double v[8];
 #pragma unroll
-    for (int c = 0; c < 32; ++c) row[c] = src[c];
+    for (int q = 0; q < 8; ++q) v[q] = src[q];
     bool ok = true;
+    double my_il = 0.0;
 #pragma unroll
-    for (int j = 0; j < 32; ++j) {
-        const double p = lane_bcast(row[j], j);
-        ok = ok && (p > 0.0);
-        const double il = rsqrt_nr(p);
-        row[j] *= il;   // lane j holds p itself: p / sqrt(p)
+    for (int b = 0; b < 4; ++b) {
+        double *buf = Sp + (b & 1) * 8 * 64;
+        if (wave == b) {
 #pragma unroll
-        for (int c = j + 1; c < 32; ++c) row[c] -= row[j] * lane_bcast(row[j], c);   // L[c][j] lives in lane c (the diagonal tile's rows)
+            for (int jl = 0; jl < 8; ++jl) {
+                const int j = 8 * b + jl;   // the pivot's row of D lives in lane j
+                const double p = lane_bcast(v[jl], j);
+                ok = ok && (p > 0.0);
+                const double il = rsqrt_nr(p);
+                my_il = (r == j) ? il : my_il;
+                v[jl] *= il;   // lane j holds p itself: p / sqrt(p)
+#pragma unroll
+                for (int q = jl + 1; q < 8; ++q) v[q] -= v[jl] * lane_bcast(v[jl], 8 * b + q);   // L[c][j] lives in lane c
+                buf[jl * 64 + lane] = v[jl];
+            }
+        }
+        if (b < 3) {
+            __syncthreads();
+            if (wave > b) {
+#pragma unroll
+                for (int jl = 0; jl < 8; ++jl) {
+                    const double mrow = buf[jl * 64 + lane];
+                    const double *bc = buf + jl * 64 + 8 * wave;   // wave-uniform address: broadcast reads
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] -= mrow * bc[q];
+                }
+            }
+        }
     }
-    if (low) {
+    if (diag) {
+        if (!low) {
 #pragma unroll
-        for (int c = 0; c < 32; ++c) Town[r * CP_LDT + c] = row[c];
+            for (int q = 0; q < 8; ++q) Xt[r * CP_LDT + 8 * wave + q] = (8 * wave + q <= r) ? v[q] : 0.0;
+            if ((r >> 3) == wave) ild[r] = my_il;
+        }
+    } else if (low) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) Xt[r * CP_LDT + 8 * wave + q] = v[q];
     }
     return ok;
 }
 
-// The diagonal tile's owner: factor D (32 x 32, lower part; lanes 32-63 shadow lanes 0-31) in registers; L goes back to D with zeros
-// above the diagonal, the reciprocal pivots to `ild` (32 doubles) for the inversion that follows LATER, off the column's critical path
-__device__ __forceinline__ bool cp_factor_diag(double *D, double *ild, const int lane) {
-    const int r = lane & 31;
-    double row[32];
-#pragma unroll
-    for (int c = 0; c < 32; ++c) row[c] = D[r * CP_LDT + c];
-    bool ok = true;
-    double my_il = 0.0;
-#pragma unroll
-    for (int j = 0; j < 32; ++j) {
-        const double p = lane_bcast(row[j], j);
-        ok = ok && (p > 0.0);
-        const double il = rsqrt_nr(p);
-        my_il = (r == j) ? il : my_il;
-        row[j] *= il;
-#pragma unroll
-        for (int c = j + 1; c < 32; ++c) row[c] -= row[j] * lane_bcast(row[j], c);
-    }
-    if (lane < 32) {
-#pragma unroll
-        for (int c = 0; c < 32; ++c) D[r * CP_LDT + c] = c <= r ? row[c] : 0.0;
-        ild[r] = my_il;
-    }
-    return ok;
-}
 // Li = L^-1 (lower, zeros stored above the diagonal) by forward substitution, one column per lane, column-oriented: once x[m] is known
 // every later equation gets its term (31 - m independent FMAs; ba_dense_chol.hpp's factor_and_invert_tile, second half)
 __device__ __forceinline__ void cp_invert_diag(const double *D, double *Li, const double *ild, const int lane) {
@@ -233,6 +243,7 @@ __global__ __launch_bounds__(256) void chol_persist_kernel(const CholPersistArgs
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nb = a.nb, G = gridDim.x, wg = blockIdx.x;
     double *P = cp_sm, *Q = P + 32 * CHOL_LDP, *slot0 = Q + 32 * CHOL_LDP;
+    double *Sp = P;   // the panel's sub-panel exchange (2 x 8 x 64 doubles) shares the operand buffers: never in use at the same time
     int *meta = reinterpret_cast<int *>(slot0 + (size_t)a.slots * CP_SLOT);   // [0..7] packed tile of the slot, [16] wait word
     int *wword = meta + 16;
     auto Town = [&](const int s) { return slot0 + (size_t)s * CP_SLOT; };
@@ -311,21 +322,14 @@ __global__ __launch_bounds__(256) void chol_persist_kernel(const CholPersistArgs
         if (ncrit) {
             if (m >= 0) apply_column(m, m + 1, m + 1);
             CP_STAMP(m + 1, 2);
-            for (int round = 0; round * 4 < ncrit; ++round) {   // one wave per tile
-                int mine = -1, idx = 0;
-#pragma unroll
-                for (int s = 0; s < CP_MAX_SLOTS; ++s)
-                    if (pk[s] != 0xFFFF && (pk[s] & 255) == m + 1) {
-                        if (idx == round * 4 + wave) mine = s;
-                        ++idx;
-                    }
-                if (mine < 0) continue;
+            for (int s = 0; s < a.slots; ++s) {   // the four waves factor one panel together; a workgroup rarely has a second one in a column
                 int i, j;
-                tile(mine, i, j);
-                const bool ok = (i == j) ? cp_factor_diag(Town(mine), Sv(mine), lane) : cp_panel(Td(mine), Town(mine), lane);
+                tile(s, i, j);
+                if (j != m + 1) continue;
+                const bool ok = cp_panel4(i == j ? Town(s) : Td(s), Town(s), i == j, Sv(s), Sp, lane, wave);
                 if (!__builtin_amdgcn_readfirstlane((int)__all(ok)) && lane == 0) atomicOr(a.status, 2);
+                __syncthreads();
             }
-            __syncthreads();
             CP_STAMP(m + 1, 3);
             int published = 0;
             for (int s = 0; s < a.slots; ++s) {

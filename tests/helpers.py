@@ -46,3 +46,24 @@ def assert_jac_close(a, ref, rtol=JAC_RTOL, rows=None):
 def assert_resid_close(r, ref, uv, rtol=RES_RTOL):
     err = resid_rel_err(r, ref, uv)
     assert err <= rtol, f"residual max rel err {err:.3e} > {rtol:.1e}"
+
+
+def jac_error_report(a, ref, P):
+    """Where a Jacobian (rows x P) differs from a reference, beyond the one floored figure the gate uses:
+    floored      max |a - ref| / max(|ref|, 1e-6 ||row||_inf)            (the product tolerance's rule)
+    plain        max |a - ref| / |ref| over ALL non-zero reference entries (nothing excused by the floor)
+    col_*        the block column (0 .. P - 1) the worst entry of either kind sits in
+    under_floor  share of the non-zero reference entries smaller than 1e-6 of their row's largest"""
+    a, ref = np.asarray(a, dtype=np.longdouble).reshape(-1, P), np.asarray(ref, dtype=np.longdouble).reshape(-1, P)
+    rows = np.max(np.abs(ref), axis=1, keepdims=True)
+    d = np.abs(a - ref)
+    fl = d / np.maximum(np.abs(ref), ROW_FLOOR * rows)
+    nz = ref != 0
+    pl = np.where(nz, d / np.where(nz, np.abs(ref), 1), 0)
+    return {"floored": float(fl.max()), "col_floored": int(np.argmax(fl.max(axis=0))), "plain": float(pl.max()), "col_plain": int(np.argmax(pl.max(axis=0))),
+            "under_floor": float(np.mean((np.abs(ref) < ROW_FLOOR * rows)[nz]))}
+
+
+def describe(rep):
+    return (f"floored {rep['floored']:.2e} (column {rep['col_floored']}), plain {rep['plain']:.2e} (column {rep['col_plain']}), "
+            f"{100 * rep['under_floor']:.1f} % of the non-zero entries under the row floor")

@@ -355,7 +355,7 @@ def test_zero_pose_and_nonfinite_passthrough(Engine):
 
 # ---- full-size configs: sampled oracle comparison + size-independent properties ------------------
 @pytest.mark.parametrize("number,chain", [(2, "template"), (3, "template"), (4, "self")])
-def test_full_size_config(Engine, number, chain):
+def test_full_size_config(Engine, number, chain, capsys):
     rig = synthetic.config_rig(number)
     N = rig.n_det
     assert N > 1e5
@@ -371,6 +371,21 @@ def test_full_size_config(Engine, number, chain):
     P = e.P
     H.assert_resid_close(r[idx], ref_r, rig.detections[idx, 3:])
     H.assert_jac_close(j.reshape(N, 2 * P)[idx].reshape(-1, P), ref_j)
+    # (1b) whose rounding is it?  The same formulas in x87 extended precision (64-bit mantissa) on a sub-sample: the kernel and
+    # the float64 oracle are each held against that yardstick.  The oracle restates the reference's own arithmetic (z**7 / z**8
+    # denominators, per-detection Rodrigues), which loses ~3e-11 on the point columns of the self chain; the kernel's normalised
+    # form stays well inside — the 1e-10 gate above is spent on the ORACLE's rounding, not on the kernel's.
+    from oracle import ba_oracle_np as onp
+    sub = idx[:: max(1, idx.shape[0] // 4000)]
+    _, ext_j = onp.evaluate(chain, rig.detections[sub], ps, tm, counts=counts, dtype=np.longdouble)
+    pos = np.searchsorted(idx, sub)
+    hip_sub = j.reshape(N, 2 * P)[sub].reshape(-1, P)
+    orc_sub = ref_j.reshape(-1, 2 * P)[pos].reshape(-1, P)
+    rep_hip, rep_orc, rep_gate = H.jac_error_report(hip_sub, ext_j, P), H.jac_error_report(orc_sub, ext_j, P), H.jac_error_report(hip_sub, orc_sub, P)
+    with capsys.disabled():
+        print(f"\n[config {number}, chain {chain}, {sub.shape[0]} detections] kernel vs extended precision: {H.describe(rep_hip)}"
+              f"\n    float64 oracle vs extended precision: {H.describe(rep_orc)}\n    kernel vs oracle (the gate): {H.describe(rep_gate)}")
+    assert rep_hip["floored"] <= 0.2 * H.JAC_RTOL, rep_hip      # a margin of 5 against the yardstick (measured 6e-12 .. 9e-12: the conditioning of the entries themselves)
     # (2) permutation equivariance: evaluating a shuffled table gives the shuffled rows, bit for bit
     perm = np.random.default_rng(0).permutation(N)
     e2 = make_engine(Engine, rig, chain, det=rig.detections[perm])
