@@ -196,4 +196,261 @@ __global__ __launch_bounds__(256) void triangulate_kernel(const int32_t *__restr
     }
 }
 
+// ---- round 4: the same algorithm with a group's views ON CHIP and without IEEE divides ---------------------------------------------------
+// Where round 3's 106 us went (97 k points, 1e6 observations): not traffic.  A view cost ~25 FP64 divides / square roots (undistort 6,
+// reflector 2, two Givens folds 8 x 3), the merge of the G private factors 2 x 4 x 4 x 3 more, every inverse-iteration step 12 —
+// each a ~25-35-instruction software sequence: ~9 k VALU instructions per wave of 16 points, issue-bound (24 waves per CU).
+//   * every division and square root on the path is a hardware estimate + two Newton steps (tri_rcp / tri_rsq: ~6-9 instructions,
+//     <= 1-2 ulp), a Givens rotation needs ONE of them (c = a / h, s = b / h, h = h^2 / h from 1 / sqrt(h^2)), the reciprocals of
+//     the 4 x 4 factor's diagonal are formed once per point instead of twice per step;
+//   * lane g keeps its views g, g + G, ... in REGISTERS (Householder row r_i, 1 / alpha_i, the lambda component): V views per lane,
+//     G V per point (24 at the default G = 4, V = 6: 161 VGPRs, three waves per SIMD); only views beyond that use the 48 B / observation scratch of the first
+//     version.  Loops over the register views are unrolled and cut at the wave's largest per-lane count (uniform branch), absent
+//     views are all-zero records that change no sum — a point's result still does not depend on its wave neighbours.
+__device__ __forceinline__ double tri_rcp(const double x) {
+    double y = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-x, y, 1.0);
+    return fma(y, e, y);
+}
+__device__ __forceinline__ double tri_rsq(const double x) {   // 1 / sqrt(x), x > 0
+    double y = __builtin_amdgcn_rsq(x);
+    y = y * (1.5 - 0.5 * x * y * y);
+    y = y * (1.5 - 0.5 * x * y * y);
+    return y;
+}
+
+__device__ __forceinline__ void undistort5_fast(const double u, const double v, const double *__restrict__ ct, double &uo, double &vo) {
+    const double fx = ct[22], cx = ct[23], fy = ct[24], cy = ct[25];
+    const double k0 = ct[26], k1 = ct[27], p0 = ct[28], p1 = ct[29], k2 = ct[30];
+    const double x0 = (u - cx) * tri_rcp(fx), y0 = (v - cy) * tri_rcp(fy);
+    double x = x0, y = y0;
+#pragma unroll
+    for (int it = 0; it < 5; ++it) {
+        const double r2 = x * x + y * y;
+        const double k_inv = tri_rcp(1.0 + k0 * r2 + k1 * (r2 * r2) + k2 * (r2 * r2 * r2));
+        const double xD = 2.0 * p0 * x * y + p1 * (r2 + 2.0 * (x * x));
+        const double yD = p0 * (r2 + 2.0 * (y * y)) + 2.0 * p1 * x * y;
+        x = (x0 - xD) * k_inv;
+        y = (y0 - yD) * k_inv;
+    }
+    uo = x * fx + cx;
+    vo = y * fy + cy;
+}
+
+__device__ __forceinline__ void view_rows_fast(const double *__restrict__ P, const double u, const double v, double &inv_alpha, double (&r)[4],
+                                               double (&c0)[4], double (&c1)[4]) {
+    const double n2 = u * u + v * v + 1.0;
+    const double inx = tri_rsq(n2), nx = n2 * inx;
+    const double alpha = (u >= 0.0) ? -nx : nx;   // opposite sign of x_1: no cancellation in v_1
+    inv_alpha = (u >= 0.0) ? -inx : inx;
+    const double v0 = u - alpha, v1 = v, v2 = 1.0;
+    const double f = 2.0 * tri_rcp(v0 * v0 + v1 * v1 + v2 * v2);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const double t = f * (v0 * P[k] + v1 * P[4 + k] + v2 * P[8 + k]);
+        r[k] = P[k] - v0 * t;
+        c0[k] = P[4 + k] - v1 * t;
+        c1[k] = P[8 + k] - v2 * t;
+    }
+}
+
+// fold one row into the upper-triangular 4x4 factor: branch-free, one reciprocal square root per rotation
+__device__ __forceinline__ void givens_insert_fast(double (&R)[4][4], double (&row)[4]) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const double a = R[k][k], b = row[k];
+        const double h2 = a * a + b * b;
+        const bool rot = b != 0.0;                        // b == 0: the identity (also keeps 0 / 0 out of an empty factor)
+        const double ih = rot ? tri_rsq(h2) : 0.0;
+        const double c = rot ? a * ih : 1.0, s = b * ih;
+#pragma unroll
+        for (int j = k; j < 4; ++j) {
+            const double rk = R[k][j], rw = row[j];
+            R[k][j] = c * rk + s * rw;
+            row[j] = c * rw - s * rk;
+        }
+    }
+}
+
+template <int G, int V>
+__global__ __launch_bounds__(256) void triangulate_reg_kernel(const int32_t *__restrict__ cam, const double2 *__restrict__ uv,
+                                                              const int64_t *__restrict__ start, const double *__restrict__ cam_tab,
+                                                              double4 *__restrict__ scr_r, double2 *__restrict__ scr_al,
+                                                              double *__restrict__ pts, int64_t n_pts, const int32_t *__restrict__ order) {
+    const int64_t gid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+    const int g = threadIdx.x & (G - 1);
+    const bool live = gid < n_pts;  // whole groups are live or dead; dead groups still take part in the shuffles
+    const int64_t jv = live ? gid : n_pts - 1;
+    const int64_t j = order ? order[jv] : jv;   // points of equal view counts side by side (tri_order_*_kernel)
+    const int64_t s0 = start[j], s1 = live ? start[j + 1] : s0;
+    // the wave's largest number of register views per lane: the unrolled loops stop there (uniform)
+    int nv = (int)((s1 - s0 - g + G - 1) / G);
+    nv = nv < 0 ? 0 : (nv > V ? V : nv);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) nv = max(nv, __shfl_xor(nv, off));
+    const int nv_w = __builtin_amdgcn_readfirstlane(nv);
+
+    double R[4][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    double rr[V][4], ia[V], lam[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) {   // pass 1: undistort, Householder rows, fold the C rows into R
+        rr[v][0] = rr[v][1] = rr[v][2] = rr[v][3] = 0.0;
+        ia[v] = lam[v] = 0.0;
+        if (v >= nv_w) continue;
+        const int64_t q = s0 + g + (int64_t)v * G;
+        const bool have = q < s1;
+        const int64_t qc = have ? q : s0;   // some readable observation for absent views (dead groups: the last point's first)
+        const double *ct = cam_tab + (int64_t)cam[qc] * TRI_CAM_STRIDE;
+        const double2 m = uv[qc];
+        double uu, vv, inv_alpha, r[4], c0[4], c1[4];
+        undistort5_fast(m.x, m.y, ct, uu, vv);
+        view_rows_fast(ct, uu, vv, inv_alpha, r, c0, c1);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            rr[v][k] = have ? r[k] : 0.0;
+            c0[k] = have ? c0[k] : 0.0;   // a zero row folds as the identity
+            c1[k] = have ? c1[k] : 0.0;
+        }
+        ia[v] = have ? -inv_alpha : 0.0;   // 1 / E_i
+        givens_insert_fast(R, c0);
+        givens_insert_fast(R, c1);
+    }
+    for (int64_t q = s0 + g + (int64_t)V * G; q < s1; q += G) {   // views beyond the registers: the scratch records of the first version
+        const double *ct = cam_tab + (int64_t)cam[q] * TRI_CAM_STRIDE;
+        const double2 m = uv[q];
+        double uu, vv, inv_alpha, r[4], c0[4], c1[4];
+        undistort5_fast(m.x, m.y, ct, uu, vv);
+        view_rows_fast(ct, uu, vv, inv_alpha, r, c0, c1);
+        scr_r[q] = make_double4(r[0], r[1], r[2], r[3]);
+        scr_al[q] = make_double2(-inv_alpha, 0.0);
+        givens_insert_fast(R, c0);
+        givens_insert_fast(R, c1);
+    }
+    if constexpr (G > 1) {
+        // merge the G private factors: after step `off` every lane holds the factor of its 2*off-lane block
+#pragma unroll
+        for (int off = 1; off < G; off <<= 1) {
+            double Rp[4][4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) Rp[a][b] = (b >= a) ? __shfl_xor(R[a][b], off, G) : 0.0;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                double row[4] = {Rp[a][0], Rp[a][1], Rp[a][2], Rp[a][3]};
+                givens_insert_fast(R, row);
+            }
+        }
+        // the two partners of a step fold in opposite orders; all lanes adopt lane 0's copy
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = a; b < 4; ++b) R[a][b] = __shfl(R[a][b], 0, G);
+    }
+    const double i0 = tri_rcp(R[0][0]), i1 = tri_rcp(R[1][1]), i2 = tri_rcp(R[2][2]), i3 = tri_rcp(R[3][3]);
+    double zX[4] = {0.5, 0.5, 0.5, 0.5};
+    double scale = 1.0;  // z_lambda = scale * stored component
+    double X0 = 0, X1 = 0, X2 = 0;
+    bool done = false;
+    for (int it = 0; it < 10; ++it) {
+        // forward solve  [E 0; R^T R_C^T] y = z
+        double acc[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            if (v >= nv_w) break;
+            const double yl = (lam[v] * scale) * ia[v];
+            lam[v] = done ? lam[v] : yl;
+            acc[0] += rr[v][0] * yl; acc[1] += rr[v][1] * yl; acc[2] += rr[v][2] * yl; acc[3] += rr[v][3] * yl;
+        }
+        for (int64_t q = s0 + g + (int64_t)V * G; q < s1; q += G) {
+            const double4 r = scr_r[q];
+            double2 al = scr_al[q];
+            const double yl = (al.y * scale) * al.x;
+            if (!done) scr_al[q] = make_double2(al.x, yl);
+            acc[0] += r.x * yl; acc[1] += r.y * yl; acc[2] += r.z * yl; acc[3] += r.w * yl;
+        }
+        if constexpr (G > 1) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k] = group_sum<G>(acc[k]);
+        }
+        double y[4], w[4];
+        y[0] = (zX[0] - acc[0]) * i0;
+        y[1] = (zX[1] - acc[1] - R[0][1] * y[0]) * i1;
+        y[2] = (zX[2] - acc[2] - R[0][2] * y[0] - R[1][2] * y[1]) * i2;
+        y[3] = (zX[3] - acc[3] - R[0][3] * y[0] - R[1][3] * y[1] - R[2][3] * y[2]) * i3;
+        // back solve  [E R; 0 R_C] w = y
+        w[3] = y[3] * i3;
+        w[2] = (y[2] - R[2][3] * w[3]) * i2;
+        w[1] = (y[1] - R[1][2] * w[2] - R[1][3] * w[3]) * i1;
+        w[0] = (y[0] - R[0][1] * w[1] - R[0][2] * w[2] - R[0][3] * w[3]) * i0;
+        double part = 0.0;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            if (v >= nv_w) break;
+            const double wl = (lam[v] - (rr[v][0] * w[0] + rr[v][1] * w[1] + rr[v][2] * w[2] + rr[v][3] * w[3])) * ia[v];
+            lam[v] = done ? lam[v] : wl;
+            part += wl * wl;
+        }
+        for (int64_t q = s0 + g + (int64_t)V * G; q < s1; q += G) {
+            const double4 r = scr_r[q];
+            const double2 al = scr_al[q];
+            const double wl = (al.y - (r.x * w[0] + r.y * w[1] + r.z * w[2] + r.w * w[3])) * al.x;
+            if (!done) scr_al[q] = make_double2(al.x, wl);
+            part += wl * wl;
+        }
+        if constexpr (G > 1) part = group_sum<G>(part);
+        const double nrm2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2] + w[3] * w[3] + part;
+        const double iw3 = tri_rcp(w[3]);
+        const double n0 = w[0] * iw3, n1 = w[1] * iw3, n2 = w[2] * iw3;
+        const double change = fmax(fabs(n0 - X0), fmax(fabs(n1 - X1), fabs(n2 - X2)));
+        const double size = fmax(fabs(n0), fmax(fabs(n1), fabs(n2)));
+        if (!done) {  // a converged group is frozen: its result must not depend on its wave neighbours
+            scale = tri_rsq(nrm2);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) zX[k] = w[k] * scale;
+            X0 = n0; X1 = n1; X2 = n2;
+            done = it > 0 && !(change > 1e-14 * size);  // also leaves on NaN
+        }
+        if (__all(done || !live)) break;  // the shuffles are wave-wide: leave together
+    }
+    if (live && g == 0) {
+        pts[3 * j + 0] = X0;
+        pts[3 * j + 1] = X1;
+        pts[3 * j + 2] = X2;
+    }
+}
+
+// ---- visiting order: points sorted by their number of views (counting sort, 256 buckets) ------------------------------------------------
+// A wave of triangulate_reg_kernel runs as many register-view slots as its busiest lane needs; with the points in table order a wave
+// mixes 2-view and 22-view points and most lanes idle through most slots (rig-32: mean 3.0 slots needed, 4.1 run).  Walking the points
+// in order of their view count makes a wave's groups alike.  Built once per set of observations, on the stream of the first run.
+__global__ __launch_bounds__(256) void tri_order_count_kernel(const int64_t *__restrict__ start, const int64_t n_pts, int32_t *__restrict__ hist) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_pts) return;
+    const int64_t v = start[j + 1] - start[j];
+    atomicAdd(hist + (int)(v < 0 ? 0 : (v > 255 ? 255 : v)), 1);
+}
+__global__ __launch_bounds__(256) void tri_order_scan_kernel(int32_t *__restrict__ hist) {   // one workgroup: hist[256] -> exclusive offsets in hist[256 .. 511]
+    __shared__ int32_t sm[256];
+    const int t = threadIdx.x;
+    sm[t] = hist[t];
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        const int32_t add = t >= off ? sm[t - off] : 0;
+        __syncthreads();
+        sm[t] += add;
+        __syncthreads();
+    }
+    hist[256 + t] = sm[t] - hist[t];
+}
+__global__ __launch_bounds__(256) void tri_order_scatter_kernel(const int64_t *__restrict__ start, const int64_t n_pts, int32_t *__restrict__ hist, int32_t *__restrict__ order) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_pts) return;
+    const int64_t v = start[j + 1] - start[j];
+    const int pos = atomicAdd(hist + 256 + (int)(v < 0 ? 0 : (v > 255 ? 255 : v)), 1);
+    order[pos] = (int32_t)j;
+}
+
 }  // namespace pcs

@@ -235,6 +235,10 @@ struct pcs_triangulator {
     // current problem (device pointers: handle-owned or the caller's)
     const int32_t *cur_cam = nullptr; const double *cur_uv = nullptr; const int64_t *cur_start = nullptr;
     int64_t n_obs = 0, n_pts = -1;
+    int32_t *d_order = nullptr, *d_hist = nullptr;   // points by view count (built by the first run of a set of observations)
+    int64_t order_capacity = 0;
+    bool order_valid = false, sort_points = true;
+    int variant = 1; // 1: views in registers + divide-free rotations (round 4; 3: eight instead of six register views per lane); 0: round 3's kernel (PCS_TRI_VARIANT=0)
     int lanes = 4;   // lanes per point: 1, 2, 4, 8 or 16 (profiles/r01/tri_legacy_bench.log: 4 is fastest at 2-22 views)
     // Ordering across streams, as in pcs_engine: `done` is recorded after every run; whatever touches the camera table, the
     // handle-owned observation copies, the scratch or the output next first waits for it — on the host where the host
@@ -270,6 +274,9 @@ int pcs_tri_create(pcs_triangulator **out, int device, int64_t n_cams) {
     const char *lanes_env = getenv("PCS_TRI_LANES");   // A/B switch
     const int lanes = lanes_env ? atoi(lanes_env) : 4;
     t->lanes = (lanes == 1 || lanes == 2 || lanes == 8 || lanes == 16) ? lanes : 4;
+    const char *var_env = getenv("PCS_TRI_VARIANT");
+    t->variant = var_env ? atoi(var_env) : 1;
+    t->sort_points = getenv("PCS_TRI_NO_SORT") == nullptr;   // A/B switch
     hipError_t e = hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&t->e0);
     if (e == hipSuccess) e = hipEventCreate(&t->e1);
@@ -289,7 +296,7 @@ int pcs_tri_destroy(pcs_triangulator *t) {
     (void)hipSetDevice(t->device);
     if (t->stream) (void)hipStreamSynchronize(t->stream);
     (void)tri_wait_done_host(t);   // a run on a caller stream may still read the tables
-    for (void *b : {(void *)t->d_tab, (void *)t->d_cam, (void *)t->d_uv, (void *)t->d_start, t->d_scr, t->d_scl, (void *)t->d_pts})
+    for (void *b : {(void *)t->d_tab, (void *)t->d_cam, (void *)t->d_uv, (void *)t->d_start, t->d_scr, t->d_scl, (void *)t->d_pts, (void *)t->d_order, (void *)t->d_hist})
         if (b) (void)hipFree(b);
     if (t->e0) (void)hipEventDestroy(t->e0);
     if (t->e1) (void)hipEventDestroy(t->e1);
@@ -342,6 +349,7 @@ int pcs_tri_set_observations(pcs_triangulator *t, int64_t n_obs, const int32_t *
     HIPCHK(hipStreamSynchronize(t->stream));   // the caller may reuse its host arrays
     t->cur_cam = t->d_cam; t->cur_uv = t->d_uv; t->cur_start = t->d_start;
     t->n_obs = n_obs; t->n_pts = n_pts;
+    t->order_valid = false;
     t->out_owned = false;   // results of an earlier problem are not this problem's
     return PCS_OK;
 }
@@ -350,6 +358,7 @@ int pcs_tri_set_observations_device(pcs_triangulator *t, int64_t n_obs, const in
     if (!t || n_obs < 0 || n_pts < 0 || !d_start_inds || (n_obs > 0 && (!d_cam || !d_uv))) return fail(PCS_ERR_ARG, "pcs_tri_set_observations_device: bad arguments");
     t->cur_cam = d_cam; t->cur_uv = d_uv; t->cur_start = d_start_inds;   // caller-owned, not range-checked (stay on the device)
     t->n_obs = n_obs; t->n_pts = n_pts;
+    t->order_valid = false;
     t->out_owned = false;
     return PCS_OK;
 }
@@ -361,7 +370,8 @@ int pcs_tri_run(pcs_triangulator *t, double *d_pts, void *stream) {
     if (t->n_pts == 0) return PCS_OK;
     HIPCHK(hipSetDevice(t->device));
     hipStream_t s = stream ? (hipStream_t)stream : t->stream;
-    const bool grows = t->n_obs > t->scr_capacity || t->n_obs > t->scl_capacity || (!d_pts && t->n_pts > t->out_capacity);
+    const bool need_order = t->variant != 0 && t->sort_points && !t->order_valid && t->n_pts < (1ll << 31);
+    const bool grows = t->n_obs > t->scr_capacity || t->n_obs > t->scl_capacity || (!d_pts && t->n_pts > t->out_capacity) || (need_order && t->n_pts > t->order_capacity);
     if (t->have_done) {   // scratch and output are shared between runs: the previous one finishes first
         if (grows || s == hipStreamLegacy || t->done_stream == hipStreamLegacy) HIPCHK(hipEventSynchronize(t->done));   // frees need the host to wait
         else if (s != t->done_stream) HIPCHK(hipStreamWaitEvent(s, t->done, 0));
@@ -378,14 +388,40 @@ int pcs_tri_run(pcs_triangulator *t, double *d_pts, void *stream) {
     }
     const int lanes = t->lanes;
     const dim3 grid((unsigned)((t->n_pts * lanes + 255) / 256));
+    if (need_order) {
+        // the visiting order of this set of observations, on the run's own stream (the caller's start_inds may have been produced there)
+        rc = tri_grow((void **)&t->d_order, &t->order_capacity, t->n_pts, sizeof(int32_t));
+        if (rc) return rc;
+        if (!t->d_hist) HIPCHK(hipMalloc(&t->d_hist, sizeof(int32_t) * 512));
+        HIPCHK(hipMemsetAsync(t->d_hist, 0, sizeof(int32_t) * 512, s));
+        const dim3 pg((unsigned)((t->n_pts + 255) / 256));
+        hipLaunchKernelGGL(tri_order_count_kernel, pg, dim3(256), 0, s, t->cur_start, t->n_pts, t->d_hist);
+        hipLaunchKernelGGL(tri_order_scan_kernel, dim3(1), dim3(256), 0, s, t->d_hist);
+        hipLaunchKernelGGL(tri_order_scatter_kernel, pg, dim3(256), 0, s, t->cur_start, t->n_pts, t->d_hist, t->d_order);
+        HIPCHK(hipGetLastError());
+        t->order_valid = true;
+    }
 #define PCS_TRI_LAUNCH(G_)                                                                                                     \
     hipExtLaunchKernelGGL(triangulate_kernel<G_>, grid, dim3(256), 0, s, t->e0, t->e1, 0, t->cur_cam, (const double2 *)t->cur_uv, \
                           t->cur_start, (const double *)t->d_tab, (double4 *)t->d_scr, (double2 *)t->d_scl, d_pts, t->n_pts)
-    if (lanes == 1) PCS_TRI_LAUNCH(1);
-    else if (lanes == 2) PCS_TRI_LAUNCH(2);
-    else if (lanes == 8) PCS_TRI_LAUNCH(8);
-    else if (lanes == 16) PCS_TRI_LAUNCH(16);
-    else PCS_TRI_LAUNCH(4);
+#define PCS_TRI_LAUNCH_REG(G_, V_)                                                                                                     \
+    hipExtLaunchKernelGGL((triangulate_reg_kernel<G_, V_>), grid, dim3(256), 0, s, t->e0, t->e1, 0, t->cur_cam, (const double2 *)t->cur_uv, \
+                          t->cur_start, (const double *)t->d_tab, (double4 *)t->d_scr, (double2 *)t->d_scl, d_pts, t->n_pts, (const int32_t *)(t->order_valid ? t->d_order : nullptr))
+    if (t->variant == 0) {   // round 3's form (views in the global scratch, IEEE divides): kept for A/B (PCS_TRI_VARIANT=0)
+        if (lanes == 1) PCS_TRI_LAUNCH(1);
+        else if (lanes == 2) PCS_TRI_LAUNCH(2);
+        else if (lanes == 8) PCS_TRI_LAUNCH(8);
+        else if (lanes == 16) PCS_TRI_LAUNCH(16);
+        else PCS_TRI_LAUNCH(4);
+    } else {                 // views in registers (6 or 8 per lane; further ones in the scratch), divide-free rotations
+        if (lanes == 1) PCS_TRI_LAUNCH_REG(1, 8);
+        else if (lanes == 2) PCS_TRI_LAUNCH_REG(2, 8);
+        else if (lanes == 8) PCS_TRI_LAUNCH_REG(8, 8);
+        else if (lanes == 16) PCS_TRI_LAUNCH_REG(16, 8);
+        else if (t->variant == 3) PCS_TRI_LAUNCH_REG(4, 8);
+        else PCS_TRI_LAUNCH_REG(4, 6);   // 24 views in registers at 161 VGPRs (three waves per SIMD): 51 us against 55 us for (4, 8)
+    }
+#undef PCS_TRI_LAUNCH_REG
 #undef PCS_TRI_LAUNCH
     HIPCHK(hipGetLastError());
     t->timed = true;
