@@ -256,30 +256,36 @@ int pcs_normal_entry_map(int chain, int pass, int32_t *out);
 int pcs_normal_descriptors(int chain, int pass, int trail_group, int32_t *out);
 
 /*
- * Generated chains (round 3).  The reference composes ANY list of function blocks (afb:735-748) and code-generates the loss /
- * Jacobian / chain rule for it (afb:290-419, afb:492-652, mm:147-263).  pycamset_amd/chain_compiler.py emits a ChainSpec for a
- * composition  projection + T_1 + ... + T_M + source  (T_i in {rigidTform3d, extrinsic3D}, source in {template_points,
- * free_point}), has hipcc compile csrc/ba_generic.hpp for it (gfx950 code object) and hands the file to pcs_genchain_create.
- *   code_object_path   .hsaco with the entry points pcs_genchain_prep / pcs_genchain_eval_{1,2,3} / pcs_genchain_gather
- *   n_transforms = M,  src_kind 0 template_points / 1 free_point;  row length P = 9 + 6 M + (6 | 3)
- *   rigid parameter groups (one Rodrigues slab each): first parameter-string column and entity count per group; which group
- *   and which index (camera / image) each block reads is compiled into the code object
- *   intr_off / point_off: first column of the projection and of the free_point group
- * Outputs and layouts as pcs_eval: resid (N, 2), jac (2N, P) dense block rows, u row then v row.  pcs_genchain_set_gather +
- * pcs_genchain_eval_compact replace `data[:n][good_mask]` (afb:644-651) by a static gather on the device.
+ * Generated chains.  The reference composes ANY list of function blocks (afb:735-748) and code-generates the loss / Jacobian /
+ * chain rule for it (afb:290-419, afb:492-652, mm:147-263); user-written blocks are its extension point (afb:689-775).
+ * pycamset_amd/chain_compiler.py does the same for the GPU: for a composition
+ *     [projection | user block with 2 outputs] + {rigidTform3d | extrinsic3D | user block}* + [template_points | free_point | user source]
+ * it emits the straight-line evaluation of one detection (the user blocks' device bodies pasted in), has hipcc compile it with
+ * csrc/ba_generic.hpp for gfx950 and hands the code object to pcs_genchain_create.
+ *   code_object_path   .hsaco with the entry points pcs_genchain_prep / pcs_genchain_eval_{1,2,3}[_f32] / pcs_genchain_compact_{2,3}[_f32]
+ *   row_len = P (sum of the blocks' parameter counts, <= 64), uses_template: the source is template_points
+ *   rigid parameter groups (one Rodrigues slab each): first parameter-string column and entity count per group;
+ *   user_off[u]: first column of the parameter group of user block u; intr_off / point_off: projection / free_point groups
+ *   (which group and which index — camera / image / key — every block reads is compiled into the code object)
+ *   dtype: PCS_F64 | PCS_F32 | PCS_MIXED as for pcs_create (FP64 arithmetic, float streams)
+ * Outputs and layouts as pcs_eval: resid (N, 2), jac (2N, P) dense block rows, u row then v row, elements of the handle's dtype.
+ * pcs_genchain_set_unfixed + pcs_genchain_eval_compact[_device] write only the unfixed columns, in CSR data order, at the store
+ * (`data[:n][good_mask]`, afb:644-651, never exists as a dense array): keep[i] bit j = local column j of detection i is free,
+ * row_off[i] = offset of its u row in the data array.
  */
 typedef struct pcs_genchain pcs_genchain;
-int pcs_genchain_create(pcs_genchain **out, const char *code_object_path, int n_transforms, int src_kind, int n_groups, const int64_t *group_off,
-                     const int32_t *group_count, int64_t intr_off, int64_t point_off, int64_t n_params, int64_t n_cams, int64_t n_imgs,
-                     int64_t n_keys, int device);
+int pcs_genchain_create(pcs_genchain **out, const char *code_object_path, int row_len, int uses_template, int n_groups, const int64_t *group_off,
+                     const int32_t *group_count, int n_user, const int64_t *user_off, int64_t intr_off, int64_t point_off, int64_t n_params, int64_t n_cams,
+                     int64_t n_imgs, int64_t n_keys, int dtype, int device);
 int pcs_genchain_destroy(pcs_genchain *h);
 int pcs_genchain_row_len(const pcs_genchain *h);
 int pcs_genchain_set_detections_table(pcs_genchain *h, const double *det5, int64_t n);
 int pcs_genchain_set_template(pcs_genchain *h, const double *points);
-int pcs_genchain_eval(pcs_genchain *h, const double *param_str, double *resid, double *jac);
-int pcs_genchain_eval_device(pcs_genchain *h, const double *d_param_str, double *d_resid, double *d_jac, void *stream);
-int pcs_genchain_set_gather(pcs_genchain *h, const int64_t *src, int64_t nnz);
-int pcs_genchain_eval_compact(pcs_genchain *h, const double *param_str, double *resid, double *data);
+int pcs_genchain_eval(pcs_genchain *h, const double *param_str, void *resid, void *jac);
+int pcs_genchain_eval_device(pcs_genchain *h, const double *d_param_str, void *d_resid, void *d_jac, void *stream);
+int pcs_genchain_set_unfixed(pcs_genchain *h, const uint64_t *keep, const int64_t *row_off, int64_t nnz);
+int pcs_genchain_eval_compact(pcs_genchain *h, const double *param_str, void *resid, void *data);
+int pcs_genchain_eval_compact_device(pcs_genchain *h, const double *d_param_str, void *d_resid, void *d_data, void *stream);
 int pcs_genchain_device_buffers(pcs_genchain *h, void **d_resid, void **d_jac);
 int pcs_genchain_synchronize(pcs_genchain *h, void *stream);
 int pcs_genchain_last_kernel_ms(pcs_genchain *h, float *slab_prep_ms, float *eval_ms);

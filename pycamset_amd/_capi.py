@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_uint8, c_void_p
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_uint8, c_uint64, c_void_p
 from pathlib import Path
 
 PKG_DIR = Path(__file__).resolve().parent
@@ -57,16 +57,17 @@ SYMBOLS = {
     "pcs_dense_spd_solve": (c_int, [c_int, c_int64, _P, c_int64, _P, _P, _P, _P, _P]),
     "pcs_dense_spd_solve_algo": (c_int, [c_int, c_int64, _P, c_int64, _P, _P, _P, _P, _P, c_int]),
     "pcs_normal_descriptors": (c_int, [c_int, c_int, c_int, POINTER(c_int32)]),
-    "pcs_genchain_create": (c_int, [POINTER(_P), c_char_p, c_int, c_int, c_int, POINTER(c_int64), POINTER(c_int32), c_int64, c_int64, c_int64,
-                                 c_int64, c_int64, c_int64, c_int]),
+    "pcs_genchain_create": (c_int, [POINTER(_P), c_char_p, c_int, c_int, c_int, POINTER(c_int64), POINTER(c_int32), c_int, POINTER(c_int64), c_int64, c_int64,
+                                    c_int64, c_int64, c_int64, c_int64, c_int, c_int]),
     "pcs_genchain_destroy": (c_int, [_P]),
     "pcs_genchain_row_len": (c_int, [_P]),
     "pcs_genchain_set_detections_table": (c_int, [_P, POINTER(c_double), c_int64]),
     "pcs_genchain_set_template": (c_int, [_P, POINTER(c_double)]),
-    "pcs_genchain_eval": (c_int, [_P, POINTER(c_double), POINTER(c_double), POINTER(c_double)]),
+    "pcs_genchain_eval": (c_int, [_P, POINTER(c_double), _P, _P]),
     "pcs_genchain_eval_device": (c_int, [_P, _P, _P, _P, _P]),
-    "pcs_genchain_set_gather": (c_int, [_P, POINTER(c_int64), c_int64]),
-    "pcs_genchain_eval_compact": (c_int, [_P, POINTER(c_double), POINTER(c_double), POINTER(c_double)]),
+    "pcs_genchain_set_unfixed": (c_int, [_P, POINTER(c_uint64), POINTER(c_int64), c_int64]),
+    "pcs_genchain_eval_compact": (c_int, [_P, POINTER(c_double), _P, _P]),
+    "pcs_genchain_eval_compact_device": (c_int, [_P, _P, _P, _P, _P]),
     "pcs_genchain_device_buffers": (c_int, [_P, POINTER(_P), POINTER(_P)]),
     "pcs_genchain_synchronize": (c_int, [_P, _P]),
     "pcs_genchain_last_kernel_ms": (c_int, [_P, POINTER(c_float), POINTER(c_float)]),

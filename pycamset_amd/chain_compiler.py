@@ -2,15 +2,17 @@
 
 The reference's ``optimisation_function`` accepts any list of blocks (``a + b + c``, abstract_function_blocks.py:735-748)
 and code-generates the loss, the Jacobian driver and the chain rule for it (afb:290-419, afb:492-652,
-matmul_map.py:147-263); user blocks are its documented extension point.  The three chains its handlers build have
-hand-fused kernels here (csrc/ba_kernels.hpp).  Every other valid composition of the five known blocks
+matmul_map.py:147-263); user blocks are its documented extension point (afb:689-775).  The three chains its handlers build
+have hand-fused kernels here (csrc/ba_kernels.hpp).  Every other valid composition
 
-    projection + T_1 + ... + T_M + source      T_i in {rigidTform3d (per image), extrinsic3D (per camera)}
-                                               source in {template_points (per image), free_point (per key)}
+    first + middle* + source     first  in {projection, user block with num_out = 2}
+                                 middle in {rigidTform3d (per image), extrinsic3D (per camera), user block}
+                                 source in {template_points (per image), free_point (per key), user block with num_inp = 0}
 
-goes through this module: ``ChainSpec`` turns the block list into the tables of csrc/ba_generic.hpp (which rigid parameter
-group and which index each block reads), ``emit_source`` writes the ~15-line translation unit that instantiates the
-generic kernels for it, ``compile_chain`` has hipcc build a gfx950 code object (cached by content hash under
+goes through this module: ``ChainSpec`` validates the block list and lays out the parameter string, ``emit_source`` writes
+the translation unit — the user blocks' device bodies (``function_blocks.device_function_block``) and the straight-line
+evaluation of one detection: blocks right to left, then the chain rule left to right, calling the built-in blocks' helpers of
+csrc/ba_generic.hpp —, ``compile_chain`` has hipcc build a gfx950 code object (cached by content hash under
 ``pycamset_amd/_chains/``; hipcc cross-compiles without a GPU, so ``__graft_entry__.build()`` pre-builds the chains the
 tests use), and ``ChainEngine`` drives it through the C ABI (``pcs_genchain_*``, include/pcs_hip.h) with the subset of
 ``Engine``'s interface the operator API needs.  There is no interpreter and no CPU fallback: a composition outside the
@@ -25,7 +27,7 @@ from __future__ import annotations
 import hashlib
 import os
 import subprocess
-from ctypes import POINTER, byref, c_double, c_float, c_int32, c_int64, c_void_p
+from ctypes import POINTER, byref, c_double, c_float, c_int32, c_int64, c_uint64, c_void_p
 from dataclasses import dataclass, field
 from pathlib import Path
 
@@ -39,28 +41,61 @@ CSRC = PKG / "csrc"
 CACHE = PKG / "_chains"
 LINK_CAM, LINK_IMG, LINK_KEY = 0, 1, 2          # afb:42-46 key_type
 SRC_TEMPLATE, SRC_FREE = 0, 1
-MAX_TRANSFORMS, MAX_GROUPS = 6, 8
+MAX_GROUPS = 8
+
+
+BUILTIN_KINDS = {"projection": "projection", "rigidTform3d": "rigid", "extrinsic3D": "rigid", "template_points": "template_points", "free_point": "free_point"}
+MAX_BLOCKS, MAX_USER = 10, 8
+_LINK_CPP = {LINK_CAM: "pcs::LINK_CAM", LINK_IMG: "pcs::LINK_IMG", LINK_KEY: "pcs::LINK_KEY"}
+
+
+@dataclass
+class BlockInfo:
+    """One block of a composition as the code generator sees it."""
+    name: str            # class name
+    kind: str            # 'projection' | 'rigid' | 'template_points' | 'free_point' | 'user'
+    link: int            # LINK_CAM / LINK_IMG / LINK_KEY of its parameter group
+    n_params: int
+    nin: int
+    nout: int
+    group: int           # index into ChainSpec.groups
+    slab: int | None = None    # rigid blocks: which Rodrigues slab
+    uidx: int | None = None    # user blocks: ordinal among the user blocks
+    device_fun: str = ""
+    device_jac: str = ""
+    cpp_name: str = ""
 
 
 @dataclass
 class ChainSpec:
-    """What csrc/ba_generic.hpp needs to know about a composition."""
-    names: tuple                       # block class names, in block order
-    n_transforms: int                  # M
-    src_kind: int                      # SRC_TEMPLATE / SRC_FREE
-    block_group: tuple                 # rigid-group id of transform block i (0..M-1) and, for a template source, of the source (entry M)
-    block_link: tuple                  # LINK_CAM / LINK_IMG of the same blocks
-    # parameter groups in string order: (kind, link, n_params) with kind in {"intr", "rigid", "point"}; rigid groups carry their slab id
+    """What the code generator and the host side need to know about a composition."""
+    blocks: list
+    # parameter groups in string order: dict(kind in {'intr', 'rigid', 'point', 'user'}, link, n_params, slab)
     groups: list = field(default_factory=list)
-    group_of_block: tuple = ()         # for EVERY block (projection and free_point included): index into `groups`
+
+    @property
+    def names(self) -> tuple:
+        return tuple(b.name for b in self.blocks)
+
+    @property
+    def group_of_block(self) -> tuple:
+        return tuple(b.group for b in self.blocks)
 
     @property
     def P(self) -> int:
-        return 9 + 6 * self.n_transforms + (6 if self.src_kind == SRC_TEMPLATE else 3)
+        return sum(b.n_params for b in self.blocks)
 
     @property
     def n_rigid_groups(self) -> int:
         return sum(1 for g in self.groups if g["kind"] == "rigid")
+
+    @property
+    def uses_template(self) -> bool:
+        return self.blocks[-1].kind == "template_points"
+
+    @property
+    def user_blocks(self) -> list:
+        return [b for b in self.blocks if b.kind == "user"]
 
     @classmethod
     def from_blocks(cls, function_blocks) -> "ChainSpec":
@@ -68,43 +103,68 @@ class ChainSpec:
 
         def bad(why):
             return NotImplementedError(
-                f"chain '{' + '.join(names)}' cannot be compiled: {why}.  Supported: projection + any number (<= {MAX_TRANSFORMS}) of "
-                "rigidTform3d / extrinsic3D + template_points | free_point")
+                f"chain '{' + '.join(names)}' cannot be compiled: {why}.  A chain is: [projection | a user block with num_out = 2] + any "
+                "rigidTform3d / extrinsic3D / user blocks + [template_points | free_point | a user block with num_inp = 0], each block's "
+                "num_inp equal to the next block's num_out (pycamset_amd.function_blocks.device_function_block declares a user block)")
 
-        if len(names) < 2 or names[0] != "projection":
-            raise bad("the first block must be `projection`")
-        if names[-1] not in ("template_points", "free_point"):
-            raise bad("the last block must produce the 3-D point (`template_points` or `free_point`)")
-        mids = names[1:-1]
-        if any(n not in ("rigidTform3d", "extrinsic3D") for n in mids):
-            raise bad("only rigid transforms may stand between the projection and the point source")
-        if len(mids) > MAX_TRANSFORMS:
-            raise bad("too many transforms")
-        groups, seen, block_group, block_link, group_of_block = [], {}, [], [], []
-        rigid_id = 0
-        for b in function_blocks:
-            key = id(b.params)                      # the reference tells groups apart by object identity (afb:160-163)
+        if len(names) < 2:
+            raise bad("a chain needs at least two blocks")
+        if len(names) > MAX_BLOCKS:
+            raise bad("too many blocks")
+        groups, seen, blocks = [], {}, []
+        rigid_id = user_id = 0
+        for pos, b in enumerate(function_blocks):
             name = type(b).__name__
+            is_user = bool(getattr(b, "device_fun", None)) and bool(getattr(b, "device_jac", None))
+            if not is_user and name not in BUILTIN_KINDS:
+                raise bad(f"block {name} is neither one of the five shipped blocks nor a device_function_block (it has no device_fun / device_jac)")
+            kind = "user" if is_user else BUILTIN_KINDS[name]
+            key = id(b.params)                      # the reference tells groups apart by object identity (afb:160-163)
+            gkind = {"projection": "intr", "rigid": "rigid", "template_points": "rigid", "free_point": "point", "user": "user"}[kind]
+            link, npar = int(b.params.link_type), int(b.params.n_params)
+            if link not in (LINK_CAM, LINK_IMG, LINK_KEY):
+                raise bad(f"block {name}: parameters must be per camera, per image or per key")
             if key not in seen:
-                kind = "intr" if name == "projection" else "point" if name == "free_point" else "rigid"
-                g = dict(kind=kind, link=int(b.params.link_type), n_params=int(b.params.n_params), slab=None)
-                if kind == "rigid":
-                    if g["link"] not in (LINK_CAM, LINK_IMG) or g["n_params"] != 6:
+                g = dict(kind=gkind, link=link, n_params=npar, slab=None)
+                if gkind == "rigid":
+                    if link not in (LINK_CAM, LINK_IMG) or npar != 6:
                         raise bad(f"block {name} does not carry a 6-parameter per-camera / per-image transform")
                     g["slab"] = rigid_id
                     rigid_id += 1
                 seen[key] = len(groups)
                 groups.append(g)
             g = groups[seen[key]]
-            group_of_block.append(seen[key])
-            if name in ("rigidTform3d", "extrinsic3D", "template_points"):
-                block_group.append(g["slab"])
-                block_link.append(g["link"])
+            if g["kind"] != gkind:
+                raise bad(f"block {name} shares its parameter object with a block of another kind")
+            info = BlockInfo(name=name, kind=kind, link=link, n_params=npar, nin=int(b.num_inp), nout=int(b.num_out), group=seen[key], slab=g["slab"])
+            if kind == "user":
+                if npar < 1 or info.nout < 1 or info.nin < 0:
+                    raise bad(f"user block {name}: n_params >= 1, num_out >= 1, num_inp >= 0 expected")
+                info.uidx, info.device_fun, info.device_jac = user_id, str(b.device_fun), str(b.device_jac)
+                info.cpp_name = f"{''.join(ch if ch.isalnum() else '_' for ch in name)}_{user_id}"
+                user_id += 1
+            elif kind == "template_points":
+                info.nin = 0
+            blocks.append(info)
         if rigid_id > MAX_GROUPS:
             raise bad("too many rigid parameter groups")
-        src_kind = SRC_TEMPLATE if names[-1] == "template_points" else SRC_FREE
-        return cls(names=names, n_transforms=len(mids), src_kind=src_kind, block_group=tuple(block_group), block_link=tuple(block_link), groups=groups,
-                   group_of_block=tuple(group_of_block))
+        if user_id > MAX_USER:
+            raise bad("too many user blocks")
+        # shape of the chain: out of block i + 1 is the input of block i (afb:375-383); the first block yields the pixel
+        if blocks[0].kind not in ("projection", "user") or blocks[0].nout != 2:
+            raise bad("the first block must produce the two pixel coordinates (`projection` or a user block with num_out = 2)")
+        if blocks[-1].nin != 0:
+            raise bad("the last block must be a source (num_inp = 0: `template_points`, `free_point` or a user block)")
+        for i, b in enumerate(blocks):
+            if b.kind == "projection" and i != 0:
+                raise bad("`projection` can only be the first block")
+            if b.kind in ("template_points", "free_point") and i != len(blocks) - 1:
+                raise bad(f"`{b.name}` can only be the last block")
+            if b.kind == "rigid" and (i == 0 or i == len(blocks) - 1):
+                raise bad(f"`{b.name}` needs a block on either side")
+            if i + 1 < len(blocks) and b.nin != blocks[i + 1].nout:
+                raise bad(f"block {i} ({b.name}) takes {b.nin} inputs but block {i + 1} ({blocks[i + 1].name}) produces {blocks[i + 1].nout}")
+        return cls(blocks=blocks, groups=groups)
 
     # -- the reference's parameter-string layout for given entity counts (afb:793-818) --------------------
     def layout(self, n_cams: int, n_imgs: int, n_keys: int) -> dict:
@@ -117,25 +177,81 @@ class ChainSpec:
         intr = [starts[i] for i, g in enumerate(self.groups) if g["kind"] == "intr"]
         point = [starts[i] for i, g in enumerate(self.groups) if g["kind"] == "point"]
         return dict(n_params=off, starts=starts, rigid_off=[r[0] for r in rigid], rigid_count=[r[1] for r in rigid],
-                    intr_off=intr[0], point_off=point[0] if point else 0)
+                    intr_off=intr[0] if intr else 0, point_off=point[0] if point else 0, user_off=[starts[b.group] for b in self.user_blocks])
 
 
 def emit_source(spec: ChainSpec) -> str:
-    """The translation unit of one chain: a ChainSpec struct + the entry points of csrc/ba_generic.hpp."""
-    link_name = {LINK_CAM: "pcs::LINK_CAM", LINK_IMG: "pcs::LINK_IMG"}
-    groups = list(spec.block_group) or [-1]
-    links = [link_name[l] for l in spec.block_link] or ["-1"]
-    src = "pcs::SRC_TEMPLATE" if spec.src_kind == SRC_TEMPLATE else "pcs::SRC_FREE"
-    return (
-        f"// generated by pycamset_amd/chain_compiler.py for: {' + '.join(spec.names)}\n"
-        '#include "ba_generic.hpp"\n'
-        "struct Chain {\n"
-        f"    static constexpr int M = {spec.n_transforms}, SRC = {src}, P = {spec.P};\n"
-        f"    __host__ __device__ static constexpr int group(int b) {{ constexpr int t[] = {{{', '.join(str(g) for g in groups)}}}; return t[b]; }}\n"
-        f"    __host__ __device__ static constexpr int link(int b) {{ constexpr int t[] = {{{', '.join(links)}}}; return t[b]; }}\n"
-        "};\n"
-        "PCS_GENCHAIN_ENTRY_POINTS(Chain)\n"
-    )
+    """The translation unit of one chain: the user blocks' device bodies, `struct Chain` with the straight-line evaluation of one
+    detection (forward right to left, chain rule left to right — what the reference writes into template_functions/*.py,
+    afb:350-387, afb:552-599, mm:218-243) and the entry points of csrc/ba_generic.hpp."""
+    B, P = spec.blocks, spec.P
+    nb = len(B)
+    out = [f"// generated by pycamset_amd/chain_compiler.py for: {' + '.join(spec.names)}", '#include "ba_generic.hpp"']
+    for b in spec.user_blocks:
+        out += ["namespace user {",
+                f"struct {b.cpp_name} {{   // user block {b.uidx}: {b.name}",
+                f"    static constexpr int NP = {b.n_params}, NIN = {b.nin}, NOUT = {b.nout};",
+                "    // out[NOUT]",
+                "    __device__ static __forceinline__ void fun(const double *params, const double *inp, double *out) {",
+                b.device_fun,
+                "    }",
+                "    // out[NOUT x (NP + NIN)], row-major, parameter columns first (compute_jac's layout, afb:738-748)",
+                "    __device__ static __forceinline__ void jac(const double *params, const double *inp, double *out) {",
+                b.device_jac,
+                "    }",
+                "};",
+                "}  // namespace user"]
+    fwd, rule = [], []
+    col = 0
+    cols = []
+    for b in B:
+        cols.append(col)
+        col += b.n_params
+    # forward: the source first (afb:375-383 walks the blocks in reverse)
+    for i in reversed(range(nb)):
+        b = B[i]
+        x_in = f"x{i + 1}"
+        if b.kind == "free_point":
+            fwd.append(f"double x{i}[3]; {{ const double *pp = c.point(); x{i}[0] = pp[0]; x{i}[1] = pp[1]; x{i}[2] = pp[2]; }}")
+        elif b.kind == "template_points":
+            fwd.append(f"double x{i}[3], E{i}[9]; {{ const double *tp = c.tpoint(); const double X[3] = {{tp[0], tp[1], tp[2]}}; "
+                       f"pcs::rigid_fwd<JAC>(c.slab({b.slab}, {_LINK_CPP[b.link]}), X, x{i}, E{i}); }}")
+        elif b.kind == "rigid":
+            fwd.append(f"double x{i}[3], E{i}[9]; pcs::rigid_fwd<JAC>(c.slab({b.slab}, {_LINK_CPP[b.link]}), {x_in}, x{i}, E{i});")
+        elif b.kind == "user":
+            inp = x_in if b.nin > 0 else "nullptr"
+            fwd.append(f"double x{i}[{b.nout}]; const double *p{i} = c.user({b.uidx}, {_LINK_CPP[b.link]}, {b.n_params}); user::{b.cpp_name}::fun(p{i}, {inp}, x{i});")
+        elif b.kind == "projection":
+            fwd.append(f"double Ap[18], Ax[2][3]; pcs::project_generic<JAC>(c.intr(), {x_in}[0], {x_in}[1], {x_in}[2], u, v, Ap, Ax);")
+    if B[0].kind == "user":
+        fwd.append("u = x0[0]; v = x0[1];")
+    # chain rule, first block to source: S{i} = d(u, v) / d(input of block i)
+    prev = None
+    for i, b in enumerate(B):
+        nin = max(b.nin, 1)
+        if b.kind == "projection":
+            rule.append(f"double S{i}[2][3]; pcs::chain_projection<P>(Ap, Ax, J, S{i});")
+        elif b.kind == "user":
+            if prev is None:
+                rule.append("const double Sid[2][2] = {{1.0, 0.0}, {0.0, 1.0}};")
+                prev = "Sid"
+            inp = f"x{i + 1}" if b.nin > 0 else "nullptr"
+            rule.append(f"double Jb{i}[{b.nout * (b.n_params + b.nin)}]; user::{b.cpp_name}::jac(p{i}, {inp}, Jb{i});")
+            rule.append(f"double S{i}[2][{nin}]; pcs::chain_user<P, {cols[i]}, {b.n_params}, {b.nin}, {b.nout}>({prev}, Jb{i}, J, S{i});")
+        elif b.kind == "rigid":
+            rule.append(f"double S{i}[2][3]; pcs::chain_rigid<P, {cols[i]}>({prev}, E{i}, c.slab({b.slab}, {_LINK_CPP[b.link]}), J, S{i});")
+        elif b.kind == "template_points":
+            rule.append(f"pcs::chain_template<P, {cols[i]}>({prev}, E{i}, J);")
+        elif b.kind == "free_point":
+            rule.append(f"pcs::chain_free<P, {cols[i]}>({prev}, J);")
+        prev = f"S{i}"
+    out += ["struct Chain {",
+            f"    static constexpr int P = {P};",
+            "    template <bool JAC, typename Ctx>",
+            "    __device__ static __forceinline__ void eval(const Ctx &c, double &u, double &v, double (&J)[2 * P]) {"]
+    out += ["        " + ln for ln in fwd]
+    out += ["        if constexpr (JAC) {"] + ["            " + ln for ln in rule] + ["        }", "    }", "};", "PCS_GENCHAIN_ENTRY_POINTS(Chain)", ""]
+    return "\n".join(out)
 
 
 def _header_digest() -> str:
@@ -147,7 +263,7 @@ def _header_digest() -> str:
 
 def code_object_path(spec: ChainSpec) -> Path:
     key = hashlib.sha256((emit_source(spec) + _header_digest()).encode()).hexdigest()[:20]
-    return CACHE / f"chain_{'_'.join(n[:4] for n in spec.names)}_{key}.hsaco"
+    return CACHE / f"chain_{'_'.join(''.join(ch for ch in n if ch.isalnum())[:4] for n in spec.names)}_{key}.hsaco"
 
 
 def compile_chain(spec: ChainSpec, verbose: bool = False) -> Path:
@@ -179,25 +295,35 @@ def block_param_inds(spec: ChainSpec, lay: dict, det_idx: np.ndarray) -> np.ndar
 
 
 def csr_structure_of(cols: np.ndarray, n_params: int, unfixed=None):
-    """(indices, indptr, dense positions of the kept entries) of the CSR Jacobian with the fixed columns removed
-    (afb:465-489); each detection's index row serves its u row and its v row (afb:475-479)."""
+    """(indices, indptr, keep, row_off) of the CSR Jacobian with the fixed columns removed (afb:465-489); each detection's index
+    row serves its u row and its v row (afb:475-479).  ``keep`` (N,) uint64: bit j = local column j of the detection is free;
+    ``row_off`` (N,) int64: offset of its u row in the data array — what the device needs to write the data array directly."""
     mask = np.ones(n_params, dtype=bool) if unfixed is None else np.asarray(unfixed, dtype=bool)
     if mask.shape[0] != n_params:
         raise ValueError("unfixed mask must have one entry per parameter")
+    if cols.shape[1] > 64:
+        raise NotImplementedError("rows longer than 64 parameters do not fit the 64-bit keep mask")
     conv = np.concatenate([[0], np.cumsum(mask)])
+    kept = mask[cols]                                   # (N, P)
     rows2 = np.repeat(cols, 2, axis=0)
-    keep2 = mask[rows2]
+    keep2 = np.repeat(kept, 2, axis=0)
     indices = conv[rows2[keep2]].astype(np.int64)
-    indptr = np.concatenate([[0], np.cumsum(keep2.sum(axis=1))]).astype(np.int64)
-    return indices, indptr, np.ascontiguousarray(np.flatnonzero(keep2.ravel()), dtype=np.int64)
+    cnt = kept.sum(axis=1).astype(np.int64)
+    indptr = np.concatenate([[0], np.cumsum(np.repeat(cnt, 2))]).astype(np.int64)
+    keep = (kept.astype(np.uint64) << np.arange(cols.shape[1], dtype=np.uint64)[None, :]).sum(axis=1).astype(np.uint64)
+    row_off = np.concatenate([[0], np.cumsum(2 * cnt)[:-1]]).astype(np.int64) if cols.shape[0] else np.zeros(0, dtype=np.int64)
+    return indices, indptr, np.ascontiguousarray(keep), np.ascontiguousarray(row_off)
 
 
 class ChainEngine:
     """One generated chain on one device — the ``Engine`` interface the operator API uses (NumPy in / NumPy out)."""
 
-    dtype = "f64"
-
-    def __init__(self, function_blocks, n_cams: int, n_imgs: int, n_keys: int, *, device: int = 0):
+    def __init__(self, function_blocks, n_cams: int, n_imgs: int, n_keys: int, *, device: int = 0, dtype: str = "f64"):
+        """``dtype`` like Engine's: 'f64', or FP64 arithmetic with float outputs — 'mixed' (double measurements) / 'f32' (float
+        measurements too)."""
+        if dtype not in ("f64", "f32", "mixed"):
+            raise ValueError("dtype must be 'f64', 'f32' or 'mixed'")
+        self.dtype = dtype
         self.spec = ChainSpec.from_blocks(function_blocks)
         self.chain = " + ".join(self.spec.names)
         self.n_cams, self.n_imgs, self.n_keys, self.device = int(n_cams), int(n_imgs), int(n_keys), int(device)
@@ -205,12 +331,14 @@ class ChainEngine:
         self.lay = self.spec.layout(self.n_cams, self.n_imgs, self.n_keys)
         self.n_params = self.lay["n_params"]
         path = compile_chain(self.spec)
-        ng = self.spec.n_rigid_groups
+        ng, nu = self.spec.n_rigid_groups, len(self.spec.user_blocks)
         off = (c_int64 * max(1, ng))(*self.lay["rigid_off"])
         cnt = (c_int32 * max(1, ng))(*self.lay["rigid_count"])
+        uoff = (c_int64 * max(1, nu))(*self.lay["user_off"])
         self._h = c_void_p()
-        check(lib().pcs_genchain_create(byref(self._h), str(path).encode(), self.spec.n_transforms, self.spec.src_kind, ng, off, cnt,
-                                        self.lay["intr_off"], self.lay["point_off"], self.n_params, self.n_cams, self.n_imgs, self.n_keys, self.device))
+        check(lib().pcs_genchain_create(byref(self._h), str(path).encode(), self.P, int(self.spec.uses_template), ng, off, cnt, nu, uoff,
+                                        self.lay["intr_off"], self.lay["point_off"], self.n_params, self.n_cams, self.n_imgs, self.n_keys,
+                                        {"f64": 0, "f32": 1, "mixed": 2}[self.dtype], self.device))
         self.n = 0
         self.nnz = None
         self.mask_key = None
@@ -252,18 +380,27 @@ class ChainEngine:
             raise ValueError(f"parameter string has {p.shape[0]} entries, the chain expects {self.n_params}")
         return p
 
+    @property
+    def out_dtype(self):
+        return np.float64 if self.dtype == "f64" else np.float32
+
     def eval(self, param_str, want_resid: bool = True, want_jac: bool = True, pinned_ring: int = 0):
         p = self._check_params(param_str)
-        r = np.empty((self.n, 2)) if want_resid else None
-        j = np.empty((2 * self.n, self.P)) if want_jac else None
-        dp = POINTER(c_double)
-        check(lib().pcs_genchain_eval(self._h, p.ctypes.data_as(dp), r.ctypes.data_as(dp) if want_resid else None, j.ctypes.data_as(dp) if want_jac else None))
+        r = np.empty((self.n, 2), dtype=self.out_dtype) if want_resid else None
+        j = np.empty((2 * self.n, self.P), dtype=self.out_dtype) if want_jac else None
+        check(lib().pcs_genchain_eval(self._h, p.ctypes.data_as(POINTER(c_double)), c_void_p(r.ctypes.data if want_resid else 0), c_void_p(j.ctypes.data if want_jac else 0)))
         return r, j
 
     def eval_device(self, d_param_str: int, d_resid: int | None, d_jac: int | None, stream: int | None = None):
         from .engine import _stream_arg
 
         check(lib().pcs_genchain_eval_device(self._h, c_void_p(d_param_str), c_void_p(d_resid or 0), c_void_p(d_jac or 0), _stream_arg(stream)))
+
+    def eval_compact_device(self, d_param_str: int, d_resid: int | None, d_data: int, stream: int | None = None):
+        """Only the unfixed columns (set_unfixed), in CSR data order, at the device-resident parameter string."""
+        from .engine import _stream_arg
+
+        check(lib().pcs_genchain_eval_compact_device(self._h, c_void_p(d_param_str), c_void_p(d_resid or 0), c_void_p(d_data), _stream_arg(stream)))
 
     def device_buffers(self):
         r, j = c_void_p(), c_void_p()
@@ -287,13 +424,14 @@ class ChainEngine:
         return block_param_inds(self.spec, self.lay, self._det)
 
     def csr_structure(self, unfixed=None):
-        indices, indptr, _ = csr_structure_of(self.block_param_inds(), self.n_params, unfixed)
+        indices, indptr, _, _ = csr_structure_of(self.block_param_inds(), self.n_params, unfixed)
         return indices, indptr
 
     def set_unfixed(self, unfixed) -> int:
-        _, _, src = csr_structure_of(self.block_param_inds(), self.n_params, unfixed)
-        check(lib().pcs_genchain_set_gather(self._h, src.ctypes.data_as(POINTER(c_int64)), src.shape[0]))
-        self.nnz = int(src.shape[0])
+        _, indptr, keep, row_off = csr_structure_of(self.block_param_inds(), self.n_params, unfixed)
+        nnz = int(indptr[-1])
+        check(lib().pcs_genchain_set_unfixed(self._h, keep.ctypes.data_as(POINTER(c_uint64)), row_off.ctypes.data_as(POINTER(c_int64)), nnz))
+        self.nnz = nnz
         self.mask_key = None if unfixed is None else hash(np.asarray(unfixed, dtype=bool).tobytes())
         return self.nnz
 
@@ -301,8 +439,7 @@ class ChainEngine:
         if self.nnz is None:
             raise RuntimeError("call set_unfixed() first")
         p = self._check_params(param_str)
-        r = np.empty((self.n, 2)) if want_resid else None
-        d = np.empty(self.nnz)
-        dp = POINTER(c_double)
-        check(lib().pcs_genchain_eval_compact(self._h, p.ctypes.data_as(dp), r.ctypes.data_as(dp) if want_resid else None, d.ctypes.data_as(dp)))
+        r = np.empty((self.n, 2), dtype=self.out_dtype) if want_resid else None
+        d = np.empty(self.nnz, dtype=self.out_dtype)
+        check(lib().pcs_genchain_eval_compact(self._h, p.ctypes.data_as(POINTER(c_double)), c_void_p(r.ctypes.data if want_resid else 0), c_void_p(d.ctypes.data)))
         return r, d

@@ -6,13 +6,20 @@
 // pycamset_amd/chain_compiler.py does the same for the GPU: it turns a block list
 //     projection + T_1 + ... + T_M + source        T_i in {rigidTform3d (per image), extrinsic3D (per camera)},
 //                                                  source in {template_points (per image), free_point (per key)}
-// into a `ChainSpec` — a struct of constexpr tables, emitted as a ~20-line .hip file that includes this header — and has
-// hipcc compile it for gfx950 (--genco).  Everything below is generic over that struct: block maths (the same Rodrigues
-// slabs, prepared per parameter group by generic_slab_prep_kernel), the chain rule the reference builds symbolically
-//     S_0 = A_x;  columns of T_i = [S_{i-1} E_i | S_{i-1}],  E_i[:, a] = dR_i/dr_a X_in,i;  S_i = S_{i-1} R_i
-// (mm:181-243: the product of identity-embedded block Jacobians), and the coalesced store phase of the hand-fused kernels
-// (store_jac_tile).  The three chains the reference's handlers build keep their hand-fused kernels (ba_kernels.hpp); a
-// generated kernel for one of them computes the same function (tests compare them).
+// into straight-line device code — `struct Chain { P; eval<JAC>(ctx, u, v, J) }`, a .hip file of a few dozen lines that includes
+// this header — and has hipcc compile it for gfx950 (--genco).  Round 4: the composition may also contain USER blocks
+// (pycamset_amd.function_blocks.device_function_block — the counterpart of the reference's extension point, the
+// abstract_function_block ABC, afb:689-775): a block declares its parameter group, num_inp / num_out and two device bodies
+// (forward, Jacobian in the reference's `compute_jac` layout num_out x [params | inp]); the bodies are pasted into the
+// generated translation unit and chained by the same rule.  This header holds what the generated code calls: the built-in
+// blocks' maths (the same Rodrigues slabs, prepared per parameter group by generic_slab_prep_body), the chain rule the
+// reference builds symbolically
+//     S = d(u, v) / d(output of the block);  columns of block b = S . d out_b / d params_b;  S <- S . d out_b / d inp_b
+// (mm:181-243: the product of identity-embedded block Jacobians; for a rigid block [S E | S] and S R), the kernel bodies
+// (tile per wave, scalar-load slabs when a tile shares camera and image) and the coalesced store phases of the hand-fused
+// kernels (store_jac_tile; compaction at the store like ba_compact_tile_kernel).  The three chains the reference's handlers
+// build keep their hand-fused kernels (ba_kernels.hpp); a generated kernel for one of them computes the same function (tests
+// compare them).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -36,9 +43,13 @@ struct GenericArgs {
     int32_t group_count[GENERIC_MAX_GROUPS];
     int32_t n_groups;
     int64_t intr_off, point_off;             // projection / free_point groups
+    int64_t user_off[GENERIC_MAX_GROUPS];    // first column of the parameter group of user block u (in block order)
     void *resid, *jac, *sink;
     int64_t n, n_tiles;
     int32_t tiles_per_wg;
+    // compaction at the store (pcs_genchain_eval_compact): per detection the kept local columns and the offset of its u row in `jac` (= data)
+    const uint64_t *keep;
+    const int64_t *row_off;
 };
 
 // one thread per slab element over all rigid groups (same element functions as slab_prep_kernel)
@@ -101,88 +112,114 @@ struct IntrRow {
     __device__ __forceinline__ double operator[](const int j) const { return principal_or_nan(p[j], j, p[0], p[2]); }
 };
 
-// One detection through a generated chain.  `slab(i)` returns the slab accessor of transform block i (0 .. M-1, in block
-// order) and of the template source (i = M); X = template point or free point.
-template <typename Spec, bool JAC, typename SlabOf, typename IntrPtr>
-__device__ __forceinline__ void eval_generic(SlabOf slab, IntrPtr intr, const double X0, const double X1, const double X2, double &u, double &v,
-                                             double (&J)[2 * Spec::P]) {
-    constexpr int M = Spec::M;
-    constexpr int P = Spec::P;
-    double Xc[3] = {X0, X1, X2};
-    double Qs[9];
-    if constexpr (Spec::SRC == SRC_TEMPLATE) {   // template_points: the pose of the target (fbi:188-211)
-        const auto ps = slab(M);
-        const double a0 = Xc[0], a1 = Xc[1], a2 = Xc[2];
-        if constexpr (JAC) {
-#pragma unroll
-            for (int a = 0; a < 3; ++a)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) Qs[c * 3 + a] = ps[POSE_DR + a * 9 + c * 3 + 0] * a0 + ps[POSE_DR + a * 9 + c * 3 + 1] * a1 + ps[POSE_DR + a * 9 + c * 3 + 2] * a2;
-        }
-#pragma unroll
-        for (int c = 0; c < 3; ++c) Xc[c] = ps[POSE_R + 3 * c + 0] * a0 + ps[POSE_R + 3 * c + 1] * a1 + ps[POSE_R + 3 * c + 2] * a2 + ps[POSE_T + c];
-    }
-    // transforms, rightmost first (the chain applies its blocks right to left)
-    double E[M > 0 ? M : 1][9];
-#pragma unroll
-    for (int i = M - 1; i >= 0; --i) {
-        const auto ps = slab(i);
-        const double a0 = Xc[0], a1 = Xc[1], a2 = Xc[2];
-        if constexpr (JAC) {
-#pragma unroll
-            for (int a = 0; a < 3; ++a)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) E[i][c * 3 + a] = ps[POSE_DR + a * 9 + c * 3 + 0] * a0 + ps[POSE_DR + a * 9 + c * 3 + 1] * a1 + ps[POSE_DR + a * 9 + c * 3 + 2] * a2;
-        }
-#pragma unroll
-        for (int c = 0; c < 3; ++c) Xc[c] = ps[POSE_R + 3 * c + 0] * a0 + ps[POSE_R + 3 * c + 1] * a1 + ps[POSE_R + 3 * c + 2] * a2 + ps[POSE_T + c];
-    }
-    double Ap[18], Ax[2][3];
-    project_generic<JAC>(intr, Xc[0], Xc[1], Xc[2], u, v, Ap, Ax);
+// ---- what generated code calls --------------------------------------------------------------------------------------------------------
+// rigid block (rigidTform3d / extrinsic3D / template_points, fbi:143-211): xout = R xin + t;  E[:, a] = dR/dr_a xin (3 x 3, row-major)
+template <bool JAC, typename Slab>
+__device__ __forceinline__ void rigid_fwd(const Slab ps, const double (&xin)[3], double (&xout)[3], double (&E)[9]) {
     if constexpr (JAC) {
 #pragma unroll
-        for (int r = 0; r < 2; ++r)
+        for (int a = 0; a < 3; ++a)
 #pragma unroll
-            for (int j = 0; j < 9; ++j) J[r * P + j] = Ap[r * 9 + j];
-        double S[2][3] = {{Ax[0][0], Ax[0][1], Ax[0][2]}, {Ax[1][0], Ax[1][1], Ax[1][2]}};
+            for (int c = 0; c < 3; ++c) E[c * 3 + a] = ps[POSE_DR + a * 9 + c * 3 + 0] * xin[0] + ps[POSE_DR + a * 9 + c * 3 + 1] * xin[1] + ps[POSE_DR + a * 9 + c * 3 + 2] * xin[2];
+    }
 #pragma unroll
-        for (int i = 0; i < M; ++i) {
-            const auto ps = slab(i);
+    for (int c = 0; c < 3; ++c) xout[c] = ps[POSE_R + 3 * c + 0] * xin[0] + ps[POSE_R + 3 * c + 1] * xin[1] + ps[POSE_R + 3 * c + 2] * xin[2] + ps[POSE_T + c];
+}
+// projection as the FIRST block: its parameter columns are A_p, S = A_x
+template <int P>
+__device__ __forceinline__ void chain_projection(const double (&Ap)[18], const double (&Ax)[2][3], double (&J)[2 * P], double (&S)[2][3]) {
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
+    for (int r = 0; r < 2; ++r) {
 #pragma unroll
-                for (int a = 0; a < 3; ++a) J[r * P + 9 + 6 * i + a] = S[r][0] * E[i][0 * 3 + a] + S[r][1] * E[i][1 * 3 + a] + S[r][2] * E[i][2 * 3 + a];
+        for (int j = 0; j < 9; ++j) J[r * P + j] = Ap[r * 9 + j];
 #pragma unroll
-                for (int c = 0; c < 3; ++c) J[r * P + 9 + 6 * i + 3 + c] = S[r][c];
-            }
-            double Sn[2][3];
+        for (int c = 0; c < 3; ++c) S[r][c] = Ax[r][c];
+    }
+}
+// rigid block in the middle: columns [S E | S] at COL0, S <- S R
+template <int P, int COL0, typename Slab>
+__device__ __forceinline__ void chain_rigid(const double (&S)[2][3], const double (&E)[9], const Slab ps, double (&J)[2 * P], double (&Sn)[2][3]) {
 #pragma unroll
-            for (int r = 0; r < 2; ++r)
+    for (int r = 0; r < 2; ++r) {
 #pragma unroll
-                for (int c = 0; c < 3; ++c) Sn[r][c] = S[r][0] * ps[POSE_R + 0 * 3 + c] + S[r][1] * ps[POSE_R + 1 * 3 + c] + S[r][2] * ps[POSE_R + 2 * 3 + c];
+        for (int a = 0; a < 3; ++a) J[r * P + COL0 + a] = S[r][0] * E[0 * 3 + a] + S[r][1] * E[1 * 3 + a] + S[r][2] * E[2 * 3 + a];
 #pragma unroll
-            for (int r = 0; r < 2; ++r)
+        for (int c = 0; c < 3; ++c) J[r * P + COL0 + 3 + c] = S[r][c];
 #pragma unroll
-                for (int c = 0; c < 3; ++c) S[r][c] = Sn[r][c];
+        for (int c = 0; c < 3; ++c) Sn[r][c] = S[r][0] * ps[POSE_R + 0 * 3 + c] + S[r][1] * ps[POSE_R + 1 * 3 + c] + S[r][2] * ps[POSE_R + 2 * 3 + c];
+    }
+}
+// template_points as the source: columns [S Q | S]
+template <int P, int COL0>
+__device__ __forceinline__ void chain_template(const double (&S)[2][3], const double (&Q)[9], double (&J)[2 * P]) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) J[r * P + COL0 + a] = S[r][0] * Q[0 * 3 + a] + S[r][1] * Q[1 * 3 + a] + S[r][2] * Q[2 * 3 + a];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) J[r * P + COL0 + 3 + c] = S[r][c];
+    }
+}
+// free_point as the source: d X / d point = I (fbi:234-240)
+template <int P, int COL0>
+__device__ __forceinline__ void chain_free(const double (&S)[2][3], double (&J)[2 * P]) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) J[r * P + COL0 + c] = S[r][c];
+}
+// user block: Jb = its compute_jac output, NOUT x (NP + NIN) row-major, parameter columns first (afb:738-748's layout).
+// Columns S Jb[:, :NP] at COL0; Sn = S Jb[:, NP:] (nothing for a source block, NIN = 0).
+template <int P, int COL0, int NP, int NIN, int NOUT>
+__device__ __forceinline__ void chain_user(const double (&S)[2][NOUT], const double (&Jb)[NOUT * (NP + NIN)], double (&J)[2 * P], double (&Sn)[2][NIN > 0 ? NIN : 1]) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            double t = 0.0;
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) t += S[r][o] * Jb[o * (NP + NIN) + p];
+            J[r * P + COL0 + p] = t;
         }
-        constexpr int C0 = 9 + 6 * M;
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            if constexpr (Spec::SRC == SRC_TEMPLATE) {
+        for (int i = 0; i < NIN; ++i) {
+            double t = 0.0;
 #pragma unroll
-                for (int a = 0; a < 3; ++a) J[r * P + C0 + a] = S[r][0] * Qs[0 * 3 + a] + S[r][1] * Qs[1 * 3 + a] + S[r][2] * Qs[2 * 3 + a];
-#pragma unroll
-                for (int c = 0; c < 3; ++c) J[r * P + C0 + 3 + c] = S[r][c];
-            } else {
-#pragma unroll
-                for (int c = 0; c < 3; ++c) J[r * P + C0 + c] = S[r][c];   // free_point: d X / d point = I (fbi:234-240)
-            }
+            for (int o = 0; o < NOUT; ++o) t += S[r][o] * Jb[o * (NP + NIN) + NP + i];
+            Sn[r][i] = t;
         }
     }
 }
 
+// What a generated `Chain::eval` sees of one detection: slabs of the rigid groups (scalar loads when the tile shares camera and image),
+// intrinsics, the source point, a user block's parameters of this detection's camera / image / key.
+template <bool UNIFORM>
+struct ChainCtx {
+    const GenericArgs &a;
+    int c, im, k;   // UNIFORM: c and im are wave-uniform
+    __device__ __forceinline__ int index_of(const int link) const { return link == LINK_CAM ? c : link == LINK_IMG ? im : k; }
+    __device__ __forceinline__ auto slab(const int g, const int link) const {
+        const double *p = a.slab[g] + (int64_t)index_of(link) * POSE_STRIDE;
+        if constexpr (UNIFORM) return ScalarSlab(p);
+        else return p;
+    }
+    __device__ __forceinline__ IntrRow intr() const { return IntrRow{a.prm + a.intr_off + 9 * (int64_t)c}; }
+    __device__ __forceinline__ const double *point() const { return a.prm + a.point_off + 3 * (int64_t)k; }
+    __device__ __forceinline__ const double *tpoint() const { return a.tmpl + 3 * (int64_t)k; }
+    __device__ __forceinline__ const double *user(const int u, const int link, const int np) const { return a.prm + a.user_off[u] + (int64_t)np * index_of(link); }
+};
+
+// one detection of a tile through the generated chain
+template <typename Spec, bool JAC>
+__device__ __forceinline__ void eval_tile_lane(const GenericArgs &a, const int c, const int im, const int k, double &u, double &v, double (&J)[2 * Spec::P]) {
+    const int c0 = __builtin_amdgcn_readfirstlane(c), im0 = __builtin_amdgcn_readfirstlane(im);
+    if (__all(c == c0 && im == im0)) Spec::template eval<JAC>(ChainCtx<true>{a, c0, im0, k}, u, v, J);   // every slab through scalar loads
+    else Spec::template eval<JAC>(ChainCtx<false>{a, c, im, k}, u, v, J);
+}
+
 // Fused residual + Jacobian for a generated chain: the hand-fused kernel's tile-per-wave structure, scalar-load slabs when the
-// tile shares camera and image, transposed non-temporal stores.  MODE as in ba_eval_kernel (1 residual, 2 Jacobian, 3 both).
+// tile shares camera and image, transposed non-temporal stores.  MODE as in ba_eval_kernel (1 residual, 2 Jacobian, 3 both);
+// TO = the type the outputs are WRITTEN in (arithmetic is FP64 for every dtype, like the hand-fused kernels).
 template <typename Spec, int MODE, typename TO>
 __device__ __forceinline__ void generic_eval_body(const GenericArgs &a) {
     constexpr int P = Spec::P;
@@ -206,19 +243,9 @@ __device__ __forceinline__ void generic_eval_body(const GenericArgs &a) {
         int c, im, k;
         load_indices(a.tab, ic, c, im, k);
         const double2v m = load_uv(a.tab, ic);
-        const double *pt = Spec::SRC == SRC_TEMPLATE ? a.tmpl + 3 * (int64_t)k : a.prm + a.point_off + 3 * (int64_t)k;
-        const double X0 = pt[0], X1 = pt[1], X2 = pt[2];
-        auto link_index = [&](const int link, const int cc, const int ii) { return link == LINK_CAM ? cc : ii; };
         double u, v;
         double J[P2];
-        const int c0 = __builtin_amdgcn_readfirstlane(c), im0 = __builtin_amdgcn_readfirstlane(im);
-        if (__all(c == c0 && im == im0)) {   // one camera and one image in the tile: every slab through scalar loads
-            auto slab = [&](const int blk) { return ScalarSlab(a.slab[Spec::group(blk)] + (int64_t)link_index(Spec::link(blk), c0, im0) * POSE_STRIDE); };
-            eval_generic<Spec, JAC>(slab, IntrRow{a.prm + a.intr_off + 9 * (int64_t)c0}, X0, X1, X2, u, v, J);
-        } else {
-            auto slab = [&](const int blk) { return static_cast<const double *>(a.slab[Spec::group(blk)]) + (int64_t)link_index(Spec::link(blk), c, im) * POSE_STRIDE; };
-            eval_generic<Spec, JAC>(slab, IntrRow{a.prm + a.intr_off + 9 * (int64_t)c}, X0, X1, X2, u, v, J);
-        }
+        eval_tile_lane<Spec, JAC>(a, c, im, k, u, v, J);
         if constexpr (RES) {
             O2 r;
             r.x = (TO)(u - m.x);
@@ -229,16 +256,92 @@ __device__ __forceinline__ void generic_eval_body(const GenericArgs &a) {
     }
 }
 
-// data[i] = dense[src[i]]: the fixed-parameter mask of a generated chain as a static gather (afb:644-651 on the device)
-struct GatherArgs {
-    const double *dense;
-    const int64_t *src;
-    double *data;
-    int64_t nnz;
-};
-__device__ __forceinline__ void generic_gather_body(const GatherArgs &g) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < g.nnz) g.data[i] = g.dense[g.src[i]];
+// The same evaluation with the fixed-parameter mask applied AT THE STORE (afb:627-651 on the device; round 3 wrote the dense J
+// and gathered it): every lane packs the kept entries of its two rows into the wave-private LDS image at its offset inside the
+// tile's contiguous range of the CSR data array, then the wave streams the range out — ba_compact_tile_kernel's store phase with
+// a 64-bit keep mask (generated chains reach P = 51).  `a.jac` is the data array here.
+template <typename Spec, int MODE, typename TO>
+__device__ __forceinline__ void generic_compact_body(const GenericArgs &a) {
+    constexpr int P = Spec::P;
+    constexpr int P2 = 2 * P;
+    constexpr bool RES = (MODE & MODE_RESID) != 0;
+    constexpr int VS = 16 / sizeof(TO);
+    constexpr int LINE = 128 / sizeof(TO);           // scalars per 128-byte line
+    constexpr int WAVE_LDS = HALF * P2 + LINE + 64;  // packed range + alignment shift + one dummy slot per lane
+    using O2 = typename Vec2<TO>::type;
+    using V16 = __attribute__((ext_vector_type(VS))) TO;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6, lane = threadIdx.x & 63;
+    TO *tr = reinterpret_cast<TO *>(smem_raw) + wave * ((WAVE_LDS + VS - 1) / VS * VS);
+    TO *dummy = tr + HALF * P2 + LINE + lane;
+    TO *resid = static_cast<TO *>(a.resid);
+    TO *data = static_cast<TO *>(a.jac);
+    const int64_t tile0 = (int64_t)blockIdx.x * a.tiles_per_wg;
+    const int64_t tile1 = min(tile0 + (int64_t)a.tiles_per_wg, a.n_tiles);
+    for (int64_t tile = tile0 + wave; tile < tile1; tile += n_waves) {
+        const int64_t i = tile * TILE + lane;
+        const bool valid = i < a.n;
+        const int64_t ic = valid ? i : a.n - 1;
+        int c, im, k;
+        load_indices(a.tab, ic, c, im, k);
+        const double2v m = load_uv(a.tab, ic);
+        const uint64_t keep_raw = a.keep[ic];      // requested with the indices: after the evaluation they would cost a memory latency per tile
+        const int64_t off_raw = a.row_off[ic];
+        asm volatile("" ::: "memory");
+        double u, v;
+        double J[P2];
+        eval_tile_lane<Spec, true>(a, c, im, k, u, v, J);
+        if constexpr (RES) {
+            O2 r;
+            r.x = (TO)(u - m.x);
+            r.y = (TO)(v - m.y);
+            __builtin_nontemporal_store(r, valid ? reinterpret_cast<O2 *>(resid) + i : static_cast<O2 *>(a.sink));
+        }
+        const uint64_t keep = valid ? keep_raw : 0ull;
+        const int cnt = __popcll(keep);
+        const int64_t off = off_raw + (valid ? 0 : 2 * (int64_t)__popcll(keep_raw));  // tail lanes: end of data
+        const int64_t off0 = __shfl(off, 0);                  // first entry of the tile
+        const int lo = (int)(off - off0);                     // this detection's offset inside the tile range
+        const int mid = __shfl(lo, HALF);                     // pass boundary
+        const int end = __shfl(lo + 2 * cnt, TILE - 1);       // tile range length
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int s0 = h ? mid : 0;
+            const int len = (h ? end : mid) - s0;
+            TO *g0 = data + off0 + s0;                                             // first global element of the pass
+            const int mis = (int)((reinterpret_cast<uintptr_t>(g0) / sizeof(TO)) & (LINE - 1));
+            const bool mine = (lane >> 5) == h;
+            TO *ru = tr + mis + (lo - s0);
+            TO *rv = ru + cnt;
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+                const bool on = mine && ((keep >> j) & 1ull);
+                const int pos = __popcll(keep & ((1ull << j) - 1ull));
+                *(on ? ru + pos : dummy) = (TO)J[j];
+                *(on ? rv + pos : dummy) = (TO)J[P + j];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // stream [mis, mis + len) of the LDS image to g0 - mis + [mis, mis + len): whole 16-byte units where the unit lies
+            // inside the range, scalars at the ragged ends (the image is shifted by `mis`, so units are line-aligned in memory)
+            TO *gbase = g0 - mis;
+            const int first = mis / VS, last = (mis + len + VS - 1) / VS;   // units [first, last)
+            for (int q = first + lane; q < last; q += 64) {
+                const int e0 = q * VS;
+                if (e0 >= mis && e0 + VS <= mis + len) {
+                    __builtin_nontemporal_store(*reinterpret_cast<const V16 *>(tr + e0), reinterpret_cast<V16 *>(gbase + e0));
+                } else {
+#pragma unroll
+                    for (int e = 0; e < VS; ++e)
+                        if (e0 + e >= mis && e0 + e < mis + len) gbase[e0 + e] = tr[e0 + e];
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
 }
 
 // What chain_compiler.py appends after the ChainSpec struct it emits: the entry points of the code object.
@@ -247,6 +350,12 @@ __device__ __forceinline__ void generic_gather_body(const GatherArgs &g) {
     extern "C" __global__ __launch_bounds__(256) void pcs_genchain_eval_1(const pcs::GenericArgs a) { pcs::generic_eval_body<Spec, 1, double>(a); } \
     extern "C" __global__ __launch_bounds__(256) void pcs_genchain_eval_2(const pcs::GenericArgs a) { pcs::generic_eval_body<Spec, 2, double>(a); } \
     extern "C" __global__ __launch_bounds__(256) void pcs_genchain_eval_3(const pcs::GenericArgs a) { pcs::generic_eval_body<Spec, 3, double>(a); } \
-    extern "C" __global__ void pcs_genchain_gather(const pcs::GatherArgs g) { pcs::generic_gather_body(g); }
+    extern "C" __global__ __launch_bounds__(256) void pcs_genchain_eval_1_f32(const pcs::GenericArgs a) { pcs::generic_eval_body<Spec, 1, float>(a); } \
+    extern "C" __global__ __launch_bounds__(256) void pcs_genchain_eval_2_f32(const pcs::GenericArgs a) { pcs::generic_eval_body<Spec, 2, float>(a); } \
+    extern "C" __global__ __launch_bounds__(256) void pcs_genchain_eval_3_f32(const pcs::GenericArgs a) { pcs::generic_eval_body<Spec, 3, float>(a); } \
+    extern "C" __global__ __launch_bounds__(256) void pcs_genchain_compact_2(const pcs::GenericArgs a) { pcs::generic_compact_body<Spec, 2, double>(a); } \
+    extern "C" __global__ __launch_bounds__(256) void pcs_genchain_compact_3(const pcs::GenericArgs a) { pcs::generic_compact_body<Spec, 3, double>(a); } \
+    extern "C" __global__ __launch_bounds__(256) void pcs_genchain_compact_2_f32(const pcs::GenericArgs a) { pcs::generic_compact_body<Spec, 2, float>(a); } \
+    extern "C" __global__ __launch_bounds__(256) void pcs_genchain_compact_3_f32(const pcs::GenericArgs a) { pcs::generic_compact_body<Spec, 3, float>(a); }
 
 }  // namespace pcs

@@ -15,10 +15,11 @@ Same names, argument meaning and return layouts as
 The blocks here are *declarations*: the arithmetic of every block (and the chain rule the
 reference code-generates with matmul_map.py) lives in the fused HIP kernels behind the C ABI.  The three
 chains the reference's handlers build run on hand-fused kernels (csrc/ba_kernels.hpp); every other valid
-composition ``projection + {rigidTform3d | extrinsic3D}* + (template_points | free_point)`` is compiled on first
-use into a fused kernel of its own (pycamset_amd/chain_compiler.py -> csrc/ba_generic.hpp, hipcc --genco) — the
-counterpart of the reference's code generator (afb:424-463, afb:492-652, mm:147-263).  Anything outside that family
-raises, loudly: there is no interpreter fallback.
+composition of the shipped blocks AND of user blocks (``device_function_block`` below: the reference's extension point,
+afb:689-775, with the two bodies given as device code) is compiled on first use into a fused kernel of its own
+(pycamset_amd/chain_compiler.py -> csrc/ba_generic.hpp, hipcc --genco) — the counterpart of the reference's code generator
+(afb:424-463, afb:492-652, mm:147-263).  A block that is neither shipped nor a device_function_block raises, loudly: there
+is no interpreter fallback.
 """
 from __future__ import annotations
 
@@ -64,6 +65,35 @@ class abstract_function_block:  # afb:689-748
         if isinstance(other, optimisation_function):
             return optimisation_function(other.function_blocks + [self])
         raise ValueError(f"could not combine function block with {other}")
+
+
+class device_function_block(abstract_function_block):
+    """A USER block for generated chains — the GPU counterpart of subclassing the reference's ``abstract_function_block``
+    (afb:689-775: ``num_inp``, ``num_out``, ``params``, ``compute_fun``, ``compute_jac``).  Declare the same three attributes
+    and give the two bodies as HIP device code:
+
+        class cam_scale(device_function_block):          # one isotropic scale per camera, between projection and extrinsic
+            num_inp, num_out = 3, 3
+            params = param_type(key_type.PER_CAM, 1)
+            device_fun = "for (int i = 0; i < 3; ++i) out[i] = params[0] * inp[i];"
+            device_jac = '''for (int o = 0; o < 3; ++o) {
+                                out[o * 4 + 0] = inp[o];                                   // d out / d params
+                                for (int i = 0; i < 3; ++i) out[o * 4 + 1 + i] = (o == i) ? params[0] : 0.0;   // d out / d inp
+                            }'''
+
+        op_fun = projection() + cam_scale() + extrinsic3D() + template_points()
+
+    ``device_fun`` is the body of ``void fun(const double *params, const double *inp, double *out)`` (``out[num_out]``);
+    ``device_jac`` the body of ``void jac(const double *params, const double *inp, double *out)`` with ``out`` laid out like
+    ``compute_jac``'s output: ``num_out`` rows of ``n_params + num_inp`` entries, parameter columns first (afb:738-748).
+    ``params`` points at this block's parameters of the detection's camera / image / key (``params.link_type``) inside the
+    parameter string; ``inp`` is the next block's output (NULL for a source, ``num_inp = 0``).  Everything is FP64; the bodies are
+    pasted into the chain's translation unit (pycamset_amd/chain_compiler.py) next to the built-in blocks and chained by the
+    same rule S <- S . d out / d inp.  A first block must have ``num_out = 2`` (the pixel), neighbours must agree
+    (``num_inp`` of a block = ``num_out`` of the next), the last block is a source.  As in the reference, blocks that share
+    one ``param_type`` OBJECT share one parameter group (afb:160-163)."""
+    device_fun: str = ""
+    device_jac: str = ""
 
 
 class projection(abstract_function_block):  # fbi:21-140
@@ -170,11 +200,9 @@ class optimisation_function:  # afb:111-685
                 if self.counts is not None:
                     C, I, K = (max(a, b) for a, b in zip(self.counts, (C, I, K)))
             if self.chain == "generated":
-                if self.dtype != "f64":
-                    raise NotImplementedError("generated chains write FP64 outputs; the float engines exist for the three hand-fused chains")
                 from .chain_compiler import ChainEngine
 
-                eng = ChainEngine(self.function_blocks, C, I, K, device=self.device)
+                eng = ChainEngine(self.function_blocks, C, I, K, device=self.device, dtype=self.dtype)
             else:
                 eng = Engine(self.chain, C, I, K, dtype=self.dtype, device=self.device)
             eng.set_detections_table(det)

@@ -510,16 +510,77 @@ def round3_vectors(mods):
         print("generic", tag, "P", res["block_param_inds"].shape[1], "nnz", res["data_all"].shape)
 
 
+USER_CHAINS = {
+    # chains with USER blocks (tests/golden/_user_blocks.py, written on the reference's ABC): the reference's extension point
+    "user_cam_scale": ("projection", "cam_scale", "extrinsic3D", "template_points"),
+    "user_division": ("division_projection", "extrinsic3D", "rigidTform3d", "free_point"),
+}
+
+
+def user_block_level(mods, ub, rig, names, seed=6):
+    """The reference's code generator on a chain that contains user-written blocks: residual, Jacobian (all columns and masked),
+    structure, block_param_inds; the slab each block consumes is stored in block order."""
+    rng = np.random.default_rng(seed)
+    blocks = [getattr(ub, n)() if hasattr(ub, n) else getattr(mods.fb, n)() for n in names]
+    op = blocks[0]
+    for b in blocks[1:]:
+        op = op + b
+    slabs = []
+    for n in names:
+        if n == "projection":
+            slabs.append(rig.intr)
+        elif n == "division_projection":
+            slabs.append(np.concatenate([rig.intr[:, :4], rng.normal(0.0, 0.05, (rig.n_cams, 1))], axis=1))
+        elif n == "cam_scale":
+            slabs.append(rng.uniform(0.8, 1.2, (rig.n_cams, 1)))
+        elif n == "extrinsic3D":
+            slabs.append(rig.extr)
+        elif n in ("rigidTform3d", "template_points"):
+            slabs.append(rig.poses)
+        elif n == "free_point":
+            slabs.append(rig.points)
+    template = rig.points if names[-1] == "template_points" else None
+    param_str = op.build_param_list(*slabs)
+    unfixed = rng.random(param_str.shape[0]) > 0.3
+    call = (lambda f: f(param_str, template)) if template is not None else (lambda f: f(param_str))
+    out = dict(detections=rig.detections, param_str=param_str, points=rig.points, blocks=np.array(names), unfixed=unfixed)
+    for i, sl in enumerate(slabs):
+        out[f"slab_{i}"] = np.array(sl)
+    out["resid"] = np.array(call(op.make_full_loss_fn(rig.detections, 2)))
+    d, c, rp = call(op.make_jacobean(rig.detections, 2))
+    out["data_all"], out["indices_all"], out["indptr_all"] = np.array(d), np.array(c), np.array(rp)
+    d, c, rp = call(op.make_jacobean(rig.detections, 2, unfixed_params=unfixed))
+    out["data_masked"], out["indices_masked"], out["indptr_masked"] = np.array(d), np.array(c), np.array(rp)
+    out["block_param_inds"] = np.array(op.get_block_param_inds(rig.detections, 1, unthreaded=True)).astype(np.int64)
+    return out
+
+
+def round4_vectors(mods):
+    """User-written blocks through the reference's generator (round-3 review: the extension point)."""
+    import importlib
+
+    ub = importlib.import_module("_user_blocks")     # tests/golden is on sys.path; the module imports the reference's ABC
+    small = synthetic.tiny_rig(seed=34, n_cams=3, n_imgs=5, n_keys=8, visibility=0.85)
+    for tag, names in USER_CHAINS.items():
+        res = user_block_level(mods, ub, small, names)
+        np.savez_compressed(HERE / f"{tag}.npz", **res)
+        print(tag, "P", res["block_param_inds"].shape[1], "nnz", res["data_all"].shape, "max |resid|", float(np.max(np.abs(res["resid"]))))
+
+
 def main():
     import argparse
 
     import _refload
 
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", choices=["round1", "round2", "round3"], default=None, help="regenerate one group of fixtures only")
+    ap.add_argument("--only", choices=["round1", "round2", "round3", "round4"], default=None, help="regenerate one group of fixtures only")
     args = ap.parse_args()
     with _refload.reference_modules() as mods:
         ch, fb, th, sbh, fph, TargetDetection = mods.ch, mods.fb, mods.th, mods.sbh, mods.fph, mods.TargetDetection
+        if args.only in (None, "round4"):
+            round4_vectors(mods)
+        if args.only == "round4":
+            return
         if args.only in (None, "round3"):
             round3_vectors(mods)
         if args.only == "round3":

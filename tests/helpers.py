@@ -67,3 +67,35 @@ def jac_error_report(a, ref, P):
 def describe(rep):
     return (f"floored {rep['floored']:.2e} (column {rep['col_floored']}), plain {rep['plain']:.2e} (column {rep['col_plain']}), "
             f"{100 * rep['under_floor']:.1f} % of the non-zero entries under the row floor")
+
+
+def user_blocks(fb):
+    """The two user blocks of tests/golden/_user_blocks.py (written there on the reference's ABC) as device code."""
+
+    class cam_scale(fb.device_function_block):
+        num_inp, num_out = 3, 3
+        params = fb.param_type(fb.key_type.PER_CAM, 1)
+        device_fun = "for (int i = 0; i < 3; ++i) out[i] = params[0] * inp[i];"
+        device_jac = """for (int o = 0; o < 3; ++o) {
+            out[o * 4 + 0] = inp[o];
+            for (int i = 0; i < 3; ++i) out[o * 4 + 1 + i] = (o == i) ? params[0] : 0.0;
+        }"""
+
+    class division_projection(fb.device_function_block):
+        num_inp, num_out = 3, 2
+        params = fb.param_type(fb.key_type.PER_CAM, 5)
+        device_fun = """const double iz = 1.0 / inp[2], x = inp[0] * iz, y = inp[1] * iz;
+        const double d = 1.0 / (1.0 + params[4] * (x * x + y * y));
+        out[0] = params[0] * x * d + params[1];
+        out[1] = params[2] * y * d + params[3];"""
+        device_jac = """const double iz = 1.0 / inp[2], x = inp[0] * iz, y = inp[1] * iz, r2 = x * x + y * y;
+        const double d = 1.0 / (1.0 + params[4] * r2), d2 = d * d;
+        for (int q = 0; q < 16; ++q) out[q] = 0.0;
+        out[0] = x * d; out[1] = 1.0; out[4] = -params[0] * x * r2 * d2;
+        const double ux = params[0] * (d - 2.0 * params[4] * x * x * d2), uy = -2.0 * params[0] * params[4] * x * y * d2;
+        out[5] = ux * iz; out[6] = uy * iz; out[7] = -(x * ux + y * uy) * iz;
+        out[8 + 2] = y * d; out[8 + 3] = 1.0; out[8 + 4] = -params[2] * y * r2 * d2;
+        const double vx = -2.0 * params[2] * params[4] * x * y * d2, vy = params[2] * (d - 2.0 * params[4] * y * y * d2);
+        out[8 + 5] = vx * iz; out[8 + 6] = vy * iz; out[8 + 7] = -(x * vx + y * vy) * iz;"""
+
+    return {"cam_scale": cam_scale, "division_projection": division_projection}

@@ -9,6 +9,7 @@ import pytest
 from oracle import ba_oracle as orc
 from pycamset_amd import handlers, synthetic
 from pycamset_amd.detections import TargetDetection
+from tests import helpers as H
 from tests.test_oracle_golden import assert_close
 
 
@@ -258,18 +259,69 @@ def test_chain_compiler_layout_and_structure_match_the_reference_generator(golde
     assert lay["n_params"] == g["param_str"].shape[0]
     cols = cc.block_param_inds(spec, lay, det[:, :3].astype(np.int64))
     assert cols.shape[1] == spec.P and np.array_equal(cols, g["block_param_inds"])
-    idx, ptr, _ = cc.csr_structure_of(cols, lay["n_params"], None)
+    idx, ptr, keep, off = cc.csr_structure_of(cols, lay["n_params"], None)
     assert np.array_equal(idx, g["indices_all"]) and np.array_equal(ptr, g["indptr_all"])
-    idx, ptr, src = cc.csr_structure_of(cols, lay["n_params"], g["unfixed"])
+    assert np.all(keep == (1 << spec.P) - 1) and np.array_equal(off, 2 * spec.P * np.arange(det.shape[0]))
+    idx, ptr, keep, off = cc.csr_structure_of(cols, lay["n_params"], g["unfixed"])
     assert np.array_equal(idx, g["indices_masked"]) and np.array_equal(ptr, g["indptr_masked"])
-    assert np.array_equal(g["data_all"][src], g["data_masked"])      # the gather list IS data[:n][good_mask] (afb:644-651)
+    # the per-detection tables the device packs with (csrc/ba_generic.hpp generic_compact_body) describe data[:n][good_mask] (afb:644-651)
+    _check_compaction_tables(g["data_all"], g["data_masked"], keep, off, spec.P)
     src_text = cc.emit_source(spec)
-    assert f"M = {len(names) - 2}" in src_text and "PCS_GENCHAIN_ENTRY_POINTS" in src_text
+    assert f"static constexpr int P = {spec.P};" in src_text and "PCS_GENCHAIN_ENTRY_POINTS" in src_text
     obj = cc.compile_chain(spec)
     assert obj.exists() and obj.stat().st_size > 10_000
     # blocks of one class share ONE parameter group, like the reference's object-identity rule (afb:160-163)
     twice = cc.ChainSpec.from_blocks([fb.projection(), fb.rigidTform3d(), fb.rigidTform3d(), fb.free_point()])
-    assert twice.n_rigid_groups == 1 and twice.block_group == (0, 0) and twice.layout(2, 3, 4)["n_params"] == 18 + 18 + 12
+    assert twice.n_rigid_groups == 1 and [b.slab for b in twice.blocks] == [None, 0, 0, None] and twice.layout(2, 3, 4)["n_params"] == 18 + 18 + 12
+
+
+def _check_compaction_tables(data_all, data_masked, keep, off, P):
+    """Pack the dense block rows exactly like the device does — detection i's kept u entries at off[i], its v entries behind them."""
+    dense = np.asarray(data_all).reshape(-1, 2, P)
+    out = np.full(data_masked.shape[0], np.nan)
+    for i in range(dense.shape[0]):
+        sel = [j for j in range(P) if (int(keep[i]) >> j) & 1]
+        out[int(off[i]): int(off[i]) + len(sel)] = dense[i, 0, sel]
+        out[int(off[i]) + len(sel): int(off[i]) + 2 * len(sel)] = dense[i, 1, sel]
+    assert np.array_equal(out, data_masked)
+
+
+@pytest.mark.parametrize("tag", ["user_cam_scale", "user_division"])
+def test_user_blocks_layout_structure_and_code_generation(golden_dir, tag):
+    """The reference's extension point (afb:689-775): chains that contain USER-written blocks, run through the reference's own
+    code generator (make_golden.py --only round4; the blocks are tests/golden/_user_blocks.py).  The GPU counterpart declares
+    the same blocks as device code (function_blocks.device_function_block): parameter-string layout, block_param_inds and both
+    CSR structures must reproduce the reference bit for bit, and the generated translation unit must compile for gfx950."""
+    from pycamset_amd import function_blocks as fb
+    from pycamset_amd import chain_compiler as cc
+    g = np.load(golden_dir / f"{tag}.npz")
+    ub = H.user_blocks(fb)
+    names = [str(n) for n in g["blocks"]]
+    blocks = [ub[n]() if n in ub else getattr(fb, n)() for n in names]
+    spec = cc.ChainSpec.from_blocks(blocks)
+    assert [b.kind for b in spec.blocks].count("user") == 1
+    det = g["detections"]
+    C, I, K = (int(det[:, j].max()) + 1 for j in range(3))
+    lay = spec.layout(C, I, K)
+    assert lay["n_params"] == g["param_str"].shape[0] and spec.P == g["block_param_inds"].shape[1]
+    cols = cc.block_param_inds(spec, lay, det[:, :3].astype(np.int64))
+    assert np.array_equal(cols, g["block_param_inds"])
+    idx, ptr, _, _ = cc.csr_structure_of(cols, lay["n_params"], None)
+    assert np.array_equal(idx, g["indices_all"]) and np.array_equal(ptr, g["indptr_all"])
+    idx, ptr, keep, off = cc.csr_structure_of(cols, lay["n_params"], g["unfixed"])
+    assert np.array_equal(idx, g["indices_masked"]) and np.array_equal(ptr, g["indptr_masked"])
+    _check_compaction_tables(g["data_all"], g["data_masked"], keep, off, spec.P)
+    text = cc.emit_source(spec)
+    assert "namespace user" in text and "pcs::chain_user<" in text
+    assert cc.compile_chain(spec).stat().st_size > 10_000
+    # what the composition rules refuse: a block that is neither shipped nor a device block; neighbours that do not fit
+    class plain(fb.abstract_function_block):
+        num_inp, num_out = 3, 3
+        params = fb.param_type(fb.key_type.PER_CAM, 1)
+    for bad in ([fb.projection(), plain(), fb.free_point()], [fb.projection(), ub["division_projection"](), fb.free_point()],
+                [ub["cam_scale"](), fb.extrinsic3D(), fb.free_point()]):
+        with pytest.raises(NotImplementedError):
+            cc.ChainSpec.from_blocks(bad)
 
 
 def test_initial_params_must_be_supplied():
