@@ -286,6 +286,14 @@ int pcs_genchain_eval_device(pcs_genchain *h, const double *d_param_str, void *d
 int pcs_genchain_set_unfixed(pcs_genchain *h, const uint64_t *keep, const int64_t *row_off, int64_t nnz);
 int pcs_genchain_eval_compact(pcs_genchain *h, const double *param_str, void *resid, void *data);
 int pcs_genchain_eval_compact_device(pcs_genchain *h, const double *d_param_str, void *d_resid, void *d_data, void *stream);
+/* Products with the chain's Jacobian kept on the device — what a solver needs from J (optimisation_handling.py:88-98: column norms,
+ * J^T f, mat-vecs), for ANY generated chain: pcs_genchain_linearize writes residual + dense block rows at param_str into the
+ * handle's buffers (PCS_F64 chains), pcs_genchain_matfree applies them (csrc/ba_blockrow.hpp) with the op codes and vector shapes
+ * of pcs_matfree.  pcs_genchain_set_blocks (once, after create) tells which global column a local column stands for: block b
+ * covers local columns [col0_b, col0_b + np_b), its parameters of entity e (link_b: 0 camera, 1 image, 2 key) start at start_b + np_b e. */
+int pcs_genchain_set_blocks(pcs_genchain *h, int n_blocks, const int32_t *col0, const int32_t *n_params, const int32_t *link, const int64_t *start);
+int pcs_genchain_linearize(pcs_genchain *h, const double *param_str);
+int pcs_genchain_matfree(pcs_genchain *h, int op, const double *in, double *out, double *cost);
 int pcs_genchain_device_buffers(pcs_genchain *h, void **d_resid, void **d_jac);
 int pcs_genchain_synchronize(pcs_genchain *h, void *stream);
 int pcs_genchain_last_kernel_ms(pcs_genchain *h, float *slab_prep_ms, float *eval_ms);

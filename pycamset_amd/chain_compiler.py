@@ -339,6 +339,11 @@ class ChainEngine:
         check(lib().pcs_genchain_create(byref(self._h), str(path).encode(), self.P, int(self.spec.uses_template), ng, off, cnt, nu, uoff,
                                         self.lay["intr_off"], self.lay["point_off"], self.n_params, self.n_cams, self.n_imgs, self.n_keys,
                                         {"f64": 0, "f32": 1, "mixed": 2}[self.dtype], self.device))
+        # which global column a local column stands for (pcs_genchain_matfree)
+        nb = len(self.spec.blocks)
+        col0 = np.concatenate([[0], np.cumsum([b.n_params for b in self.spec.blocks])[:-1]]).astype(np.int32)
+        check(lib().pcs_genchain_set_blocks(self._h, nb, (c_int32 * nb)(*col0), (c_int32 * nb)(*[b.n_params for b in self.spec.blocks]),
+                                            (c_int32 * nb)(*[b.link for b in self.spec.blocks]), (c_int64 * nb)(*[self.lay["starts"][b.group] for b in self.spec.blocks])))
         self.n = 0
         self.nnz = None
         self.mask_key = None
@@ -416,6 +421,39 @@ class ChainEngine:
         a, b = c_float(), c_float()
         check(lib().pcs_genchain_last_kernel_ms(self._h, byref(a), byref(b)))
         return float(a.value), float(b.value)
+
+    # -- products with the Jacobian kept on the device (the interface device_solver.JacobianOperator drives; csrc/ba_blockrow.hpp) ------
+    OP_JV, OP_JTU, OP_JTJV, OP_DIAG, OP_GRAD = 0, 1, 2, 3, 4
+
+    def linearize(self, param_str):
+        """Residual + dense block rows at ``param_str`` into the handle's device buffers; the products below refer to this point."""
+        check(lib().pcs_genchain_linearize(self._h, self._check_params(param_str).ctypes.data_as(POINTER(c_double))))
+
+    def _matfree(self, op: int, vin, n_out: int, want_cost: bool = False):
+        out = np.empty(n_out)
+        cost = c_double(0.0)
+        dp = POINTER(c_double)
+        check(lib().pcs_genchain_matfree(self._h, op, vin.ctypes.data_as(dp) if vin is not None else None, out.ctypes.data_as(dp), byref(cost) if want_cost else None))
+        return (out, float(cost.value)) if want_cost else out
+
+    def jv(self, v) -> np.ndarray:
+        return self._matfree(self.OP_JV, self._check_params(v), 2 * self.n)
+
+    def jtu(self, u) -> np.ndarray:
+        u = np.ascontiguousarray(u, dtype=np.float64).ravel()
+        if u.shape[0] != 2 * self.n:
+            raise ValueError("u must have 2N entries")
+        return self._matfree(self.OP_JTU, u, self.n_params)
+
+    def jtjv(self, v) -> np.ndarray:
+        return self._matfree(self.OP_JTJV, self._check_params(v), self.n_params)
+
+    def jtj_diag(self) -> np.ndarray:
+        return self._matfree(self.OP_DIAG, None, self.n_params)
+
+    def grad(self) -> tuple[np.ndarray, float]:
+        """(J^T r, sum r^2) at the linearisation point."""
+        return self._matfree(self.OP_GRAD, None, self.n_params, want_cost=True)
 
     # -- static structure (integer work on the host, like the reference's afb:192-233, afb:465-489) -------------------------
     def block_param_inds(self) -> np.ndarray:

@@ -122,10 +122,20 @@ LEAD_LIMIT = 16384          # leading parameters up to which lm_solve(linear_sol
 BLOCKED_BYTES_LIMIT = 16e9  # and total bytes of the two packed buffers + V
 
 
-def blocked_fits(engine) -> bool:
-    lay = engine.normal_layout()
-    return lay["n_lead"] <= LEAD_LIMIT and 8.0 * (2 * lay["packed_len"] + lay["n_lead"] * lay["n_trail"] + lay["n_lead"] ** 2) <= BLOCKED_BYTES_LIMIT
+REGION_LIMIT = 2 ** 29     # doubles per region of the packed buffer: the build addresses A, B and C with 32-bit byte offsets (pcs_engine.hip enqueue_normal)
 
+
+def blocked_fits(engine) -> bool:
+    """Can ``linear_solver='auto'`` take the blocked normal equations + Schur / Cholesky step on this engine?  False for generated
+    chains (no block-reduced build: they use the products of csrc/ba_blockrow.hpp), for leading groups beyond LEAD_LIMIT, for
+    buffers beyond BLOCKED_BYTES_LIMIT and for any single region A / B / C of 2^29 doubles or more (the build would refuse it)."""
+    if not hasattr(engine, "normal_layout"):
+        return False
+    lay = engine.normal_layout()
+    n_lead, n_trail, tb = lay["n_lead"], lay["n_trail"], lay["tb"]
+    if max(n_lead * n_lead, n_lead * n_trail, n_trail * tb) >= REGION_LIMIT:
+        return False
+    return n_lead <= LEAD_LIMIT and 8.0 * (2 * lay["packed_len"] + n_lead * n_trail + n_lead ** 2) <= BLOCKED_BYTES_LIMIT
 
 
 class NormalEquations:

@@ -321,3 +321,77 @@ class FreePointBundleHandler(TemplateBundleHandler):  # fph:102-201
 
     def _point_mask(self, visible_feature_mask):
         return np.ones(self.flat_point_data.shape[0], dtype=bool)  # fph:130
+
+
+
+class ChainProblem:
+    """The handler protocol for ANY chain of function blocks — what ``device_solver.lm_solve`` and a scipy caller need from a
+    handler (template_handler.py:154-240: ``op_fun``, ``make_loss_fun``, ``make_loss_jac``, ``get_bundle_adjustment_inputs``) without
+    the target / camera-set model around it.  The three bundle handlers above are tied to the reference's three chains; a chain
+    the user composes (generated kernels, user blocks) brings its own parameter groups, so this class takes them as they are:
+
+        op   = projection() + extrinsic3D() + rigidTform3d() + template_points()
+        prob = ChainProblem(op, detections, [intr, extr, poses_a, poses_b], template=points,
+                            unfixed=[None, None, None, mask_b])            # one array per block, like build_param_list
+        res  = lm_solve(prob, prob.x0)                                     # J stays on the device
+        scipy.optimize.least_squares(prob.make_loss_fun(), prob.x0, jac=prob.make_loss_jac(), x_scale='jac')
+
+    ``slabs``: one array per argument of ``build_param_list`` (afb:669-681), i.e. per parameter GROUP in string order (blocks that
+    share a parameter object share one array); ``unfixed``: a boolean array per slab (None = all free).  The free vector ``x`` is the
+    concatenation of the slabs' free entries in string order."""
+
+    def __init__(self, op_fun, detections, slabs, *, template=None, unfixed=None):
+        self.op_fun = op_fun
+        self.det = np.ascontiguousarray(detections, dtype=np.float64)
+        self.slabs = [np.array(s, dtype=np.float64) for s in slabs]
+        masks = unfixed if unfixed is not None else [None] * len(self.slabs)
+        if len(masks) != len(self.slabs):
+            raise ValueError("one unfixed mask (or None) per slab")
+        self.unfixed = [np.ones(s.shape, dtype=bool) if m is None else np.broadcast_to(np.asarray(m, dtype=bool), s.shape).copy() for s, m in zip(self.slabs, masks)]
+        self.template = None if template is None else np.ascontiguousarray(template, dtype=np.float64).reshape(-1, 3)
+        self.x0 = np.concatenate([s[m] for s, m in zip(self.slabs, self.unfixed)])
+
+    # -- what lm_solve asks of a handler ---------------------------------------------------------------------------------------------
+    def _flat_detections(self):
+        return self.det
+
+    def _template_arg(self):
+        return self.template
+
+    def _jac_mask(self):
+        return np.concatenate([m.ravel() for m in self.unfixed])
+
+    def get_bundle_adjustment_inputs(self, x):
+        x = np.asarray(x, dtype=np.float64)
+        out, at = [], 0
+        for s, m in zip(self.slabs, self.unfixed):
+            k = int(m.sum())
+            t = s.copy()
+            t[m] = x[at: at + k]
+            at += k
+            out.append(t)
+        if at != x.shape[0]:
+            raise ValueError(f"x has {x.shape[0]} entries, the problem has {at} free parameters")
+        return out
+
+    # -- the closures scipy takes (th:157-193) -------------------------------------------------------------------------------------
+    def _param_str(self, x):
+        return self.op_fun.build_param_list(*self.get_bundle_adjustment_inputs(x))
+
+    def make_loss_fun(self, threads=1):
+        loss = self.op_fun.make_full_loss_fn(self.det, threads)
+        tm = () if self.template is None else (self.template,)
+        return lambda x: np.asarray(loss(self._param_str(x), *tm)).reshape(-1)
+
+    def make_loss_jac(self, threads=1):
+        from scipy.sparse import csr_array
+
+        jac = self.op_fun.make_jacobean(self.det, threads, unfixed_params=self._jac_mask())
+        tm = () if self.template is None else (self.template,)
+        shape = (2 * self.det.shape[0], int(self._jac_mask().sum()))
+
+        def jac_fn(x):
+            data, indices, indptr = jac(self._param_str(x), *tm)
+            return csr_array((data, indices, indptr), shape=shape)
+
+        return jac_fn

@@ -643,6 +643,57 @@ def test_user_blocks_match_the_reference_code_generator(golden_dir, tag):
         assert np.max(np.abs(fd - analytic)) <= 2e-5 * max(1.0, np.max(np.abs(analytic))), (col, fd, analytic)
 
 
+def test_generated_chain_products_and_device_lm_reach_the_scipy_solution(golden_dir):
+    """Row f2 for generated chains: with the dense block rows kept on the device (pcs_genchain_linearize) the products J v,
+    J^T u, J^T (J v), diag(J^T J), J^T r (csrc/ba_blockrow.hpp) equal the CSR closure's, and `lm_solve` on
+    `projection + extrinsic3D + rigidTform3d + template_points` — not one of the handlers' chains — ends where
+    scipy.optimize.least_squares on the same closures ends (optimisation_handling.py:88-98)."""
+    from pycamset_amd.device_solver import JacobianOperator, lm_solve
+    rig = synthetic.make_rig("gen-lm", 4, 10, synthetic.charuco_points(7, 8.0), seed=61, visibility=0.9)
+    det = rig.detections
+    rng = np.random.default_rng(5)
+    op = fb.projection() + fb.extrinsic3D() + fb.rigidTform3d() + fb.template_points()
+    assert op.chain == "generated"
+    second = np.concatenate([rng.normal(0, 0.02, (rig.n_imgs, 3)), rng.normal(0, 0.002, (rig.n_imgs, 3))], axis=1)   # a small second per-image transform
+    # truth: (intr, extr, second, poses); measured = exact projection of the truth + noise; start = truth perturbed
+    ps_true = op.build_param_list(rig.intr_true, rig.extr_true, second, rig.poses_true)
+    uv = op.make_full_loss_fn(det, 1)(ps_true, rig.points) + det[:, 3:]
+    det = det.copy()
+    det[:, 3:] = uv + rng.normal(0, 0.3, uv.shape)
+    op = fb.projection() + fb.extrinsic3D() + fb.rigidTform3d() + fb.template_points()      # a fresh engine on the new table
+    fix_ext = np.ones((rig.n_cams, 6), dtype=bool)
+    fix_ext[0] = False                                                   # gauge: camera 0 stays where it is,
+    fix_second = np.zeros((rig.n_imgs, 6), dtype=bool)
+    fix_second[1:] = True                                                # and so does the first image's second transform (it is redundant with its pose)
+    start = [rig.intr_true * (1 + 1e-3 * rng.standard_normal(rig.intr_true.shape)), rig.extr_true + 1e-3 * rng.standard_normal(rig.extr_true.shape),
+             second + 1e-3 * rng.standard_normal(second.shape), rig.poses_true + 1e-3 * rng.standard_normal(rig.poses_true.shape)]
+    start[1][0] = rig.extr_true[0]
+    start[2][0] = second[0]
+    prob = handlers.ChainProblem(op, det, start, template=rig.points, unfixed=[None, fix_ext, fix_second, None])
+    loss_fn, jac_fn = prob.make_loss_fun(), prob.make_loss_jac()
+    # (1) products against the CSR closure
+    eng = op._engine_for(det)
+    opr = JacobianOperator(eng, prob._jac_mask())
+    ps0 = op.build_param_list(*prob.get_bundle_adjustment_inputs(prob.x0))
+    op._bind_template(eng, rig.points)
+    opr.linearize(ps0)
+    Jc = jac_fn(prob.x0)
+    r0 = loss_fn(prob.x0)
+    v = rng.standard_normal(prob.x0.shape[0])
+    u = rng.standard_normal(2 * det.shape[0])
+    for got, want in ((opr.jv(v), Jc @ v), (opr.jtu(u), Jc.T @ u), (opr.jtjv(v), Jc.T @ (Jc @ v)), (opr.diag(), np.asarray(Jc.multiply(Jc).sum(axis=0)).ravel()),
+                      (opr.grad()[0], Jc.T @ r0)):
+        assert np.max(np.abs(got - want)) <= 1e-9 * np.max(np.abs(want))
+    assert abs(opr.grad()[1] - r0 @ r0) <= 1e-12 * (r0 @ r0)
+    # (2) the solve
+    ref = least_squares(loss_fn, prob.x0.copy(), jac=jac_fn, x_scale="jac", max_nfev=40)
+    res = lm_solve(prob, prob.x0.copy(), max_iter=40)
+    assert res.history == sorted(res.history, reverse=True)
+    assert res.cost <= ref.cost * (1 + 1e-3), (res.cost, ref.cost)
+    assert abs(0.5 * np.sum(loss_fn(res.x) ** 2) - res.cost) <= 1e-9 * res.cost
+    assert res.cost < 0.05 * res.history[0]
+
+
 def test_generated_kernel_for_the_template_chain_against_the_hand_fused_one(capsys):
     """The chain compiler applied to `projection + extrinsic3D + template_points` itself (bypassing the hand-fused fast path):
     same function as ba_eval_kernel on the headline rig (N = 1e6) — values to 1e-12 of the row scale, golden parity on the
