@@ -256,7 +256,7 @@ def emit_source(spec: ChainSpec) -> str:
 
 def _header_digest() -> str:
     h = hashlib.sha256()
-    for name in ("ba_generic.hpp", "ba_kernels.hpp", "ba_device.hpp"):
+    for name in ("ba_generic.hpp", "ba_kernels.hpp", "ba_device.hpp", "ba_rtc_prelude.hpp"):
         h.update((CSRC / name).read_bytes())
     return h.hexdigest()
 
@@ -266,18 +266,78 @@ def code_object_path(spec: ChainSpec) -> Path:
     return CACHE / f"chain_{'_'.join(''.join(ch for ch in n if ch.isalnum())[:4] for n in spec.names)}_{key}.hsaco"
 
 
+def _hiprtc():
+    """libhiprtc through ctypes, or None: the HIP runtime-compilation library is part of a runtime-only ROCm install, hipcc is not."""
+    import ctypes
+
+    for name in ("libhiprtc.so", "/opt/rocm/lib/libhiprtc.so"):
+        try:
+            return ctypes.CDLL(name)
+        except OSError:
+            continue
+    return None
+
+
+def _compile_with_hiprtc(src_text: str, out: Path) -> str | None:
+    """Compile the translation unit with hiprtc (no hipcc, no GPU needed); returns None on success, the log otherwise."""
+    import ctypes
+
+    rtc = _hiprtc()
+    if rtc is None:
+        return "libhiprtc.so not found"
+    prog = ctypes.c_void_p()
+    rtc.hiprtcCreateProgram.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    rtc.hiprtcCompileProgram.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_char_p)]
+    if rtc.hiprtcCreateProgram(ctypes.byref(prog), src_text.encode(), b"chain.hip", 0, None, None) != 0:
+        return "hiprtcCreateProgram failed"
+    try:
+        opts = [b"--offload-arch=gfx950", b"-O3", b"-std=c++17", f"-I{CSRC}".encode()]
+        rc = rtc.hiprtcCompileProgram(prog, len(opts), (ctypes.c_char_p * len(opts))(*opts))
+        n = ctypes.c_size_t()
+        if rc != 0:
+            rtc.hiprtcGetProgramLogSize(prog, ctypes.byref(n))
+            log = ctypes.create_string_buffer(n.value + 1)
+            rtc.hiprtcGetProgramLog(prog, log)
+            return log.value.decode(errors="replace")[-2000:] or f"hiprtcCompileProgram returned {rc}"
+        if rtc.hiprtcGetCodeSize(prog, ctypes.byref(n)) != 0 or n.value == 0:
+            return "hiprtcGetCodeSize failed"
+        code = ctypes.create_string_buffer(n.value)
+        if rtc.hiprtcGetCode(prog, code) != 0:
+            return "hiprtcGetCode failed"
+        out.write_bytes(code.raw[: n.value])
+        return None
+    finally:
+        rtc.hiprtcDestroyProgram(ctypes.byref(prog))
+
+
 def compile_chain(spec: ChainSpec, verbose: bool = False) -> Path:
-    """gfx950 code object of the chain, built by hipcc unless an up-to-date one is cached."""
+    """gfx950 code object of the chain unless an up-to-date one is cached.  Compiler: hiprtc (runtime compilation: works on a box
+    without hipcc — a runtime-only ROCm install — and without a GPU), hipcc --genco when hiprtc is missing or refuses the unit;
+    ``PCS_CHAIN_COMPILER=hipcc|hiprtc`` forces one."""
     out = code_object_path(spec)
     if out.exists():
         return out
     CACHE.mkdir(exist_ok=True)
     src = out.with_suffix(".hip")
-    src.write_text(emit_source(spec))
+    text = emit_source(spec)
+    src.write_text(text)
+    which = os.environ.get("PCS_CHAIN_COMPILER", "auto")
+    log = None
+    if which in ("auto", "hiprtc"):
+        log = _compile_with_hiprtc(text, out)
+        if log is None:
+            if verbose:
+                print(f"hiprtc: {out}", flush=True)
+            return out
+        if which == "hiprtc":
+            raise RuntimeError(f"hiprtc failed compiling the chain {' + '.join(spec.names)}:\n{log}")
     cmd = [os.environ.get("HIPCC", "hipcc"), "--genco", "--offload-arch=gfx950", "-O3", "-std=c++17", f"-I{CSRC}", str(src), "-o", str(out)]
     if verbose:
         print(" ".join(cmd), flush=True)
-    proc = subprocess.run(cmd, capture_output=True, text=True)
+    try:
+        proc = subprocess.run(cmd, capture_output=True, text=True)
+    except FileNotFoundError as e:
+        raise RuntimeError(f"no compiler for the chain {' + '.join(spec.names)}: hiprtc said `{log}`, and hipcc is not installed ({e})") from None
     if proc.returncode != 0 or not out.exists():
         raise RuntimeError(f"hipcc failed compiling the chain {' + '.join(spec.names)}:\n{proc.stderr[-2000:]}")
     return out

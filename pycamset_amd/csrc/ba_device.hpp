@@ -10,9 +10,13 @@
 // detection.  Here the transcendental part is hoisted: `slab_prep` evaluates R, t, dR/dr once
 // per camera and once per pose ("slabs"), and the per-detection code is FMAs plus one divide.
 #pragma once
+#ifndef __HIPCC_RTC__   // a chain compiled by hiprtc (pycamset_amd/chain_compiler.py): the HIP runtime declarations are pre-included, host headers do not exist
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#else
+#include "ba_rtc_prelude.hpp"
+#endif
 
 namespace pcs {
 

@@ -21,9 +21,13 @@
 // build keep their hand-fused kernels (ba_kernels.hpp); a generated kernel for one of them computes the same function (tests
 // compare them).
 #pragma once
+#ifndef __HIPCC_RTC__   // a chain compiled by hiprtc (pycamset_amd/chain_compiler.py): the HIP runtime declarations are pre-included, host headers do not exist
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#else
+#include "ba_rtc_prelude.hpp"
+#endif
 
 #include "ba_device.hpp"
 #include "ba_kernels.hpp"

@@ -17,9 +17,13 @@
 // cancels, and single-precision sums left 5e-3 relative error in Jacobian entries.
 // The launch plumbing and the C ABI are in pcs_engine.hip.
 #pragma once
+#ifndef __HIPCC_RTC__   // a chain compiled by hiprtc (pycamset_amd/chain_compiler.py): the HIP runtime declarations are pre-included, host headers do not exist
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#else
+#include "ba_rtc_prelude.hpp"
+#endif
 
 #include "ba_device.hpp"
 

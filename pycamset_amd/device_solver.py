@@ -353,11 +353,11 @@ class BlockedNormalEquations:
         pred = 0.5 * (lam[0] * torch.dot(self.dvec, self.delta * self.delta) - torch.dot(self.gm, self.delta))
         return pred, (self.status[0] == 0) & torch.isfinite(pred)
 
-    def gradient(self, slot: int, lam):
-        """masked J^T r of the state in packed[slot] (free entries), as NumPy — one read-back, used once at the end."""
-        self.solve(slot, lam)
-        self.status.zero_()
-        return self.gm[self.free_idx].cpu().numpy()
+    def gradient(self, slot: int, lam=None):
+        """masked J^T r of the state in packed[slot] (free entries), as NumPy — one read-back, used once at the end.  g sits in the
+        packed buffer right behind the blocks ([A | B | C | g | cost]); no solve is needed to read it."""
+        g0 = self.packed[slot].numel() - 1 - self.n_params
+        return self.packed[slot][g0: g0 + self.n_params][self.free_idx].cpu().numpy()
 
 
 def _lm_solve_blocked(ne: BlockedNormalEquations, ps0: np.ndarray, *, max_iter, ftol, xtol, gtol, lam0, verbose):

@@ -184,12 +184,22 @@ class optimisation_function:  # afb:111-685
         if det.ndim != 2 or det.shape[1] != 5:
             raise ValueError("detections must be the flattened (N, 5) table [cam, im, key, u, v]")
         # Which table the engine holds.  Hashing 40 MB per call (1e6 detections) cost lm_solve 20 ms of its 28: the SAME array
-        # object with the same sampled rows is taken as the same table (the reference's closures capture their tables when they
-        # are made, afb:406-419 — later in-place edits never reach them either); anything else is hashed in full.
+        # OBJECT with the same sampled rows is taken as the same table.  "Same object" is a weak reference that is still alive
+        # and still refers to the array passed in — an id() alone could belong to a new array that reuses a freed address.  In-place
+        # edits of rows outside the sample are NOT seen, on purpose: the reference's closures capture their tables when they are
+        # made (afb:406-419) and later edits never reach them either; pass a new array for a new table.  Anything else is hashed in full.
+        import weakref
+
         sample = det[:: max(1, det.shape[0] // 256)]
-        quick = (id(detections), det.shape, det.ctypes.data, hash(sample.tobytes()))
-        if self._engine is not None and quick == getattr(self, "_engine_quick", None):
+        quick = (det.shape, det.ctypes.data, hash(sample.tobytes()))
+        held = getattr(self, "_engine_ref", None)
+        same_object = held is not None and held() is detections
+        if self._engine is not None and same_object and quick == getattr(self, "_engine_quick", None):
             return self._engine
+        try:
+            self._engine_ref = weakref.ref(detections)
+        except TypeError:                     # not weak-referenceable (a list, a tuple): never take the fast path
+            self._engine_ref = None
         key = (det.shape, hash(det.tobytes()))
         self._engine_quick = quick
         if self._engine is None or key != self._engine_key:

@@ -9,8 +9,11 @@ computes into the other device buffer:
     copy stream      wait done[b] -> dev[b] -> host[k] (page-locked) -> record free[b], ready[k]
 
 ``free[b]`` guards the device buffer (a later step must not overwrite what a copy is still reading), ``ready[k]`` tells
-the host consumer that host buffer ``k`` holds its step.  bench.py --stream-to-host and tests/test_gpu_parity.py use this
-class.
+the host consumer that host buffer ``k`` holds its step.  A HOST buffer is handed out by ``wait(k)`` and belongs to the
+consumer until it gives it back with ``release(k)``: ``step()`` refuses to queue a copy into a buffer that is still out
+(a Jacobian somebody is reading must never change under its reader — the guarantee ``Engine``'s page-locked ring gives).
+A consumer that never calls ``wait`` (bench.py --stream-to-host measures the copy rate only) is never in the way.
+bench.py --stream-to-host and tests/test_gpu_parity.py use this class.
 """
 from __future__ import annotations
 
@@ -33,6 +36,11 @@ class JacobianHostStreamer:
         for e in self.free:
             e.record(self.copy_stream)
         self.step_no = 0
+        self.out = [False] * n_host_buffers     # host[k] was handed to the consumer by wait(k) and has not been released
+        # torch's default stream has the NULL handle, which the C ABI can only name as hipStreamLegacy — two spellings the runtime
+        # does not order against each other in both directions (BlockedNormalEquations.on_stream): a caller on the default
+        # stream gets its evaluations on a stream of this object, ordered after / before the caller's work by events
+        self.compute_stream = torch.cuda.Stream(self.dev)
 
     def step(self, d_param_str: int, d_resid: int | None) -> int:
         """Queue one evaluation at the device-resident parameter string and the copy of its Jacobian; returns the index of
@@ -40,11 +48,20 @@ class JacobianHostStreamer:
         torch = self.torch
         b = self.step_no % len(self.dev_bufs)
         k = self.step_no % len(self.host)
+        if self.out[k]:
+            raise RuntimeError(f"host buffer {k} is still with its consumer: call release({k}) before the step that reuses it "
+                               f"(or build the streamer with more than {len(self.host)} host buffers)")
         self.step_no += 1
-        compute = torch.cuda.current_stream(self.dev)
+        cur = torch.cuda.current_stream(self.dev)
+        compute = cur
+        if cur.cuda_stream == 0:
+            compute = self.compute_stream
+            compute.wait_stream(cur)
         compute.wait_event(self.free[b])
         self.eng.eval_device_resident(d_param_str, d_resid, self.dev_bufs[b].data_ptr(), compute.cuda_stream)
         self.done[b].record(compute)
+        if compute is not cur:
+            cur.wait_stream(compute)      # later work of the caller (the next parameter update) follows the evaluation
         with torch.cuda.stream(self.copy_stream):
             self.copy_stream.wait_event(self.done[b])
             self.host[k].copy_(self.dev_bufs[b], non_blocking=True)
@@ -53,6 +70,12 @@ class JacobianHostStreamer:
         return k
 
     def wait(self, k: int):
-        """Block until host buffer ``k`` holds the Jacobian of the step that was routed to it; returns the tensor."""
+        """Block until host buffer ``k`` holds the Jacobian of the step that was routed to it; returns the tensor, which stays
+        untouched until ``release(k)``."""
         self.ready[k].synchronize()
+        self.out[k] = True
         return self.host[k]
+
+    def release(self, k: int):
+        """The consumer is done with host buffer ``k``: a later step may copy into it again."""
+        self.out[k] = False

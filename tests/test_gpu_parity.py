@@ -872,10 +872,17 @@ def test_config5_jacobian_streamed_to_host(Engine):
     for k, ref in zip(slots, refs):
         got = st.wait(k).numpy()
         assert np.array_equal(got, ref), f"host buffer {k} does not hold its step's Jacobian"
+    # a host buffer handed out by wait() belongs to its consumer: a step that would copy into it is refused until release()
+    with pytest.raises(RuntimeError, match="still with its consumer"):
+        st.step(d_ps[0].data_ptr(), d_r.data_ptr())
+    kept = st.host[0].numpy().copy()
+    for k in slots:
+        st.release(k)
     # a second round through the same ring: host buffers are reused once their consumer is done with them
     slots2 = [st.step(dp.data_ptr(), d_r.data_ptr()) for dp in reversed(d_ps)]
     for k, ref in zip(slots2, reversed(refs)):
         assert np.array_equal(st.wait(k).numpy(), ref)
+    assert np.array_equal(kept, refs[0])
     torch.cuda.synchronize()
     e.close()
 
