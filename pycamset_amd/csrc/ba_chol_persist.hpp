@@ -45,7 +45,6 @@ struct CholPersistArgs {
     int32_t *flags;         // CP_COL + nb words, filled with 0xFF bytes (= -1) by the host: counters start at -1
     int32_t *status;        // |= 2: a pivot was not positive; |= 4: a wait ran out of time (results are not valid)
     int32_t n, ld, nb, slots;   // nb = block columns; slots = tiles per workgroup (LDS is sized for it)
-    int32_t wide;               // rows of S are 16-byte aligned (even ld, aligned base): published tiles travel as 16-byte sc1 loads / stores
     int64_t timeout_ticks;
 #ifdef CP_TRACE
     int64_t *trace;             // developer builds (tools/probes/chol_persist_probe.hip): [workgroup][column][8] wall-clock stamps
@@ -133,34 +132,6 @@ __device__ __forceinline__ void cp_fetch(const CholPersistArgs &a, double (&v)[4
             const int gr = i * 32 + r, gc = m * 32 + c;
             if (gr < a.n) v[q] = cp_ld(a.S + (int64_t)gr * a.ld + gc);   // gc < gr < n
         }
-    }
-}
-// The same two tiles (i, m) and (j, m) of S as 16-byte requests: thread t owns the pairs pi = t + 256 q (q < 2) of a tile — row pi >> 4,
-// columns 2 (pi & 15), + 1 —, half as many requests per tile; all of them leave before the one wait.  (The compiler does not know
-// when an asm load lands: the wait names every destination as an in/out operand, so no use can move above it.)
-typedef double cp_d2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void cp_fetch2_wide(const CholPersistArgs &a, double (&vp)[4], double (&vq)[4], const int i, const int j, const int m, const int tid) {
-    cp_d2 w[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int pi = tid + 256 * (q & 1), r = pi >> 4, c = 2 * (pi & 15);
-        const int gr = (q < 2 ? i : j) * 32 + r;
-        w[q] = cp_d2{0.0, 0.0};
-        if (gr < a.n && (q < 2 || i != j)) {
-            const double *p = a.S + (int64_t)gr * a.ld + m * 32 + c;
-            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(w[q]) : "v"(p) : "memory");
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]) : : "memory");
-    vp[0] = w[0].x; vp[1] = w[0].y; vp[2] = w[1].x; vp[3] = w[1].y;
-    vq[0] = w[2].x; vq[1] = w[2].y; vq[2] = w[3].x; vq[3] = w[3].y;
-}
-__device__ __forceinline__ void cp_park_wide(double *dst, const double (&v)[4], const int tid) {
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int pi = tid + 256 * q, r = pi >> 4, c = 2 * (pi & 15);
-        dst[r * CHOL_LDP + c] = v[2 * q];
-        dst[r * CHOL_LDP + c + 1] = v[2 * q + 1];
     }
 }
 __device__ __forceinline__ void cp_park(double *dst, const double (&v)[4], const int tid) {   // -> MFMA operand buffer (row stride CHOL_LDP)
@@ -329,16 +300,10 @@ __global__ __launch_bounds__(256) void chol_persist_kernel(const CholPersistArgs
             tile(s, i, j);
             if (i < 0 || j < jlo || j > jhi) continue;
             double vp[4], vq[4];
-            if (a.wide && i != nb) {
-                cp_fetch2_wide(a, vp, vq, i, j, m, tid);
-                cp_park_wide(P, vp, tid);
-                if (i != j) cp_park_wide(Q, vq, tid);
-            } else {
-                cp_fetch(a, vp, i, m, tid);
-                if (i != j) cp_fetch(a, vq, j, m, tid);
-                cp_park(P, vp, tid);
-                if (i != j) cp_park(Q, vq, tid);
-            }
+            cp_fetch(a, vp, i, m, tid);
+            if (i != j) cp_fetch(a, vq, j, m, tid);
+            cp_park(P, vp, tid);
+            if (i != j) cp_park(Q, vq, tid);
             __syncthreads();
             cp_apply(P, Q, Town(s), Td(s), i == j, lane, wave);
             __syncthreads();
@@ -375,17 +340,6 @@ __global__ __launch_bounds__(256) void chol_persist_kernel(const CholPersistArgs
                 const double *To = Town(s);
                 if (i == nb) {
                     if (tid < 32) cp_st(a.ypub + j * 32 + tid, To[tid]);
-                } else if (a.wide && (j + 1) * 32 <= a.n) {
-#pragma unroll
-                    for (int qq = 0; qq < 2; ++qq) {
-                        const int pi = tid + 256 * qq, r = pi >> 4, c = 2 * (pi & 15);
-                        const int gr = i * 32 + r;
-                        if (gr < a.n) {
-                            const cp_d2 w = {To[r * CP_LDT + c], To[r * CP_LDT + c + 1]};
-                            double *p = a.S + (int64_t)gr * a.ld + j * 32 + c;
-                            asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(w) : "memory");
-                        }
-                    }
                 } else {
 #pragma unroll
                     for (int qq = 0; qq < 4; ++qq) {
@@ -490,7 +444,7 @@ inline bool cp_fits(const int64_t n, const int n_cus) {
 
 // Enqueue memset + kernel on `s`.  The caller has checked cp_fits and set the device.
 inline hipError_t cp_launch(const int64_t n, double *d_S, const int64_t ld, const double *d_rhs, double *d_x, double *d_work, int32_t *d_status,
-                            const int n_cus, hipStream_t s, const double timeout_s = 0.25, int64_t *trace = nullptr, const bool wide_ok = true) {
+                            const int n_cus, hipStream_t s, const double timeout_s = 0.25, int64_t *trace = nullptr) {
     const int64_t nb = (n + 31) / 32, T = cp_tiles(nb);
     const int G = (int)(T < n_cus ? T : n_cus);
     const int slots = (int)((T + G - 1) / G);
@@ -500,7 +454,6 @@ inline hipError_t cp_launch(const int64_t n, double *d_S, const int64_t ld, cons
     a.xpub = d_work + cp_flag_doubles(nb);
     a.ypub = a.xpub + nb * 32;
     a.n = (int32_t)n; a.ld = (int32_t)ld; a.nb = (int32_t)nb; a.slots = slots;
-    a.wide = (wide_ok && ld % 2 == 0 && reinterpret_cast<uintptr_t>(d_S) % 16 == 0) ? 1 : 0;
     a.timeout_ticks = (int64_t)(timeout_s * 1.0e8);
 #ifdef CP_TRACE
     a.trace = trace;
