@@ -209,6 +209,36 @@ int pcs_schur_finish(pcs_engine *h, const double *d_linvt, const double *d_u, co
 int pcs_lm_decide(pcs_engine *h, const double *d_cost_old, const double *d_cost_new, const double *d_dvec, const double *d_gm, const double *d_delta,
                   const double *d_ps, const uint8_t *d_fixed, int32_t *d_status, double *d_lambda, double *d_stats, void *stream);
 
+/* One whole LM trial in ONE call (round 4) — the device-steered form of the loop optimisation_handling.py:88-98 leaves to scipy.
+ * Queues, on `stream`: the damped Schur step from packed_cur at *lambda (pcs_schur_prepare, pcs_schur_syrk, pcs_dense_spd_solve_algo,
+ * pcs_schur_vtx, pcs_schur_finish: delta and ps_new = ps_cur + delta), the blocked normal equations at ps_new into packed_new, the
+ * decision (pcs_lm_decide's arithmetic + the loop's termination rules from `ctrl`), the copy packed_new -> packed_cur, ps_new ->
+ * ps_cur when the trial was accepted, and a 10-double read-back into stats_host (page-locked; may be NULL).  Every kernel of the
+ * sequence first reads *stop_flag and does nothing when it is set, so a caller may queue the NEXT trial before it has seen this
+ * one's verdict: the GPU never waits for the host between trials.
+ *   ctrl (9 doubles, device): [0] stop code, 0 = running (1 gtol reached before the step, 2 `ctrl[7]` consecutive rejections, 3 ftol,
+ *        4 xtol, 5 `ctrl[3]` accepted steps, 9 the one-launch dense solve gave up — set spd_algorithm = PCS_SPD_LAUNCHES, clear ctrl[0] and
+ *        *stop_flag and queue the trial again), [1] consecutive rejections, [2] accepted steps, [3] iteration limit, [4] ftol, [5] xtol,
+ *        [6] gtol, [7] rejection limit, [8] trials decided
+ *   stats (10 doubles, device): pcs_lm_decide's eight, [8] the stop code after this trial, [9] the trial's number (ctrl[8]) or -1 for a
+ *        launch that found the flag raised (nothing was computed; everything else in `stats` is then stale).
+ * All pointers are device memory except stats_host; sizes as for the entry points named above. */
+typedef struct pcs_lm_buffers {
+    double *packed_cur, *packed_new;      /* [A | B | C | g | cost] of the current and of the trial state (pcs_normal_layout) */
+    const uint8_t *fixed;
+    double *lambda;
+    double *linvt, *u, *V, *S, *rhs, *dvec, *gm;   /* pcs_schur_prepare's outputs */
+    int32_t *status;
+    double *xlead, *w, *spd_work;         /* n_lead | n_trail | pcs_dense_spd_work_len(n_lead) */
+    double *delta, *ps_cur, *ps_new;      /* n_params each */
+    double *ctrl;
+    int32_t *stop_flag, *accept_flag;
+    double *stats;
+    double *stats_host;
+    int32_t spd_algorithm;                /* PCS_SPD_* */
+} pcs_lm_buffers;
+int pcs_lm_trial(pcs_engine *h, const pcs_lm_buffers *b, void *stream);
+
 /* The two products of the Schur step around the dense solve, on raw device pointers (float64, row-major):
  *   pcs_schur_syrk   S -= V V' on the LOWER triangle of S (n_lead x n_lead, row stride lds; V n_lead x n_trail, row stride ldv) and,
  *                    when d_u is given, rhs += V u — FP64 matrix cores, one workgroup per 32 x 32 tile and K split

@@ -21,6 +21,12 @@ DTYPE_IDS = {"f64": 0, "f32": 1, "mixed": 2}   # mixed: FP64 arithmetic, FP32 re
 
 # every symbol include/pcs_hip.h declares: name -> (restype, argtypes)
 _P = c_void_p
+class LmBuffers(ctypes.Structure):
+    """include/pcs_hip.h pcs_lm_buffers: the device buffers of one LM trial (pcs_lm_trial)."""
+    _fields_ = [(n, c_void_p) for n in ("packed_cur", "packed_new", "fixed", "lam", "linvt", "u", "V", "S", "rhs", "dvec", "gm", "status", "xlead", "w", "spd_work",
+                                        "delta", "ps_cur", "ps_new", "ctrl", "stop_flag", "accept_flag", "stats", "stats_host")] + [("spd_algorithm", ctypes.c_int32)]
+
+
 SYMBOLS = {
     "pcs_version": (c_int, []),
     "pcs_last_error": (c_char_p, []),
@@ -51,6 +57,7 @@ SYMBOLS = {
     "pcs_schur_prepare": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pcs_schur_finish": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pcs_lm_decide": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "pcs_lm_trial": (c_int, [_P, _P, _P]),
     "pcs_schur_syrk": (c_int, [c_int, c_int64, c_int64, _P, c_int64, _P, c_int64, _P, _P, _P]),
     "pcs_schur_vtx": (c_int, [c_int, c_int64, c_int64, _P, c_int64, _P, _P, _P]),
     "pcs_dense_spd_work_len": (c_int64, [c_int64]),

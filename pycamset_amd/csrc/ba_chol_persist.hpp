@@ -46,6 +46,7 @@ struct CholPersistArgs {
     int32_t *status;        // |= 2: a pivot was not positive; |= 4: a wait ran out of time (results are not valid)
     int32_t n, ld, nb, slots;   // nb = block columns; slots = tiles per workgroup (LDS is sized for it)
     int64_t timeout_ticks;
+    const int32_t *stop;        // optional device word: non-zero = do nothing (a launch queued behind the end of an LM loop, ba_schur.hpp)
 #ifdef CP_TRACE
     int64_t *trace;             // developer builds (tools/probes/chol_persist_probe.hip): [workgroup][column][8] wall-clock stamps
 #endif
@@ -240,6 +241,7 @@ __device__ __forceinline__ void cp_invert_diag(const double *D, double *Li, cons
 
 __global__ __launch_bounds__(256) void chol_persist_kernel(const CholPersistArgs a) {
     extern __shared__ double cp_sm[];
+    if (a.stop && *a.stop) return;   // every workgroup reads the same word: all leave, or none
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nb = a.nb, G = gridDim.x, wg = blockIdx.x;
     double *P = cp_sm, *Q = P + 32 * CHOL_LDP, *slot0 = Q + 32 * CHOL_LDP;
@@ -444,7 +446,7 @@ inline bool cp_fits(const int64_t n, const int n_cus) {
 
 // Enqueue memset + kernel on `s`.  The caller has checked cp_fits and set the device.
 inline hipError_t cp_launch(const int64_t n, double *d_S, const int64_t ld, const double *d_rhs, double *d_x, double *d_work, int32_t *d_status,
-                            const int n_cus, hipStream_t s, const double timeout_s = 0.25, int64_t *trace = nullptr) {
+                            const int n_cus, hipStream_t s, const double timeout_s = 0.25, int64_t *trace = nullptr, const int32_t *d_stop = nullptr) {
     const int64_t nb = (n + 31) / 32, T = cp_tiles(nb);
     const int G = (int)(T < n_cus ? T : n_cus);
     const int slots = (int)((T + G - 1) / G);
@@ -455,6 +457,7 @@ inline hipError_t cp_launch(const int64_t n, double *d_S, const int64_t ld, cons
     a.ypub = a.xpub + nb * 32;
     a.n = (int32_t)n; a.ld = (int32_t)ld; a.nb = (int32_t)nb; a.slots = slots;
     a.timeout_ticks = (int64_t)(timeout_s * 1.0e8);
+    a.stop = d_stop;
 #ifdef CP_TRACE
     a.trace = trace;
 #else

@@ -37,6 +37,7 @@ struct CholArgs {
     int32_t n, ld, k;   // k = block column of this launch
     const double *rhs;  // the forward substitution L y = rhs rides along with the factorisation: the workgroup that owns a
     double *y;          // diagonal tile forms its block of y as soon as the tile's inverse exists (rows of L left of it are final)
+    const int32_t *stop;   // optional device word: non-zero = do nothing (a launch queued behind the end of an LM loop, ba_schur.hpp)
 };
 
 // tile element (r, c) of block (bi, bj), or the identity outside the matrix (a ragged last block is padded by the identity)
@@ -146,6 +147,7 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(const CholArgs a) {
     __shared__ double Li[NB][CHOL_LDF];   // L_kk^-1 (lower)
     __shared__ double X[NB][CHOL_LDP];    // this workgroup's panel tile
     __shared__ int flag_bad;
+    if (a.stop && *a.stop) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int k = a.k;
     const int bi = k + blockIdx.x;      // blockIdx.x > 0: a tile below the diagonal
@@ -198,6 +200,7 @@ __global__ __launch_bounds__(256) void chol_step_kernel(const CholArgs a) {
     __shared__ double D[NB][CHOL_LDF];
     __shared__ double Li[NB][CHOL_LDF];
     __shared__ int flag_bad;
+    if (a.stop && *a.stop) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int k = a.k;
     // workgroups 0 .. m - 1 (m = block rows of the trailing matrix): its first column, the launch's critical path — dispatched
@@ -336,6 +339,7 @@ struct CholSolveArgs {
     double *x;            // n
     int32_t n, ld;
     int32_t kb0, kb1;     // this launch solves the blocks kb1 - 1 down to kb0 (at most 16: one unknown per thread)
+    const int32_t *stop;
 };
 
 // L' x = y for the block range [kb0, kb1) in ONE workgroup of 512 threads, COLUMN-oriented: once a block of the solution is
@@ -350,6 +354,7 @@ struct CholSolveArgs {
 template <int NB>
 __global__ __launch_bounds__(512) void chol_solve_kernel(const CholSolveArgs a) {
     extern __shared__ double sm[];
+    if (a.stop && *a.stop) return;
     constexpr int T = 512;
     const int tid = threadIdx.x;
     const int n = a.n;
@@ -414,7 +419,8 @@ __global__ __launch_bounds__(512) void chol_solve_kernel(const CholSolveArgs a) 
 // diagonal): a solved piece of the backward sweep leaves the rest of y.  64 columns per workgroup, sixteen waves share the rows,
 // one writer per entry (deterministic).
 __global__ __launch_bounds__(1024) void chol_gemv_t_kernel(const double *__restrict__ L, const int ld, const double *__restrict__ x, double *__restrict__ y,
-                                                           const int r0, const int r1, const int c0, const int c1) {
+                                                           const int r0, const int r1, const int c0, const int c1, const int32_t *__restrict__ stop) {
+    if (stop && *stop) return;
     const int col = threadIdx.x & 63, part = threadIdx.x >> 6;
     const int j = c0 + blockIdx.x * 64 + col;
     __shared__ double red[16][64];

@@ -164,7 +164,9 @@ __global__ void slab_prep_kernel(const double *__restrict__ prm, T *__restrict__
 __global__ void normal_prologue_kernel(const double *__restrict__ prm, T *__restrict__ cam_slab, T *__restrict__ pose_slab,
                                        T *__restrict__ points, int n_cams, int n_imgs, int n_keys, int64_t extr_off,
                                        int64_t pose_off, int64_t point_off, int has_pose, int copy_points, int prep_blocks,
-                                       double *__restrict__ Hm, int64_t n_h, double *__restrict__ g, int64_t n_g, double *__restrict__ cost) {
+                                       double *__restrict__ Hm, int64_t n_h, double *__restrict__ g, int64_t n_g, double *__restrict__ cost,
+                                       const int32_t *__restrict__ stop) {
+    if (stop && *stop) return;   // a build queued behind the end of an LM loop (ba_schur.hpp PCS_STOP_GUARD)
     if ((int)blockIdx.x < prep_blocks) {
         slab_prep_element((int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)prep_blocks * blockDim.x, prm, cam_slab, pose_slab, points, n_cams,
                           n_imgs, n_keys, extr_off, pose_off, point_off, has_pose, copy_points);

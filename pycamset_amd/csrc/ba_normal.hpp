@@ -73,6 +73,7 @@ struct NormalArgs {
     int64_t extr_off, pose_off, point_off;
     int64_t n_params;
     int32_t tiles_per_wave;
+    const int32_t *stop;   // optional device word: non-zero = do nothing (a build queued behind the end of an LM loop, ba_schur.hpp)
     int32_t debug;  // profiling switches (results are wrong while set): 2 no flush atomics, 8 no MFMA phase, 16 no evaluation,
                     // 32 run boundaries ignored, 64 no LDS image writes, 128 flush = clear only; host side: 256 / 512 / 1024 skip the shared /
                     // (cam, key) / (image, key) pass
@@ -194,6 +195,7 @@ __global__ __launch_bounds__(64, 2) void ba_normal_mfma_kernel(const NormalArgs 
     using D2 = __attribute__((ext_vector_type(2))) double;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_image[];
+    if (a.stop && *a.stop) return;
     const int lane = threadIdx.x;
     const T *cam_slab = static_cast<const T *>(a.cam_slab);
     const T *pose_slab = static_cast<const T *>(a.pose_slab);
@@ -532,6 +534,7 @@ __global__ __launch_bounds__(64, 3) void ba_normal_imgkey_kernel(const NormalArg
     constexpr int P = chain_P(CHAIN);
     constexpr int P2 = 2 * P;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_image[];
+    if (a.stop && *a.stop) return;
     const int lane = threadIdx.x;
     const T *cam_slab = static_cast<const T *>(a.cam_slab);
     const T *pose_slab = static_cast<const T *>(a.pose_slab);

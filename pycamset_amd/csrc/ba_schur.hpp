@@ -38,11 +38,16 @@ struct SchurArgs {
     double *gm;                 // n_params: g with the fixed entries zeroed
     int32_t *status;            // bit 0: a trailing block was not positive definite
     int64_t n_lead, n_trail, n_ent, trail_off;
+    const int32_t *stop;        // optional: a device word; non-zero = the LM loop has ended, this (speculatively queued) launch does nothing
 };
+// Every kernel of an LM trial starts with this: the host queues trial t + 1 before it has read the verdict of trial t
+// (pcs_lm_trial), and lm_decide_kernel raises the flag when the loop is over — what was queued behind it then drains as no-ops.
+#define PCS_STOP_GUARD(a) do { if ((a).stop && *(a).stop) return; } while (0)
 
 // One lane = one trailing entity.
 template <int TB>
 __global__ __launch_bounds__(256) void schur_trail_kernel(const SchurArgs a) {
+    PCS_STOP_GUARD(a);
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= a.n_ent) return;
     const double lam = *a.lambda;
@@ -119,6 +124,7 @@ __global__ __launch_bounds__(256) void schur_trail_kernel(const SchurArgs a) {
 // One lane = one tb-chunk of one leading row: V[r, e, :] = b L_e^-T with b = the masked B[r, e, :].
 template <int TB>
 __global__ __launch_bounds__(256) void schur_v_kernel(const SchurArgs a) {
+    PCS_STOP_GUARD(a);
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= a.n_lead * a.n_ent) return;
     const int64_t r = t / a.n_ent, e = t - r * a.n_ent;
@@ -148,6 +154,7 @@ __global__ __launch_bounds__(256) void schur_v_kernel(const SchurArgs a) {
 
 // One lane = one entry of the leading block: S = sym(A) with fixed rows / columns -> identity and the damped diagonal.
 __global__ __launch_bounds__(256) void schur_lead_kernel(const SchurArgs a) {
+    PCS_STOP_GUARD(a);
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= a.n_lead * a.n_lead) return;
     const int64_t r = t / a.n_lead, c = t - r * a.n_lead;
@@ -181,11 +188,13 @@ struct SchurSyrkArgs {
     const double *u;     // n_trail (may be null: no rhs update)
     double *rhs;         // n_lead
     int32_t n_lead, n_trail, ldv, lds, ksplit, kchunk;   // kchunk: columns per split (multiple of 64)
+    const int32_t *stop;
 };
 constexpr int SYRK_LD = 68;
 using schur_d4 = __attribute__((ext_vector_type(4))) double;
 
 __global__ __launch_bounds__(256) void schur_syrk_kernel(const SchurSyrkArgs a) {
+    PCS_STOP_GUARD(a);
     __shared__ double P[32][SYRK_LD];
     __shared__ double Q[32][SYRK_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -260,7 +269,8 @@ __global__ __launch_bounds__(256) void schur_syrk_kernel(const SchurSyrkArgs a) 
 // w = V' x (n_trail outputs): 64 columns per workgroup, the reads of a row coalesced across a wave, sixteen waves share the rows
 // (four did at first: 19 workgroups x 4 waves x 120 dependent loads = 15 us for 4.6 MB)
 __global__ __launch_bounds__(1024) void schur_vtx_kernel(const double *__restrict__ V, const double *__restrict__ x, double *__restrict__ w,
-                                                         const int n_lead, const int n_trail, const int ldv) {
+                                                         const int n_lead, const int n_trail, const int ldv, const int32_t *__restrict__ stop) {
+    if (stop && *stop) return;
     const int col = threadIdx.x & 63, part = threadIdx.x >> 6;
     const int j = blockIdx.x * 64 + col;
     __shared__ double red[16][64];
@@ -290,10 +300,12 @@ struct SchurBackArgs {
     const double *ps_in;                // optional: the current parameter string ...
     double *ps_out;                     // ... and where the trial string ps_in + delta goes
     int64_t n_lead, n_ent, trail_off;
+    const int32_t *stop;
 };
 
 template <int TB>
 __global__ __launch_bounds__(256) void schur_back_kernel(const SchurBackArgs a) {
+    PCS_STOP_GUARD(a);
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t < a.n_lead) {
         const double d = a.fixed[t] ? 0.0 : a.xl[t];
@@ -318,22 +330,36 @@ __global__ __launch_bounds__(256) void schur_back_kernel(const SchurBackArgs a) 
 }
 
 // The accept / reject decision of one LM trial, on the device (one workgroup): predicted reduction of the damped model,
-// actual reduction, gain ratio, the next damping parameter (Nielsen-free classic schedule: x 1/3 above 0.75, x 1 above 0.25,
-// x 2 below, x 4 on a rejected or failed step — device_solver.lm_solve's host rule), and the eight numbers the host reads to
-// steer the loop.  Nothing else of an iteration ever reaches the host.
+// actual reduction, gain ratio, the next damping parameter (classic schedule: x 1/3 above 0.75, x 1 above 0.25,
+// x 2 below, x 4 on a rejected or failed step — device_solver.lm_solve's host rule), and the numbers the host reads to
+// follow the loop.  Nothing else of an iteration ever reaches the host.
+// Round 4: with a control block (`ctrl`) the kernel also applies the loop's TERMINATION rules (gtol before the step, ftol / xtol
+// after an accepted one, the limit of consecutive rejections, the iteration limit) and raises `*stop_flag`: the host no longer has
+// to read a verdict before it may queue the next trial — whatever it queued speculatively starts with PCS_STOP_GUARD.
+//   ctrl[0] stop code (0 = running; 1 gtol, 2 damping exhausted, 3 ftol, 4 xtol, 5 iteration limit, 9 = the dense solve gave up: host must
+//           repeat the trial)   [1] consecutive rejections   [2] accepted steps   [3] iteration limit   [4] ftol [5] xtol [6] gtol
+//           [7] rejection limit   [8] trials decided so far
 struct LmDecideArgs {
     const double *cost_old, *cost_new;     // sum r^2 of the current state and of the trial state
     const double *dvec, *gm, *delta, *ps;  // n_params each: damping diagonal, masked gradient, step, CURRENT parameter string
     const uint8_t *fixed;
     int32_t *status;                        // != 0: the step is invalid (a factorisation failed); cleared here for the next solve
     double *lambda;                         // in: the damping the step was computed with; out: the next one
-    double *stats;                          // out[8]: accepted (-1: the trial is void, see below), max |g|, relative cost drop, |step|, |x|, new sum r^2, old sum r^2, lambda used
+    double *stats;                          // out[10]: accepted (-1: the trial is void, see below), max |g|, relative cost drop, |step|, |x|, new sum r^2,
+                                            // old sum r^2, lambda used, stop code after this trial, trial number (-1: a no-op launch behind a raised flag)
     int64_t n_params;
+    double *ctrl;                           // optional control block (see above)
+    int32_t *stop_flag;                     // with ctrl: the word PCS_STOP_GUARD reads
+    int32_t *accept_flag;                   // with ctrl: 1 when this trial was accepted (lm_accept_kernel copies the trial state over the current one)
 };
 
 __global__ __launch_bounds__(1024) void lm_decide_kernel(const LmDecideArgs a) {
     __shared__ double red[4][1024];
     const int tid = threadIdx.x;
+    if (a.ctrl && a.ctrl[0] != 0.0) {   // queued behind the end of the loop: nothing to decide
+        if (tid == 0) { a.stats[9] = -1.0; *a.accept_flag = 0; }
+        return;
+    }
     double gd = 0.0, dd = 0.0, gmax = 0.0, xx = 0.0, ss = 0.0;
     for (int64_t i = tid; i < a.n_params; i += 1024) {
         const double d = a.delta[i], g = a.gm[i];
@@ -370,19 +396,57 @@ __global__ __launch_bounds__(1024) void lm_decide_kernel(const LmDecideArgs a) {
         const int st = *a.status;
         const bool ok = st == 0 && pred == pred && fabs(pred) < 1.0e300;
         const double rho = pred > 0.0 ? actual / pred : -1.0;
-        const bool acc = ok && c_new == c_new && fabs(c_new) < 1.0e300 && actual > 0.0;
+        bool acc = ok && c_new == c_new && fabs(c_new) < 1.0e300 && actual > 0.0;
         const double factor = rho > 0.75 ? 1.0 / 3.0 : rho > 0.25 ? 1.0 : 2.0;
-        *a.lambda = acc ? fmax(lam * factor, 1e-12) : lam * 4.0;
+        const double rel_drop = actual / (0.5 * c_old), step_norm = sqrt(red[0][0]), x_norm = sqrt(s_xx);
+        double code = 0.0;
+        const bool void_trial = (st & 4) != 0;   // the dense solve did not complete (ba_chol_persist.hpp's time limit): the host repeats the trial
+        if (a.ctrl) {
+            double *c = a.ctrl;
+            if (void_trial) { code = 9.0; acc = false; }
+            else if (s_gmax <= c[6]) { code = 1.0; acc = false; }             // the state BEFORE this step was already stationary: the step is dropped
+            else if (acc) {
+                c[1] = 0.0;
+                c[2] += 1.0;
+                if (rel_drop <= c[4]) code = 3.0;
+                else if (step_norm <= c[5] * (c[5] + x_norm)) code = 4.0;
+                else if (c[2] >= c[3]) code = 5.0;
+            } else {
+                c[1] += 1.0;
+                if (c[1] >= c[7]) code = 2.0;
+            }
+            c[8] += 1.0;
+            c[0] = code;
+            a.stats[8] = code;
+            a.stats[9] = c[8];
+            *a.accept_flag = acc ? 1 : 0;
+            *a.stop_flag = code != 0.0 ? 1 : 0;
+        }
+        if (!void_trial && code != 1.0) *a.lambda = acc ? fmax(lam * factor, 1e-12) : lam * 4.0;
         *a.status = 0;
-        a.stats[0] = (st & 4) ? -1.0 : acc ? 1.0 : 0.0;   // -1: the dense solve did not complete (ba_chol_persist.hpp's time limit): the host repeats the trial
+        a.stats[0] = void_trial ? -1.0 : acc ? 1.0 : 0.0;
         a.stats[1] = s_gmax;
-        a.stats[2] = actual / (0.5 * c_old);
-        a.stats[3] = sqrt(red[0][0]);
-        a.stats[4] = sqrt(s_xx);
+        a.stats[2] = rel_drop;
+        a.stats[3] = step_norm;
+        a.stats[4] = x_norm;
         a.stats[5] = c_new;
         a.stats[6] = c_old;
         a.stats[7] = lam;
     }
+}
+
+// An accepted trial becomes the current state: packed[trial] -> packed[current], trial parameter string -> current one.  Always
+// queued (the host does not know the verdict yet); copies only when lm_decide_kernel has set the accept flag — 6.5 MB on rig-32.
+__global__ __launch_bounds__(256) void lm_accept_kernel(const int32_t *__restrict__ accept_flag, const double *__restrict__ packed_new, double *__restrict__ packed_cur,
+                                                        const int64_t n_packed, const double *__restrict__ ps_new, double *__restrict__ ps_cur, const int64_t n_params) {
+    if (*accept_flag == 0) return;
+    using D2 = __attribute__((ext_vector_type(2))) double;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (int64_t)gridDim.x * blockDim.x;
+    const D2 *src = reinterpret_cast<const D2 *>(packed_new);
+    D2 *dst = reinterpret_cast<D2 *>(packed_cur);
+    for (int64_t i = t; i < n_packed / 2; i += nt) dst[i] = src[i];
+    if (t == 0 && (n_packed & 1)) packed_cur[n_packed - 1] = packed_new[n_packed - 1];
+    for (int64_t i = t; i < n_params; i += nt) ps_cur[i] = ps_new[i];
 }
 
 }  // namespace pcs

@@ -1109,7 +1109,7 @@ static BlockLayout block_layout(const pcs_engine *h) {
 
 // slab_prep + the normal-equations passes on `s`; d_prm holds the parameter string; outputs are zeroed here.
 // blocked: d_H points at the packed [A | B | C] (contiguous), see pcs_normal_blocks_device.
-static int enqueue_normal(pcs_engine *h, const double *d_prm, double *d_H, double *d_g, double *d_cost, hipStream_t s, bool blocked = false) {
+static int enqueue_normal(pcs_engine *h, const double *d_prm, double *d_H, double *d_g, double *d_cost, hipStream_t s, bool blocked = false, const int32_t *d_stop = nullptr) {
     if (h->n <= 0) return fail(PCS_ERR_STATE, "no detections set");
     if (h->n > INT32_MAX) return fail(PCS_ERR_ARG, "normal equations: tables beyond 2^31 rows are not supported (visiting orders are int32)");
     if (h->chain == PCS_CHAIN_TEMPLATE && !h->have_template) return fail(PCS_ERR_STATE, "template points not set");
@@ -1126,6 +1126,7 @@ static int enqueue_normal(pcs_engine *h, const double *d_prm, double *d_H, doubl
     HIPCHK(hipSetDevice(h->device));
     int rc0 = ensure_point_orders(h);
     if (rc0) return rc0;
+    if (d_stop && reinterpret_cast<uintptr_t>(d_H) % 16) return fail(PCS_ERR_ARG, "normal equations behind a stop flag need a 16-byte aligned buffer");
     if (reinterpret_cast<uintptr_t>(d_H) % 16 == 0) {   // slab_prep and the zeroing of the outputs in one launch
         HIPCHK(order_after_done(h, s));
         const int has_pose = h->chain != PCS_CHAIN_FREE, copy_points = h->chain != PCS_CHAIN_TEMPLATE;
@@ -1136,7 +1137,7 @@ static int enqueue_normal(pcs_engine *h, const double *d_prm, double *d_H, doubl
         const int zero_blocks = (int)std::min<int64_t>((n_h / 2 + 63) / 64 + 1, (int64_t)h->n_cu * 32);
         hipLaunchKernelGGL(normal_prologue_kernel, dim3((unsigned)(prep_blocks + zero_blocks)), dim3(64), 0, s, d_prm, (double *)h->d_cam_slab,
                            (double *)h->d_pose_slab, (double *)h->d_points, (int)h->n_cams, (int)h->n_imgs, (int)h->n_keys, h->extr_off,
-                           h->pose_off, h->point_off, has_pose, copy_points, prep_blocks, d_H, n_h, d_g, h->n_params, d_cost);
+                           h->pose_off, h->point_off, has_pose, copy_points, prep_blocks, d_H, n_h, d_g, h->n_params, d_cost, d_stop);
         HIPCHK(hipGetLastError());
         h->linearized = true;
     } else {
@@ -1161,6 +1162,7 @@ static int enqueue_normal(pcs_engine *h, const double *d_prm, double *d_H, doubl
     a.extr_off = h->extr_off; a.pose_off = h->pose_off; a.point_off = h->point_off;
     a.n_params = h->n_params;
     a.debug = h->normal_debug;
+    a.stop = d_stop;
     // every wave walks a contiguous range of tiles, so its register accumulators survive across tiles.  One-wave
     // workgroups; the LDS image (22.9 KB for 22 columns x 64 rows) allows 7 per CU, and exactly one resident round of
     // waves is fastest (92 us against 105 us with two rounds on rig-32, profiles/r02/sweeps.md).
@@ -1657,18 +1659,15 @@ int pcs_normal_blocks_device(pcs_engine *h, const double *d_param_str, double *d
     return enqueue_normal(h, d_param_str, d_packed, d_g, d_g + h->n_params, s, true);
 }
 
-int pcs_schur_prepare(pcs_engine *h, double *d_packed, const uint8_t *d_fixed, const double *d_lambda, double *d_linvt, double *d_u,
-                      double *d_V, double *d_S, double *d_rhs, double *d_dvec, double *d_gm, int32_t *d_status, void *stream) {
-    if (!h || !d_packed || !d_fixed || !d_lambda || !d_linvt || !d_u || !d_V || !d_S || !d_rhs || !d_dvec || !d_gm || !d_status)
-        return fail(PCS_ERR_ARG, "pcs_schur_prepare: bad arguments");
-    HIPCHK(hipSetDevice(h->device));
-    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+static int enqueue_schur_prepare(pcs_engine *h, double *d_packed, const uint8_t *d_fixed, const double *d_lambda, double *d_linvt, double *d_u,
+                                 double *d_V, double *d_S, double *d_rhs, double *d_dvec, double *d_gm, int32_t *d_status, hipStream_t s, const int32_t *d_stop) {
     const BlockLayout L = block_layout(h);
     SchurArgs a{};
     a.A = d_packed; a.B = d_packed + L.a_len(); a.C = a.B + L.b_len(); a.g = a.C + L.c_len();
     a.fixed = d_fixed; a.lambda = d_lambda;
     a.linvt = d_linvt; a.u = d_u; a.V = d_V; a.S = d_S; a.rhs = d_rhs; a.dvec = d_dvec; a.gm = d_gm; a.status = d_status;
     a.n_lead = L.n_lead; a.n_trail = L.n_trail; a.n_ent = L.n_ent; a.trail_off = L.trail_off;
+    a.stop = d_stop;
     auto blocks = [](int64_t n) { return dim3((unsigned)((n + 255) / 256)); };
     if (L.n_ent > 0) {
         if (L.tb == 6) hipLaunchKernelGGL(schur_trail_kernel<6>, blocks(L.n_ent), dim3(256), 0, s, a);
@@ -1687,14 +1686,38 @@ int pcs_schur_prepare(pcs_engine *h, double *d_packed, const uint8_t *d_fixed, c
     return PCS_OK;
 }
 
+int pcs_schur_prepare(pcs_engine *h, double *d_packed, const uint8_t *d_fixed, const double *d_lambda, double *d_linvt, double *d_u,
+                      double *d_V, double *d_S, double *d_rhs, double *d_dvec, double *d_gm, int32_t *d_status, void *stream) {
+    if (!h || !d_packed || !d_fixed || !d_lambda || !d_linvt || !d_u || !d_V || !d_S || !d_rhs || !d_dvec || !d_gm || !d_status)
+        return fail(PCS_ERR_ARG, "pcs_schur_prepare: bad arguments");
+    HIPCHK(hipSetDevice(h->device));
+    return enqueue_schur_prepare(h, d_packed, d_fixed, d_lambda, d_linvt, d_u, d_V, d_S, d_rhs, d_dvec, d_gm, d_status, stream ? (hipStream_t)stream : h->stream, nullptr);
+}
+
 int pcs_lm_decide(pcs_engine *h, const double *d_cost_old, const double *d_cost_new, const double *d_dvec, const double *d_gm, const double *d_delta,
                   const double *d_ps, const uint8_t *d_fixed, int32_t *d_status, double *d_lambda, double *d_stats, void *stream) {
     if (!h || !d_cost_old || !d_cost_new || !d_dvec || !d_gm || !d_delta || !d_ps || !d_fixed || !d_status || !d_lambda || !d_stats)
         return fail(PCS_ERR_ARG, "pcs_lm_decide: bad arguments");
     HIPCHK(hipSetDevice(h->device));
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
-    LmDecideArgs a{d_cost_old, d_cost_new, d_dvec, d_gm, d_delta, d_ps, d_fixed, d_status, d_lambda, d_stats, h->n_params};
+    LmDecideArgs a{d_cost_old, d_cost_new, d_dvec, d_gm, d_delta, d_ps, d_fixed, d_status, d_lambda, d_stats, h->n_params, nullptr, nullptr, nullptr};
     hipLaunchKernelGGL(lm_decide_kernel, dim3(1), dim3(1024), 0, s, a);
+    HIPCHK(hipGetLastError());
+    return PCS_OK;
+}
+
+static int enqueue_schur_finish(pcs_engine *h, const double *d_linvt, const double *d_u, const double *d_w, const double *d_xlead, const uint8_t *d_fixed,
+                                double *d_delta, const double *d_ps_in, double *d_ps_out, hipStream_t s, const int32_t *d_stop) {
+    const BlockLayout L = block_layout(h);
+    SchurBackArgs a{};
+    a.linvt = d_linvt; a.u = d_u; a.w = d_w; a.xl = d_xlead; a.fixed = d_fixed; a.delta = d_delta;
+    a.ps_in = d_ps_in; a.ps_out = d_ps_out;
+    a.n_lead = L.n_lead; a.n_ent = L.n_ent; a.trail_off = L.trail_off;
+    a.stop = d_stop;
+    const int64_t n = std::max(L.n_lead, L.n_ent);
+    const dim3 grid((unsigned)((n + 255) / 256));
+    if (L.tb == 6) hipLaunchKernelGGL(schur_back_kernel<6>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(schur_back_kernel<3>, grid, dim3(256), 0, s, a);
     HIPCHK(hipGetLastError());
     return PCS_OK;
 }
@@ -1704,24 +1727,27 @@ int pcs_schur_finish(pcs_engine *h, const double *d_linvt, const double *d_u, co
     if (!h || !d_linvt || !d_u || !d_w || !d_xlead || !d_fixed || !d_delta || ((d_ps_in == nullptr) != (d_ps_out == nullptr)))
         return fail(PCS_ERR_ARG, "pcs_schur_finish: bad arguments");
     HIPCHK(hipSetDevice(h->device));
-    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
-    const BlockLayout L = block_layout(h);
-    SchurBackArgs a{};
-    a.linvt = d_linvt; a.u = d_u; a.w = d_w; a.xl = d_xlead; a.fixed = d_fixed; a.delta = d_delta;
-    a.ps_in = d_ps_in; a.ps_out = d_ps_out;
-    a.n_lead = L.n_lead; a.n_ent = L.n_ent; a.trail_off = L.trail_off;
-    const int64_t n = std::max(L.n_lead, L.n_ent);
-    const dim3 grid((unsigned)((n + 255) / 256));
-    if (L.tb == 6) hipLaunchKernelGGL(schur_back_kernel<6>, grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(schur_back_kernel<3>, grid, dim3(256), 0, s, a);
-    HIPCHK(hipGetLastError());
-    return PCS_OK;
+    return enqueue_schur_finish(h, d_linvt, d_u, d_w, d_xlead, d_fixed, d_delta, d_ps_in, d_ps_out, stream ? (hipStream_t)stream : h->stream, nullptr);
 }
 
 int64_t pcs_dense_spd_work_len(int64_t n) {   // launch-per-column form: inverses + diagonal tiles + y; one-launch form: flags + x + y
     if (n <= 0) return -1;
     const int64_t nb = (n + 31) / 32;
     return std::max<int64_t>(2 * nb * 32 * 32 + nb * 32, cp_work_doubles(nb));
+}
+
+static int enqueue_schur_syrk(int64_t n_lead, int64_t n_trail, const double *d_V, int64_t ldv, double *d_S, int64_t lds, const double *d_u, double *d_rhs,
+                              hipStream_t s, const int32_t *d_stop) {
+    const int64_t nb = (n_lead + 31) / 32, tiles = nb * (nb + 1) / 2;
+    // split K until ~512 workgroups exist (rig-32: 120 tiles x 5; the 2e4-point free chain: 21 tiles x 25 of 60 000 columns)
+    int64_t ksplit = std::min<int64_t>((512 + tiles - 1) / tiles, (n_trail + 127) / 128);
+    ksplit = std::max<int64_t>(1, ksplit);
+    int64_t kchunk = ((n_trail + ksplit - 1) / ksplit + 63) / 64 * 64;
+    ksplit = (n_trail + kchunk - 1) / kchunk;
+    SchurSyrkArgs a{d_V, d_S, d_u, d_rhs, (int32_t)n_lead, (int32_t)n_trail, (int32_t)ldv, (int32_t)lds, (int32_t)ksplit, (int32_t)kchunk, d_stop};
+    hipLaunchKernelGGL(schur_syrk_kernel, dim3((unsigned)(tiles * ksplit)), dim3(256), 0, s, a);
+    HIPCHK(hipGetLastError());
+    return PCS_OK;
 }
 
 int pcs_schur_syrk(int device, int64_t n_lead, int64_t n_trail, const double *d_V, int64_t ldv, double *d_S, int64_t lds, const double *d_u,
@@ -1731,16 +1757,7 @@ int pcs_schur_syrk(int device, int64_t n_lead, int64_t n_trail, const double *d_
     if (device < 0 || device >= pcs_device_count()) return fail(PCS_ERR_NODEVICE, "pcs_schur_syrk: device %d not available", device);
     if (n_trail == 0) return PCS_OK;
     HIPCHK(hipSetDevice(device));
-    const int64_t nb = (n_lead + 31) / 32, tiles = nb * (nb + 1) / 2;
-    // split K until ~512 workgroups exist (rig-32: 120 tiles x 5; the 2e4-point free chain: 21 tiles x 25 of 60 000 columns)
-    int64_t ksplit = std::min<int64_t>((512 + tiles - 1) / tiles, (n_trail + 127) / 128);
-    ksplit = std::max<int64_t>(1, ksplit);
-    int64_t kchunk = ((n_trail + ksplit - 1) / ksplit + 63) / 64 * 64;
-    ksplit = (n_trail + kchunk - 1) / kchunk;
-    SchurSyrkArgs a{d_V, d_S, d_u, d_rhs, (int32_t)n_lead, (int32_t)n_trail, (int32_t)ldv, (int32_t)lds, (int32_t)ksplit, (int32_t)kchunk};
-    hipLaunchKernelGGL(schur_syrk_kernel, dim3((unsigned)(tiles * ksplit)), dim3(256), 0, (hipStream_t)stream, a);
-    HIPCHK(hipGetLastError());
-    return PCS_OK;
+    return enqueue_schur_syrk(n_lead, n_trail, d_V, ldv, d_S, lds, d_u, d_rhs, (hipStream_t)stream, nullptr);
 }
 
 int pcs_schur_vtx(int device, int64_t n_lead, int64_t n_trail, const double *d_V, int64_t ldv, const double *d_x, double *d_w, void *stream) {
@@ -1748,7 +1765,7 @@ int pcs_schur_vtx(int device, int64_t n_lead, int64_t n_trail, const double *d_V
     if (device < 0 || device >= pcs_device_count()) return fail(PCS_ERR_NODEVICE, "pcs_schur_vtx: device %d not available", device);
     if (n_trail == 0) return PCS_OK;
     HIPCHK(hipSetDevice(device));
-    hipLaunchKernelGGL(schur_vtx_kernel, dim3((unsigned)((n_trail + 63) / 64)), dim3(1024), 0, (hipStream_t)stream, d_V, d_x, d_w, (int)n_lead, (int)n_trail, (int)ldv);
+    hipLaunchKernelGGL(schur_vtx_kernel, dim3((unsigned)((n_trail + 63) / 64)), dim3(1024), 0, (hipStream_t)stream, d_V, d_x, d_w, (int)n_lead, (int)n_trail, (int)ldv, (const int32_t *)nullptr);
     HIPCHK(hipGetLastError());
     return PCS_OK;
 }
@@ -1768,8 +1785,16 @@ int pcs_dense_spd_solve(int device, int64_t n, double *d_S, int64_t ld, const do
     return pcs_dense_spd_solve_algo(device, n, d_S, ld, d_rhs, d_x, d_work, d_status, stream, PCS_SPD_AUTO);
 }
 
+static int enqueue_dense_spd(int device, int64_t n, double *d_S, int64_t ld, const double *d_rhs, double *d_x, double *d_work, int32_t *d_status, void *stream,
+                             int algorithm, const int32_t *d_stop);
+
 int pcs_dense_spd_solve_algo(int device, int64_t n, double *d_S, int64_t ld, const double *d_rhs, double *d_x, double *d_work, int32_t *d_status, void *stream,
                              int algorithm) {
+    return enqueue_dense_spd(device, n, d_S, ld, d_rhs, d_x, d_work, d_status, stream, algorithm, nullptr);
+}
+
+static int enqueue_dense_spd(int device, int64_t n, double *d_S, int64_t ld, const double *d_rhs, double *d_x, double *d_work, int32_t *d_status, void *stream,
+                             int algorithm, const int32_t *d_stop) {
     constexpr int NB = 32;
     if (n <= 0 || n > (1 << 15) || ld < n || !d_S || !d_rhs || !d_x || !d_work || !d_status) return fail(PCS_ERR_ARG, "pcs_dense_spd_solve: bad arguments");
     if (algorithm != PCS_SPD_AUTO && algorithm != PCS_SPD_LAUNCHES && algorithm != PCS_SPD_ONE_LAUNCH) return fail(PCS_ERR_ARG, "pcs_dense_spd_solve: unknown algorithm %d", algorithm);
@@ -1781,7 +1806,7 @@ int pcs_dense_spd_solve_algo(int device, int64_t n, double *d_S, int64_t ld, con
         const bool fits = cp_fits(n, cus);
         if (algorithm == PCS_SPD_ONE_LAUNCH && !fits) return fail(PCS_ERR_ARG, "pcs_dense_spd_solve: n = %lld does not fit the one-launch form on %d compute units", (long long)n, cus);
         if (fits && (algorithm == PCS_SPD_ONE_LAUNCH || (algorithm == PCS_SPD_AUTO && !env_launches))) {
-            HIPCHK(cp_launch(n, d_S, ld, d_rhs, d_x, d_work, d_status, cus, (hipStream_t)stream));
+            HIPCHK(cp_launch(n, d_S, ld, d_rhs, d_x, d_work, d_status, cus, (hipStream_t)stream, 0.25, nullptr, d_stop));
             return PCS_OK;
         }
     }
@@ -1789,7 +1814,7 @@ int pcs_dense_spd_solve_algo(int device, int64_t n, double *d_S, int64_t ld, con
     const int nblk = (int)((n + NB - 1) / NB);
     double *d_ldiag = d_work + (int64_t)nblk * NB * NB;
     double *d_y = d_ldiag + (int64_t)nblk * NB * NB;
-    CholArgs a{d_S, d_work, d_ldiag, d_status, (int32_t)n, (int32_t)ld, 0, d_rhs, d_y};
+    CholArgs a{d_S, d_work, d_ldiag, d_status, (int32_t)n, (int32_t)ld, 0, d_rhs, d_y, d_stop};
     a.k = 0;
     hipLaunchKernelGGL(chol_panel_kernel<NB>, dim3((unsigned)nblk), dim3(256), 0, s, a);
     for (int k = 0; k + 1 < nblk; ++k) {   // trailing update with column k + panel step of column k + 1, one launch
@@ -1814,13 +1839,62 @@ int pcs_dense_spd_solve_algo(int device, int64_t n, double *d_S, int64_t ld, con
             run(s, base, mid, kb1);
             const int r0 = mid * NBk, r1 = std::min<int>(kb1 * NBk, base.n), c0 = kb0 * NBk, c1 = mid * NBk;
             hipLaunchKernelGGL(chol_gemv_t_kernel, dim3((unsigned)((c1 - c0 + 63) / 64)), dim3(1024), 0, s, (const double *)base.L, (int)base.ld, (const double *)base.x, base.y,
-                               r0, r1, c0, c1);
+                               r0, r1, c0, c1, base.stop);
             run(s, base, kb0, mid);
         }
     };
-    CholSolveArgs b{d_S, d_work, d_ldiag, d_y, d_x, (int32_t)n, (int32_t)ld, 0, nblk};
+    CholSolveArgs b{d_S, d_work, d_ldiag, d_y, d_x, (int32_t)n, (int32_t)ld, 0, nblk, d_stop};
     Rec::run(s, b, 0, nblk);
     HIPCHK(hipGetLastError());
+    return PCS_OK;
+}
+
+// One whole Levenberg-Marquardt trial, queued in one call: damped Schur step from packed_cur at *lambda (+ the trial parameter
+// string), normal equations at the trial string into packed_new, the decision INCLUDING the loop's termination rules, the copy of an
+// accepted trial over the current state, and the read-back of the ten numbers the host follows the loop with.  Every kernel starts
+// with PCS_STOP_GUARD on b->stop_flag, so the host may queue trial t + 1 before it has read the verdict of trial t.
+int pcs_lm_trial(pcs_engine *h, const pcs_lm_buffers *b, void *stream) {
+    if (!h || !b || !b->packed_cur || !b->packed_new || !b->fixed || !b->lambda || !b->linvt || !b->u || !b->V || !b->S || !b->rhs || !b->dvec || !b->gm ||
+        !b->status || !b->xlead || !b->w || !b->spd_work || !b->delta || !b->ps_cur || !b->ps_new || !b->ctrl || !b->stop_flag || !b->accept_flag || !b->stats)
+        return fail(PCS_ERR_ARG, "pcs_lm_trial: bad arguments");
+    if (reinterpret_cast<uintptr_t>(b->packed_cur) % 16 || reinterpret_cast<uintptr_t>(b->packed_new) % 16) return fail(PCS_ERR_ARG, "pcs_lm_trial: the packed buffers must be 16-byte aligned");
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    const BlockLayout L = block_layout(h);
+    const int32_t *stop = b->stop_flag;
+    int rc = enqueue_schur_prepare(h, b->packed_cur, b->fixed, b->lambda, b->linvt, b->u, b->V, b->S, b->rhs, b->dvec, b->gm, b->status, s, stop);
+    if (rc) return rc;
+    const int64_t ldv = std::max<int64_t>(1, L.n_trail);
+    if (L.n_trail > 0 && L.n_lead > 0) {
+        rc = enqueue_schur_syrk(L.n_lead, L.n_trail, b->V, ldv, b->S, L.n_lead, b->u, b->rhs, s, stop);
+        if (rc) return rc;
+    }
+    const double *w = b->u;
+    if (L.n_lead > 0) {
+        rc = enqueue_dense_spd(h->device, L.n_lead, b->S, L.n_lead, b->rhs, b->xlead, b->spd_work, b->status, s, b->spd_algorithm, stop);
+        if (rc) return rc;
+        if (L.n_trail > 0) {
+            hipLaunchKernelGGL(schur_vtx_kernel, dim3((unsigned)((L.n_trail + 63) / 64)), dim3(1024), 0, s, (const double *)b->V, (const double *)b->xlead, b->w, (int)L.n_lead,
+                               (int)L.n_trail, (int)ldv, stop);
+            HIPCHK(hipGetLastError());
+            w = b->w;
+        }
+    }
+    rc = enqueue_schur_finish(h, b->linvt, b->u, w, b->xlead, b->fixed, b->delta, b->ps_cur, b->ps_new, s, stop);
+    if (rc) return rc;
+    const int64_t n_packed = L.a_len() + L.b_len() + L.c_len() + h->n_params + 1;
+    double *g_new = b->packed_new + L.a_len() + L.b_len() + L.c_len();
+    rc = enqueue_normal(h, b->ps_new, b->packed_new, g_new, g_new + h->n_params, s, true, stop);
+    if (rc) return rc;
+    LmDecideArgs a{b->packed_cur + n_packed - 1, b->packed_new + n_packed - 1, b->dvec, b->gm, b->delta, b->ps_cur, b->fixed, b->status, b->lambda, b->stats,
+                   h->n_params, b->ctrl, b->stop_flag, b->accept_flag};
+    hipLaunchKernelGGL(lm_decide_kernel, dim3(1), dim3(1024), 0, s, a);
+    HIPCHK(hipGetLastError());
+    const int copy_blocks = (int)std::min<int64_t>((n_packed / 2 + 255) / 256 + 1, (int64_t)h->n_cu * 8);
+    hipLaunchKernelGGL(lm_accept_kernel, dim3((unsigned)copy_blocks), dim3(256), 0, s, (const int32_t *)b->accept_flag, (const double *)b->packed_new, b->packed_cur, n_packed,
+                       (const double *)b->ps_new, b->ps_cur, h->n_params);
+    HIPCHK(hipGetLastError());
+    if (b->stats_host) HIPCHK(hipMemcpyAsync(b->stats_host, b->stats, sizeof(double) * 10, hipMemcpyDeviceToHost, s));
     return PCS_OK;
 }
 

@@ -375,10 +375,115 @@ def _lm_solve_blocked(ne: BlockedNormalEquations, ps0: np.ndarray, *, max_iter, 
     eng.set_option("timing_every", 0)
     eng.set_option("lazy_done_event", 2)
     try:
-        return _lm_loop_blocked(ne, ps0, max_iter=max_iter, ftol=ftol, xtol=xtol, gtol=gtol, lam0=lam0, verbose=verbose)
+        loop = _lm_loop_blocked if ne.reduce_fn is not None else _lm_loop_device   # sharded: the all-reduce sits between build and decision
+        return loop(ne, ps0, max_iter=max_iter, ftol=ftol, xtol=xtol, gtol=gtol, lam0=lam0, verbose=verbose)
     finally:
         eng.set_option("lazy_done_event", saved[1])   # flushes the pending record while the stream exists
         eng.set_option("timing_every", saved[0])
+
+
+_RINGS = {}
+
+
+def _stats_ring(torch, dev, ring: int):
+    key = (dev.index, ring)
+    if key not in _RINGS:
+        _RINGS[key] = ([torch.zeros(10, dtype=torch.float64).pin_memory() for _ in range(ring)], [torch.cuda.Event() for _ in range(ring)])
+    return _RINGS[key]
+
+
+STOP_MESSAGES = {0: "maximum number of iterations reached", 1: "gtol reached", 2: "no further decrease (damping exhausted)", 3: "ftol reached", 4: "xtol reached",
+                 5: "maximum number of iterations reached"}
+STOP_STATUS = {0: 0, 1: 1, 2: 2, 3: 3, 4: 4, 5: 0}
+
+
+def _lm_loop_device(ne: BlockedNormalEquations, ps0: np.ndarray, *, max_iter, ftol, xtol, gtol, lam0, verbose):
+    """The single-GPU loop, steered by the DEVICE (round 4): one ``pcs_lm_trial`` call queues a whole trial — step, build at the trial
+    string, the decision WITH the termination rules, the copy of an accepted trial over the current state, a 10-double read-back — and
+    every kernel of it starts by reading a stop word.  The host therefore queues trial t + 1 BEFORE it reads the verdict of trial t:
+    the GPU never idles between trials (38-53 us per trial on rig-32, profiles/r04/lm_trace_rig32.log), and when the loop ends the one
+    speculative trial behind it drains as a dozen empty launches.  Same rules and the same results as `_lm_loop_blocked`."""
+    from ._capi import LmBuffers
+    from .engine import SPD_ALGORITHMS
+
+    torch = ne.torch
+    dev = ne.dev
+    with torch.cuda.device(dev), torch.cuda.stream(ne.stream):
+        stream = ne.stream.cuda_stream
+        ps = torch.from_numpy(np.ascontiguousarray(ps0, dtype=np.float64)).to(dev)
+        ps_new = torch.empty_like(ps)
+        lam = torch.full((1,), float(lam0), dtype=torch.float64, device=dev)
+        ctrl = torch.tensor([0.0, 0.0, 0.0, float(max_iter), ftol, xtol, gtol, 12.0, 0.0], dtype=torch.float64, device=dev)
+        flags = torch.zeros(2, dtype=torch.int32, device=dev)          # [stop, accepted]
+        stats_dev = torch.zeros(10, dtype=torch.float64, device=dev)
+        ring = 4
+        stats_host, done = _stats_ring(torch, dev, ring)   # page-locked: allocated once per device, not per solve (hipHostMalloc costs ~0.2 ms)
+        ne.build(ps, 0)
+        sumsq = float(ne.cost(0).item())
+        history = [0.5 * sumsq]
+
+        def buffers(k):
+            b = LmBuffers()
+            b.packed_cur, b.packed_new = ne.packed[0].data_ptr(), ne.packed[1].data_ptr()
+            b.fixed, b.lam = ne.fixed.data_ptr(), lam.data_ptr()
+            b.linvt, b.u, b.V, b.S, b.rhs, b.dvec, b.gm = (t.data_ptr() for t in (ne.linvt, ne.u, ne.V, ne.S, ne.rhs, ne.dvec, ne.gm))
+            b.status, b.xlead, b.w, b.spd_work = ne.status.data_ptr(), ne.xl.data_ptr(), ne.w.data_ptr(), ne.chol_work.data_ptr()
+            b.delta, b.ps_cur, b.ps_new = ne.delta.data_ptr(), ps.data_ptr(), ps_new.data_ptr()
+            b.ctrl, b.stop_flag, b.accept_flag = ctrl.data_ptr(), flags.data_ptr(), flags.data_ptr() + 4
+            b.stats, b.stats_host = stats_dev.data_ptr(), stats_host[k % ring].data_ptr()
+            b.spd_algorithm = SPD_ALGORITHMS[ne.spd_algorithm]
+            return b
+
+        def enqueue(k):
+            ne.eng.lm_trial(buffers(k), stream)
+            done[k % ring].record()
+
+        code, nfev, n_lin, it = 0, 1, 0, 0
+        limit = 12 * max_iter + 16          # every accepted step is preceded by fewer than 12 rejections
+        queued = 0
+        enqueue(queued)
+        queued += 1
+        read = 0
+        while read < limit:
+            if code == 0 and queued < limit:   # speculate: the next trial goes out before this one's verdict is read
+                enqueue(queued)
+                queued += 1
+            done[read % ring].synchronize()
+            st = stats_host[read % ring].numpy().copy()
+            read += 1
+            if st[9] < 0:                       # a launch that found the flag raised: nothing happened
+                if read >= queued:
+                    break
+                continue
+            n_lin += 1
+            nfev += 1
+            if verbose:
+                print(f"  trial {int(st[9])}: lam {st[7]:.2e} cost {0.5 * st[6]:.6e} -> {0.5 * st[5]:.6e} accepted {bool(st[0] > 0)} stop {int(st[8])}")
+            if st[0] > 0:
+                it += 1
+                history.append(0.5 * float(st[5]))
+            code = int(st[8])
+            if code == 9:   # the one-launch dense solve gave up waiting: repeat the trial with the launch-per-column form
+                torch.cuda.current_stream().synchronize()      # whatever was queued behind it has drained as no-ops
+                ne.spd_algorithm = "launches"
+                ctrl[0] = 0.0
+                flags.zero_()
+                nfev -= 1
+                n_lin -= 1
+                code = 0
+                read = queued                                   # forget the drained launches
+                if queued < limit:
+                    enqueue(queued)
+                    queued += 1
+                continue
+            if code != 0 and read >= queued:
+                break
+        torch.cuda.current_stream().synchronize()
+        g = ne.gradient(0)
+        x = ps[ne.free_idx].cpu().numpy()
+        cost = 0.5 * float(ne.cost(0).item())
+    return DeviceLMResult(x=x, cost=cost, grad=g, optimality=float(np.max(np.abs(g))) if g.size else 0.0, nit=it, nfev=nfev,
+                          n_jtjv=n_lin, status=STOP_STATUS.get(code, 0), message=STOP_MESSAGES.get(code, f"stopped ({code})"), history=history)
 
 
 def _lm_loop_blocked(ne: BlockedNormalEquations, ps0: np.ndarray, *, max_iter, ftol, xtol, gtol, lam0, verbose):
@@ -412,8 +517,7 @@ def _lm_loop_blocked(ne: BlockedNormalEquations, ps0: np.ndarray, *, max_iter, f
                 verdict.synchronize()
                 stats = stats_host.numpy().copy()
                 if stats[0] < 0:   # the one-launch dense solve gave up waiting (status bit 2): nothing of this trial is valid —
-                    ne.spd_algorithm = "launches"   # repeat it with the launch-per-column form, at the damping it was meant to have
-                    lam.mul_(0.25)
+                    ne.spd_algorithm = "launches"   # repeat it with the launch-per-column form (the decision left the damping alone)
                     continue
                 gmax = float(stats[1])
                 if verbose:
@@ -619,7 +723,16 @@ def lm_solve(handler, x0, *, max_iter: int = 50, ftol: float = 1e-8, xtol: float
         if linear_solver == "auto":   # blocked J^T J while its regions fit comfortably; beyond that matrix-free CG
             linear_solver = "cholesky" if blocked_fits(eng) else "pcg"
         if linear_solver == "cholesky":
-            ne = BlockedNormalEquations(eng, handler._jac_mask(), reduce_fn=reduce_fn)
+            # the solver's device workspace (two packed states, V, S, a stream) lives with the engine: a second solve on the same
+            # table and mask — the usual case: a calibration re-run with other start values or tolerances — allocates nothing
+            mask = np.asarray(handler._jac_mask(), dtype=bool)
+            key = (hash(mask.tobytes()), id(reduce_fn))
+            cache = eng.__dict__.setdefault("_blocked_solvers", {})
+            ne = cache.get(key)
+            if ne is None:
+                cache.clear()
+                ne = cache[key] = BlockedNormalEquations(eng, mask, reduce_fn=reduce_fn)
+            ne.spd_algorithm = "auto"
             ps0 = op_fun.build_param_list(*handler.get_bundle_adjustment_inputs(np.array(x0, dtype=np.float64)))
             return _lm_solve_blocked(ne, ps0, max_iter=max_iter, ftol=ftol, xtol=xtol, gtol=gtol, lam0=lam0, verbose=verbose)
         operator = JacobianOperator(eng, handler._jac_mask(), reduce_fn=reduce_fn)

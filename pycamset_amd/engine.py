@@ -108,6 +108,7 @@ class Engine:
     # -- lifetime -----------------------------------------------------------------------------
     def close(self):
         self._rings = {}
+        self.__dict__.pop("_blocked_solvers", None)   # device_solver's cached workspace refers to this engine
         if getattr(self, "_h", None) is not None and self._h:
             lib().pcs_destroy(self._h)
             self._h = c_void_p()
@@ -297,6 +298,13 @@ class Engine:
     def lm_decide(self, d_cost_old, d_cost_new, d_dvec, d_gm, d_delta, d_ps, d_fixed, d_status, d_lambda, d_stats, stream=None):
         check(lib().pcs_lm_decide(self._h, *(c_void_p(p) for p in (d_cost_old, d_cost_new, d_dvec, d_gm, d_delta, d_ps, d_fixed, d_status, d_lambda, d_stats)),
                                   _stream_arg(stream)))
+
+    def lm_trial(self, buffers, stream=None):
+        """One whole LM trial (step, build at the trial string, decision with the termination rules, accept copy, read-back) in one
+        call; ``buffers`` = a filled ``_capi.LmBuffers`` (include/pcs_hip.h pcs_lm_buffers)."""
+        import ctypes
+
+        check(lib().pcs_lm_trial(self._h, ctypes.byref(buffers), _stream_arg(stream)))
 
     # -- evaluation: device buffers -----------------------------------------------------------
     def eval_device(self, param_str, d_resid: int | None, d_jac: int | None, stream: int | None = None):
