@@ -266,6 +266,99 @@ __global__ __launch_bounds__(256) void schur_syrk_kernel(const SchurSyrkArgs a) 
     }
 }
 
+// The same update on 64 x 64 tiles, for large leading groups (rig-32-self: 1 680 x 1 458).  With 32 x 32 tiles every workgroup
+// streams 2 x 32 rows of V for 32 x 32 outputs: 1 431 tiles x 1 458 columns x 512 B = 1.05 GB through L2 / Infinity Cache for a
+// 19.6 MB matrix — 175 us, bandwidth-bound at 6 TB/s while the matrix cores idle two thirds of the time (their floor: 60 us).
+// A 64 x 64 tile halves the bytes per FMA: four waves = four 32 x 32 quadrants (2 x 2 MFMA tiles each: two operand reads feed
+// four v_mfma_f64_16x16x4 per k-step), both row blocks staged 32 columns at a time (row stride 36 doubles), the next chunk in
+// flight meanwhile.  Same K split, same atomics, same rhs += V u by the diagonal tiles.
+constexpr int SYRK64_LD = 36;
+__global__ __launch_bounds__(256) void schur_syrk64_kernel(const SchurSyrkArgs a) {
+    PCS_STOP_GUARD(a);
+    __shared__ double P[64][SYRK64_LD];
+    __shared__ double Q[64][SYRK64_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int t = blockIdx.x / a.ksplit, kc = blockIdx.x % a.ksplit;
+    int bi = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);   // t -> (bi, bj), 0 <= bj <= bi
+    while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
+    while (bi * (bi + 1) / 2 > t) --bi;
+    const int bj = t - bi * (bi + 1) / 2;
+    const bool diag = bi == bj;
+    const int k_begin = kc * a.kchunk, k_end = min(a.n_trail, k_begin + a.kchunk);
+    const int i0 = 32 * (wave >> 1), j0 = 32 * (wave & 1);   // this wave's quadrant
+    schur_d4 acc[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) acc[x][y] = schur_d4{0.0, 0.0, 0.0, 0.0};
+    const double *pq = diag ? &P[0][0] : &Q[0][0];
+    const double *pa = &P[0][0] + (i0 + (lane & 15)) * SYRK64_LD + (lane >> 4);
+    const double *pb = pq + (j0 + (lane & 15)) * SYRK64_LD + (lane >> 4);
+    double dot = 0.0;   // diagonal tiles: this thread's share of (V u)[row], row = tid / 4
+    double pn[8], qn[8];   // the next 32-column chunk: 64 rows x 32 columns per operand = 8 doubles per thread
+    auto fetch = [&](const int k0) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int e = tid + 256 * q, r = e >> 5, c = e & 31;
+            const int gk = k0 + c;
+            const int gi = bi * 64 + r, gj = bj * 64 + r;
+            pn[q] = (gi < a.n_lead && gk < k_end) ? a.V[(int64_t)gi * a.ldv + gk] : 0.0;
+            qn[q] = (!diag && gj < a.n_lead && gk < k_end) ? a.V[(int64_t)gj * a.ldv + gk] : 0.0;
+        }
+    };
+    if (k_begin < k_end) fetch(k_begin);
+    for (int k0 = k_begin; k0 < k_end; k0 += 32) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int e = tid + 256 * q, r = e >> 5, c = e & 31;
+            P[r][c] = pn[q];
+            if (!diag) Q[r][c] = qn[q];
+        }
+        __syncthreads();
+        if (k0 + 32 < k_end) fetch(k0 + 32);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const double a0 = pa[4 * s], a1 = pa[16 * SYRK64_LD + 4 * s];
+            const double b0 = pb[4 * s], b1 = pb[16 * SYRK64_LD + 4 * s];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (diag && a.u) {
+            const int r = tid >> 2, part = tid & 3;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int gk = k0 + part * 8 + c;
+                dot += P[r][part * 8 + c] * (gk < k_end ? a.u[gk] : 0.0);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gi = bi * 64 + i0 + 16 * x + (lane >> 4) + 4 * r, gj = bj * 64 + j0 + 16 * y + (lane & 15);
+                if (gi < a.n_lead && gj <= gi) {
+                    double *dst = a.S + (int64_t)gi * a.lds + gj;
+                    if (a.ksplit == 1) *dst -= acc[x][y][r];
+                    else unsafeAtomicAdd(dst, -acc[x][y][r]);
+                }
+            }
+    if (diag && a.u) {
+        dot += __shfl_xor(dot, 1);
+        dot += __shfl_xor(dot, 2);
+        const int gi = bi * 64 + (tid >> 2);
+        if ((tid & 3) == 0 && gi < a.n_lead) {
+            if (a.ksplit == 1) a.rhs[gi] += dot;
+            else unsafeAtomicAdd(a.rhs + gi, dot);
+        }
+    }
+}
+
 // w = V' x (n_trail outputs): 64 columns per workgroup, the reads of a row coalesced across a wave, sixteen waves share the rows
 // (four did at first: 19 workgroups x 4 waves x 120 dependent loads = 15 us for 4.6 MB)
 __global__ __launch_bounds__(1024) void schur_vtx_kernel(const double *__restrict__ V, const double *__restrict__ x, double *__restrict__ w,

@@ -1738,14 +1738,21 @@ int64_t pcs_dense_spd_work_len(int64_t n) {   // launch-per-column form: inverse
 
 static int enqueue_schur_syrk(int64_t n_lead, int64_t n_trail, const double *d_V, int64_t ldv, double *d_S, int64_t lds, const double *d_u, double *d_rhs,
                               hipStream_t s, const int32_t *d_stop) {
-    const int64_t nb = (n_lead + 31) / 32, tiles = nb * (nb + 1) / 2;
+    // 64 x 64 tiles once 32 x 32 ones alone would fill the chip twice over (their operand traffic, not the matrix cores, is the bound then:
+    // rig-32-self 175 us -> ~100 us); PCS_SYRK_TILE=32 / 64 forces one form (A/B)
+    static const int forced = getenv("PCS_SYRK_TILE") ? atoi(getenv("PCS_SYRK_TILE")) : 0;
+    const int64_t nb32 = (n_lead + 31) / 32;
+    const bool big = forced == 64 || (forced != 32 && nb32 * (nb32 + 1) / 2 >= 1024);
+    const int64_t tw = big ? 64 : 32;
+    const int64_t nb = (n_lead + tw - 1) / tw, tiles = nb * (nb + 1) / 2;
     // split K until ~512 workgroups exist (rig-32: 120 tiles x 5; the 2e4-point free chain: 21 tiles x 25 of 60 000 columns)
     int64_t ksplit = std::min<int64_t>((512 + tiles - 1) / tiles, (n_trail + 127) / 128);
     ksplit = std::max<int64_t>(1, ksplit);
     int64_t kchunk = ((n_trail + ksplit - 1) / ksplit + 63) / 64 * 64;
     ksplit = (n_trail + kchunk - 1) / kchunk;
     SchurSyrkArgs a{d_V, d_S, d_u, d_rhs, (int32_t)n_lead, (int32_t)n_trail, (int32_t)ldv, (int32_t)lds, (int32_t)ksplit, (int32_t)kchunk, d_stop};
-    hipLaunchKernelGGL(schur_syrk_kernel, dim3((unsigned)(tiles * ksplit)), dim3(256), 0, s, a);
+    if (big) hipLaunchKernelGGL(schur_syrk64_kernel, dim3((unsigned)(tiles * ksplit)), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(schur_syrk_kernel, dim3((unsigned)(tiles * ksplit)), dim3(256), 0, s, a);
     HIPCHK(hipGetLastError());
     return PCS_OK;
 }
