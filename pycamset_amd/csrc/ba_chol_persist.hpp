@@ -40,7 +40,8 @@ struct CholPersistArgs {
     double *S;              // n x n row-major, row stride ld: lower triangle in, L out (the upper triangle is neither read nor written)
     const double *rhs;      // n
     double *x;              // n: the solution
-    double *ypub;           // nb x 32: y = L^-1 rhs, published per block column
+    double *tpub;           // optional (data-polled hand-over): nb (nb - 1) / 2 tiles of 32 x 32, tile (i, j) at i (i - 1) / 2 + j, filled with 0xFF bytes
+    double *ypub;           // nb x 32: y = L^-1 rhs, published per block column (0xFF-filled when tpub is used)
     double *xpub;           // nb x 32: x, published per block (filled with 0xFF bytes by the host)
     int32_t *flags;         // CP_COL + nb words, filled with 0xFF bytes (= -1) by the host: counters start at -1
     int32_t *status;        // |= 2: a pivot was not positive; |= 4: a wait ran out of time (results are not valid)
@@ -121,7 +122,9 @@ __device__ __forceinline__ void cp_decode(const int nb, int t, int &i, int &j) {
 }
 
 // this thread's four entries (e = tid + 256 q -> row e >> 5, column e & 31: whole 256-byte rows per half wave) of the PUBLISHED tile
-// (i, m), i > m, requested with sc1 loads; i == nb: the rhs row, y_m' in row 0
+// (i, m), i > m, requested with sc1 loads; i == nb: the rhs row, y_m' in row 0.  Counter form: from S, after the column's counter
+// has been seen.  Data-polled form (a.tpub): from the tile's slot in `tpub`, whole 8 KB tiles — the caller checks the values against
+// the 0xFF fill and asks again until none is left (cp_fetch_polled).
 __device__ __forceinline__ void cp_fetch(const CholPersistArgs &a, double (&v)[4], const int i, const int m, const int tid) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -129,9 +132,38 @@ __device__ __forceinline__ void cp_fetch(const CholPersistArgs &a, double (&v)[4
         v[q] = 0.0;
         if (i == a.nb) {
             if (r == 0) v[q] = cp_ld(a.ypub + m * 32 + c);
+        } else if (a.tpub) {
+            v[q] = cp_ld(a.tpub + ((int64_t)i * (i - 1) / 2 + m) * 1024 + e);
         } else {
             const int gr = i * 32 + r, gc = m * 32 + c;
             if (gr < a.n) v[q] = cp_ld(a.S + (int64_t)gr * a.ld + gc);   // gc < gr < n
+        }
+    }
+}
+__device__ __forceinline__ bool cp_is_fill(const double (&v)[4]) {
+    bool f = false;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) f = f || (__builtin_bit_cast(uint64_t, v[q]) == CP_FILL);
+    return f;
+}
+// Data-polled hand-over: fetch the operand tile(s) of an update until no value is the fill any more — the producer's stores are
+// the signal (no counter, no acknowledged write, no second round trip).  All threads call it; false = the launch is being abandoned.
+__device__ __forceinline__ bool cp_fetch_polled(const CholPersistArgs &a, double (&vp)[4], double (&vq)[4], const int i, const int j, const int m, const int tid) {
+    const uint64_t t0 = wall_clock64();
+    for (int spins = 1;; ++spins) {
+        cp_fetch(a, vp, i, m, tid);
+        if (i != j) cp_fetch(a, vq, j, m, tid);
+        const bool pending = cp_is_fill(vp) || (i != j && cp_is_fill(vq));
+        if (!__syncthreads_or(pending)) return true;
+        __builtin_amdgcn_s_sleep(1);
+        if ((spins & 63) == 0) {
+            int give_up = 0;
+            if (tid == 0 && (cp_ldi(a.flags + CP_ABORT) >= 0 || (int64_t)(wall_clock64() - t0) > a.timeout_ticks)) {
+                __hip_atomic_store(a.flags + CP_ABORT, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                atomicOr(a.status, 4);
+                give_up = 1;
+            }
+            if (__syncthreads_or(give_up)) return false;
         }
     }
 }
@@ -296,33 +328,38 @@ __global__ __launch_bounds__(256) void chol_persist_kernel(const CholPersistArgs
     // Block column m applied to every slot whose column is in [jlo, jhi]: fetch (sc1) -> park -> products, tile by tile.  (Requesting the
     // next tile's operands before the current tile's products, or all tiles' operands first, changed nothing: the trailing updates
     // hide behind the next column's factorisation either way — profiles/r04/README.md.)
-    auto apply_column = [&](const int m, const int jlo, const int jhi) {
+    auto apply_column = [&](const int m, const int jlo, const int jhi) -> bool {
         for (int s = 0; s < a.slots; ++s) {
             int i, j;
             tile(s, i, j);
             if (i < 0 || j < jlo || j > jhi) continue;
             double vp[4], vq[4];
-            cp_fetch(a, vp, i, m, tid);
-            if (i != j) cp_fetch(a, vq, j, m, tid);
+            if (a.tpub) {
+                if (!cp_fetch_polled(a, vp, vq, i, j, m, tid)) return false;
+            } else {
+                cp_fetch(a, vp, i, m, tid);
+                if (i != j) cp_fetch(a, vq, j, m, tid);
+            }
             cp_park(P, vp, tid);
             if (i != j) cp_park(Q, vq, tid);
             __syncthreads();
             cp_apply(P, Q, Town(s), Td(s), i == j, lane, wave);
             __syncthreads();
         }
+        return true;
     };
 
     // ---- factorisation: iteration m consumes block column m and produces the tiles of column m + 1 ----------------------------------------
     for (int m = -1; m < max_j; ++m) {
         CP_STAMP(m + 1, 0);
-        if (m >= 0 && !cp_wait_wg(a, CP_COL + m, nb - m, wword, tid)) return;
+        if (m >= 0 && !a.tpub && !cp_wait_wg(a, CP_COL + m, nb - m, wword, tid)) return;   // data-polled form: the tiles themselves are the signal
         CP_STAMP(m + 1, 1);
         // urgent: the tiles of column m + 1
         int ncrit = 0;
 #pragma unroll
         for (int s = 0; s < CP_MAX_SLOTS; ++s) ncrit += pk[s] != 0xFFFF && (pk[s] & 255) == m + 1;
         if (ncrit) {
-            if (m >= 0) apply_column(m, m + 1, m + 1);
+            if (m >= 0 && !apply_column(m, m + 1, m + 1)) return;
             CP_STAMP(m + 1, 2);
             for (int s = 0; s < a.slots; ++s) {   // the four waves factor one panel together; a workgroup rarely has a second one in a column
                 int i, j;
@@ -342,6 +379,17 @@ __global__ __launch_bounds__(256) void chol_persist_kernel(const CholPersistArgs
                 const double *To = Town(s);
                 if (i == nb) {
                     if (tid < 32) cp_st(a.ypub + j * 32 + tid, To[tid]);
+                } else if (a.tpub) {
+                    // data-polled form: the whole 32 x 32 tile (padding included) into its slot — write-through, nobody waits for an
+                    // acknowledgement — and the in-range part into S (plain stores: the result, read by nobody in this launch)
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) {
+                        const int e = tid + 256 * qq, r = e >> 5, c = e & 31;
+                        const double v = To[r * CP_LDT + c];
+                        cp_st(a.tpub + ((int64_t)i * (i - 1) / 2 + j) * 1024 + e, v);
+                        const int gr = i * 32 + r, gc = j * 32 + c;
+                        if (gr < a.n && gc < a.n) a.S[(int64_t)gr * a.ld + gc] = v;
+                    }
                 } else {
 #pragma unroll
                     for (int qq = 0; qq < 4; ++qq) {
@@ -351,7 +399,7 @@ __global__ __launch_bounds__(256) void chol_persist_kernel(const CholPersistArgs
                     }
                 }
             }
-            if (published) {
+            if (published && !a.tpub) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
                 CP_STAMP(m + 1, 4);
@@ -363,20 +411,63 @@ __global__ __launch_bounds__(256) void chol_persist_kernel(const CholPersistArgs
             }
         }
         // the rest of the trailing matrix, in the shadow of the next column's factorisation
-        if (m >= 0) apply_column(m, m + 2, 1 << 29);
+        if (m >= 0 && !apply_column(m, m + 2, 1 << 29)) return;
         CP_STAMP(m + 1, 5);
     }
 
     // ---- backward substitution L' x = y: wave 0 of the diagonal tiles' owners, everything in registers ------------------------------------
     if (wave != 0 || !has_diag) return;
     const int k = wg, c = lane & 31;
-    if (!cp_wait_wave(a, CP_COL + k, nb - k, lane)) return;   // y_k is part of column k (long complete for all but the last blocks)
-    double t = cp_ld(a.ypub + k * 32 + c);                    // t = y_k - sum_{i > k} L_ik' x_i, lane c holds entry c
+    double t;                                                 // t = y_k - sum_{i > k} L_ik' x_i, lane c holds entry c
+    if (a.tpub) {                                             // y_k: polled like the tiles (0xFF fill until it is written)
+        const uint64_t t0 = wall_clock64();
+        for (int spins = 1;; ++spins) {
+            t = cp_ld(a.ypub + k * 32 + c);
+            if (__all(__builtin_bit_cast(uint64_t, t) != CP_FILL)) break;
+            __builtin_amdgcn_s_sleep(1);
+            if ((spins & 63) == 0) {
+                int give_up = 0;
+                if (lane == 0 && (cp_ldi(a.flags + CP_ABORT) >= 0 || (int64_t)(wall_clock64() - t0) > a.timeout_ticks)) {
+                    __hip_atomic_store(a.flags + CP_ABORT, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    atomicOr(a.status, 4);
+                    give_up = 1;
+                }
+                if (__builtin_amdgcn_readfirstlane(give_up)) return;
+            }
+        }
+    } else {
+        if (!cp_wait_wave(a, CP_COL + k, nb - k, lane)) return;   // y_k is part of column k (long complete for all but the last blocks)
+        t = cp_ld(a.ypub + k * 32 + c);
+    }
     auto fetch_col = [&](double (&dst)[32], const int i) {    // column c of tile (i, k): what lane c needs for L_ik' x_i
 #pragma unroll
         for (int r = 0; r < 32; ++r) {
             const int gr = i * 32 + r;
-            dst[r] = (gr < a.n) ? cp_ld(a.S + (int64_t)gr * a.ld + k * 32 + c) : 0.0;
+            if (a.tpub) dst[r] = cp_ld(a.tpub + ((int64_t)i * (i - 1) / 2 + k) * 1024 + r * 32 + c);   // may still hold the fill: col_ready() below
+            else dst[r] = (gr < a.n) ? cp_ld(a.S + (int64_t)gr * a.ld + k * 32 + c) : 0.0;
+        }
+    };
+    // Data-polled form: nothing orders this workgroup's arrival here after the OTHER workgroups' tiles of column k (the owner of the
+    // last columns' diagonal tiles gets here while they are still being factored): the column is asked for again until no fill is left.
+    auto col_ready = [&](double (&dst)[32], const int i) -> bool {
+        if (!a.tpub) return true;
+        const uint64_t t0 = wall_clock64();
+        for (int spins = 1;; ++spins) {
+            bool f = false;
+#pragma unroll
+            for (int r = 0; r < 32; ++r) f = f || (__builtin_bit_cast(uint64_t, dst[r]) == CP_FILL);
+            if (!__any(f)) return true;
+            __builtin_amdgcn_s_sleep(1);
+            if ((spins & 63) == 0) {
+                int give_up = 0;
+                if (lane == 0 && (cp_ldi(a.flags + CP_ABORT) >= 0 || (int64_t)(wall_clock64() - t0) > a.timeout_ticks)) {
+                    __hip_atomic_store(a.flags + CP_ABORT, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    atomicOr(a.status, 4);
+                    give_up = 1;
+                }
+                if (__builtin_amdgcn_readfirstlane(give_up)) return false;
+            }
+            fetch_col(dst, i);
         }
     };
     double col[32];
@@ -399,6 +490,7 @@ __global__ __launch_bounds__(256) void chol_persist_kernel(const CholPersistArgs
             }
         }
         if (i == k + 1) CP_STAMP(k, 6);
+        if (!col_ready(col, i)) return;
         double acc = 0.0;
 #pragma unroll
         for (int r = 0; r < 32; ++r) acc += col[r] * lane_bcast(xi, r);
@@ -433,10 +525,11 @@ __global__ __launch_bounds__(256) void chol_persist_kernel(const CholPersistArgs
 
 namespace pcs {
 
-// Workspace of the persistent solve inside pcs_dense_spd_solve's d_work: [flags (CP_COL + nb ints, padded) | xpub nb x 32 | ypub nb x 32];
-// flags and xpub are one contiguous range so that ONE memset of 0xFF bytes prepares a launch.
+// Workspace of the persistent solve inside pcs_dense_spd_solve's d_work: [flags (CP_COL + nb ints, padded) | xpub nb x 32 | ypub nb x 32 |
+// tpub nb (nb - 1) / 2 tiles]; everything a launch needs at the fill value is one contiguous range: ONE memset of 0xFF bytes
+// (flags + xpub in the counter form; all of it in the data-polled form).
 inline int64_t cp_flag_doubles(const int64_t nb) { return ((CP_COL + nb) * 4 + 63) / 64 * 8; }   // whole 64-byte lines
-inline int64_t cp_work_doubles(const int64_t nb) { return cp_flag_doubles(nb) + 2 * nb * 32; }
+inline int64_t cp_work_doubles(const int64_t nb) { return cp_flag_doubles(nb) + 2 * nb * 32 + nb * (nb - 1) / 2 * 1024; }
 
 // Can the persistent form take an n x n system on a device with `n_cus` compute units?  (one workgroup per CU, CP_MAX_SLOTS tiles each)
 inline bool cp_fits(const int64_t n, const int n_cus) {
@@ -446,7 +539,7 @@ inline bool cp_fits(const int64_t n, const int n_cus) {
 
 // Enqueue memset + kernel on `s`.  The caller has checked cp_fits and set the device.
 inline hipError_t cp_launch(const int64_t n, double *d_S, const int64_t ld, const double *d_rhs, double *d_x, double *d_work, int32_t *d_status,
-                            const int n_cus, hipStream_t s, const double timeout_s = 0.25, int64_t *trace = nullptr, const int32_t *d_stop = nullptr) {
+                            const int n_cus, hipStream_t s, const double timeout_s = 0.25, int64_t *trace = nullptr, const int32_t *d_stop = nullptr, const bool poll_data = true) {
     const int64_t nb = (n + 31) / 32, T = cp_tiles(nb);
     const int G = (int)(T < n_cus ? T : n_cus);
     const int slots = (int)((T + G - 1) / G);
@@ -455,6 +548,7 @@ inline hipError_t cp_launch(const int64_t n, double *d_S, const int64_t ld, cons
     a.flags = reinterpret_cast<int32_t *>(d_work);
     a.xpub = d_work + cp_flag_doubles(nb);
     a.ypub = a.xpub + nb * 32;
+    a.tpub = poll_data ? a.ypub + nb * 32 : nullptr;
     a.n = (int32_t)n; a.ld = (int32_t)ld; a.nb = (int32_t)nb; a.slots = slots;
     a.timeout_ticks = (int64_t)(timeout_s * 1.0e8);
     a.stop = d_stop;
@@ -464,7 +558,7 @@ inline hipError_t cp_launch(const int64_t n, double *d_S, const int64_t ld, cons
     (void)trace;
 #endif
     const size_t lds = cp_lds_bytes(slots);
-    hipError_t e = hipMemsetAsync(d_work, 0xFF, sizeof(double) * (size_t)(cp_flag_doubles(nb) + nb * 32), s);
+    hipError_t e = hipMemsetAsync(d_work, 0xFF, sizeof(double) * (size_t)(poll_data ? cp_work_doubles(nb) : cp_flag_doubles(nb) + nb * 32), s);
     if (e != hipSuccess) return e;
     static bool attr_set = false;   // one code object per process: the attribute sticks to the function
     if (!attr_set) {

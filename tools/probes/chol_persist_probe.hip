@@ -69,7 +69,7 @@ static int run(int n, int reps, int pipe) {
     for (int r = 0; r < reps; ++r) {
         CK(hipMemcpyAsync(dS, dS0, sizeof(double) * n * n, hipMemcpyDeviceToDevice, s));
         CK(hipEventRecord(e0, s));
-        CK(pcs::cp_launch(n, dS, n, drhs, dx, dwork, dstatus, cus, s, 0.05, nullptr));
+        CK(pcs::cp_launch(n, dS, n, drhs, dx, dwork, dstatus, cus, s, 0.05, nullptr, nullptr, pipe != 0));
         CK(hipEventRecord(e1, s));
         CK(hipStreamSynchronize(s));
         float ms;
@@ -84,7 +84,7 @@ static int run(int n, int reps, int pipe) {
         CK(hipMalloc(&dtr, tl * 8));
         CK(hipMemset(dtr, 0, tl * 8));
         CK(hipMemcpyAsync(dS, dS0, sizeof(double) * n * n, hipMemcpyDeviceToDevice, s));
-        CK(pcs::cp_launch(n, dS, n, drhs, dx, dwork, dstatus, cus, s, 0.05, dtr));
+        CK(pcs::cp_launch(n, dS, n, drhs, dx, dwork, dstatus, cus, s, 0.05, dtr, nullptr, pipe != 0));
         CK(hipStreamSynchronize(s));
         std::vector<int64_t> tr(tl);
         CK(hipMemcpy(tr.data(), dtr, tl * 8, hipMemcpyDeviceToHost));
@@ -147,7 +147,7 @@ int main(int argc, char **argv) {
     if (ns.empty()) ns = {1, 31, 32, 33, 97, 480, 1003, 1680};
     for (int rep = 0; rep < 2; ++rep)
         for (int n : ns)
-            for (int pipe = 0; pipe < 1; ++pipe)
+            for (int pipe = 0; pipe < 2; ++pipe)   // 0: one counter per block column, 1: the published tiles themselves are polled
                 if (run(n, 12, pipe)) return 1;
     return 0;
 }
