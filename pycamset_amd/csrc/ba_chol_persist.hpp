@@ -13,15 +13,19 @@
 //     the operand it has loaded anyway), so when column j - 1 arrives it can factor the 64 x 32 panel [A_jj; A_ij] at once — one
 //     wave, one row per lane, the elimination of the diagonal tile carries the 32 rows below it along in the same instructions.
 //     No inverse of the diagonal factor on the critical path, no hand-off of the diagonal tile: ONE hand-off per block column;
-//   * published tiles go to S itself (write-through `sc1` stores, `s_waitcnt vmcnt(0)`, workgroup barrier, one agent-scope atomic
-//     add on the column's counter); consumers poll the counter with `sc1` loads and read the tiles with `sc1` loads
-//     (MI355X_MICROARCH.md, "Hand-offs measured with sc1 loads in place of the acquire", first row);
+//   * a published tile goes, whole, to its own slot of a workspace the host has filled with 0xFF bytes (write-through `sc1` stores,
+//     nobody waits for an acknowledgement) and THE DATA IS THE SIGNAL: a consumer reads the slot with `sc1` loads and asks again
+//     until no word holds the fill pattern (an all-ones NaN that no arithmetic produces).  No counter, no `s_waitcnt vmcnt(0)` +
+//     barrier + atomic on the producer's side, no second round trip on the consumer's: the per-column counter this replaced cost
+//     ~2.5 us more per block column (n = 480: 215 -> 157 us; profiles/r04/README.md).  L also goes to S (plain stores: the result);
 //   * each workgroup orders its work by urgency: tiles of the NEXT column first (update, factor, publish), the rest of the trailing
 //     matrix afterwards, in the shadow of the next column's factorisation.
 // Backward substitution L' x = y: distributed over the owners of the diagonal tiles, one wave each.  Owner k keeps
-// s_k = sum_{i > k} L_ik' x_i up to date as the x_i appear (the tile for the next x is already in registers when it arrives),
-// x_k = L_kk^-T (y_k - s_k) with the tile's inverse (formed off the critical path, right after the tile was factored), and
-// publishes x_k as 32 data words that the consumers poll directly (a word differs from the 0xFF..FF fill once it is written).
+// t_k = y_k - sum_{i > k + 1} L_ik' x_i up to date as the x_i appear (every lane loads the 32 words of x_i itself — uniform
+// addresses, so the products need no cross-lane broadcast — and the tile for the next x is already in registers when it arrives).
+// The last arrival is the one on the chain, so its work is prepared: W = (L_k+1,k L_kk^-1)' and u = L_kk^-T t_k are ready, and
+// x_k = u - W x_k+1 is 32 multiply-adds between "x_k+1 visible" and "x_k stored" (2.3 -> 1.x us per block; the hand-off itself is
+// ~1 us).  x is published as 32 data words polled directly, like the tiles.
 //
 // Safety: every wait has a time limit (CholPersistArgs::timeout_ticks of the 100 MHz wall clock) and watches one abort word;
 // a workgroup that gives up sets it and bit 2 (value 4) of *status, and every other workgroup leaves at its next wait — the
@@ -40,10 +44,11 @@ struct CholPersistArgs {
     double *S;              // n x n row-major, row stride ld: lower triangle in, L out (the upper triangle is neither read nor written)
     const double *rhs;      // n
     double *x;              // n: the solution
-    double *tpub;           // optional (data-polled hand-over): nb (nb - 1) / 2 tiles of 32 x 32, tile (i, j) at i (i - 1) / 2 + j, filled with 0xFF bytes
-    double *ypub;           // nb x 32: y = L^-1 rhs, published per block column (0xFF-filled when tpub is used)
-    double *xpub;           // nb x 32: x, published per block (filled with 0xFF bytes by the host)
-    int32_t *flags;         // CP_COL + nb words, filled with 0xFF bytes (= -1) by the host: counters start at -1
+    // the hand-over workspace, filled with 0xFF bytes by the host (one memset): a word differs from the fill once it is written
+    double *tpub;           // nb (nb - 1) / 2 tiles of 32 x 32 (padding included): tile (i, j), i > j, at i (i - 1) / 2 + j
+    double *ypub;           // nb x 32: y = L^-1 rhs, one block per block column
+    double *xpub;           // nb x 32: x, one block per diagonal owner
+    int32_t *flags;         // CP_FLAGS words (= -1 after the fill): the abort word and the "originals are loaded" counter
     int32_t *status;        // |= 2: a pivot was not positive; |= 4: a wait ran out of time (results are not valid)
     int32_t n, ld, nb, slots;   // nb = block columns; slots = tiles per workgroup (LDS is sized for it)
     int64_t timeout_ticks;
@@ -58,7 +63,7 @@ struct CholPersistArgs {
 #define CP_STAMP(col, k) do { } while (0)
 #endif
 
-constexpr int CP_ABORT = 0, CP_LOADED = 1, CP_COL = 8;   // flag words
+constexpr int CP_ABORT = 0, CP_LOADED = 1, CP_FLAGS = 16;   // flag words (one 64-byte line)
 constexpr int CP_LDT = 33;                               // row stride of a resident tile (row-per-lane access: conflict-free)
 constexpr int CP_SLOT = 2 * 32 * CP_LDT + 32;            // doubles per slot: the tile, the private diagonal copy (diagonal owner: the inverse), s_k
 constexpr int CP_MAX_SLOTS = 8;
@@ -85,19 +90,24 @@ __device__ __forceinline__ bool cp_spin(const CholPersistArgs &a, const int word
         }
     }
 }
-// the whole workgroup waits (two barriers); counters start at -1, so "count arrivals" means target - 1
-__device__ __forceinline__ bool cp_wait_wg(const CholPersistArgs &a, const int word, const int arrivals, int *lds_word, const int tid) {
-    if (tid == 0) *lds_word = cp_spin(a, word, arrivals - 1) ? 1 : 0;
-    __syncthreads();
-    const int ok = *lds_word;
-    __syncthreads();
-    return ok != 0;
-}
-// one wave waits (no barrier)
+// one wave waits (no barrier); counters start at -1, so "count arrivals" means target - 1
 __device__ __forceinline__ bool cp_wait_wave(const CholPersistArgs &a, const int word, const int arrivals, const int lane) {
     int ok = 1;
     if (lane == 0) ok = cp_spin(a, word, arrivals - 1) ? 1 : 0;
     return __builtin_amdgcn_readfirstlane(ok) != 0;
+}
+
+// between two polls of a DATA word by one wave: a short sleep; every 64th time the abort word and the clock.  false = abandon the launch
+__device__ __forceinline__ bool cp_poll_again(const CholPersistArgs &a, const uint64_t t0, const int spins, const int lane) {
+    __builtin_amdgcn_s_sleep(1);
+    if (spins & 63) return true;
+    int give_up = 0;
+    if (lane == 0 && (cp_ldi(a.flags + CP_ABORT) >= 0 || (int64_t)(wall_clock64() - t0) > a.timeout_ticks)) {
+        __hip_atomic_store(a.flags + CP_ABORT, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        atomicOr(a.status, 4);
+        give_up = 1;
+    }
+    return __builtin_amdgcn_readfirstlane(give_up) == 0;
 }
 
 // entry (gr, gc) of the ORIGINAL matrix, symmetric, with the identity padding of a ragged last block
@@ -122,21 +132,17 @@ __device__ __forceinline__ void cp_decode(const int nb, int t, int &i, int &j) {
 }
 
 // this thread's four entries (e = tid + 256 q -> row e >> 5, column e & 31: whole 256-byte rows per half wave) of the PUBLISHED tile
-// (i, m), i > m, requested with sc1 loads; i == nb: the rhs row, y_m' in row 0.  Counter form: from S, after the column's counter
-// has been seen.  Data-polled form (a.tpub): from the tile's slot in `tpub`, whole 8 KB tiles — the caller checks the values against
-// the 0xFF fill and asks again until none is left (cp_fetch_polled).
+// (i, m), i > m, requested with sc1 loads from the tile's slot; i == nb: the rhs row, y_m' in row 0.  The caller checks the values
+// against the fill and asks again until none is left (cp_fetch_polled).
 __device__ __forceinline__ void cp_fetch(const CholPersistArgs &a, double (&v)[4], const int i, const int m, const int tid) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const int e = tid + 256 * q, r = e >> 5, c = e & 31;
+        const int e = tid + 256 * q;
         v[q] = 0.0;
         if (i == a.nb) {
-            if (r == 0) v[q] = cp_ld(a.ypub + m * 32 + c);
-        } else if (a.tpub) {
-            v[q] = cp_ld(a.tpub + ((int64_t)i * (i - 1) / 2 + m) * 1024 + e);
+            if (e < 32) v[q] = cp_ld(a.ypub + m * 32 + e);
         } else {
-            const int gr = i * 32 + r, gc = m * 32 + c;
-            if (gr < a.n) v[q] = cp_ld(a.S + (int64_t)gr * a.ld + gc);   // gc < gr < n
+            v[q] = cp_ld(a.tpub + ((int64_t)i * (i - 1) / 2 + m) * 1024 + e);
         }
     }
 }
@@ -146,8 +152,8 @@ __device__ __forceinline__ bool cp_is_fill(const double (&v)[4]) {
     for (int q = 0; q < 4; ++q) f = f || (__builtin_bit_cast(uint64_t, v[q]) == CP_FILL);
     return f;
 }
-// Data-polled hand-over: fetch the operand tile(s) of an update until no value is the fill any more — the producer's stores are
-// the signal (no counter, no acknowledged write, no second round trip).  All threads call it; false = the launch is being abandoned.
+// Fetch the operand tile(s) of an update until no value is the fill any more — the producer's stores are the signal.
+// All threads call it; false = the launch is being abandoned.
 __device__ __forceinline__ bool cp_fetch_polled(const CholPersistArgs &a, double (&vp)[4], double (&vq)[4], const int i, const int j, const int m, const int tid) {
     const uint64_t t0 = wall_clock64();
     for (int spins = 1;; ++spins) {
@@ -192,66 +198,112 @@ __device__ __forceinline__ void cp_apply(const double *P, const double *Q, doubl
     }
 }
 
+// 1 / sqrt(p) on the pivot chain: hardware estimate y (~2^-26) + ONE third-order step, y (1 + h / 2 + 3 h^2 / 8) with h = 1 - p y^2
+// (error ~ h^3: full double precision) — four dependent operations where two Newton steps are six.
+__device__ __forceinline__ double cp_rsqrt(const double p) {
+    const double y = __builtin_amdgcn_rsq(p);
+    const double h = __builtin_fma(-(p * y), y, 1.0);
+    return __builtin_fma(y * h, __builtin_fma(h, 0.375, 0.5), y);
+}
+
+#ifdef CP_TRACE
+__device__ int64_t cp_dbg[4 * 16];
+#define CP_DBG(k) do { if (lane == 0 && blockIdx.x == gridDim.x - 1) cp_dbg[wave * 16 + (k)] = (int64_t)wall_clock64(); } while (0)   // developer builds: the last workgroup's last panel
+#else
+#define CP_DBG(k) do { } while (0)
+#endif
+
 // The 64 x 32 panel [D; X] — D = the (private copy of the) diagonal tile, X = the tile below it — factored by the FOUR waves of the
 // workgroup: lane r of every wave is row r of the panel (lanes 0-31 D, lanes 32-63 X; the elimination of D carries X along, X ends as
-// X L^-T without any inverse), wave w holds the panel's columns 8 w .. 8 w + 7 in registers.  Block b of eight columns is factored by
-// wave b alone (pivot and column entries from lane j by v_readlane), parked in LDS as `Sp[jl][row]`, and the waves behind it
-// subtract its eight rank-1 terms from their own columns — row multiplier `Sp[jl][lane]`, column multiplier `Sp[jl][c]` as a
-// broadcast read.  Critical path: 4 sub-panels (8 pivots, 28 updates each) + 3 x (barrier + one block update) instead of one
-// wave's 32 pivots and 496 updates: 5.6 us -> ~2.6 us per block column, and 16 VGPRs of panel instead of 64.
-// `Sp`: 2 x 8 x 64 doubles.  D == X's tile for the diagonal owner (diag = true): lanes 32-63 shadow lanes 0-31, L goes back to the
-// tile with zeros above the diagonal, the reciprocal pivots to `ild` (32 doubles, for the inversion that follows later).
-// All four waves call it (it contains barriers); returns false in the wave that met a non-positive pivot.
-__device__ __forceinline__ bool cp_panel4(const double *Dt, double *Xt, const bool diag, double *ild, double *Sp, const int lane, const int wave) {
+// X L^-T without any inverse), wave w holds the panel's columns 8 w .. 8 w + 7 in registers.  Wave w factors ITS eight columns (pivot
+// and column entries from lane j by v_readlane) and parks each finished column in LDS as `Sp[column][row]`; the waves behind it
+// subtract that column's rank-1 term from their own columns — row multiplier `Sp[j][lane]`, column multiplier `Sp[j][c]` as a
+// broadcast read — COLUMN BY COLUMN AS THEY APPEAR: a finished column is announced by an LDS word (`*seq` = columns finished since
+// the kernel started; LDS serves one wave's requests in order, so the word follows the column), and when wave w - 1 stores its
+// last column wave w has one rank-1 term left before its own first pivot.  (With a barrier and a block update between the four
+// sub-panels the waves behind waited 0.6 us per sub-panel for updates that could have been done while the columns were
+// produced: 4.3 -> ~2.9 us per panel, tools/probes/chol_persist_probe.hip's per-wave stamps.)
+// `Sp`: 32 x 64 doubles.  `done`: the panels this workgroup has factored so far (every wave counts them itself).
+// D == X's tile for the diagonal owner (diag = true): lanes 32-63 shadow lanes 0-31, L goes back to the tile with zeros above the
+// diagonal, the reciprocal pivots to `ild` (32 doubles, for the inversion that follows later).
+// All four waves call it, between two workgroup barriers of the caller's; returns false in the wave that met a non-positive pivot.
+template <int W>   // W = the calling wave: its lanes' indices are compile-time constants
+__device__ __forceinline__ bool cp_panel_wave(const double *Dt, double *Xt, const bool diag, double *ild, double *Sp, int *seq, const int base, const int lane) {
     const int r = lane & 31;
     const bool low = lane >= 32;
-    const double *src = ((low && !diag) ? Xt : Dt) + r * CP_LDT + 8 * wave;
+    const double *src = ((low && !diag) ? Xt : Dt) + r * CP_LDT + 8 * W;
     double v[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) v[q] = src[q];
     bool ok = true;
     double my_il = 0.0;
+    const int wave = W;
+    CP_DBG(0);
+    // the columns of the waves before this one, as they appear: the word and the column are requested together (LDS answers in
+    // order, so a column read behind a word that says "stored" is the stored one) — one LDS round trip per column
+    for (int j = 0; j < 8 * W; ++j) {
+        double mrow, bc[8];
+        for (;;) {
+            const int seen = __hip_atomic_load(seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // program order only
+            mrow = Sp[j * 64 + lane];
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        double *buf = Sp + (b & 1) * 8 * 64;
-        if (wave == b) {
-#pragma unroll
-            for (int jl = 0; jl < 8; ++jl) {
-                const int j = 8 * b + jl;   // the pivot's row of D lives in lane j
-                const double p = lane_bcast(v[jl], j);
-                ok = ok && (p > 0.0);
-                const double il = rsqrt_nr(p);
-                my_il = (r == j) ? il : my_il;
-                v[jl] *= il;   // lane j holds p itself: p / sqrt(p)
-#pragma unroll
-                for (int q = jl + 1; q < 8; ++q) v[q] -= v[jl] * lane_bcast(v[jl], 8 * b + q);   // L[c][j] lives in lane c
-                buf[jl * 64 + lane] = v[jl];
-            }
+            for (int q = 0; q < 8; ++q) bc[q] = Sp[j * 64 + 8 * W + q];   // wave-uniform address: broadcast reads
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (seen >= base + j + 1) break;
         }
-        if (b < 3) {
-            __syncthreads();
-            if (wave > b) {
 #pragma unroll
-                for (int jl = 0; jl < 8; ++jl) {
-                    const double mrow = buf[jl * 64 + lane];
-                    const double *bc = buf + jl * 64 + 8 * wave;   // wave-uniform address: broadcast reads
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) v[q] -= mrow * bc[q];
-                }
-            }
-        }
+        for (int q = 0; q < 8; ++q) v[q] -= mrow * bc[q];
     }
+    CP_DBG(1);
+    // The pivots are one dependent chain (broadcast -> 1/sqrt -> scale -> the NEXT column's update -> broadcast ...): the next pivot's
+    // reciprocal root is started as soon as its column has its update; the other columns' updates and the store fill its latency.
+    // (Left to itself the scheduler sinks every update to just before its column's pivot: jl dependent multiply-adds on the chain.)
+    double p = lane_bcast(v[0], 8 * W);
+    double il = cp_rsqrt(p);
+#pragma unroll
+    for (int jl = 0; jl < 8; ++jl) {
+        const int j = 8 * W + jl;   // the pivot's row of D lives in lane j
+        ok = ok && (p > 0.0);
+        my_il = (r == j) ? il : my_il;
+        v[jl] *= il;   // lane j holds p itself: p / sqrt(p)
+        if (jl + 1 < 8) {
+            v[jl + 1] -= v[jl] * lane_bcast(v[jl], j + 1);   // L[c][j] lives in lane c
+            p = lane_bcast(v[jl + 1], j + 1);
+            il = cp_rsqrt(p);
+        }
+        if (W < 3) {
+            Sp[j * 64 + lane] = v[jl];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            if (lane == 0) __hip_atomic_store(seq, base + j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+#pragma unroll
+        for (int q = jl + 2; q < 8; ++q) v[q] -= v[jl] * lane_bcast(v[jl], 8 * W + q);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    CP_DBG(2);
     if (diag) {
         if (!low) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) Xt[r * CP_LDT + 8 * wave + q] = (8 * wave + q <= r) ? v[q] : 0.0;
-            if ((r >> 3) == wave) ild[r] = my_il;
+            for (int q = 0; q < 8; ++q) Xt[r * CP_LDT + 8 * W + q] = (8 * W + q <= r) ? v[q] : 0.0;
+            if ((r >> 3) == W) ild[r] = my_il;
         }
     } else if (low) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) Xt[r * CP_LDT + 8 * wave + q] = v[q];
+        for (int q = 0; q < 8; ++q) Xt[r * CP_LDT + 8 * W + q] = v[q];
     }
+    CP_DBG(3);
     return ok;
+}
+__device__ __forceinline__ bool cp_panel4(const double *Dt, double *Xt, const bool diag, double *ild, double *Sp, int *seq, const int done,
+                                          const int lane, const int wave) {
+    const int base = done * 32;
+    switch (wave) {
+    case 0: return cp_panel_wave<0>(Dt, Xt, diag, ild, Sp, seq, base, lane);
+    case 1: return cp_panel_wave<1>(Dt, Xt, diag, ild, Sp, seq, base, lane);
+    case 2: return cp_panel_wave<2>(Dt, Xt, diag, ild, Sp, seq, base, lane);
+    default: return cp_panel_wave<3>(Dt, Xt, diag, ild, Sp, seq, base, lane);
+    }
 }
 
 // Li = L^-1 (lower, zeros stored above the diagonal) by forward substitution, one column per lane, column-oriented: once x[m] is known
@@ -277,9 +329,10 @@ __global__ __launch_bounds__(256) void chol_persist_kernel(const CholPersistArgs
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nb = a.nb, G = gridDim.x, wg = blockIdx.x;
     double *P = cp_sm, *Q = P + 32 * CHOL_LDP, *slot0 = Q + 32 * CHOL_LDP;
-    double *Sp = P;   // the panel's sub-panel exchange (2 x 8 x 64 doubles) shares the operand buffers: never in use at the same time
-    int *meta = reinterpret_cast<int *>(slot0 + (size_t)a.slots * CP_SLOT);   // [0..7] packed tile of the slot, [16] wait word
-    int *wword = meta + 16;
+    double *Sp = P;   // the panel's column exchange (32 x 64 doubles) shares the operand buffers P and Q: never in use at the same time
+    int *meta = reinterpret_cast<int *>(slot0 + (size_t)a.slots * CP_SLOT);   // [0..7] packed tile of the slot, [32] the panels' column count
+    int *seq = meta + 32;
+    int panels = 0;
     auto Town = [&](const int s) { return slot0 + (size_t)s * CP_SLOT; };
     auto Td = [&](const int s) { return slot0 + (size_t)s * CP_SLOT + 32 * CP_LDT; };
     auto Sv = [&](const int s) { return slot0 + (size_t)s * CP_SLOT + 2 * 32 * CP_LDT; };
@@ -292,6 +345,7 @@ __global__ __launch_bounds__(256) void chol_persist_kernel(const CholPersistArgs
         if (tid < a.slots) cp_decode(nb, wg + tid * G, i, j);
         meta[tid] = i < 0 ? 0xFFFF : (i << 8 | j);
     }
+    if (tid == 0) *seq = 0;
     __syncthreads();
     int pk[CP_MAX_SLOTS], max_j = -1;
 #pragma unroll
@@ -325,26 +379,44 @@ __global__ __launch_bounds__(256) void chol_persist_kernel(const CholPersistArgs
     __syncthreads();
     if (tid == 0) __hip_atomic_fetch_add(a.flags + CP_LOADED, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the originals of S are in LDS: diagonal tiles of S may be overwritten once every workgroup has said so
 
-    // Block column m applied to every slot whose column is in [jlo, jhi]: fetch (sc1) -> park -> products, tile by tile.  (Requesting the
-    // next tile's operands before the current tile's products, or all tiles' operands first, changed nothing: the trailing updates
-    // hide behind the next column's factorisation either way — profiles/r04/README.md.)
+    // Block column m applied to every slot whose column is in [jlo, jhi]: fetch (sc1) -> park -> products, tile by tile, the NEXT tile's
+    // operands requested before the current tile's products (a fetch is a ~1 us round trip; park + products + two barriers measure
+    // 1.3 us per tile, 0.43 us of it the sixteen matrix instructions: with five or six tiles per workgroup — the first columns of
+    // n = 1 680 — the trailing update, not the panel chain, sets the pace: 12 us per block column there, 7.5 us later).
     auto apply_column = [&](const int m, const int jlo, const int jhi) -> bool {
-        for (int s = 0; s < a.slots; ++s) {
+        auto next_slot = [&](int s) {
+            for (; s < a.slots; ++s) {
+                int i, j;
+                tile(s, i, j);
+                if (i >= 0 && j >= jlo && j <= jhi) break;
+            }
+            return s;
+        };
+        int s = next_slot(0);
+        double vp[4], vq[4];
+        if (s < a.slots) {
             int i, j;
             tile(s, i, j);
-            if (i < 0 || j < jlo || j > jhi) continue;
-            double vp[4], vq[4];
-            if (a.tpub) {
-                if (!cp_fetch_polled(a, vp, vq, i, j, m, tid)) return false;
-            } else {
-                cp_fetch(a, vp, i, m, tid);
-                if (i != j) cp_fetch(a, vq, j, m, tid);
-            }
+            cp_fetch(a, vp, i, m, tid);
+            if (i != j) cp_fetch(a, vq, j, m, tid);
+        }
+        while (s < a.slots) {
+            int i, j;
+            tile(s, i, j);
+            if (__syncthreads_or(cp_is_fill(vp) || (i != j && cp_is_fill(vq))) && !cp_fetch_polled(a, vp, vq, i, j, m, tid)) return false;
             cp_park(P, vp, tid);
             if (i != j) cp_park(Q, vq, tid);
             __syncthreads();
+            const int sn = next_slot(s + 1);
+            if (sn < a.slots) {
+                int in, jn;
+                tile(sn, in, jn);
+                cp_fetch(a, vp, in, m, tid);
+                if (in != jn) cp_fetch(a, vq, jn, m, tid);
+            }
             cp_apply(P, Q, Town(s), Td(s), i == j, lane, wave);
             __syncthreads();
+            s = sn;
         }
         return true;
     };
@@ -352,7 +424,6 @@ __global__ __launch_bounds__(256) void chol_persist_kernel(const CholPersistArgs
     // ---- factorisation: iteration m consumes block column m and produces the tiles of column m + 1 ----------------------------------------
     for (int m = -1; m < max_j; ++m) {
         CP_STAMP(m + 1, 0);
-        if (m >= 0 && !a.tpub && !cp_wait_wg(a, CP_COL + m, nb - m, wword, tid)) return;   // data-polled form: the tiles themselves are the signal
         CP_STAMP(m + 1, 1);
         // urgent: the tiles of column m + 1
         int ncrit = 0;
@@ -365,23 +436,23 @@ __global__ __launch_bounds__(256) void chol_persist_kernel(const CholPersistArgs
                 int i, j;
                 tile(s, i, j);
                 if (j != m + 1) continue;
-                const bool ok = cp_panel4(i == j ? Town(s) : Td(s), Town(s), i == j, Sv(s), Sp, lane, wave);
+                const bool ok = cp_panel4(i == j ? Town(s) : Td(s), Town(s), i == j, Sv(s), Sp, seq, panels++, lane, wave);
                 if (!__builtin_amdgcn_readfirstlane((int)__all(ok)) && lane == 0) atomicOr(a.status, 2);
                 __syncthreads();
             }
             CP_STAMP(m + 1, 3);
-            int published = 0;
+            bool published = false;
             for (int s = 0; s < a.slots; ++s) {
                 int i, j;
                 tile(s, i, j);
                 if (j != m + 1 || i == j) continue;   // nobody waits for a diagonal tile: it goes to S at the very end
-                ++published;
+                published = true;
                 const double *To = Town(s);
                 if (i == nb) {
                     if (tid < 32) cp_st(a.ypub + j * 32 + tid, To[tid]);
-                } else if (a.tpub) {
-                    // data-polled form: the whole 32 x 32 tile (padding included) into its slot — write-through, nobody waits for an
-                    // acknowledgement — and the in-range part into S (plain stores: the result, read by nobody in this launch)
+                } else {
+                    // the whole 32 x 32 tile (padding included) into its slot — write-through, nobody waits for an acknowledgement —
+                    // and the in-range part into S (plain stores: the result, read by nobody in this launch)
 #pragma unroll
                     for (int qq = 0; qq < 4; ++qq) {
                         const int e = tid + 256 * qq, r = e >> 5, c = e & 31;
@@ -390,21 +461,9 @@ __global__ __launch_bounds__(256) void chol_persist_kernel(const CholPersistArgs
                         const int gr = i * 32 + r, gc = j * 32 + c;
                         if (gr < a.n && gc < a.n) a.S[(int64_t)gr * a.ld + gc] = v;
                     }
-                } else {
-#pragma unroll
-                    for (int qq = 0; qq < 4; ++qq) {
-                        const int e = tid + 256 * qq, r = e >> 5, c = e & 31;
-                        const int gr = i * 32 + r, gc = j * 32 + c;
-                        if (gr < a.n && gc < a.n) cp_st(a.S + (int64_t)gr * a.ld + gc, To[r * CP_LDT + c]);
-                    }
                 }
             }
-            if (published && !a.tpub) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                CP_STAMP(m + 1, 4);
-                if (tid == 0) __hip_atomic_fetch_add(a.flags + CP_COL + m + 1, published, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            if (published) CP_STAMP(m + 1, 4);
             if (has_diag && wg == m + 1) {   // the inverse of the fresh diagonal factor (for the backward sweep), now that nobody waits for this workgroup
                 if (wave == 0) cp_invert_diag(Town(0), Td(0), Sv(0), lane);
                 __syncthreads();
@@ -415,93 +474,116 @@ __global__ __launch_bounds__(256) void chol_persist_kernel(const CholPersistArgs
         CP_STAMP(m + 1, 5);
     }
 
-    // ---- backward substitution L' x = y: wave 0 of the diagonal tiles' owners, everything in registers ------------------------------------
+    // ---- backward substitution L' x = y: wave 0 of the diagonal tiles' owners ---------------------------------------------------------------
+    // (every wave is past its last read of P and Q: apply_column ends with a barrier)
     if (wave != 0 || !has_diag) return;
     const int k = wg, c = lane & 31;
-    double t;                                                 // t = y_k - sum_{i > k} L_ik' x_i, lane c holds entry c
-    if (a.tpub) {                                             // y_k: polled like the tiles (0xFF fill until it is written)
+    auto any_fill = [&](const double (&v)[32]) -> bool {
+        bool f = false;
+#pragma unroll
+        for (int r = 0; r < 32; ++r) f = f || (__builtin_bit_cast(uint64_t, v[r]) == CP_FILL);
+        return __any(f);
+    };
+    // the 32 words of x_i into every lane (uniform addresses): a product with them needs no broadcast
+    auto load_x = [&](double (&x)[32], const int i) {
+#pragma unroll
+        for (int r = 0; r < 32; ++r) x[r] = cp_ld(a.xpub + i * 32 + r);
+    };
+    // column c of the published tile (i, k): what lane c needs for (L_ik' x_i)[c].  Nothing orders this workgroup's arrival here after
+    // the OTHER workgroups' tiles of column k (the owner of one of the last diagonal tiles gets here while they are still being
+    // factored): the values are checked against the fill where they are used.
+    auto load_col = [&](double (&dst)[32], const int i) {
+#pragma unroll
+        for (int r = 0; r < 32; ++r) dst[r] = cp_ld(a.tpub + ((int64_t)i * (i - 1) / 2 + k) * 1024 + r * 32 + c);
+    };
+    double t;                                                 // t = y_k - sum_{i > k + 1} L_ik' x_i, lane c holds entry c
+    {
         const uint64_t t0 = wall_clock64();
         for (int spins = 1;; ++spins) {
             t = cp_ld(a.ypub + k * 32 + c);
             if (__all(__builtin_bit_cast(uint64_t, t) != CP_FILL)) break;
-            __builtin_amdgcn_s_sleep(1);
-            if ((spins & 63) == 0) {
-                int give_up = 0;
-                if (lane == 0 && (cp_ldi(a.flags + CP_ABORT) >= 0 || (int64_t)(wall_clock64() - t0) > a.timeout_ticks)) {
-                    __hip_atomic_store(a.flags + CP_ABORT, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    atomicOr(a.status, 4);
-                    give_up = 1;
-                }
-                if (__builtin_amdgcn_readfirstlane(give_up)) return;
-            }
+            if (!cp_poll_again(a, t0, spins, lane)) return;
         }
-    } else {
-        if (!cp_wait_wave(a, CP_COL + k, nb - k, lane)) return;   // y_k is part of column k (long complete for all but the last blocks)
-        t = cp_ld(a.ypub + k * 32 + c);
     }
-    auto fetch_col = [&](double (&dst)[32], const int i) {    // column c of tile (i, k): what lane c needs for L_ik' x_i
-#pragma unroll
-        for (int r = 0; r < 32; ++r) {
-            const int gr = i * 32 + r;
-            if (a.tpub) dst[r] = cp_ld(a.tpub + ((int64_t)i * (i - 1) / 2 + k) * 1024 + r * 32 + c);   // may still hold the fill: col_ready() below
-            else dst[r] = (gr < a.n) ? cp_ld(a.S + (int64_t)gr * a.ld + k * 32 + c) : 0.0;
-        }
-    };
-    // Data-polled form: nothing orders this workgroup's arrival here after the OTHER workgroups' tiles of column k (the owner of the
-    // last columns' diagonal tiles gets here while they are still being factored): the column is asked for again until no fill is left.
-    auto col_ready = [&](double (&dst)[32], const int i) -> bool {
-        if (!a.tpub) return true;
+    const double *Li = Td(0);
+    double *Wl = Q;                                           // W' = L_k+1,k L_kk^-1, row r at Wl[32 r ..]: lane c reads its column
+    if (k + 1 < nb) {
+        // the tile below the diagonal tile, whole, into LDS (P, flat 32 x 32) ...
+        double *Lt = P;
         const uint64_t t0 = wall_clock64();
         for (int spins = 1;; ++spins) {
+            double v[16];
             bool f = false;
 #pragma unroll
-            for (int r = 0; r < 32; ++r) f = f || (__builtin_bit_cast(uint64_t, dst[r]) == CP_FILL);
-            if (!__any(f)) return true;
-            __builtin_amdgcn_s_sleep(1);
-            if ((spins & 63) == 0) {
-                int give_up = 0;
-                if (lane == 0 && (cp_ldi(a.flags + CP_ABORT) >= 0 || (int64_t)(wall_clock64() - t0) > a.timeout_ticks)) {
-                    __hip_atomic_store(a.flags + CP_ABORT, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    atomicOr(a.status, 4);
-                    give_up = 1;
-                }
-                if (__builtin_amdgcn_readfirstlane(give_up)) return false;
+            for (int q = 0; q < 16; ++q) {
+                v[q] = cp_ld(a.tpub + ((int64_t)(k + 1) * k / 2 + k) * 1024 + lane + 64 * q);
+                f = f || (__builtin_bit_cast(uint64_t, v[q]) == CP_FILL);
             }
-            fetch_col(dst, i);
-        }
-    };
-    double col[32];
-    if (nb - 1 > k) fetch_col(col, nb - 1);
-    for (int i = nb - 1; i > k; --i) {
-        double xi;   // poll the 32 data words of x_i themselves: a word differs from the fill once it is written
-        const uint64_t t0 = wall_clock64();
-        for (int spins = 1;; ++spins) {
-            xi = cp_ld(a.xpub + i * 32 + c);
-            if (__all(__builtin_bit_cast(uint64_t, xi) != CP_FILL)) break;
-            __builtin_amdgcn_s_sleep(1);
-            if ((spins & 63) == 0) {
-                int give_up = 0;
-                if (lane == 0 && (cp_ldi(a.flags + CP_ABORT) >= 0 || (int64_t)(wall_clock64() - t0) > a.timeout_ticks)) {
-                    __hip_atomic_store(a.flags + CP_ABORT, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    atomicOr(a.status, 4);
-                    give_up = 1;
-                }
-                if (__builtin_amdgcn_readfirstlane(give_up)) return;
-            }
-        }
-        if (i == k + 1) CP_STAMP(k, 6);
-        if (!col_ready(col, i)) return;
-        double acc = 0.0;
+            if (!__any(f)) {
 #pragma unroll
-        for (int r = 0; r < 32; ++r) acc += col[r] * lane_bcast(xi, r);
-        t -= acc;
-        if (i - 1 > k) fetch_col(col, i - 1);   // the next arrival's tile, requested before that x is polled
+                for (int q = 0; q < 16; ++q) Lt[lane + 64 * q] = v[q];
+                break;
+            }
+            if (!cp_poll_again(a, t0, spins, lane)) return;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ... and W'[r][c] = sum_q L[r][q] Li[q][c]: lane c with its column of the inverse in registers, L[r][.] as broadcast reads
+        double li[32];
+#pragma unroll
+        for (int q = 0; q < 32; ++q) li[q] = Li[q * CP_LDT + c];
+        for (int r = 0; r < 32; ++r) {
+            double w = 0.0;
+#pragma unroll
+            for (int q = 0; q < 32; ++q) w += Lt[r * 32 + q] * li[q];
+            if (lane < 32) Wl[r * 32 + c] = w;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
     {
-        const double *Li = Td(0);
-        double xk = 0.0;
+        double col[32], x[32];
+        if (nb - 1 > k + 1) load_col(col, nb - 1);
+        for (int i = nb - 1; i > k + 1; --i) {
+            const uint64_t t0 = wall_clock64();
+            double acc;
+            for (int spins = 1;; ++spins) {
+                load_x(x, i);
+                acc = 0.0;
 #pragma unroll
-        for (int r = 0; r < 32; ++r) xk += Li[r * CP_LDT + c] * lane_bcast(t, r);   // x_k = L_kk^-T t (the inverse is stored with its zeros)
+                for (int r = 0; r < 32; ++r) acc += col[r] * x[r];
+                // the fill is a NaN and goes through the sum: only a NaN result is looked at word by word (a genuine NaN passes)
+                if (__all(acc == acc) || !(any_fill(x) || any_fill(col))) break;
+                if (!cp_poll_again(a, t0, spins, lane)) return;
+                load_col(col, i);
+            }
+            t -= acc;
+            if (i - 1 > k + 1) load_col(col, i - 1);   // the next arrival's tile, requested before that x is polled
+        }
+    }
+    {
+        double u = 0.0;   // u = L_kk^-T t (the inverse is stored with its zeros)
+#pragma unroll
+        for (int r = 0; r < 32; ++r) u += Li[r * CP_LDT + c] * lane_bcast(t, r);
+        double xk = u;
+        if (k + 1 < nb) {
+            double w[32], x[32];
+#pragma unroll
+            for (int r = 0; r < 32; ++r) w[r] = Wl[r * 32 + c];
+            const uint64_t t0 = wall_clock64();
+            for (int spins = 1;; ++spins) {
+                load_x(x, k + 1);
+                double acc = 0.0;
+#pragma unroll
+                for (int r = 0; r < 32; ++r) acc += w[r] * x[r];
+                xk = u - acc;
+                if (__all(xk == xk) || !any_fill(x)) break;
+                if (!cp_poll_again(a, t0, spins, lane)) return;
+            }
+            CP_STAMP(k, 6);
+        }
         if (lane < 32) {
             cp_st(a.xpub + k * 32 + c, xk);
             if (k * 32 + c < a.n) a.x[k * 32 + c] = xk;
@@ -525,11 +607,10 @@ __global__ __launch_bounds__(256) void chol_persist_kernel(const CholPersistArgs
 
 namespace pcs {
 
-// Workspace of the persistent solve inside pcs_dense_spd_solve's d_work: [flags (CP_COL + nb ints, padded) | xpub nb x 32 | ypub nb x 32 |
-// tpub nb (nb - 1) / 2 tiles]; everything a launch needs at the fill value is one contiguous range: ONE memset of 0xFF bytes
-// (flags + xpub in the counter form; all of it in the data-polled form).
-inline int64_t cp_flag_doubles(const int64_t nb) { return ((CP_COL + nb) * 4 + 63) / 64 * 8; }   // whole 64-byte lines
-inline int64_t cp_work_doubles(const int64_t nb) { return cp_flag_doubles(nb) + 2 * nb * 32 + nb * (nb - 1) / 2 * 1024; }
+// Workspace of the persistent solve inside pcs_dense_spd_solve's d_work: [flags | xpub nb x 32 | ypub nb x 32 | tpub nb (nb - 1) / 2 tiles],
+// all of it at the fill value when the kernel starts: ONE memset of 0xFF bytes.
+inline int64_t cp_flag_doubles() { return CP_FLAGS * 4 / 8; }
+inline int64_t cp_work_doubles(const int64_t nb) { return cp_flag_doubles() + 2 * nb * 32 + nb * (nb - 1) / 2 * 1024; }
 
 // Can the persistent form take an n x n system on a device with `n_cus` compute units?  (one workgroup per CU, CP_MAX_SLOTS tiles each)
 inline bool cp_fits(const int64_t n, const int n_cus) {
@@ -539,16 +620,16 @@ inline bool cp_fits(const int64_t n, const int n_cus) {
 
 // Enqueue memset + kernel on `s`.  The caller has checked cp_fits and set the device.
 inline hipError_t cp_launch(const int64_t n, double *d_S, const int64_t ld, const double *d_rhs, double *d_x, double *d_work, int32_t *d_status,
-                            const int n_cus, hipStream_t s, const double timeout_s = 0.25, int64_t *trace = nullptr, const int32_t *d_stop = nullptr, const bool poll_data = true) {
+                            const int n_cus, hipStream_t s, const double timeout_s = 0.25, int64_t *trace = nullptr, const int32_t *d_stop = nullptr) {
     const int64_t nb = (n + 31) / 32, T = cp_tiles(nb);
     const int G = (int)(T < n_cus ? T : n_cus);
     const int slots = (int)((T + G - 1) / G);
     CholPersistArgs a{};
     a.S = d_S; a.rhs = d_rhs; a.x = d_x; a.status = d_status;
     a.flags = reinterpret_cast<int32_t *>(d_work);
-    a.xpub = d_work + cp_flag_doubles(nb);
+    a.xpub = d_work + cp_flag_doubles();
     a.ypub = a.xpub + nb * 32;
-    a.tpub = poll_data ? a.ypub + nb * 32 : nullptr;
+    a.tpub = a.ypub + nb * 32;
     a.n = (int32_t)n; a.ld = (int32_t)ld; a.nb = (int32_t)nb; a.slots = slots;
     a.timeout_ticks = (int64_t)(timeout_s * 1.0e8);
     a.stop = d_stop;
@@ -558,7 +639,7 @@ inline hipError_t cp_launch(const int64_t n, double *d_S, const int64_t ld, cons
     (void)trace;
 #endif
     const size_t lds = cp_lds_bytes(slots);
-    hipError_t e = hipMemsetAsync(d_work, 0xFF, sizeof(double) * (size_t)(poll_data ? cp_work_doubles(nb) : cp_flag_doubles(nb) + nb * 32), s);
+    hipError_t e = hipMemsetAsync(d_work, 0xFF, sizeof(double) * (size_t)cp_work_doubles(nb), s);
     if (e != hipSuccess) return e;
     static bool attr_set = false;   // one code object per process: the attribute sticks to the function
     if (!attr_set) {

@@ -69,7 +69,7 @@ static int run(int n, int reps, int pipe) {
     for (int r = 0; r < reps; ++r) {
         CK(hipMemcpyAsync(dS, dS0, sizeof(double) * n * n, hipMemcpyDeviceToDevice, s));
         CK(hipEventRecord(e0, s));
-        CK(pcs::cp_launch(n, dS, n, drhs, dx, dwork, dstatus, cus, s, 0.05, nullptr, nullptr, pipe != 0));
+        CK(pcs::cp_launch(n, dS, n, drhs, dx, dwork, dstatus, cus, s, 0.05, nullptr));
         CK(hipEventRecord(e1, s));
         CK(hipStreamSynchronize(s));
         float ms;
@@ -84,7 +84,7 @@ static int run(int n, int reps, int pipe) {
         CK(hipMalloc(&dtr, tl * 8));
         CK(hipMemset(dtr, 0, tl * 8));
         CK(hipMemcpyAsync(dS, dS0, sizeof(double) * n * n, hipMemcpyDeviceToDevice, s));
-        CK(pcs::cp_launch(n, dS, n, drhs, dx, dwork, dstatus, cus, s, 0.05, dtr, nullptr, pipe != 0));
+        CK(pcs::cp_launch(n, dS, n, drhs, dx, dwork, dstatus, cus, s, 0.05, dtr));
         CK(hipStreamSynchronize(s));
         std::vector<int64_t> tr(tl);
         CK(hipMemcpy(tr.data(), dtr, tl * 8, hipMemcpyDeviceToHost));
@@ -117,7 +117,17 @@ static int run(int n, int reps, int pipe) {
                 const int64_t *q = &tr[((size_t)w * (nb + 1) + k) * 8];
                 if (q[7]) printf("  k %2d: seen %7.2f  stored %7.2f\n", k, q[6] ? (q[6] - t0) * 0.01 : 0.0, (q[7] - t0) * 0.01);
             }
-        hipFree(dtr);
+        {
+            int64_t dbg[64];
+            CK(hipMemcpyFromSymbol(dbg, HIP_SYMBOL(pcs::cp_dbg), sizeof(dbg)));
+            printf("  last workgroup's last panel, [us since wave 0's entry] per wave: entry | earlier columns applied | own columns factored | stored\n");
+            for (int w = 0; w < 4; ++w) {
+                printf("   wave %d:", w);
+                for (int q = 0; q < 4; ++q) printf(" %5.2f", dbg[w * 16 + q] ? (dbg[w * 16 + q] - dbg[0]) * 0.01 : -1.0);
+                printf("\n");
+            }
+        }
+        (void)hipFree(dtr);
     }
     int32_t st;
     CK(hipMemcpy(&st, dstatus, 4, hipMemcpyDeviceToHost));
@@ -137,7 +147,7 @@ static int run(int n, int reps, int pipe) {
     printf("pipe %d  n %5d  nb %3d  tiles %5lld  wgs %3d  slots %d  lds %6zu B : status %d  |x - x_ref| / |x| %.2e  |L - L_ref| rel %.2e  upper untouched %d   time mean %.1f us  min %.1f us\n",
            pipe, n, (int)nb, (long long)T, G, (int)((T + G - 1) / G), pcs::cp_lds_bytes((int)((T + G - 1) / G)), st, ex / mx, eL, (int)upper_ok, sum / (reps - 1) * 1e3, best * 1e3);
     fflush(stdout);
-    hipFree(dS); hipFree(dS0); hipFree(drhs); hipFree(dx); hipFree(dwork); hipFree(dstatus);
+    for (void *q : {(void *)dS, (void *)dS0, (void *)drhs, (void *)dx, (void *)dwork, (void *)dstatus}) (void)hipFree(q);
     return 0;
 }
 
@@ -147,7 +157,7 @@ int main(int argc, char **argv) {
     if (ns.empty()) ns = {1, 31, 32, 33, 97, 480, 1003, 1680};
     for (int rep = 0; rep < 2; ++rep)
         for (int n : ns)
-            for (int pipe = 0; pipe < 2; ++pipe)   // 0: one counter per block column, 1: the published tiles themselves are polled
+            for (int pipe = 0; pipe < 1; ++pipe)
                 if (run(n, 12, pipe)) return 1;
     return 0;
 }
