@@ -313,6 +313,9 @@ int pcs_genchain_set_detections_table(pcs_genchain *h, const double *det5, int64
 int pcs_genchain_set_template(pcs_genchain *h, const double *points);
 int pcs_genchain_eval(pcs_genchain *h, const double *param_str, void *resid, void *jac);
 int pcs_genchain_eval_device(pcs_genchain *h, const double *d_param_str, void *d_resid, void *d_jac, void *stream);
+/* A step of a generated chain is ONE launch (the default, like pcs_eval's fused kernel: every wave prepares the Rodrigues slabs of its
+ * tile's (camera, image) pairs itself); on = 0 puts the slab preparation in a launch of its own in front.  Same bits either way. */
+int pcs_genchain_set_one_launch(pcs_genchain *h, int on);
 int pcs_genchain_set_unfixed(pcs_genchain *h, const uint64_t *keep, const int64_t *row_off, int64_t nnz);
 int pcs_genchain_eval_compact(pcs_genchain *h, const double *param_str, void *resid, void *data);
 int pcs_genchain_eval_compact_device(pcs_genchain *h, const double *d_param_str, void *d_resid, void *d_data, void *stream);

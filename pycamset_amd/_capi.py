@@ -72,6 +72,7 @@ SYMBOLS = {
     "pcs_genchain_set_template": (c_int, [_P, POINTER(c_double)]),
     "pcs_genchain_eval": (c_int, [_P, POINTER(c_double), _P, _P]),
     "pcs_genchain_eval_device": (c_int, [_P, _P, _P, _P, _P]),
+    "pcs_genchain_set_one_launch": (c_int, [_P, c_int]),
     "pcs_genchain_set_unfixed": (c_int, [_P, POINTER(c_uint64), POINTER(c_int64), c_int64]),
     "pcs_genchain_eval_compact": (c_int, [_P, POINTER(c_double), _P, _P]),
     "pcs_genchain_eval_compact_device": (c_int, [_P, _P, _P, _P, _P]),

@@ -245,13 +245,24 @@ def emit_source(spec: ChainSpec) -> str:
         elif b.kind == "free_point":
             rule.append(f"pcs::chain_free<P, {cols[i]}>({prev}, J);")
         prev = f"S{i}"
+    slab_links = [g["link"] for g in spec.groups if g["kind"] == "rigid"]
+    link_cases = " ".join(f"g == {i} ? {_LINK_CPP[l]} :" for i, l in enumerate(slab_links))
     out += ["struct Chain {",
             f"    static constexpr int P = {P};",
+            f"    static constexpr int N_SLABS = {len(slab_links)};   // Rodrigues slabs (one per rigid parameter group) and whose transform each holds",
+            f"    __device__ static constexpr int slab_link(const int g) {{ return {link_cases} pcs::LINK_CAM; }}",
             "    template <bool JAC, typename Ctx>",
             "    __device__ static __forceinline__ void eval(const Ctx &c, double &u, double &v, double (&J)[2 * P]) {"]
     out += ["        " + ln for ln in fwd]
     out += ["        if constexpr (JAC) {"] + ["            " + ln for ln in rule] + ["        }", "    }", "};", "PCS_GENCHAIN_ENTRY_POINTS(Chain)", ""]
     return "\n".join(out)
+
+
+# Multiply-adds are fused where the SOURCE has them in one expression, not wherever the optimiser finds a product next to a sum
+# (hipcc's default, `fast`): one detection's values then do not depend on which kernel the chain was inlined into — the dense
+# kernel, the one that packs at the store and both launch forms write the same bits (with `fast`, 6 % of the entries of a user
+# chain's template columns differed in the last two bits between the dense and the packing kernel).
+FP_CONTRACT = "-ffp-contract=on"
 
 
 def _header_digest() -> str:
@@ -262,7 +273,7 @@ def _header_digest() -> str:
 
 
 def code_object_path(spec: ChainSpec) -> Path:
-    key = hashlib.sha256((emit_source(spec) + _header_digest()).encode()).hexdigest()[:20]
+    key = hashlib.sha256((emit_source(spec) + _header_digest() + FP_CONTRACT).encode()).hexdigest()[:20]
     return CACHE / f"chain_{'_'.join(''.join(ch for ch in n if ch.isalnum())[:4] for n in spec.names)}_{key}.hsaco"
 
 
@@ -291,7 +302,7 @@ def _compile_with_hiprtc(src_text: str, out: Path) -> str | None:
     if rtc.hiprtcCreateProgram(ctypes.byref(prog), src_text.encode(), b"chain.hip", 0, None, None) != 0:
         return "hiprtcCreateProgram failed"
     try:
-        opts = [b"--offload-arch=gfx950", b"-O3", b"-std=c++17", f"-I{CSRC}".encode()]
+        opts = [b"--offload-arch=gfx950", b"-O3", b"-std=c++17", FP_CONTRACT.encode(), f"-I{CSRC}".encode()]
         rc = rtc.hiprtcCompileProgram(prog, len(opts), (ctypes.c_char_p * len(opts))(*opts))
         n = ctypes.c_size_t()
         if rc != 0:
@@ -331,7 +342,7 @@ def compile_chain(spec: ChainSpec, verbose: bool = False) -> Path:
             return out
         if which == "hiprtc":
             raise RuntimeError(f"hiprtc failed compiling the chain {' + '.join(spec.names)}:\n{log}")
-    cmd = [os.environ.get("HIPCC", "hipcc"), "--genco", "--offload-arch=gfx950", "-O3", "-std=c++17", f"-I{CSRC}", str(src), "-o", str(out)]
+    cmd = [os.environ.get("HIPCC", "hipcc"), "--genco", "--offload-arch=gfx950", "-O3", "-std=c++17", FP_CONTRACT, f"-I{CSRC}", str(src), "-o", str(out)]
     if verbose:
         print(" ".join(cmd), flush=True)
     try:
@@ -524,6 +535,11 @@ class ChainEngine:
     def csr_structure(self, unfixed=None):
         indices, indptr, _, _ = csr_structure_of(self.block_param_inds(), self.n_params, unfixed)
         return indices, indptr
+
+    def set_one_launch(self, on: bool) -> None:
+        """A step is one launch by default (every wave prepares the Rodrigues slabs of its tile itself, like Engine's fused kernel);
+        ``False`` runs the slab preparation as a launch of its own in front of the evaluation.  The outputs hold the same bits."""
+        check(lib().pcs_genchain_set_one_launch(self._h, int(bool(on))))
 
     def set_unfixed(self, unfixed) -> int:
         _, indptr, keep, row_off = csr_structure_of(self.block_param_inds(), self.n_params, unfixed)

@@ -453,13 +453,17 @@ __global__ __launch_bounds__(256) void chol_persist_kernel(const CholPersistArgs
                 } else {
                     // the whole 32 x 32 tile (padding included) into its slot — write-through, nobody waits for an acknowledgement —
                     // and the in-range part into S (plain stores: the result, read by nobody in this launch)
+                    double v[4];
 #pragma unroll
                     for (int qq = 0; qq < 4; ++qq) {
-                        const int e = tid + 256 * qq, r = e >> 5, c = e & 31;
-                        const double v = To[r * CP_LDT + c];
-                        cp_st(a.tpub + ((int64_t)i * (i - 1) / 2 + j) * 1024 + e, v);
-                        const int gr = i * 32 + r, gc = j * 32 + c;
-                        if (gr < a.n && gc < a.n) a.S[(int64_t)gr * a.ld + gc] = v;
+                        const int e = tid + 256 * qq;
+                        v[qq] = To[(e >> 5) * CP_LDT + (e & 31)];
+                        cp_st(a.tpub + ((int64_t)i * (i - 1) / 2 + j) * 1024 + e, v[qq]);
+                    }
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) {   // behind the stores somebody is waiting for
+                        const int e = tid + 256 * qq, gr = i * 32 + (e >> 5), gc = j * 32 + (e & 31);
+                        if (gr < a.n && gc < a.n) a.S[(int64_t)gr * a.ld + gc] = v[qq];
                     }
                 }
             }

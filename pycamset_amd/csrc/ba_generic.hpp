@@ -56,25 +56,70 @@ struct GenericArgs {
     const int64_t *row_off;
 };
 
-// one thread per slab element over all rigid groups (same element functions as slab_prep_kernel)
+// element `slot` of the slab (R | t | dR/dr | pad) of one 6-parameter transform (same element functions as slab_prep_kernel)
+__device__ __forceinline__ double generic_slab_element(const double *p6, const int slot) {
+    if (slot >= POSE_T && slot < POSE_DR) return p6[3 + slot - POSE_T];
+    if (slot == POSE_STRIDE - 1) return 0.0;
+    return rot_element(rot_terms(p6[0], p6[1], p6[2]), slot < POSE_T ? slot - POSE_R : 9 + slot - POSE_DR);
+}
+
+// two-launch form: one thread per slab element over all rigid groups
 __device__ __forceinline__ void generic_slab_prep_body(const GenericArgs &a) {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     for (int g = 0; g < a.n_groups; ++g) {
         const int64_t n_el = (int64_t)a.group_count[g] * POSE_STRIDE;
         if (t < n_el) {
             const int64_t e = t / POSE_STRIDE;
-            const int slot = (int)(t - e * POSE_STRIDE);
-            const double *p6 = a.prm + a.group_off[g] + 6 * e;
-            double v;
-            if (slot >= POSE_T && slot < POSE_DR) v = p6[3 + slot - POSE_T];
-            else if (slot == POSE_STRIDE - 1) v = 0.0;
-            else v = rot_element(rot_terms(p6[0], p6[1], p6[2]), slot < POSE_T ? slot - POSE_R : 9 + slot - POSE_DR);
-            a.slab[g][t] = v;
+            a.slab[g][t] = generic_slab_element(a.prm + a.group_off[g] + 6 * e, (int)(t - e * POSE_STRIDE));
             return;
         }
         t -= n_el;
     }
 }
+
+// One-launch form: the slabs of ONE (camera, image) pair — group g's transform of that camera or image, by the group's link — held
+// ACROSS THE LANES of the calling wave: lane l computes elements l, 64 + l, ... of the concatenated slabs (ba_kernels.hpp's
+// prep_pair_slab for any set of groups), and a slab entry is a v_readlane broadcast of a compile-time lane (WaveSlab): like the
+// scalar loads of the two-launch form the values arrive in scalar registers, and no memory is involved at all.
+__device__ __forceinline__ double lane_bcast_f64(const double v, const int src) {   // v_readlane_b32 x 2 -> a scalar register pair
+    const uint64_t b = __builtin_bit_cast(uint64_t, v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, src);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), src);
+    return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+}
+template <typename Spec>
+struct LaneSlabs {
+    static constexpr int NEL = Spec::N_SLABS * POSE_STRIDE, ROUNDS = (NEL + 63) / 64;
+    double el[ROUNDS > 0 ? ROUNDS : 1];
+    __device__ __forceinline__ void prepare(const GenericArgs &a, const int c0, const int im0, const int lane) {
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const int e = 64 * r + lane;
+            const int g = e < NEL ? e / POSE_STRIDE : 0;   // lanes past the end recompute an element of group 0 (never read)
+            const int idx = Spec::slab_link(g) == LINK_CAM ? c0 : im0;
+            el[r] = generic_slab_element(a.prm + a.group_off[g] + 6 * (int64_t)idx, e < NEL ? e - g * POSE_STRIDE : 0);
+        }
+    }
+};
+template <typename Spec>
+struct WaveSlab {
+    const LaneSlabs<Spec> &s;
+    int base;
+    __device__ __forceinline__ double operator[](const int j) const { return lane_bcast_f64(s.el[(base + j) >> 6], (base + j) & 63); }   // compile-time j
+};
+// a tile across a run boundary: the lanes of its first part take pair A's entry, the others pair B's — both broadcasts with every
+// lane active (a cross-lane read from inside a divergent branch may find the source lane's register not kept up: the compiler
+// maintains a value only in the lanes that are active where it is used)
+template <typename Spec>
+struct WaveSlab2 {
+    const LaneSlabs<Spec> &sa, &sb;
+    bool first;
+    int base;
+    __device__ __forceinline__ double operator[](const int j) const {
+        const double x = lane_bcast_f64(sa.el[(base + j) >> 6], (base + j) & 63), y = lane_bcast_f64(sb.el[(base + j) >> 6], (base + j) & 63);
+        return first ? x : y;
+    }
+};
 
 // pinhole + Brown-Conrady and its Jacobian in normalised coordinates (same rational function as fbi:27-140; see eval_detection)
 template <bool JAC, typename IntrPtr>
@@ -213,9 +258,44 @@ struct ChainCtx {
     __device__ __forceinline__ const double *user(const int u, const int link, const int np) const { return a.prm + a.user_off[u] + (int64_t)np * index_of(link); }
 };
 
-// one detection of a tile through the generated chain
-template <typename Spec, bool JAC>
-__device__ __forceinline__ void eval_tile_lane(const GenericArgs &a, const int c, const int im, const int k, double &u, double &v, double (&J)[2 * Spec::P]) {
+// the same for the one-launch form: the slabs of this detection's (camera, image) pair are held across the wave's lanes
+template <typename Spec, bool TWO>
+struct ChainCtxLanes {
+    const GenericArgs &a;
+    const LaneSlabs<Spec> &sa, &sb;   // TWO: the pairs of the tile's first and last lane; else sb is not used
+    bool first;
+    int c, im, k;
+    __device__ __forceinline__ int index_of(const int link) const { return link == LINK_CAM ? c : link == LINK_IMG ? im : k; }
+    __device__ __forceinline__ auto slab(const int g, const int) const {
+        if constexpr (TWO) return WaveSlab2<Spec>{sa, sb, first, g * POSE_STRIDE};
+        else return WaveSlab<Spec>{sa, g * POSE_STRIDE};
+    }
+    __device__ __forceinline__ IntrRow intr() const { return IntrRow{a.prm + a.intr_off + 9 * (int64_t)c}; }
+    __device__ __forceinline__ const double *point() const { return a.prm + a.point_off + 3 * (int64_t)k; }
+    __device__ __forceinline__ const double *tpoint() const { return a.tmpl + 3 * (int64_t)k; }
+    __device__ __forceinline__ const double *user(const int u, const int link, const int np) const { return a.prm + a.user_off[u] + (int64_t)np * index_of(link); }
+};
+
+// one detection of a tile through the generated chain.  ONE (the one-launch step, no slab-preparation launch ran; the host picks it
+// for tables in which every tile lies inside a run of one (camera, image) pair or across ONE run boundary — the reference's table
+// order): the wave prepares the slabs of the first lane's pair and, if the tile has a second one, of the last lane's pair; a tile
+// across a boundary is evaluated once, every lane picking its pair's entries (WaveSlab2).  No loop over pairs: a loop carries J
+// across its iterations next to the J being computed, +100 VGPRs and one wave per SIMD instead of two.
+template <typename Spec, bool JAC, bool ONE>
+__device__ __forceinline__ void eval_tile_lane(const GenericArgs &a, const int lane, const int c, const int im, const int k, double &u, double &v, double (&J)[2 * Spec::P]) {
+    if constexpr (ONE && Spec::N_SLABS > 0) {
+        const int c0 = __builtin_amdgcn_readfirstlane(c), im0 = __builtin_amdgcn_readfirstlane(im);
+        const bool first = c == c0 && im == im0;
+        LaneSlabs<Spec> sa, sb;
+        sa.prepare(a, c0, im0, lane);
+        if (__all(first)) {
+            Spec::template eval<JAC>(ChainCtxLanes<Spec, false>{a, sa, sa, true, c, im, k}, u, v, J);
+        } else {
+            sb.prepare(a, __builtin_amdgcn_readlane(c, 63), __builtin_amdgcn_readlane(im, 63), lane);   // tail lanes repeat the last detection
+            Spec::template eval<JAC>(ChainCtxLanes<Spec, true>{a, sa, sb, first, c, im, k}, u, v, J);
+        }
+        return;
+    }
     const int c0 = __builtin_amdgcn_readfirstlane(c), im0 = __builtin_amdgcn_readfirstlane(im);
     if (__all(c == c0 && im == im0)) Spec::template eval<JAC>(ChainCtx<true>{a, c0, im0, k}, u, v, J);   // every slab through scalar loads
     else Spec::template eval<JAC>(ChainCtx<false>{a, c, im, k}, u, v, J);
@@ -224,7 +304,7 @@ __device__ __forceinline__ void eval_tile_lane(const GenericArgs &a, const int c
 // Fused residual + Jacobian for a generated chain: the hand-fused kernel's tile-per-wave structure, scalar-load slabs when the
 // tile shares camera and image, transposed non-temporal stores.  MODE as in ba_eval_kernel (1 residual, 2 Jacobian, 3 both);
 // TO = the type the outputs are WRITTEN in (arithmetic is FP64 for every dtype, like the hand-fused kernels).
-template <typename Spec, int MODE, typename TO>
+template <typename Spec, int MODE, typename TO, bool ONE = false>
 __device__ __forceinline__ void generic_eval_body(const GenericArgs &a) {
     constexpr int P = Spec::P;
     constexpr int P2 = 2 * P;
@@ -249,7 +329,7 @@ __device__ __forceinline__ void generic_eval_body(const GenericArgs &a) {
         const double2v m = load_uv(a.tab, ic);
         double u, v;
         double J[P2];
-        eval_tile_lane<Spec, JAC>(a, c, im, k, u, v, J);
+        eval_tile_lane<Spec, JAC, ONE>(a, lane, c, im, k, u, v, J);
         if constexpr (RES) {
             O2 r;
             r.x = (TO)(u - m.x);
@@ -264,7 +344,7 @@ __device__ __forceinline__ void generic_eval_body(const GenericArgs &a) {
 // and gathered it): every lane packs the kept entries of its two rows into the wave-private LDS image at its offset inside the
 // tile's contiguous range of the CSR data array, then the wave streams the range out — ba_compact_tile_kernel's store phase with
 // a 64-bit keep mask (generated chains reach P = 51).  `a.jac` is the data array here.
-template <typename Spec, int MODE, typename TO>
+template <typename Spec, int MODE, typename TO, bool ONE = false>
 __device__ __forceinline__ void generic_compact_body(const GenericArgs &a) {
     constexpr int P = Spec::P;
     constexpr int P2 = 2 * P;
@@ -294,7 +374,7 @@ __device__ __forceinline__ void generic_compact_body(const GenericArgs &a) {
         asm volatile("" ::: "memory");
         double u, v;
         double J[P2];
-        eval_tile_lane<Spec, true>(a, c, im, k, u, v, J);
+        eval_tile_lane<Spec, true, ONE>(a, lane, c, im, k, u, v, J);
         if constexpr (RES) {
             O2 r;
             r.x = (TO)(u - m.x);
@@ -348,18 +428,29 @@ __device__ __forceinline__ void generic_compact_body(const GenericArgs &a) {
     }
 }
 
-// What chain_compiler.py appends after the ChainSpec struct it emits: the entry points of the code object.
+// What chain_compiler.py appends after the ChainSpec struct it emits: the entry points of the code object — every kernel in the
+// two-launch form (behind pcs_genchain_prep) and in the one-launch form (`_one`).
 #define PCS_GENCHAIN_ENTRY_POINTS(Spec)                                                                                              \
     extern "C" __global__ void pcs_genchain_prep(const pcs::GenericArgs a) { pcs::generic_slab_prep_body(a); }                        \
-    extern "C" __global__ __launch_bounds__(256) void pcs_genchain_eval_1(const pcs::GenericArgs a) { pcs::generic_eval_body<Spec, 1, double>(a); } \
-    extern "C" __global__ __launch_bounds__(256) void pcs_genchain_eval_2(const pcs::GenericArgs a) { pcs::generic_eval_body<Spec, 2, double>(a); } \
-    extern "C" __global__ __launch_bounds__(256) void pcs_genchain_eval_3(const pcs::GenericArgs a) { pcs::generic_eval_body<Spec, 3, double>(a); } \
-    extern "C" __global__ __launch_bounds__(256) void pcs_genchain_eval_1_f32(const pcs::GenericArgs a) { pcs::generic_eval_body<Spec, 1, float>(a); } \
-    extern "C" __global__ __launch_bounds__(256) void pcs_genchain_eval_2_f32(const pcs::GenericArgs a) { pcs::generic_eval_body<Spec, 2, float>(a); } \
-    extern "C" __global__ __launch_bounds__(256) void pcs_genchain_eval_3_f32(const pcs::GenericArgs a) { pcs::generic_eval_body<Spec, 3, float>(a); } \
-    extern "C" __global__ __launch_bounds__(256) void pcs_genchain_compact_2(const pcs::GenericArgs a) { pcs::generic_compact_body<Spec, 2, double>(a); } \
-    extern "C" __global__ __launch_bounds__(256) void pcs_genchain_compact_3(const pcs::GenericArgs a) { pcs::generic_compact_body<Spec, 3, double>(a); } \
-    extern "C" __global__ __launch_bounds__(256) void pcs_genchain_compact_2_f32(const pcs::GenericArgs a) { pcs::generic_compact_body<Spec, 2, float>(a); } \
-    extern "C" __global__ __launch_bounds__(256) void pcs_genchain_compact_3_f32(const pcs::GenericArgs a) { pcs::generic_compact_body<Spec, 3, float>(a); }
+    extern "C" __global__ __launch_bounds__(256) void pcs_genchain_eval_1(const pcs::GenericArgs a) { pcs::generic_eval_body<Spec, 1, double, false>(a); } \
+    extern "C" __global__ __launch_bounds__(256) void pcs_genchain_eval_2(const pcs::GenericArgs a) { pcs::generic_eval_body<Spec, 2, double, false>(a); } \
+    extern "C" __global__ __launch_bounds__(256) void pcs_genchain_eval_3(const pcs::GenericArgs a) { pcs::generic_eval_body<Spec, 3, double, false>(a); } \
+    extern "C" __global__ __launch_bounds__(256) void pcs_genchain_eval_1_f32(const pcs::GenericArgs a) { pcs::generic_eval_body<Spec, 1, float, false>(a); } \
+    extern "C" __global__ __launch_bounds__(256) void pcs_genchain_eval_2_f32(const pcs::GenericArgs a) { pcs::generic_eval_body<Spec, 2, float, false>(a); } \
+    extern "C" __global__ __launch_bounds__(256) void pcs_genchain_eval_3_f32(const pcs::GenericArgs a) { pcs::generic_eval_body<Spec, 3, float, false>(a); } \
+    extern "C" __global__ __launch_bounds__(256) void pcs_genchain_compact_2(const pcs::GenericArgs a) { pcs::generic_compact_body<Spec, 2, double, false>(a); } \
+    extern "C" __global__ __launch_bounds__(256) void pcs_genchain_compact_3(const pcs::GenericArgs a) { pcs::generic_compact_body<Spec, 3, double, false>(a); } \
+    extern "C" __global__ __launch_bounds__(256) void pcs_genchain_compact_2_f32(const pcs::GenericArgs a) { pcs::generic_compact_body<Spec, 2, float, false>(a); } \
+    extern "C" __global__ __launch_bounds__(256) void pcs_genchain_compact_3_f32(const pcs::GenericArgs a) { pcs::generic_compact_body<Spec, 3, float, false>(a); } \
+    extern "C" __global__ __launch_bounds__(256) void pcs_genchain_eval_1_one(const pcs::GenericArgs a) { pcs::generic_eval_body<Spec, 1, double, true>(a); } \
+    extern "C" __global__ __launch_bounds__(256) void pcs_genchain_eval_2_one(const pcs::GenericArgs a) { pcs::generic_eval_body<Spec, 2, double, true>(a); } \
+    extern "C" __global__ __launch_bounds__(256) void pcs_genchain_eval_3_one(const pcs::GenericArgs a) { pcs::generic_eval_body<Spec, 3, double, true>(a); } \
+    extern "C" __global__ __launch_bounds__(256) void pcs_genchain_eval_1_f32_one(const pcs::GenericArgs a) { pcs::generic_eval_body<Spec, 1, float, true>(a); } \
+    extern "C" __global__ __launch_bounds__(256) void pcs_genchain_eval_2_f32_one(const pcs::GenericArgs a) { pcs::generic_eval_body<Spec, 2, float, true>(a); } \
+    extern "C" __global__ __launch_bounds__(256) void pcs_genchain_eval_3_f32_one(const pcs::GenericArgs a) { pcs::generic_eval_body<Spec, 3, float, true>(a); } \
+    extern "C" __global__ __launch_bounds__(256) void pcs_genchain_compact_2_one(const pcs::GenericArgs a) { pcs::generic_compact_body<Spec, 2, double, true>(a); } \
+    extern "C" __global__ __launch_bounds__(256) void pcs_genchain_compact_3_one(const pcs::GenericArgs a) { pcs::generic_compact_body<Spec, 3, double, true>(a); } \
+    extern "C" __global__ __launch_bounds__(256) void pcs_genchain_compact_2_f32_one(const pcs::GenericArgs a) { pcs::generic_compact_body<Spec, 2, float, true>(a); } \
+    extern "C" __global__ __launch_bounds__(256) void pcs_genchain_compact_3_f32_one(const pcs::GenericArgs a) { pcs::generic_compact_body<Spec, 3, float, true>(a); }
 
 }  // namespace pcs
