@@ -622,9 +622,9 @@ inline bool cp_fits(const int64_t n, const int n_cus) {
     return n > 0 && n_cus >= nb && cp_tiles(nb) <= (int64_t)CP_MAX_SLOTS * n_cus;   // every diagonal tile on a workgroup of its own
 }
 
-// Enqueue memset + kernel on `s`.  The caller has checked cp_fits and set the device.
+// Enqueue memset (unless `prefilled`) + kernel on `s`.  The caller has checked cp_fits and set the device.
 inline hipError_t cp_launch(const int64_t n, double *d_S, const int64_t ld, const double *d_rhs, double *d_x, double *d_work, int32_t *d_status,
-                            const int n_cus, hipStream_t s, const double timeout_s = 0.25, int64_t *trace = nullptr, const int32_t *d_stop = nullptr) {
+                            const int n_cus, hipStream_t s, const double timeout_s = 0.25, int64_t *trace = nullptr, const int32_t *d_stop = nullptr, const bool prefilled = false) {
     const int64_t nb = (n + 31) / 32, T = cp_tiles(nb);
     const int G = (int)(T < n_cus ? T : n_cus);
     const int slots = (int)((T + G - 1) / G);
@@ -643,7 +643,8 @@ inline hipError_t cp_launch(const int64_t n, double *d_S, const int64_t ld, cons
     (void)trace;
 #endif
     const size_t lds = cp_lds_bytes(slots);
-    hipError_t e = hipMemsetAsync(d_work, 0xFF, sizeof(double) * (size_t)cp_work_doubles(nb), s);
+    // prefilled: an earlier kernel on `s` has set the workspace to the fill value (schur_lead_kernel in an LM trial)
+    hipError_t e = prefilled ? hipSuccess : hipMemsetAsync(d_work, 0xFF, sizeof(double) * (size_t)cp_work_doubles(nb), s);
     if (e != hipSuccess) return e;
     static bool attr_set = false;   // one code object per process: the attribute sticks to the function
     if (!attr_set) {

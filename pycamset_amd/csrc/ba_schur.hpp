@@ -39,6 +39,8 @@ struct SchurArgs {
     int32_t *status;            // bit 0: a trailing block was not positive definite
     int64_t n_lead, n_trail, n_ent, trail_off;
     const int32_t *stop;        // optional: a device word; non-zero = the LM loop has ended, this (speculatively queued) launch does nothing
+    uint64_t *fill;             // optional (schur_lead_kernel): fill_n words to set to all-ones — the hand-over workspace of the one-launch
+    int64_t fill_n;             // Cholesky that follows in the same trial (ba_chol_persist.hpp), instead of a memset launch of its own
 };
 // Every kernel of an LM trial starts with this: the host queues trial t + 1 before it has read the verdict of trial t
 // (pcs_lm_trial), and lm_decide_kernel raises the flag when the loop is over — what was queued behind it then drains as no-ops.
@@ -156,6 +158,7 @@ __global__ __launch_bounds__(256) void schur_v_kernel(const SchurArgs a) {
 __global__ __launch_bounds__(256) void schur_lead_kernel(const SchurArgs a) {
     PCS_STOP_GUARD(a);
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int64_t i = t; i < a.fill_n; i += (int64_t)gridDim.x * blockDim.x) a.fill[i] = ~0ull;
     if (t >= a.n_lead * a.n_lead) return;
     const int64_t r = t / a.n_lead, c = t - r * a.n_lead;
     const bool fr = a.fixed[r] != 0, fc = a.fixed[c] != 0;

@@ -1660,9 +1660,11 @@ int pcs_normal_blocks_device(pcs_engine *h, const double *d_param_str, double *d
 }
 
 static int enqueue_schur_prepare(pcs_engine *h, double *d_packed, const uint8_t *d_fixed, const double *d_lambda, double *d_linvt, double *d_u,
-                                 double *d_V, double *d_S, double *d_rhs, double *d_dvec, double *d_gm, int32_t *d_status, hipStream_t s, const int32_t *d_stop) {
+                                 double *d_V, double *d_S, double *d_rhs, double *d_dvec, double *d_gm, int32_t *d_status, hipStream_t s, const int32_t *d_stop,
+                                 double *d_fill = nullptr, int64_t fill_n = 0) {
     const BlockLayout L = block_layout(h);
     SchurArgs a{};
+    a.fill = reinterpret_cast<uint64_t *>(d_fill); a.fill_n = d_fill ? fill_n : 0;
     a.A = d_packed; a.B = d_packed + L.a_len(); a.C = a.B + L.b_len(); a.g = a.C + L.c_len();
     a.fixed = d_fixed; a.lambda = d_lambda;
     a.linvt = d_linvt; a.u = d_u; a.V = d_V; a.S = d_S; a.rhs = d_rhs; a.dvec = d_dvec; a.gm = d_gm; a.status = d_status;
@@ -1793,7 +1795,14 @@ int pcs_dense_spd_solve(int device, int64_t n, double *d_S, int64_t ld, const do
 }
 
 static int enqueue_dense_spd(int device, int64_t n, double *d_S, int64_t ld, const double *d_rhs, double *d_x, double *d_work, int32_t *d_status, void *stream,
-                             int algorithm, const int32_t *d_stop);
+                             int algorithm, const int32_t *d_stop, bool prefilled = false);
+
+// does a solve of size n with this algorithm request take the ONE persistent launch (csrc/ba_chol_persist.hpp)?  Wherever its tiles fit
+// the chip's LDS: n <= 1 984 on 256 CUs
+static bool dense_spd_is_one_launch(int device, int64_t n, int algorithm) {
+    static const bool env_launches = getenv("PCS_CHOL_LAUNCHES") != nullptr;   // A/B switch for whole runs
+    return n > 0 && cp_fits(n, device_cu_count(device)) && (algorithm == PCS_SPD_ONE_LAUNCH || (algorithm == PCS_SPD_AUTO && !env_launches));
+}
 
 int pcs_dense_spd_solve_algo(int device, int64_t n, double *d_S, int64_t ld, const double *d_rhs, double *d_x, double *d_work, int32_t *d_status, void *stream,
                              int algorithm) {
@@ -1801,21 +1810,17 @@ int pcs_dense_spd_solve_algo(int device, int64_t n, double *d_S, int64_t ld, con
 }
 
 static int enqueue_dense_spd(int device, int64_t n, double *d_S, int64_t ld, const double *d_rhs, double *d_x, double *d_work, int32_t *d_status, void *stream,
-                             int algorithm, const int32_t *d_stop) {
+                             int algorithm, const int32_t *d_stop, bool prefilled) {
     constexpr int NB = 32;
     if (n <= 0 || n > (1 << 15) || ld < n || !d_S || !d_rhs || !d_x || !d_work || !d_status) return fail(PCS_ERR_ARG, "pcs_dense_spd_solve: bad arguments");
     if (algorithm != PCS_SPD_AUTO && algorithm != PCS_SPD_LAUNCHES && algorithm != PCS_SPD_ONE_LAUNCH) return fail(PCS_ERR_ARG, "pcs_dense_spd_solve: unknown algorithm %d", algorithm);
     if (device < 0 || device >= pcs_device_count()) return fail(PCS_ERR_NODEVICE, "pcs_dense_spd_solve: device %d not available", device);
     HIPCHK(hipSetDevice(device));
-    {   // ONE persistent launch (csrc/ba_chol_persist.hpp) wherever its tiles fit the chip's LDS: n <= 1 984 on 256 CUs
-        static const bool env_launches = getenv("PCS_CHOL_LAUNCHES") != nullptr;   // A/B switch for whole runs
-        const int cus = device_cu_count(device);
-        const bool fits = cp_fits(n, cus);
-        if (algorithm == PCS_SPD_ONE_LAUNCH && !fits) return fail(PCS_ERR_ARG, "pcs_dense_spd_solve: n = %lld does not fit the one-launch form on %d compute units", (long long)n, cus);
-        if (fits && (algorithm == PCS_SPD_ONE_LAUNCH || (algorithm == PCS_SPD_AUTO && !env_launches))) {
-            HIPCHK(cp_launch(n, d_S, ld, d_rhs, d_x, d_work, d_status, cus, (hipStream_t)stream, 0.25, nullptr, d_stop));
-            return PCS_OK;
-        }
+    if (algorithm == PCS_SPD_ONE_LAUNCH && !cp_fits(n, device_cu_count(device)))
+        return fail(PCS_ERR_ARG, "pcs_dense_spd_solve: n = %lld does not fit the one-launch form on %d compute units", (long long)n, device_cu_count(device));
+    if (dense_spd_is_one_launch(device, n, algorithm)) {
+        HIPCHK(cp_launch(n, d_S, ld, d_rhs, d_x, d_work, d_status, device_cu_count(device), (hipStream_t)stream, 0.25, nullptr, d_stop, prefilled));
+        return PCS_OK;
     }
     hipStream_t s = (hipStream_t)stream;   // NULL = the default stream
     const int nblk = (int)((n + NB - 1) / NB);
@@ -1869,7 +1874,10 @@ int pcs_lm_trial(pcs_engine *h, const pcs_lm_buffers *b, void *stream) {
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
     const BlockLayout L = block_layout(h);
     const int32_t *stop = b->stop_flag;
-    int rc = enqueue_schur_prepare(h, b->packed_cur, b->fixed, b->lambda, b->linvt, b->u, b->V, b->S, b->rhs, b->dvec, b->gm, b->status, s, stop);
+    // the one-launch Cholesky wants its hand-over workspace at the fill value: schur_lead_kernel sets it on the way (one launch fewer)
+    const bool prefill = L.n_lead > 0 && dense_spd_is_one_launch(h->device, L.n_lead, b->spd_algorithm);
+    int rc = enqueue_schur_prepare(h, b->packed_cur, b->fixed, b->lambda, b->linvt, b->u, b->V, b->S, b->rhs, b->dvec, b->gm, b->status, s, stop,
+                                   prefill ? b->spd_work : nullptr, prefill ? cp_work_doubles((L.n_lead + 31) / 32) : 0);
     if (rc) return rc;
     const int64_t ldv = std::max<int64_t>(1, L.n_trail);
     if (L.n_trail > 0 && L.n_lead > 0) {
@@ -1878,7 +1886,7 @@ int pcs_lm_trial(pcs_engine *h, const pcs_lm_buffers *b, void *stream) {
     }
     const double *w = b->u;
     if (L.n_lead > 0) {
-        rc = enqueue_dense_spd(h->device, L.n_lead, b->S, L.n_lead, b->rhs, b->xlead, b->spd_work, b->status, s, b->spd_algorithm, stop);
+        rc = enqueue_dense_spd(h->device, L.n_lead, b->S, L.n_lead, b->rhs, b->xlead, b->spd_work, b->status, s, b->spd_algorithm, stop, prefill);
         if (rc) return rc;
         if (L.n_trail > 0) {
             hipLaunchKernelGGL(schur_vtx_kernel, dim3((unsigned)((L.n_trail + 63) / 64)), dim3(1024), 0, s, (const double *)b->V, (const double *)b->xlead, b->w, (int)L.n_lead,

@@ -6,24 +6,31 @@ import sys
 
 rows = [r for r in csv.DictReader(open(sys.argv[1]))]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-# the last complete trial: from the last-but-one lm_decide_kernel (exclusive) to the last one (inclusive)
+# one trial = from one lm_decide_kernel (exclusive) to the next (inclusive).  The device-steered loop queues one speculative trial behind
+# the end of a solve, which drains as empty launches: take the trial of MEDIAN kernel time among those of the commonest launch count
 idx = [i for i, r in enumerate(rows) if "lm_decide_kernel" in r["Kernel_Name"]]
-if len(idx) < 2:
-    sys.exit("no two lm_decide_kernel launches in the trace")
-seg = rows[idx[-2] + 1: idx[-1] + 1]
-t_prev = int(rows[idx[-2]]["End_Timestamp"])
+if len(idx) < 3:
+    sys.exit("fewer than three lm_decide_kernel launches in the trace")
+segs = []
+for a, b in zip(idx[:-1], idx[1:]):
+    seg = rows[a + 1: b + 1]
+    busy = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in seg) / 1e3
+    segs.append((len(seg), busy, a, b))
+count = max(set(n for n, _, _, _ in segs), key=[n for n, _, _, _ in segs].count)
+cand = sorted((busy, a, b) for n, busy, a, b in segs if n == count)
+_, a, b = cand[len(cand) // 2]
+seg = rows[a + 1: b + 1]
+t_prev = int(rows[a]["End_Timestamp"])
 busy = gaps = 0.0
-short = {}
+lines = []
 for r in seg:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
     name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("pcs::", "")[:60]
     d, g = (e - s) / 1e3, (s - t_prev) / 1e3
     busy += d
     gaps += max(g, 0.0)
-    key = name
-    short.setdefault(key, [0, 0.0, 0.0])
-    short[key][0] += 1; short[key][1] += d; short[key][2] += max(g, 0.0)
+    lines.append((name, d, max(g, 0.0)))
     t_prev = e
-print(f"one trial: {len(seg)} launches, kernels {busy:.1f} us, gaps {gaps:.1f} us, span {busy + gaps:.1f} us")
-for k, (n, d, g) in sorted(short.items(), key=lambda kv: -kv[1][1]):
-    print(f"  {k:60s} x{n:3d}  kernels {d:8.1f} us   gaps before {g:7.1f} us")
+print(f"one trial (median of {len(cand)} with {count} launches): {len(seg)} launches, kernels {busy:.1f} us, gaps {gaps:.1f} us, span {busy + gaps:.1f} us")
+for name, d, g in lines:   # in launch order
+    print(f"  {name:60s} kernel {d:8.1f} us   gap before {g:6.1f} us")

@@ -1,10 +1,10 @@
 # Collect the round-4 measurements (one MI355X).  usage: bash tools/scripts/r04_collect.sh [part ...]   -> gpurun_out/r04/final/
-# parts: bench stats pmc lm chol tri gloo scaling (default: all)
+# parts: bench stats pmc lm chol tri gen gloo scaling (default: all)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/r04/final
 mkdir -p $O
 cd $R
-PARTS="${@:-bench stats pmc lm chol tri gloo scaling}"
+PARTS="${@:-bench stats pmc lm chol tri gen gloo scaling}"
 say() { echo "[r04_collect] $*"; }
 has() { case " $PARTS " in *" $1 "*) return 0;; *) return 1;; esac; }
 if has bench; then
@@ -64,6 +64,9 @@ fi
 if has tri; then
 say "triangulation"; bash tools/scripts/r04_tri.sh > /dev/null 2>&1
 cp $R/gpurun_out/r04/tri_bench_r03_kernel.log $R/gpurun_out/r04/tri_bench.log $R/gpurun_out/r04/pmc_traffic_triangulate.json $O/ 2>/dev/null
+fi
+if has gen; then
+say "generated chain: one launch against two"; timeout -k 10 300 python tools/genchain_forms.py 2>&1 < /dev/null | grep -v amdgpu > $O/genchain_forms.log
 fi
 if has gloo; then
 say "bench.py --gpus N without a launcher (gloo rehearsal on one GPU: the ranks share the card)"
