@@ -273,19 +273,34 @@ __global__ __launch_bounds__(256) void schur_syrk_kernel(const SchurSyrkArgs a) 
 // streams 2 x 32 rows of V for 32 x 32 outputs: 1 431 tiles x 1 458 columns x 512 B = 1.05 GB through L2 / Infinity Cache for a
 // 19.6 MB matrix — 175 us, bandwidth-bound at 6 TB/s while the matrix cores idle two thirds of the time (their floor: 60 us).
 // A 64 x 64 tile halves the bytes per FMA: four waves = four 32 x 32 quadrants (2 x 2 MFMA tiles each: two operand reads feed
-// four v_mfma_f64_16x16x4 per k-step), both row blocks staged 32 columns at a time (row stride 36 doubles), the next chunk in
-// flight meanwhile.  Same K split, same atomics, same rhs += V u by the diagonal tiles.
-constexpr int SYRK64_LD = 36;
+// four v_mfma_f64_16x16x4 per k-step), both row blocks staged 32 columns at a time (row stride 33 doubles: 36 cost 5 % in bank
+// conflicts, 40 cost 23 %), the next chunk in flight meanwhile.  Same atomics, same rhs += V u by the diagonal tiles; K is split so
+// that the workgroups fill whole rounds of the 2 x 256 resident ones (pcs_engine.hip: 378 tiles x 4 on rig-32-self, 147 -> 125 us).
+// Measured and dropped (tools/probes/syrk_ld_probe.hip, profiles/r04/README.md): two chunks in flight (-4 %, +32 VGPRs), 64-column
+// chunks (one wave per SIMD: slower), an XCD-aware super-tile order (no change: the operand stream is not what waits).  The matrix
+// pipe is 47 % busy over the launch (SQ_VALU_MFMA_BUSY_CYCLES = 64 x SQ_INSTS_MFMA exactly; 58 us of matrix work).
+// developer probes (tools/probes/syrk_ld_probe.hip) build the kernel with other chunk widths / row strides
+#ifndef PCS_SYRK64_KC
+#define PCS_SYRK64_KC 32
+#endif
+#ifndef PCS_SYRK64_LD
+#define PCS_SYRK64_LD (PCS_SYRK64_KC + 1)
+#endif
+constexpr int SYRK64_KC = PCS_SYRK64_KC, SYRK64_LD = PCS_SYRK64_LD;   // odd row stride: the 16 rows a quarter wave reads land on 16 different bank pairs
 __global__ __launch_bounds__(256) void schur_syrk64_kernel(const SchurSyrkArgs a) {
     PCS_STOP_GUARD(a);
     __shared__ double P[64][SYRK64_LD];
     __shared__ double Q[64][SYRK64_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int t = blockIdx.x / a.ksplit, kc = blockIdx.x % a.ksplit;
-    int bi = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);   // t -> (bi, bj), 0 <= bj <= bi
-    while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
-    while (bi * (bi + 1) / 2 > t) --bi;
-    const int bj = t - bi * (bi + 1) / 2;
+    auto tri = [](const int t, int &i, int &j) {   // t -> (i, j), 0 <= j <= i
+        i = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+        while ((i + 1) * (i + 2) / 2 <= t) ++i;
+        while (i * (i + 1) / 2 > t) --i;
+        j = t - i * (i + 1) / 2;
+    };
+    int bi, bj;
+    const int kc = blockIdx.x % a.ksplit;
+    tri(blockIdx.x / a.ksplit, bi, bj);
     const bool diag = bi == bj;
     const int k_begin = kc * a.kchunk, k_end = min(a.n_trail, k_begin + a.kchunk);
     const int i0 = 32 * (wave >> 1), j0 = 32 * (wave & 1);   // this wave's quadrant
@@ -298,11 +313,13 @@ __global__ __launch_bounds__(256) void schur_syrk64_kernel(const SchurSyrkArgs a
     const double *pa = &P[0][0] + (i0 + (lane & 15)) * SYRK64_LD + (lane >> 4);
     const double *pb = pq + (j0 + (lane & 15)) * SYRK64_LD + (lane >> 4);
     double dot = 0.0;   // diagonal tiles: this thread's share of (V u)[row], row = tid / 4
-    double pn[8], qn[8];   // the next 32-column chunk: 64 rows x 32 columns per operand = 8 doubles per thread
+    // Chunks of KC columns: 64 rows x KC columns per operand = KC / 4 doubles per thread, the next chunk in flight while one is multiplied.
+    constexpr int KC = SYRK64_KC, NQ = KC / 4;
+    double pn[NQ], qn[NQ];
     auto fetch = [&](const int k0) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int e = tid + 256 * q, r = e >> 5, c = e & 31;
+        for (int q = 0; q < NQ; ++q) {
+            const int e = tid + 256 * q, r = e / KC, c = e % KC;
             const int gk = k0 + c;
             const int gi = bi * 64 + r, gj = bj * 64 + r;
             pn[q] = (gi < a.n_lead && gk < k_end) ? a.V[(int64_t)gi * a.ldv + gk] : 0.0;
@@ -310,17 +327,17 @@ __global__ __launch_bounds__(256) void schur_syrk64_kernel(const SchurSyrkArgs a
         }
     };
     if (k_begin < k_end) fetch(k_begin);
-    for (int k0 = k_begin; k0 < k_end; k0 += 32) {
+    for (int k0 = k_begin; k0 < k_end; k0 += KC) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int e = tid + 256 * q, r = e >> 5, c = e & 31;
+        for (int q = 0; q < NQ; ++q) {
+            const int e = tid + 256 * q, r = e / KC, c = e % KC;
             P[r][c] = pn[q];
             if (!diag) Q[r][c] = qn[q];
         }
         __syncthreads();
-        if (k0 + 32 < k_end) fetch(k0 + 32);
+        if (k0 + KC < k_end) fetch(k0 + KC);
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
+        for (int s = 0; s < KC / 4; ++s) {
             const double a0 = pa[4 * s], a1 = pa[16 * SYRK64_LD + 4 * s];
             const double b0 = pb[4 * s], b1 = pb[16 * SYRK64_LD + 4 * s];
             acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
@@ -331,9 +348,9 @@ __global__ __launch_bounds__(256) void schur_syrk64_kernel(const SchurSyrkArgs a
         if (diag && a.u) {
             const int r = tid >> 2, part = tid & 3;
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const int gk = k0 + part * 8 + c;
-                dot += P[r][part * 8 + c] * (gk < k_end ? a.u[gk] : 0.0);
+            for (int c = 0; c < KC / 4; ++c) {
+                const int gk = k0 + part * (KC / 4) + c;
+                dot += P[r][part * (KC / 4) + c] * (gk < k_end ? a.u[gk] : 0.0);
             }
         }
         __syncthreads();

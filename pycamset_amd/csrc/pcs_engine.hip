@@ -1738,6 +1738,7 @@ int64_t pcs_dense_spd_work_len(int64_t n) {   // launch-per-column form: inverse
     return std::max<int64_t>(2 * nb * 32 * 32 + nb * 32, cp_work_doubles(nb));
 }
 
+static int device_cu_count(int device);
 static int enqueue_schur_syrk(int64_t n_lead, int64_t n_trail, const double *d_V, int64_t ldv, double *d_S, int64_t lds, const double *d_u, double *d_rhs,
                               hipStream_t s, const int32_t *d_stop) {
     // 64 x 64 tiles once 32 x 32 ones alone would fill the chip twice over (their operand traffic, not the matrix cores, is the bound then:
@@ -1752,6 +1753,19 @@ static int enqueue_schur_syrk(int64_t n_lead, int64_t n_trail, const double *d_V
     ksplit = std::max<int64_t>(1, ksplit);
     int64_t kchunk = ((n_trail + ksplit - 1) / ksplit + 63) / 64 * 64;
     ksplit = (n_trail + kchunk - 1) / kchunk;
+    if (big) {
+        // 64 x 64 tiles run two workgroups per CU: split K so that the workgroups fill whole rounds of the resident ones — the cost of a
+        // split = rounds x (columns per workgroup + ~64 columns' worth of ramp and atomics); rig-32-self: 378 tiles x 4 = 2.95 rounds
+        int dev = 0;
+        const int cus = hipGetDevice(&dev) == hipSuccess && device_cu_count(dev) > 0 ? device_cu_count(dev) : 256;
+        const int64_t slots = 2 * (int64_t)cus;
+        int64_t best = INT64_MAX;
+        for (int64_t ks = 1; ks <= std::max<int64_t>(1, n_trail / 128); ++ks) {
+            const int64_t kc = ((n_trail + ks - 1) / ks + 63) / 64 * 64, real = (n_trail + kc - 1) / kc;
+            const int64_t cost = (tiles * real + slots - 1) / slots * (kc + 64);
+            if (cost < best) { best = cost; ksplit = real; kchunk = kc; }
+        }
+    }
     SchurSyrkArgs a{d_V, d_S, d_u, d_rhs, (int32_t)n_lead, (int32_t)n_trail, (int32_t)ldv, (int32_t)lds, (int32_t)ksplit, (int32_t)kchunk, d_stop};
     if (big) hipLaunchKernelGGL(schur_syrk64_kernel, dim3((unsigned)(tiles * ksplit)), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(schur_syrk_kernel, dim3((unsigned)(tiles * ksplit)), dim3(256), 0, s, a);
