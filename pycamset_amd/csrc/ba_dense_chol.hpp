@@ -124,7 +124,7 @@ __device__ __forceinline__ bool factor_and_invert_tile(double (&D)[NB][NB + 1], 
 // lane l reads P[i0 + (l & 15)][4 s + (l >> 4)] and Q[j0 + (l & 15)][4 s + (l >> 4)].  Eight k-steps, 8 MFMAs and 16
 // ds_read_b64 per product and wave — the first version's VALU form read 9 LDS operands per 8 FMAs, ~4 us of a 22 us launch.
 using chol_d4 = __attribute__((ext_vector_type(4))) double;
-constexpr int CHOL_LDP = 36;   // row stride (doubles) of MFMA operand tiles: lanes (row, k) -> banks 8 row + 2 k: two passes, the minimum
+constexpr int CHOL_LDP = 33;   // row stride (doubles) of MFMA operand tiles: odd, so that the 16 rows a quarter wave reads land on 16 different bank pairs (36: 4-way conflicts, syrk64 lost 5 % to them)
 constexpr int CHOL_LDF = 33;   // row stride of the tiles the factorisation walks row-per-lane (conflict-free)
 
 template <int LDP_, int LDQ_, int KSTEPS = 8>

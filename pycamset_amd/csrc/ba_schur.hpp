@@ -180,8 +180,8 @@ __global__ __launch_bounds__(256) void schur_lead_kernel(const SchurArgs a) {
 // launch of 6 us).  Only the lower triangle of S is needed (pcs_dense_spd_solve reads nothing else), and a tile's two operands
 // are row blocks of the SAME matrix: one workgroup per 32 x 32 tile of the lower triangle (x a split of K when there are few
 // tiles: 180 leading x 60 000 trailing of the 2e4-point free chain), four waves = four 16 x 16 quadrants, both row blocks
-// staged through LDS 64 columns at a time (coalesced 512-byte row pieces; row stride 68 doubles = two LDS passes per operand
-// read), 16 v_mfma_f64_16x16x4 per staged chunk and wave, the next chunk in flight meanwhile.  The workgroups of the diagonal
+// staged through LDS 64 columns at a time (coalesced 512-byte row pieces; row stride 65 doubles: conflict-free operand
+// reads), 16 v_mfma_f64_16x16x4 per staged chunk and wave, the next chunk in flight meanwhile.  The workgroups of the diagonal
 // tiles add their rows' share of V u.  K is split until ~512 workgroups exist (two per CU hide the chunk loads of each other: one
 // workgroup per tile and no split took 108 us on rig-32, twice the library call); partial sums meet in f64 atomics — like every
 // entry of J'J itself (ba_normal.hpp), so the step's last bits were run-to-run dependent before this kernel.
@@ -193,7 +193,7 @@ struct SchurSyrkArgs {
     int32_t n_lead, n_trail, ldv, lds, ksplit, kchunk;   // kchunk: columns per split (multiple of 64)
     const int32_t *stop;
 };
-constexpr int SYRK_LD = 68;
+constexpr int SYRK_LD = 65;   // odd: a quarter wave reads 16 rows, 16 different bank pairs (68: 4-way conflicts)
 using schur_d4 = __attribute__((ext_vector_type(4))) double;
 
 __global__ __launch_bounds__(256) void schur_syrk_kernel(const SchurSyrkArgs a) {
