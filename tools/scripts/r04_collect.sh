@@ -60,6 +60,7 @@ hipcc --offload-arch=gfx950 -O3 -std=c++17 -I pycamset_amd/csrc -o tools/probes/
 CP_SHOW_TRACE=1 timeout -k 5 100 tools/probes/chol_persist_probe 480 > $O/chol_persist_trace_480.log 2>&1
 CP_SHOW_TRACE=1 timeout -k 5 100 tools/probes/chol_persist_probe 1680 > $O/chol_persist_trace_1680.log 2>&1
 timeout -k 5 100 tools/probes/chol_persist_probe 1 31 33 97 480 1003 1680 > $O/chol_persist_times.log 2>&1
+timeout -k 10 100 python tools/syrk_bench.py 2>&1 < /dev/null | grep -v amdgpu > $O/syrk_bench.log
 fi
 if has tri; then
 say "triangulation"; bash tools/scripts/r04_tri.sh > /dev/null 2>&1
