@@ -166,7 +166,13 @@ class Engine:
     def _out(self, name: str, shape, pinned_ring: int):
         """Output array: fresh pageable memory, or the next buffer of a ring of ``pinned_ring`` page-locked
         buffers.  A ring buffer is only reused once nobody else references it, so every array handed out stays
-        valid for as long as it is held — reference semantics either way."""
+        valid for as long as it is held — reference semantics either way.
+
+        What counts as "held": Python references to the array or to anything NumPy hangs on it — views
+        (``j.reshape(-1)``, slices), a ``scipy.sparse.csr_array`` built on it, ``torch.from_numpy(j)``
+        (tests/test_gpu_parity.py covers these).  What does NOT: a raw address taken from it (``j.ctypes.data``,
+        a pointer handed to a C library or queued on a stream) or a ``memoryview`` of the underlying ctypes block —
+        keep the array itself alive for as long as such a pointer is in use, as with any NumPy buffer."""
         if pinned_ring <= 0:
             return np.empty(shape)
         ring = self._rings.setdefault((name, tuple(shape), pinned_ring), {"bufs": [], "count": 0})
