@@ -88,8 +88,8 @@ constexpr int normal_slots(int chain, int pass) {
 }
 constexpr int normal_mfmas(int chain, int pass) { return (pass == PASS_SHARED && chain != CHAIN_FREE) ? 2 : 1; }
 // bytes between column slots: 2 * ROWS doubles + 16 -> slot s starts on bank (4 s) mod 64
-constexpr int normal_slot_stride(int rows) { return 2 * rows * 8 + 16; }
-constexpr int normal_lds_bytes(int chain, int pass, int rows) { return normal_slots(chain, pass) * normal_slot_stride(rows) + 64; }   // + 64: the walk's look-ahead read past the last k-step
+constexpr int normal_slot_stride(int rows) { return 2 * rows * 8 + 8; }   // an ODD number of doubles: the 16 slots a quarter wave reads an operand from start on 16 different bank pairs
+constexpr int normal_lds_bytes(int chain, int pass, int rows) { return normal_slots(chain, pass) * normal_slot_stride(rows) + 128; }   // + 128: the walk's look-ahead reads (up to three k-steps) past the last one
 
 // local column id (index into a J row; NORMAL_R = residual) stored in slot s of the image
 template <int CHAIN, int PASS>
@@ -381,14 +381,17 @@ __global__ __launch_bounds__(64, 2) void ba_normal_mfma_kernel(const NormalArgs 
 #pragma unroll
                 for (int s = 0; s < NSLOT; ++s) {
                     const int lc = slot_col<CHAIN, PASS>(s);
-                    D2 w;
-                    if (lc == NORMAL_R) { w.x = r0; w.y = r1; }
-                    else { w.x = J[lc]; w.y = J[P + lc]; }
-                    *reinterpret_cast<D2 *>(dst + s * KS) = w;
+                    double *q = reinterpret_cast<double *>(dst + s * KS);   // 8-byte aligned (odd slot stride): one ds_write2_b64
+                    q[0] = lc == NORMAL_R ? r0 : J[lc];
+                    q[1] = lc == NORMAL_R ? r1 : J[P + lc];
                 }
                 if (!valid) {   // only the table's last tile has such lanes: their rows are overwritten with zeros
 #pragma unroll
-                    for (int s = 0; s < NSLOT; ++s) *reinterpret_cast<D2 *>(dst + s * KS) = D2{0.0, 0.0};
+                    for (int s = 0; s < NSLOT; ++s) {
+                        double *q = reinterpret_cast<double *>(dst + s * KS);
+                        q[0] = 0.0;
+                        q[1] = 0.0;
+                    }
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -414,11 +417,11 @@ __global__ __launch_bounds__(64, 2) void ba_normal_mfma_kernel(const NormalArgs 
             const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)lds_image;
             auto run_steps = [&](const int s0, const int s1) {
                 if (s0 >= s1) return;
-                double x[2][NW];
-                // one running byte address per operand window: the reads of a trip are `adr + 32` and `adr + 64` (immediate offsets)
-                // and the trip costs NW additions.  The first version rebuilt every address from the step number (9 v_add per trip
-                // + a clamp of the look-ahead step on the scalar side); the look-ahead past the image's last step now simply reads
-                // the next slot's first bytes / the 64-byte pad behind the image, and that value is never used.
+                double x[3][NW];
+                // one running byte address per operand window: the reads of a trip are immediate offsets from it and the trip costs NW
+                // additions.  (The first version rebuilt every address from the step number: 9 v_add per trip + a clamp of the
+                // look-ahead step on the scalar side.)  The look-ahead past the image's last step simply reads the next slot's first
+                // bytes / the 64-byte pad behind the image, and those values are never used.
                 using LdsD = const __attribute__((address_space(3))) double *;
                 uint32_t adr[NW];   // LDS byte addresses
 #pragma unroll
@@ -426,36 +429,37 @@ __global__ __launch_bounds__(64, 2) void ba_normal_mfma_kernel(const NormalArgs 
                     adr[w] = lds_base + (uint32_t)rd_off[w] + (uint32_t)s0 * 32u;
                     asm volatile("" : "+v"(adr[w]));   // one register per window (otherwise hipcc keeps base and offset apart: an add per read)
                     x[0][w] = *(LdsD)(uintptr_t)adr[w];
+                    x[1][w] = *(LdsD)(uintptr_t)(adr[w] + 32u);
                 }
                 int s = s0;
-                // Order per step: wait for THIS step's operands, request the next step's, issue the MFMAs.  hipcc places its
-                // s_waitcnt directly before the first use of a loaded register and — left alone — sinks the next step's
-                // ds_reads below the MFMAs (one register set, s_waitcnt 0 before every MFMA pair: 150 cycles per MFMA
-                // instead of 64).  `touch` is an empty asm that uses the operands, so the wait lands before the next requests
-                // are issued; sched_barrier(0) keeps the three groups in this order.
+                // Order per step: wait for THIS step's operands, request those of the step AFTER THE NEXT, issue the MFMAs: two steps
+                // of operands are in flight (with one, the walk ran at ~136 cycles per MFMA instead of 64 — LDS latency under seven
+                // waves per CU is longer than the two MFMAs of a step; `normal_debug 8`: the walk cost 55 us of the 90).  hipcc
+                // places its s_waitcnt directly before the first use of a loaded register and — left alone — sinks the next requests
+                // below the MFMAs; `touch` is an empty asm that uses the operands, so the wait lands before the next requests are
+                // issued; sched_barrier(0) keeps the three groups in this order.
                 auto touch = [&](const double (&v)[NW]) {
 #pragma unroll
                     for (int w = 0; w < NW; ++w) asm volatile("" ::"v"(v[w]));
                 };
-                for (; s + 1 < s1; s += 2) {   // two steps per trip: the operand buffers alternate without register moves
-                    touch(x[0]);
+                auto step = [&](const int cur, const int nxt2, const uint32_t off) {   // consume buffer `cur`, refill it... with step + 3
+                    touch(x[cur]);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int w = 0; w < NW; ++w) x[1][w] = *(LdsD)(uintptr_t)(adr[w] + 32u);
+                    for (int w = 0; w < NW; ++w) x[nxt2][w] = *(LdsD)(uintptr_t)(adr[w] + off);
                     __builtin_amdgcn_sched_barrier(0);
-                    run_mfmas(x[0]);
+                    run_mfmas(x[cur]);
                     __builtin_amdgcn_sched_barrier(0);
-                    touch(x[1]);
-                    __builtin_amdgcn_sched_barrier(0);
+                };
+                for (; s + 2 < s1; s += 3) {   // three steps per trip: the operand buffers rotate without register moves
+                    step(0, 2, 64u);
+                    step(1, 0, 96u);
+                    step(2, 1, 128u);
 #pragma unroll
-                    for (int w = 0; w < NW; ++w) x[0][w] = *(LdsD)(uintptr_t)(adr[w] + 64u);
-                    __builtin_amdgcn_sched_barrier(0);
-                    run_mfmas(x[1]);
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int w = 0; w < NW; ++w) adr[w] += 64u;
+                    for (int w = 0; w < NW; ++w) adr[w] += 96u;
                 }
                 if (s < s1) run_mfmas(x[0]);
+                if (s + 1 < s1) run_mfmas(x[1]);
             };
             if (a.debug & 8) {
                 // profiling: no MFMA phase
