@@ -154,25 +154,46 @@ __global__ __launch_bounds__(256) void schur_v_kernel(const SchurArgs a) {
     }
 }
 
-// One lane = one entry of the leading block: S = sym(A) with fixed rows / columns -> identity and the damped diagonal.
+// S = sym(A) with fixed rows / columns -> identity and the damped diagonal.  One workgroup per 32 x 32 tile of S: the build writes the
+// UPPER triangle of A, so a tile below the diagonal is the transpose of A's tile above it — read coalesced into LDS and written
+// transposed (one lane per entry with `A[c][r]` for r > c read every second entry with a stride of a row: 20.7 us for the 45 MB of
+// n_lead = 1 680).
 __global__ __launch_bounds__(256) void schur_lead_kernel(const SchurArgs a) {
     PCS_STOP_GUARD(a);
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (int64_t i = t; i < a.fill_n; i += (int64_t)gridDim.x * blockDim.x) a.fill[i] = ~0ull;
-    if (t >= a.n_lead * a.n_lead) return;
-    const int64_t r = t / a.n_lead, c = t - r * a.n_lead;
-    const bool fr = a.fixed[r] != 0, fc = a.fixed[c] != 0;
-    double v = r <= c ? a.A[r * a.n_lead + c] : a.A[c * a.n_lead + r];   // the build writes the upper triangle
-    if (fr || fc) v = (r == c) ? 1.0 : 0.0;
-    if (r == c) {
-        const double d = fr ? 0.0 : fmax(v, 1e-300);
-        a.dvec[r] = d;
-        const double gr = fr ? 0.0 : a.g[r];
-        a.gm[r] = gr;
-        a.rhs[r] = -gr;
-        v += *a.lambda * d;
+    __shared__ double T[32][33];
+    const int tid = threadIdx.x;
+    {
+        const int64_t t = (int64_t)blockIdx.x * blockDim.x + tid;
+        for (int64_t i = t; i < a.fill_n; i += (int64_t)gridDim.x * blockDim.x) a.fill[i] = ~0ull;
     }
-    a.S[t] = v;
+    const int nbt = (int)((a.n_lead + 31) / 32);
+    const int bi = blockIdx.x / nbt, bj = blockIdx.x % nbt;      // tile (bi, bj) of S
+    const int ti = bi < bj ? bi : bj, tj = bi < bj ? bj : bi;    // the tile of A's upper triangle it comes from
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int e = tid + 256 * q, r = e >> 5, c = e & 31;
+        const int64_t gr = (int64_t)ti * 32 + r, gc = (int64_t)tj * 32 + c;
+        T[r][c] = (gr < a.n_lead && gc < a.n_lead) ? a.A[gr * a.n_lead + gc] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int e = tid + 256 * q, r = e >> 5, c = e & 31;
+        const int64_t gr = (int64_t)bi * 32 + r, gc = (int64_t)bj * 32 + c;
+        if (gr >= a.n_lead || gc >= a.n_lead) continue;
+        double v = bi < bj ? T[r][c] : bi > bj ? T[c][r] : (r <= c ? T[r][c] : T[c][r]);
+        const bool fr = a.fixed[gr] != 0, fc = a.fixed[gc] != 0;
+        if (fr || fc) v = (gr == gc) ? 1.0 : 0.0;
+        if (gr == gc) {
+            const double d = fr ? 0.0 : fmax(v, 1e-300);
+            a.dvec[gr] = d;
+            const double g = fr ? 0.0 : a.g[gr];
+            a.gm[gr] = g;
+            a.rhs[gr] = -g;
+            v += *a.lambda * d;
+        }
+        a.S[gr * a.n_lead + gc] = v;
+    }
 }
 
 // ---- S -= V V' (lower tiles) and rhs += V u on the FP64 matrix cores ---------------------------------------------------------------
@@ -379,31 +400,43 @@ __global__ __launch_bounds__(256) void schur_syrk64_kernel(const SchurSyrkArgs a
     }
 }
 
-// w = V' x (n_trail outputs): 64 columns per workgroup, the reads of a row coalesced across a wave, sixteen waves share the rows
-// (four did at first: 19 workgroups x 4 waves x 120 dependent loads = 15 us for 4.6 MB)
+// w = V' x (n_trail outputs): COLS columns per workgroup, the reads of a row piece coalesced, 1024 / COLS threads share the rows of a
+// column (two independent chains each).  COLS = 64 means n_trail / 64 workgroups — 19 on rig-32, 23 on rig-32-self, of 256 CUs: each
+// streams ~0.5 MB alone (8.6 / 24.5 us); with 16 columns (whole 128-byte lines per row piece) four times as many CUs take part.
+template <int COLS>
 __global__ __launch_bounds__(1024) void schur_vtx_kernel(const double *__restrict__ V, const double *__restrict__ x, double *__restrict__ w,
                                                          const int n_lead, const int n_trail, const int ldv, const int32_t *__restrict__ stop) {
     if (stop && *stop) return;
-    const int col = threadIdx.x & 63, part = threadIdx.x >> 6;
-    const int j = blockIdx.x * 64 + col;
-    __shared__ double red[16][64];
+    constexpr int NPART = 1024 / COLS;
+    const int col = threadIdx.x % COLS, part = threadIdx.x / COLS;
+    const int j = blockIdx.x * COLS + col;
+    __shared__ double red[NPART][COLS + 1];
     double s0 = 0.0, s1 = 0.0;
     if (j < n_trail) {
         int r = part;
-        for (; r + 16 < n_lead; r += 32) {   // two independent chains per thread
+        for (; r + NPART < n_lead; r += 2 * NPART) {   // two independent chains per thread
             s0 += V[(int64_t)r * ldv + j] * x[r];
-            s1 += V[(int64_t)(r + 16) * ldv + j] * x[r + 16];
+            s1 += V[(int64_t)(r + NPART) * ldv + j] * x[r + NPART];
         }
         if (r < n_lead) s0 += V[(int64_t)r * ldv + j] * x[r];
     }
     red[part][col] = s0 + s1;
     __syncthreads();
+    for (int half = NPART / 2; half >= 16; half >>= 1) {   // down to 16 partial sums per column
+        if (part < half) red[part][col] += red[part + half][col];
+        __syncthreads();
+    }
     if (part == 0 && j < n_trail) {
         double s = 0.0;
 #pragma unroll
         for (int p = 0; p < 16; ++p) s += red[p][col];
         w[j] = s;
     }
+}
+// few columns per workgroup while that brings more CUs in
+inline void launch_schur_vtx(const double *V, const double *x, double *w, const int n_lead, const int n_trail, const int ldv, const int32_t *stop, hipStream_t s) {
+    if ((n_trail + 63) / 64 >= 128) hipLaunchKernelGGL(schur_vtx_kernel<64>, dim3((unsigned)((n_trail + 63) / 64)), dim3(1024), 0, s, V, x, w, n_lead, n_trail, ldv, stop);
+    else hipLaunchKernelGGL(schur_vtx_kernel<16>, dim3((unsigned)((n_trail + 15) / 16)), dim3(1024), 0, s, V, x, w, n_lead, n_trail, ldv, stop);
 }
 
 struct SchurBackArgs {

@@ -1682,7 +1682,8 @@ static int enqueue_schur_prepare(pcs_engine *h, double *d_packed, const uint8_t 
         }
     }
     if (L.n_lead > 0) {
-        hipLaunchKernelGGL(schur_lead_kernel, blocks(L.n_lead * L.n_lead), dim3(256), 0, s, a);
+        const int64_t nbt = (L.n_lead + 31) / 32;
+        hipLaunchKernelGGL(schur_lead_kernel, dim3((unsigned)(nbt * nbt)), dim3(256), 0, s, a);
         HIPCHK(hipGetLastError());
     }
     return PCS_OK;
@@ -1788,7 +1789,7 @@ int pcs_schur_vtx(int device, int64_t n_lead, int64_t n_trail, const double *d_V
     if (device < 0 || device >= pcs_device_count()) return fail(PCS_ERR_NODEVICE, "pcs_schur_vtx: device %d not available", device);
     if (n_trail == 0) return PCS_OK;
     HIPCHK(hipSetDevice(device));
-    hipLaunchKernelGGL(schur_vtx_kernel, dim3((unsigned)((n_trail + 63) / 64)), dim3(1024), 0, (hipStream_t)stream, d_V, d_x, d_w, (int)n_lead, (int)n_trail, (int)ldv, (const int32_t *)nullptr);
+    launch_schur_vtx(d_V, d_x, d_w, (int)n_lead, (int)n_trail, (int)ldv, nullptr, (hipStream_t)stream);
     HIPCHK(hipGetLastError());
     return PCS_OK;
 }
@@ -1903,8 +1904,7 @@ int pcs_lm_trial(pcs_engine *h, const pcs_lm_buffers *b, void *stream) {
         rc = enqueue_dense_spd(h->device, L.n_lead, b->S, L.n_lead, b->rhs, b->xlead, b->spd_work, b->status, s, b->spd_algorithm, stop, prefill);
         if (rc) return rc;
         if (L.n_trail > 0) {
-            hipLaunchKernelGGL(schur_vtx_kernel, dim3((unsigned)((L.n_trail + 63) / 64)), dim3(1024), 0, s, (const double *)b->V, (const double *)b->xlead, b->w, (int)L.n_lead,
-                               (int)L.n_trail, (int)ldv, stop);
+            launch_schur_vtx(b->V, b->xlead, b->w, (int)L.n_lead, (int)L.n_trail, (int)ldv, stop, s);
             HIPCHK(hipGetLastError());
             w = b->w;
         }

@@ -313,7 +313,14 @@ def test_user_blocks_layout_structure_and_code_generation(golden_dir, tag):
     _check_compaction_tables(g["data_all"], g["data_masked"], keep, off, spec.P)
     text = cc.emit_source(spec)
     assert "namespace user" in text and "pcs::chain_user<" in text
-    assert cc.compile_chain(spec).stat().st_size > 10_000
+    # what the one-launch kernels need to prepare the slabs themselves: one slab per rigid parameter group, and whose transform it holds
+    n_rigid = sum(1 for gr in spec.groups if gr["kind"] == "rigid")
+    assert f"static constexpr int N_SLABS = {n_rigid};" in text and "slab_link(const int g)" in text
+    obj = cc.compile_chain(spec)
+    assert obj.stat().st_size > 10_000
+    blob = obj.read_bytes()
+    for entry in (b"pcs_genchain_prep", b"pcs_genchain_eval_3", b"pcs_genchain_eval_3_one", b"pcs_genchain_compact_2_f32", b"pcs_genchain_compact_2_f32_one"):
+        assert entry in blob, entry   # both launch forms of every kernel are in the code object
     # what the composition rules refuse: a block that is neither shipped nor a device block; neighbours that do not fit
     class plain(fb.abstract_function_block):
         num_inp, num_out = 3, 3
