@@ -209,8 +209,11 @@ __device__ __forceinline__ double cp_rsqrt(const double p) {
 #ifdef CP_TRACE
 __device__ int64_t cp_dbg[4 * 16];
 #define CP_DBG(k) do { if (lane == 0 && blockIdx.x == gridDim.x - 1) cp_dbg[wave * 16 + (k)] = (int64_t)wall_clock64(); } while (0)   // developer builds: the last workgroup's last panel
+__device__ int64_t cp_tile_dbg[8 * 8];   // developer builds: workgroup 100's trailing updates with column 3: five stamps per tile
+#define CP_TILE(k) do { if (tid == 0 && blockIdx.x == 100 && m == 3 && !urgent && s < 8) cp_tile_dbg[s * 8 + (k)] = (int64_t)wall_clock64(); } while (0)
 #else
 #define CP_DBG(k) do { } while (0)
+#define CP_TILE(k) do { } while (0)
 #endif
 
 // The 64 x 32 panel [D; X] — D = the (private copy of the) diagonal tile, X = the tile below it — factored by the FOUR waves of the
@@ -379,66 +382,91 @@ __global__ __launch_bounds__(256) void chol_persist_kernel(const CholPersistArgs
     __syncthreads();
     if (tid == 0) __hip_atomic_fetch_add(a.flags + CP_LOADED, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the originals of S are in LDS: diagonal tiles of S may be overwritten once every workgroup has said so
 
-    // Block column m applied to every slot whose column is in [jlo, jhi]: fetch (sc1) -> park -> products, tile by tile, the NEXT tile's
-    // operands requested before the current tile's products (a fetch is a ~1 us round trip; park + products + two barriers measure
-    // 1.3 us per tile, 0.43 us of it the sixteen matrix instructions: with five or six tiles per workgroup — the first columns of
-    // n = 1 680 — the trailing update, not the panel chain, sets the pace: 12 us per block column there, 7.5 us later).
-    auto apply_column = [&](const int m, const int jlo, const int jhi) -> bool {
+    // Block column m applied to this workgroup's tiles: fetch (sc1) -> park -> products, tile by tile, TWO tiles' operands in flight
+    // (register sets A and B alternate: a fetch is a 1-2 us round trip; park + products + two barriers measure ~1.3 us per tile,
+    // 0.43 us of it the sixteen matrix instructions).  With five or six tiles per workgroup — the first columns of n = 1 680 — the
+    // trailing update, not the panel chain, sets the pace: ~10.5 us per block column there, 7.3 us later.
+    // urgent = true: the tiles of column m + 1 below the diagonal (somebody waits for them); false: every later column AND the diagonal
+    // tile of column m + 1 — nobody waits for a diagonal tile (the owners of the tiles below it factor their own copies), its factor
+    // and inverse are needed by the backward sweep only.
+    auto apply_column = [&](const int m, const bool urgent) -> bool {
         auto next_slot = [&](int s) {
             for (; s < a.slots; ++s) {
                 int i, j;
                 tile(s, i, j);
-                if (i >= 0 && j >= jlo && j <= jhi) break;
+                if (i >= 0 && (urgent ? (j == m + 1 && i != j) : (j >= m + 2 || (j == m + 1 && i == j)))) break;
             }
             return s;
         };
-        int s = next_slot(0);
-        double vp[4], vq[4];
-        if (s < a.slots) {
+        double vpa[4], vqa[4], vpb[4], vqb[4];
+        auto request = [&](double (&vp)[4], double (&vq)[4], const int s) {
+            if (s >= a.slots) return;
             int i, j;
             tile(s, i, j);
             cp_fetch(a, vp, i, m, tid);
             if (i != j) cp_fetch(a, vq, j, m, tid);
-        }
-        while (s < a.slots) {
+        };
+        // consume the set that holds tile s; `sn2` = the tile two further on, requested into the same set once this one is parked
+        auto consume = [&](double (&vp)[4], double (&vq)[4], const int s, const int sn2) -> bool {
             int i, j;
             tile(s, i, j);
+            CP_TILE(0);
             if (__syncthreads_or(cp_is_fill(vp) || (i != j && cp_is_fill(vq))) && !cp_fetch_polled(a, vp, vq, i, j, m, tid)) return false;
+            CP_TILE(1);
             cp_park(P, vp, tid);
             if (i != j) cp_park(Q, vq, tid);
             __syncthreads();
-            const int sn = next_slot(s + 1);
-            if (sn < a.slots) {
-                int in, jn;
-                tile(sn, in, jn);
-                cp_fetch(a, vp, in, m, tid);
-                if (in != jn) cp_fetch(a, vq, jn, m, tid);
-            }
+            CP_TILE(2);
+            request(vp, vq, sn2);
             cp_apply(P, Q, Town(s), Td(s), i == j, lane, wave);
+            CP_TILE(3);
             __syncthreads();
-            s = sn;
+            CP_TILE(4);
+            return true;
+        };
+        int s0 = next_slot(0), s1 = next_slot(s0 + 1);
+        request(vpa, vqa, s0);
+        request(vpb, vqb, s1);
+        while (s0 < a.slots) {
+            const int s2 = next_slot(s1 + 1);
+            if (!consume(vpa, vqa, s0, s2)) return false;
+            if (s1 >= a.slots) break;
+            const int s3 = next_slot(s2 + 1);
+            if (!consume(vpb, vqb, s1, s3)) return false;
+            s0 = s2;
+            s1 = s3;
         }
         return true;
     };
 
     // ---- factorisation: iteration m consumes block column m and produces the tiles of column m + 1 ----------------------------------------
-    for (int m = -1; m < max_j; ++m) {
+    // One extra round at the end (`last`): this workgroup's own diagonal tile is factored and inverted THERE.  As part of its column's
+    // urgent work it made the owner of diagonal tile k late for column k + 1 whenever it also held a tile of that column (23 us
+    // iterations: the spikes of 14-22 us per block column in the first columns of n = 1 680).
+    for (int m = -1; m <= max_j; ++m) {
+        const bool last = m == max_j;
         CP_STAMP(m + 1, 0);
         CP_STAMP(m + 1, 1);
-        // urgent: the tiles of column m + 1
+        // urgent: the tiles of column m + 1 below the diagonal
         int ncrit = 0;
 #pragma unroll
-        for (int s = 0; s < CP_MAX_SLOTS; ++s) ncrit += pk[s] != 0xFFFF && (pk[s] & 255) == m + 1;
+        for (int s = 0; s < CP_MAX_SLOTS; ++s) ncrit += pk[s] != 0xFFFF && (pk[s] & 255) == m + 1 && (pk[s] >> 8) != m + 1;
+        if (last) ncrit = has_diag ? 1 : 0;
         if (ncrit) {
-            if (m >= 0 && !apply_column(m, m + 1, m + 1)) return;
+            if (!last && m >= 0 && !apply_column(m, true)) return;
             CP_STAMP(m + 1, 2);
             for (int s = 0; s < a.slots; ++s) {   // the four waves factor one panel together; a workgroup rarely has a second one in a column
                 int i, j;
                 tile(s, i, j);
-                if (j != m + 1) continue;
+                if (last ? (i != j) : (j != m + 1 || i == j)) continue;
                 const bool ok = cp_panel4(i == j ? Town(s) : Td(s), Town(s), i == j, Sv(s), Sp, seq, panels++, lane, wave);
                 if (!__builtin_amdgcn_readfirstlane((int)__all(ok)) && lane == 0) atomicOr(a.status, 2);
                 __syncthreads();
+            }
+            if (last) {   // the inverse of the diagonal factor, for the backward sweep
+                if (wave == 0) cp_invert_diag(Town(0), Td(0), Sv(0), lane);
+                __syncthreads();
+                break;
             }
             CP_STAMP(m + 1, 3);
             bool published = false;
@@ -468,13 +496,10 @@ __global__ __launch_bounds__(256) void chol_persist_kernel(const CholPersistArgs
                 }
             }
             if (published) CP_STAMP(m + 1, 4);
-            if (has_diag && wg == m + 1) {   // the inverse of the fresh diagonal factor (for the backward sweep), now that nobody waits for this workgroup
-                if (wave == 0) cp_invert_diag(Town(0), Td(0), Sv(0), lane);
-                __syncthreads();
-            }
         }
+        if (last) break;
         // the rest of the trailing matrix, in the shadow of the next column's factorisation
-        if (m >= 0 && !apply_column(m, m + 2, 1 << 29)) return;
+        if (m >= 0 && !apply_column(m, false)) return;
         CP_STAMP(m + 1, 5);
     }
 

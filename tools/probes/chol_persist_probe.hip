@@ -109,6 +109,16 @@ static int run(int n, int reps, int pipe) {
                 bulk_max = std::fmax(bulk_max, (q[5] - from) * 0.01); bulk_sum += (q[5] - from) * 0.01; ++nw;
                 wait_max = std::fmax(wait_max, (q[1] - q[0]) * 0.01);
             }
+            {   // the workgroup that publishes this column last, and where its time went (its stamps of this and the previous column)
+                int wl = -1; int64_t tl = 0;
+                for (int w = 0; w < G; ++w) { const int64_t *q = &tr[((size_t)w * (nb + 1) + j) * 8]; if (q[4] > tl) { tl = q[4]; wl = w; } }
+                if (wl >= 0 && getenv("CP_SHOW_LAST")) {
+                    const int64_t *q = &tr[((size_t)wl * (nb + 1) + j) * 8];
+                    printf("    last: wg %3d  start %7.2f  crit applied %7.2f  factored %7.2f  published %7.2f  bulk done %7.2f", wl, (q[1] - t0) * 0.01, (q[2] - t0) * 0.01, (q[3] - t0) * 0.01, (q[4] - t0) * 0.01, q[5] ? (q[5] - t0) * 0.01 : 0.0);
+                    if (j > 0) { const int64_t *p = &tr[((size_t)wl * (nb + 1) + j - 1) * 8]; printf("  | previous column: start %7.2f  bulk done %7.2f", p[1] ? (p[1] - t0) * 0.01 : 0.0, p[5] ? (p[5] - t0) * 0.01 : 0.0); }
+                    printf("\n");
+                }
+            }
             printf("  col %2d: wait end %7.2f | update %5.2f | factor %5.2f | publish %5.2f | at %7.2f ; %d | bulk max %5.2f mean %5.2f | longest wait %5.2f (%d wgs)\n", j, wend, upd, fac, pub, pat, owners, bulk_max, nw ? bulk_sum / nw : 0.0, wait_max, nw);
         }
         printf("  backward: block k: x_{k+1} seen at | x_k stored at (us since first stamp)\n");
@@ -117,6 +127,12 @@ static int run(int n, int reps, int pipe) {
                 const int64_t *q = &tr[((size_t)w * (nb + 1) + k) * 8];
                 if (q[7]) printf("  k %2d: seen %7.2f  stored %7.2f\n", k, q[6] ? (q[6] - t0) * 0.01 : 0.0, (q[7] - t0) * 0.01);
             }
+        {
+            int64_t td[64];
+            CK(hipMemcpyFromSymbol(td, HIP_SYMBOL(pcs::cp_tile_dbg), sizeof(td)));
+            printf("  workgroup 100, trailing updates with column 3, per tile [us]: wait for operands | park + barrier | products | barrier   (start since the first tile's)\n");
+            for (int q = 0; q < 8; ++q) if (td[q * 8 + 4]) printf("   slot %d: start %6.2f | %5.2f | %5.2f | %5.2f | %5.2f\n", q, (td[q * 8] - td[0]) * 0.01, (td[q * 8 + 1] - td[q * 8]) * 0.01, (td[q * 8 + 2] - td[q * 8 + 1]) * 0.01, (td[q * 8 + 3] - td[q * 8 + 2]) * 0.01, (td[q * 8 + 4] - td[q * 8 + 3]) * 0.01);
+        }
         {
             int64_t dbg[64];
             CK(hipMemcpyFromSymbol(dbg, HIP_SYMBOL(pcs::cp_dbg), sizeof(dbg)));
