@@ -45,8 +45,7 @@ struct CholPersistArgs {
     const double *rhs;      // n
     double *x;              // n: the solution
     // the hand-over workspace, filled with 0xFF bytes by the host (one memset): a word differs from the fill once it is written
-    double *tpub;           // nb (nb - 1) / 2 tiles of 32 x 32 (padding included): tile (i, j), i > j, at i (i - 1) / 2 + j
-    double *ypub;           // nb x 32: y = L^-1 rhs, one block per block column
+    double *tpub;           // nb (nb + 1) / 2 tiles of 32 x 32 (padding included): tile (i, j), j < i <= nb, at i (i - 1) / 2 + j; row nb = the rhs row: y = L^-1 rhs in the tiles' rows 0
     double *xpub;           // nb x 32: x, one block per diagonal owner
     int32_t *flags;         // CP_FLAGS words (= -1 after the fill): the abort word and the "originals are loaded" counter
     int32_t *status;        // |= 2: a pivot was not positive; |= 4: a wait ran out of time (results are not valid)
@@ -132,19 +131,12 @@ __device__ __forceinline__ void cp_decode(const int nb, int t, int &i, int &j) {
 }
 
 // this thread's four entries (e = tid + 256 q -> row e >> 5, column e & 31: whole 256-byte rows per half wave) of the PUBLISHED tile
-// (i, m), i > m, requested with sc1 loads from the tile's slot; i == nb: the rhs row, y_m' in row 0.  The caller checks the values
-// against the fill and asks again until none is left (cp_fetch_polled).
+// (i, m), i > m, requested with sc1 loads from the tile's slot; i == nb: the rhs row's tile (y_m' in row 0, zeros below — a tile like
+// any other: four loads, no branch).  The caller checks the values against the fill and asks again until none is left (cp_fetch_polled).
 __device__ __forceinline__ void cp_fetch(const CholPersistArgs &a, double (&v)[4], const int i, const int m, const int tid) {
+    const double *src = a.tpub + ((int64_t)i * (i - 1) / 2 + m) * 1024 + tid;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int e = tid + 256 * q;
-        v[q] = 0.0;
-        if (i == a.nb) {
-            if (e < 32) v[q] = cp_ld(a.ypub + m * 32 + e);
-        } else {
-            v[q] = cp_ld(a.tpub + ((int64_t)i * (i - 1) / 2 + m) * 1024 + e);
-        }
-    }
+    for (int q = 0; q < 4; ++q) v[q] = cp_ld(src + 256 * q);
 }
 __device__ __forceinline__ bool cp_is_fill(const double (&v)[4]) {
     bool f = false;
@@ -476,23 +468,19 @@ __global__ __launch_bounds__(256) void chol_persist_kernel(const CholPersistArgs
                 if (j != m + 1 || i == j) continue;   // nobody waits for a diagonal tile: it goes to S at the very end
                 published = true;
                 const double *To = Town(s);
-                if (i == nb) {
-                    if (tid < 32) cp_st(a.ypub + j * 32 + tid, To[tid]);
-                } else {
-                    // the whole 32 x 32 tile (padding included) into its slot — write-through, nobody waits for an acknowledgement —
-                    // and the in-range part into S (plain stores: the result, read by nobody in this launch)
-                    double v[4];
+                // the whole 32 x 32 tile (padding included; the rhs row's tile too: y in row 0) into its slot — write-through, nobody
+                // waits for an acknowledgement — and the in-range part into S (plain stores: the result, read by nobody in this launch)
+                double v[4];
 #pragma unroll
-                    for (int qq = 0; qq < 4; ++qq) {
-                        const int e = tid + 256 * qq;
-                        v[qq] = To[(e >> 5) * CP_LDT + (e & 31)];
-                        cp_st(a.tpub + ((int64_t)i * (i - 1) / 2 + j) * 1024 + e, v[qq]);
-                    }
+                for (int qq = 0; qq < 4; ++qq) {
+                    const int e = tid + 256 * qq;
+                    v[qq] = To[(e >> 5) * CP_LDT + (e & 31)];
+                    cp_st(a.tpub + ((int64_t)i * (i - 1) / 2 + j) * 1024 + e, v[qq]);
+                }
 #pragma unroll
-                    for (int qq = 0; qq < 4; ++qq) {   // behind the stores somebody is waiting for
-                        const int e = tid + 256 * qq, gr = i * 32 + (e >> 5), gc = j * 32 + (e & 31);
-                        if (gr < a.n && gc < a.n) a.S[(int64_t)gr * a.ld + gc] = v[qq];
-                    }
+                for (int qq = 0; qq < 4; ++qq) {   // behind the stores somebody is waiting for
+                    const int e = tid + 256 * qq, gr = i * 32 + (e >> 5), gc = j * 32 + (e & 31);
+                    if (gr < a.n && gc < a.n) a.S[(int64_t)gr * a.ld + gc] = v[qq];
                 }
             }
             if (published) CP_STAMP(m + 1, 4);
@@ -529,7 +517,7 @@ __global__ __launch_bounds__(256) void chol_persist_kernel(const CholPersistArgs
     {
         const uint64_t t0 = wall_clock64();
         for (int spins = 1;; ++spins) {
-            t = cp_ld(a.ypub + k * 32 + c);
+            t = cp_ld(a.tpub + ((int64_t)nb * (nb - 1) / 2 + k) * 1024 + c);   // row 0 of the rhs row's tile of column k
             if (__all(__builtin_bit_cast(uint64_t, t) != CP_FILL)) break;
             if (!cp_poll_again(a, t0, spins, lane)) return;
         }
@@ -636,10 +624,10 @@ __global__ __launch_bounds__(256) void chol_persist_kernel(const CholPersistArgs
 
 namespace pcs {
 
-// Workspace of the persistent solve inside pcs_dense_spd_solve's d_work: [flags | xpub nb x 32 | ypub nb x 32 | tpub nb (nb - 1) / 2 tiles],
+// Workspace of the persistent solve inside pcs_dense_spd_solve's d_work: [flags | xpub nb x 32 | tpub nb (nb + 1) / 2 tiles],
 // all of it at the fill value when the kernel starts: ONE memset of 0xFF bytes.
 inline int64_t cp_flag_doubles() { return CP_FLAGS * 4 / 8; }
-inline int64_t cp_work_doubles(const int64_t nb) { return cp_flag_doubles() + 2 * nb * 32 + nb * (nb - 1) / 2 * 1024; }
+inline int64_t cp_work_doubles(const int64_t nb) { return cp_flag_doubles() + nb * 32 + nb * (nb + 1) / 2 * 1024; }
 
 // Can the persistent form take an n x n system on a device with `n_cus` compute units?  (one workgroup per CU, CP_MAX_SLOTS tiles each)
 inline bool cp_fits(const int64_t n, const int n_cus) {
@@ -657,8 +645,7 @@ inline hipError_t cp_launch(const int64_t n, double *d_S, const int64_t ld, cons
     a.S = d_S; a.rhs = d_rhs; a.x = d_x; a.status = d_status;
     a.flags = reinterpret_cast<int32_t *>(d_work);
     a.xpub = d_work + cp_flag_doubles();
-    a.ypub = a.xpub + nb * 32;
-    a.tpub = a.ypub + nb * 32;
+    a.tpub = a.xpub + nb * 32;
     a.n = (int32_t)n; a.ld = (int32_t)ld; a.nb = (int32_t)nb; a.slots = slots;
     a.timeout_ticks = (int64_t)(timeout_s * 1.0e8);
     a.stop = d_stop;
