@@ -706,16 +706,24 @@ class _CholeskyStep:
 
 
 def lm_solve(handler, x0, *, max_iter: int = 50, ftol: float = 1e-8, xtol: float = 1e-8, gtol: float = 1e-8,
-             cg_tol: float = 1e-3, cg_max_iter: int = 200, lam0: float = 1e-3, reduce_fn=None, verbose: int = 0,
+             cg_tol: float = 1e-3, cg_max_iter: int = 200, lam0: float | None = None, reduce_fn=None, verbose: int = 0,
              operator=None, linear_solver: str = "auto") -> DeviceLMResult:
     """Levenberg-Marquardt (Marquardt scaling D = diag(J^T J)) for a pycamset_amd handler.  The damped
     normal equations are solved by Jacobi-PCG on matrix-free J^T J products (``linear_solver='pcg'``) or
     by a Cholesky factorisation of the block-reduced J^T J (``'cholesky'``).  Every quantity that depends
     on the detections is computed by the HIP engine.  ``operator`` replaces the engine-backed
-    JacobianOperator / NormalEquations (used by the CPU tests of this driver)."""
+    JacobianOperator / NormalEquations (used by the CPU tests of this driver).
+
+    ``lam0``: the initial damping (Nielsen's tau: lambda multiplies D).  ``None`` = 1e-6 with the exact (Cholesky) step, 1e-3 with
+    PCG.  The reference's solver — scipy ``least_squares(method='trf')``, optimisation_handling.py:88-98 — starts with the plain
+    Gauss-Newton step whenever that lies inside its first trust region, which it does from a calibration's starting values; 1e-3 and
+    the update lambda <- lambda max(1/3, 1 - (2 rho - 1)^3) need nine accepted steps on rig-32 to get the damping out of the way,
+    1e-6 five (scipy: four evaluations), to the same cost.  A rejected trial multiplies lambda by 2, 4, 8, ...: five of them take
+    1e-6 to 3e-2."""
     if linear_solver not in ("auto", "pcg", "cholesky"):
         raise ValueError("linear_solver must be 'auto', 'pcg' or 'cholesky'")
     op_fun = handler.op_fun
+    lam0_exact, lam0_pcg = (1e-6, 1e-3) if lam0 is None else (float(lam0), float(lam0))
     if operator is None:
         dd = handler._flat_detections()
         eng = op_fun._engine_for(dd)
@@ -734,7 +742,7 @@ def lm_solve(handler, x0, *, max_iter: int = 50, ftol: float = 1e-8, xtol: float
                 ne = cache[key] = BlockedNormalEquations(eng, mask, reduce_fn=reduce_fn)
             ne.spd_algorithm = "auto"
             ps0 = op_fun.build_param_list(*handler.get_bundle_adjustment_inputs(np.array(x0, dtype=np.float64)))
-            return _lm_solve_blocked(ne, ps0, max_iter=max_iter, ftol=ftol, xtol=xtol, gtol=gtol, lam0=lam0, verbose=verbose)
+            return _lm_solve_blocked(ne, ps0, max_iter=max_iter, ftol=ftol, xtol=xtol, gtol=gtol, lam0=lam0_exact, verbose=verbose)
         operator = JacobianOperator(eng, handler._jac_mask(), reduce_fn=reduce_fn)
     elif linear_solver == "auto":
         linear_solver = "cholesky" if hasattr(operator, "build") else "pcg"
@@ -745,7 +753,7 @@ def lm_solve(handler, x0, *, max_iter: int = 50, ftol: float = 1e-8, xtol: float
 
     x = np.array(x0, dtype=np.float64)
     st = step.evaluate(param_str(x))
-    nfev, n_lin, lam = 1, 0, lam0
+    nfev, n_lin, lam = 1, 0, (lam0_pcg if linear_solver == "pcg" else lam0_exact)
     history = [0.5 * st["sumsq"]]
     status, message = 0, "maximum number of iterations reached"
     it = 0
