@@ -359,6 +359,7 @@ def test_blocked_normal_equations_and_schur_step(chain):
         for lam_v in (1e-3, 10.0):
             lam = torch.full((1,), lam_v, dtype=torch.float64, device="cuda")
             d_trial = torch.empty_like(d_ps)
+            torch.cuda.synchronize()              # `lam` is filled on torch's stream, the solver works on its own
             delta = ne.solve(0, lam, d_ps, d_trial)
             pred, ok = ne.predicted_reduction(lam)
             torch.cuda.synchronize()

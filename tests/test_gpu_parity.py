@@ -239,6 +239,7 @@ def test_mixed_engine_has_fp32_bytes_and_fp64_accuracy(Engine, chain):
     e.set_option("variant", -1)
     d_r = torch.zeros((rig.n_det, 2), dtype=torch.float32, device="cuda")
     d_j = torch.zeros((2 * rig.n_det, e.P), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()                      # the fills run on torch's stream, the evaluation on the engine's own
     e.eval_device(ps, d_r.data_ptr(), d_j.data_ptr())
     e.synchronize()
     assert np.array_equal(d_j.cpu().numpy().astype(np.float64), j) and np.array_equal(d_r.cpu().numpy().astype(np.float64), r)
