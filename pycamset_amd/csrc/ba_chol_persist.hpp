@@ -655,7 +655,7 @@ inline hipError_t cp_launch(const int64_t n, double *d_S, const int64_t ld, cons
     (void)trace;
 #endif
     const size_t lds = cp_lds_bytes(slots);
-    // prefilled: an earlier kernel on `s` has set the workspace to the fill value (schur_lead_kernel in an LM trial)
+    // prefilled: an earlier kernel on `s` has set the workspace to the fill value (schur_trail_lead_kernel in an LM trial)
     hipError_t e = prefilled ? hipSuccess : hipMemsetAsync(d_work, 0xFF, sizeof(double) * (size_t)cp_work_doubles(nb), s);
     if (e != hipSuccess) return e;
     static bool attr_set = false;   // one code object per process: the attribute sticks to the function

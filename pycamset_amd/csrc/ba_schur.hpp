@@ -6,9 +6,9 @@
 //     [ B' C ] [x_t] = - [g_t]        C  block diagonal    trailing entities (poses of the template chain, points of the
 //                                                          self / free chains) never share a detection
 // and the damped system (H + lambda D) x = -g, D = diag(H) (Marquardt), is reduced by the Schur complement of C:
-//     C_e + lambda D_e = L_e L_e'                       per trailing entity, tb = 6 or 3, in registers      schur_trail_kernel
+//     C_e + lambda D_e = L_e L_e'                       per trailing entity, tb = 6 or 3, in registers      schur_trail_lead_kernel (trailing part)
 //     V = B L^-T   (V_e = B_e L_e^-T)                   one tb-chunk of one row per lane                   schur_v_kernel
-//     S = A + lambda D_l - V V',  rhs = -g_l + V u      u_e = L_e^-1 g_e                                    schur_lead_kernel + schur_syrk_kernel
+//     S = A + lambda D_l - V V',  rhs = -g_l + V u      u_e = L_e^-1 g_e                                    schur_trail_lead_kernel (leading part) + schur_syrk_kernel
 //     S x_l = rhs                                       dense Cholesky of the LEADING size only
 //     x_e = -L_e^-T (u_e + V_e' x_l)                                                                       schur_back_kernel
 // Round 3 ends with no library call in the step: the two products around the dense solve are schur_syrk_kernel / schur_vtx_kernel
@@ -39,18 +39,18 @@ struct SchurArgs {
     int32_t *status;            // bit 0: a trailing block was not positive definite
     int64_t n_lead, n_trail, n_ent, trail_off;
     const int32_t *stop;        // optional: a device word; non-zero = the LM loop has ended, this (speculatively queued) launch does nothing
-    uint64_t *fill;             // optional (schur_lead_kernel): fill_n words to set to all-ones — the hand-over workspace of the one-launch
+    uint64_t *fill;             // optional (schur_trail_lead_kernel): fill_n words to set to all-ones — the hand-over workspace of the one-launch
     int64_t fill_n;             // Cholesky that follows in the same trial (ba_chol_persist.hpp), instead of a memset launch of its own
+    int32_t trail_blocks;       // schur_trail_lead_kernel: the first trail_blocks workgroups take the trailing entities
 };
 // Every kernel of an LM trial starts with this: the host queues trial t + 1 before it has read the verdict of trial t
 // (pcs_lm_trial), and lm_decide_kernel raises the flag when the loop is over — what was queued behind it then drains as no-ops.
 #define PCS_STOP_GUARD(a) do { if ((a).stop && *(a).stop) return; } while (0)
 
-// One lane = one trailing entity.
+// One lane = one trailing entity (workgroup `block` of the trailing part of schur_trail_lead_kernel).
 template <int TB>
-__global__ __launch_bounds__(256) void schur_trail_kernel(const SchurArgs a) {
-    PCS_STOP_GUARD(a);
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void schur_trail_body(const SchurArgs &a, const int block) {
+    const int64_t e = (int64_t)block * blockDim.x + threadIdx.x;
     if (e >= a.n_ent) return;
     const double lam = *a.lambda;
     const double *Ce = a.C + e * TB * TB;
@@ -158,16 +158,11 @@ __global__ __launch_bounds__(256) void schur_v_kernel(const SchurArgs a) {
 // UPPER triangle of A, so a tile below the diagonal is the transpose of A's tile above it — read coalesced into LDS and written
 // transposed (one lane per entry with `A[c][r]` for r > c read every second entry with a stride of a row: 20.7 us for the 45 MB of
 // n_lead = 1 680).
-__global__ __launch_bounds__(256) void schur_lead_kernel(const SchurArgs a) {
-    PCS_STOP_GUARD(a);
+__device__ __forceinline__ void schur_lead_body(const SchurArgs &a, const int block) {
     __shared__ double T[32][33];
     const int tid = threadIdx.x;
-    {
-        const int64_t t = (int64_t)blockIdx.x * blockDim.x + tid;
-        for (int64_t i = t; i < a.fill_n; i += (int64_t)gridDim.x * blockDim.x) a.fill[i] = ~0ull;
-    }
     const int nbt = (int)((a.n_lead + 31) / 32);
-    const int bi = blockIdx.x / nbt, bj = blockIdx.x % nbt;      // tile (bi, bj) of S
+    const int bi = block / nbt, bj = block % nbt;      // tile (bi, bj) of S
     const int ti = bi < bj ? bi : bj, tj = bi < bj ? bj : bi;    // the tile of A's upper triangle it comes from
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -194,6 +189,20 @@ __global__ __launch_bounds__(256) void schur_lead_kernel(const SchurArgs a) {
         }
         a.S[gr * a.n_lead + gc] = v;
     }
+}
+
+// The two independent parts of the preparation in ONE launch: workgroups [0, trail_blocks) factor the trailing blocks
+// (schur_trail_body), the others write S, rhs and the damping diagonal tile by tile (schur_lead_body); every workgroup takes a
+// share of the optional fill (the hand-over workspace of the one-launch Cholesky that follows in an LM trial).
+template <int TB>
+__global__ __launch_bounds__(256) void schur_trail_lead_kernel(const SchurArgs a) {
+    PCS_STOP_GUARD(a);
+    {
+        const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        for (int64_t i = t; i < a.fill_n; i += (int64_t)gridDim.x * blockDim.x) a.fill[i] = ~0ull;
+    }
+    if ((int)blockIdx.x < a.trail_blocks) schur_trail_body<TB>(a, (int)blockIdx.x);
+    else schur_lead_body(a, (int)blockIdx.x - a.trail_blocks);
 }
 
 // ---- S -= V V' (lower tiles) and rhs += V u on the FP64 matrix cores ---------------------------------------------------------------
@@ -583,8 +592,13 @@ __global__ __launch_bounds__(1024) void lm_decide_kernel(const LmDecideArgs a) {
 
 // An accepted trial becomes the current state: packed[trial] -> packed[current], trial parameter string -> current one.  Always
 // queued (the host does not know the verdict yet); copies only when lm_decide_kernel has set the accept flag — 6.5 MB on rig-32.
+// Also carries the trial's ten numbers to the host.
 __global__ __launch_bounds__(256) void lm_accept_kernel(const int32_t *__restrict__ accept_flag, const double *__restrict__ packed_new, double *__restrict__ packed_cur,
-                                                        const int64_t n_packed, const double *__restrict__ ps_new, double *__restrict__ ps_cur, const int64_t n_params) {
+                                                        const int64_t n_packed, const double *__restrict__ ps_new, double *__restrict__ ps_cur, const int64_t n_params,
+                                                        const double *__restrict__ stats, double *__restrict__ stats_host) {
+    // the trial's read-back (lm_decide_kernel's ten numbers) into the host's page-locked buffer: visible to the host when this launch
+    // has completed — no copy launch behind it
+    if (stats_host && blockIdx.x == 0 && threadIdx.x < 10) stats_host[threadIdx.x] = stats[threadIdx.x];
     if (*accept_flag == 0) return;
     using D2 = __attribute__((ext_vector_type(2))) double;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (int64_t)gridDim.x * blockDim.x;

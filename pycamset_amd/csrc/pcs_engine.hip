@@ -1671,19 +1671,18 @@ static int enqueue_schur_prepare(pcs_engine *h, double *d_packed, const uint8_t 
     a.n_lead = L.n_lead; a.n_trail = L.n_trail; a.n_ent = L.n_ent; a.trail_off = L.trail_off;
     a.stop = d_stop;
     auto blocks = [](int64_t n) { return dim3((unsigned)((n + 255) / 256)); };
-    if (L.n_ent > 0) {
-        if (L.tb == 6) hipLaunchKernelGGL(schur_trail_kernel<6>, blocks(L.n_ent), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL(schur_trail_kernel<3>, blocks(L.n_ent), dim3(256), 0, s, a);
+    // trailing blocks and the leading block are independent: one launch (schur_trail_lead_kernel); V needs the trailing factors
+    const int64_t nbt = (L.n_lead + 31) / 32, trail_blocks = (L.n_ent + 255) / 256;
+    a.trail_blocks = (int32_t)trail_blocks;
+    if (trail_blocks + nbt * nbt > 0) {
+        const dim3 grid((unsigned)(trail_blocks + nbt * nbt));
+        if (L.tb == 6) hipLaunchKernelGGL(schur_trail_lead_kernel<6>, grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(schur_trail_lead_kernel<3>, grid, dim3(256), 0, s, a);
         HIPCHK(hipGetLastError());
-        if (L.n_lead > 0) {
-            if (L.tb == 6) hipLaunchKernelGGL(schur_v_kernel<6>, blocks(L.n_lead * L.n_ent), dim3(256), 0, s, a);
-            else hipLaunchKernelGGL(schur_v_kernel<3>, blocks(L.n_lead * L.n_ent), dim3(256), 0, s, a);
-            HIPCHK(hipGetLastError());
-        }
     }
-    if (L.n_lead > 0) {
-        const int64_t nbt = (L.n_lead + 31) / 32;
-        hipLaunchKernelGGL(schur_lead_kernel, dim3((unsigned)(nbt * nbt)), dim3(256), 0, s, a);
+    if (L.n_ent > 0 && L.n_lead > 0) {
+        if (L.tb == 6) hipLaunchKernelGGL(schur_v_kernel<6>, blocks(L.n_lead * L.n_ent), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(schur_v_kernel<3>, blocks(L.n_lead * L.n_ent), dim3(256), 0, s, a);
         HIPCHK(hipGetLastError());
     }
     return PCS_OK;
@@ -1889,7 +1888,7 @@ int pcs_lm_trial(pcs_engine *h, const pcs_lm_buffers *b, void *stream) {
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
     const BlockLayout L = block_layout(h);
     const int32_t *stop = b->stop_flag;
-    // the one-launch Cholesky wants its hand-over workspace at the fill value: schur_lead_kernel sets it on the way (one launch fewer)
+    // the one-launch Cholesky wants its hand-over workspace at the fill value: schur_trail_lead_kernel sets it on the way (one launch fewer)
     const bool prefill = L.n_lead > 0 && dense_spd_is_one_launch(h->device, L.n_lead, b->spd_algorithm);
     int rc = enqueue_schur_prepare(h, b->packed_cur, b->fixed, b->lambda, b->linvt, b->u, b->V, b->S, b->rhs, b->dvec, b->gm, b->status, s, stop,
                                    prefill ? b->spd_work : nullptr, prefill ? cp_work_doubles((L.n_lead + 31) / 32) : 0);
@@ -1920,10 +1919,17 @@ int pcs_lm_trial(pcs_engine *h, const pcs_lm_buffers *b, void *stream) {
     hipLaunchKernelGGL(lm_decide_kernel, dim3(1), dim3(1024), 0, s, a);
     HIPCHK(hipGetLastError());
     const int copy_blocks = (int)std::min<int64_t>((n_packed / 2 + 255) / 256 + 1, (int64_t)h->n_cu * 8);
+    // the read-back: lm_accept_kernel writes the ten numbers straight into the page-locked buffer when the device can address it (no
+    // copy launch); a buffer that is not mapped gets an asynchronous copy
+    double *stats_mapped = nullptr;
+    if (b->stats_host && hipHostGetDevicePointer(reinterpret_cast<void **>(&stats_mapped), b->stats_host, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        stats_mapped = nullptr;
+    }
     hipLaunchKernelGGL(lm_accept_kernel, dim3((unsigned)copy_blocks), dim3(256), 0, s, (const int32_t *)b->accept_flag, (const double *)b->packed_new, b->packed_cur, n_packed,
-                       (const double *)b->ps_new, b->ps_cur, h->n_params);
+                       (const double *)b->ps_new, b->ps_cur, h->n_params, (const double *)b->stats, stats_mapped);
     HIPCHK(hipGetLastError());
-    if (b->stats_host) HIPCHK(hipMemcpyAsync(b->stats_host, b->stats, sizeof(double) * 10, hipMemcpyDeviceToHost, s));
+    if (b->stats_host && !stats_mapped) HIPCHK(hipMemcpyAsync(b->stats_host, b->stats, sizeof(double) * 10, hipMemcpyDeviceToHost, s));
     return PCS_OK;
 }
 

@@ -402,7 +402,7 @@ def _lm_loop_device(ne: BlockedNormalEquations, ps0: np.ndarray, *, max_iter, ft
     string, the decision WITH the termination rules, the copy of an accepted trial over the current state, a 10-double read-back — and
     every kernel of it starts by reading a stop word.  The host therefore queues trial t + 1 BEFORE it reads the verdict of trial t:
     the GPU never idles between trials (38-53 us per trial on rig-32, profiles/r04/lm_trace_rig32.log), and when the loop ends the one
-    speculative trial behind it drains as a dozen empty launches.  Same rules and the same results as `_lm_loop_blocked`."""
+    speculative trial behind it drains as ten empty launches.  Same rules and the same results as `_lm_loop_blocked`."""
     from ._capi import LmBuffers
     from .engine import SPD_ALGORITHMS
 
