@@ -419,8 +419,7 @@ def _lm_loop_device(ne: BlockedNormalEquations, ps0: np.ndarray, *, max_iter, ft
         ring = 4
         stats_host, done = _stats_ring(torch, dev, ring)   # page-locked: allocated once per device, not per solve (hipHostMalloc costs ~0.2 ms)
         ne.build(ps, 0)
-        sumsq = float(ne.cost(0).item())
-        history = [0.5 * sumsq]
+        history = []                       # the first entry — the starting cost — comes with the first trial's read-back (no sync of its own)
 
         def buffers(k):
             b = LmBuffers()
@@ -457,6 +456,8 @@ def _lm_loop_device(ne: BlockedNormalEquations, ps0: np.ndarray, *, max_iter, ft
                 continue
             n_lin += 1
             nfev += 1
+            if not history:
+                history.append(0.5 * float(st[6]))
             if verbose:
                 print(f"  trial {int(st[9])}: lam {st[7]:.2e} cost {0.5 * st[6]:.6e} -> {0.5 * st[5]:.6e} accepted {bool(st[0] > 0)} stop {int(st[8])}")
             if st[0] > 0:
@@ -478,10 +479,12 @@ def _lm_loop_device(ne: BlockedNormalEquations, ps0: np.ndarray, *, max_iter, ft
                 continue
             if code != 0 and read >= queued:
                 break
-        torch.cuda.current_stream().synchronize()
-        g = ne.gradient(0)
-        x = ps[ne.free_idx].cpu().numpy()
-        cost = 0.5 * float(ne.cost(0).item())
+        # gradient, solution and cost in ONE read-back (g and the cost sit behind the blocks of the packed state: [A | B | C | g | cost])
+        n_free, g0 = int(ne.free_idx.numel()), ne.packed[0].numel() - 1 - ne.n_params
+        out = torch.cat([ne.packed[0][g0: g0 + ne.n_params][ne.free_idx], ps[ne.free_idx], ne.packed[0][-1:]]).cpu().numpy()
+        g, x, cost = out[:n_free], out[n_free: 2 * n_free].copy(), 0.5 * float(out[-1])
+        if not history:
+            history.append(cost)
     return DeviceLMResult(x=x, cost=cost, grad=g, optimality=float(np.max(np.abs(g))) if g.size else 0.0, nit=it, nfev=nfev,
                           n_jtjv=n_lin, status=STOP_STATUS.get(code, 0), message=STOP_MESSAGES.get(code, f"stopped ({code})"), history=history)
 
