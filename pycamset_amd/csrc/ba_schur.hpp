@@ -78,15 +78,24 @@ __device__ __forceinline__ void schur_trail_body(const SchurArgs &a, const int b
         a.gm[col0 + i] = gv[i];
         M[i][i] += lam * d;
     }
-    // Cholesky M = L L' (lower triangle of M becomes L)
+    // Cholesky M = L L' (lower triangle of M becomes L).  1 / sqrt(s) from the hardware estimate + one third-order step (full double
+    // precision, ba_chol_persist.hpp's cp_rsqrt); the library's sqrt and the 27 divisions of the first version were most of this
+    // lane's 9 us (one lane per entity: 200 lanes on rig-32 — latency, not throughput)
     bool ok = true;
+    double ild[TB];   // 1 / L[j][j]
 #pragma unroll
     for (int j = 0; j < TB; ++j) {
         double s = M[j][j];
 #pragma unroll
         for (int k = 0; k < j; ++k) s -= M[j][k] * M[j][k];
         ok = ok && (s > 0.0);
-        const double l = sqrt(s), il = 1.0 / l;
+        double il;
+        {
+            const double y = __builtin_amdgcn_rsq(s), h = __builtin_fma(-(s * y), y, 1.0);
+            il = __builtin_fma(y * h, __builtin_fma(h, 0.375, 0.5), y);
+        }
+        ild[j] = il;
+        const double l = s * il;
         M[j][j] = l;
 #pragma unroll
         for (int i = j + 1; i < TB; ++i) {
@@ -107,7 +116,7 @@ __device__ __forceinline__ void schur_trail_body(const SchurArgs &a, const int b
             double t = (i == c) ? 1.0 : 0.0;
 #pragma unroll
             for (int k = c; k < i; ++k) t -= M[i][k] * Li[k][c];
-            Li[i][c] = t / M[i][i];
+            Li[i][c] = t * ild[i];
         }
 #pragma unroll
     for (int i = 0; i < TB; ++i) {
