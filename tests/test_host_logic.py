@@ -471,7 +471,7 @@ def test_device_lm_driver_logic_on_cpu_operator():
     assert abs(res2.cost - res.cost) <= 1e-6 * res.cost and res2.nfev <= res.nfev + 2
     # the initial damping: None = 1e-6 with the exact step (the reference's trf starts with the Gauss-Newton step), 1e-3 with PCG;
     # from either value the loop gets to the same cost (this small, weakly determined rig creeps along a flat valley either way:
-    # 17-19 evaluations; rig-32 needs 5 from 1e-6 and 10 from 1e-3, tests/test_gpu_dropin.py)
+    # 17-19 evaluations; rig-32 needs 5 from 1e-6 and 10 from 1e-3, profiles/r04/README.md)
     res3 = lm_solve(h, x0.copy(), max_iter=25, operator=CpuNormal(), linear_solver="cholesky", lam0=1e-3)
     assert abs(res3.cost - res2.cost) <= 1e-6 * res2.cost and abs(res3.nfev - res2.nfev) <= 4
     res4 = lm_solve(h, x0.copy(), max_iter=25, operator=CpuNormal(), linear_solver="cholesky", lam0=1e-6)
