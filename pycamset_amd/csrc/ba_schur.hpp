@@ -606,8 +606,13 @@ __global__ __launch_bounds__(256) void lm_accept_kernel(const int32_t *__restric
                                                         const int64_t n_packed, const double *__restrict__ ps_new, double *__restrict__ ps_cur, const int64_t n_params,
                                                         const double *__restrict__ stats, double *__restrict__ stats_host) {
     // the trial's read-back (lm_decide_kernel's ten numbers) into the host's page-locked buffer: visible to the host when this launch
-    // has completed — no copy launch behind it
-    if (stats_host && blockIdx.x == 0 && threadIdx.x < 10) stats_host[threadIdx.x] = stats[threadIdx.x];
+    // has completed at the latest — no copy launch behind it, and a host that polls word 9 needs no event either
+    if (stats_host && blockIdx.x == 0 && threadIdx.x == 0) {   // [9] — the trial's number, what a polling host waits for — goes last
+#pragma unroll
+        for (int i = 0; i < 9; ++i) stats_host[i] = stats[i];
+        __threadfence_system();
+        stats_host[9] = stats[9];
+    }
     if (*accept_flag == 0) return;
     using D2 = __attribute__((ext_vector_type(2))) double;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (int64_t)gridDim.x * blockDim.x;

@@ -28,6 +28,8 @@ from __future__ import annotations
 import contextlib
 from dataclasses import dataclass, field
 
+import time
+
 import numpy as np
 
 
@@ -433,9 +435,26 @@ def _lm_loop_device(ne: BlockedNormalEquations, ps0: np.ndarray, *, max_iter, ft
             b.spd_algorithm = SPD_ALGORITHMS[ne.spd_algorithm]
             return b
 
+        # The read-back of trial k lands in page-locked memory the device writes directly (lm_accept_kernel: word 9, the trial's number —
+        # or -1 for a launch that found the stop flag raised —, last).  The host waits for THAT word instead of an event: an event record
+        # between two trials cost the GPU 5.6 us of idling per trial (the one gap in profiles/r04/lm_trace_*.log).
+        views = [t.numpy() for t in stats_host]
+
         def enqueue(k):
+            views[k % ring][9] = np.nan
             ne.eng.lm_trial(buffers(k), stream)
-            done[k % ring].record()
+
+        def wait_for(k):
+            v = views[k % ring]
+            t_end = time.perf_counter() + 30.0
+            spins = 0
+            while np.isnan(v[9]):
+                spins += 1
+                if spins & 1023 == 0:
+                    if time.perf_counter() > t_end:
+                        raise RuntimeError("device LM loop: no read-back within 30 s")
+                    time.sleep(0)
+            return v.copy()
 
         code, nfev, n_lin, it = 0, 1, 0, 0
         limit = 12 * max_iter + 16          # every accepted step is preceded by fewer than 12 rejections
@@ -447,8 +466,7 @@ def _lm_loop_device(ne: BlockedNormalEquations, ps0: np.ndarray, *, max_iter, ft
             if code == 0 and queued < limit:   # speculate: the next trial goes out before this one's verdict is read
                 enqueue(queued)
                 queued += 1
-            done[read % ring].synchronize()
-            st = stats_host[read % ring].numpy().copy()
+            st = wait_for(read)
             read += 1
             if st[9] < 0:                       # a launch that found the flag raised: nothing happened
                 if read >= queued:
