@@ -236,6 +236,12 @@ typedef struct pcs_lm_buffers {
     double *stats;
     double *stats_host;
     int32_t spd_algorithm;                /* PCS_SPD_* */
+    /* optional: when the loop ends with this trial (stop code != 0), the final state — gradient and parameters at the n_free indices
+     * free_idx (device, int64), then sum r^2 — goes to result_host (page-locked, mapped; 2 n_free + 1 doubles) BEFORE the read-back of
+     * the trial: a host that polls stats_host[9] needs no further copy and no synchronisation to return the solution */
+    const int64_t *free_idx;
+    int64_t n_free;
+    double *result_host;
 } pcs_lm_buffers;
 int pcs_lm_trial(pcs_engine *h, const pcs_lm_buffers *b, void *stream);
 

@@ -24,7 +24,8 @@ _P = c_void_p
 class LmBuffers(ctypes.Structure):
     """include/pcs_hip.h pcs_lm_buffers: the device buffers of one LM trial (pcs_lm_trial)."""
     _fields_ = [(n, c_void_p) for n in ("packed_cur", "packed_new", "fixed", "lam", "linvt", "u", "V", "S", "rhs", "dvec", "gm", "status", "xlead", "w", "spd_work",
-                                        "delta", "ps_cur", "ps_new", "ctrl", "stop_flag", "accept_flag", "stats", "stats_host")] + [("spd_algorithm", ctypes.c_int32)]
+                                        "delta", "ps_cur", "ps_new", "ctrl", "stop_flag", "accept_flag", "stats", "stats_host")] + [
+        ("spd_algorithm", ctypes.c_int32), ("free_idx", c_void_p), ("n_free", ctypes.c_int64), ("result_host", c_void_p)]
 
 
 SYMBOLS = {

@@ -515,6 +515,12 @@ struct LmDecideArgs {
     double *ctrl;                           // optional control block (see above)
     int32_t *stop_flag;                     // with ctrl: the word PCS_STOP_GUARD reads
     int32_t *accept_flag;                   // with ctrl: 1 when this trial was accepted (lm_accept_kernel copies the trial state over the current one)
+    // optional (with ctrl): when this trial ends the loop, the final state goes to result (mapped page-locked host memory):
+    // g[free_idx] | ps[free_idx] | sum r^2 of the state the loop ends in (the trial's if accepted, else the current one)
+    const double *g_cur, *g_new, *ps_new;
+    const int64_t *free_idx;
+    int64_t n_free;
+    double *result;
 };
 
 __global__ __launch_bounds__(1024) void lm_decide_kernel(const LmDecideArgs a) {
@@ -596,7 +602,21 @@ __global__ __launch_bounds__(1024) void lm_decide_kernel(const LmDecideArgs a) {
         a.stats[5] = c_new;
         a.stats[6] = c_old;
         a.stats[7] = lam;
+        red[1][0] = code;                    // for the other threads: does the loop end here, and in which state
+        red[1][1] = acc ? 1.0 : 0.0;
+        red[1][2] = acc ? c_new : c_old;
     }
+    if (!a.ctrl || !a.result) return;
+    __syncthreads();
+    if (red[1][0] == 0.0) return;
+    const bool acc = red[1][1] != 0.0;
+    const double *g = acc ? a.g_new : a.g_cur, *ps = acc ? a.ps_new : a.ps;
+    for (int64_t i = tid; i < a.n_free; i += 1024) {
+        const int64_t k = a.free_idx[i];
+        a.result[i] = g[k];
+        a.result[a.n_free + i] = ps[k];
+    }
+    if (tid == 0) a.result[2 * a.n_free] = red[1][2];
 }
 
 // An accepted trial becomes the current state: packed[trial] -> packed[current], trial parameter string -> current one.  Always

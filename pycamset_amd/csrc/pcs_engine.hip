@@ -1916,6 +1916,15 @@ int pcs_lm_trial(pcs_engine *h, const pcs_lm_buffers *b, void *stream) {
     if (rc) return rc;
     LmDecideArgs a{b->packed_cur + n_packed - 1, b->packed_new + n_packed - 1, b->dvec, b->gm, b->delta, b->ps_cur, b->fixed, b->status, b->lambda, b->stats,
                    h->n_params, b->ctrl, b->stop_flag, b->accept_flag};
+    if (b->result_host && b->free_idx && b->n_free > 0) {   // the final state straight into the host's mapped buffer when this trial ends the loop
+        double *result_mapped = nullptr;
+        if (hipHostGetDevicePointer(reinterpret_cast<void **>(&result_mapped), b->result_host, 0) == hipSuccess && result_mapped) {
+            a.g_cur = b->packed_cur + n_packed - 1 - h->n_params; a.g_new = g_new; a.ps_new = b->ps_new;
+            a.free_idx = b->free_idx; a.n_free = b->n_free; a.result = result_mapped;
+        } else {
+            (void)hipGetLastError();
+        }
+    }
     hipLaunchKernelGGL(lm_decide_kernel, dim3(1), dim3(1024), 0, s, a);
     HIPCHK(hipGetLastError());
     const int copy_blocks = (int)std::min<int64_t>((n_packed / 2 + 255) / 256 + 1, (int64_t)h->n_cu * 8);

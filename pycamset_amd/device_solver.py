@@ -384,14 +384,6 @@ def _lm_solve_blocked(ne: BlockedNormalEquations, ps0: np.ndarray, *, max_iter, 
         eng.set_option("timing_every", saved[0])
 
 
-_RINGS = {}
-
-
-def _stats_ring(torch, dev, ring: int):
-    key = (dev.index, ring)
-    if key not in _RINGS:
-        _RINGS[key] = ([torch.zeros(10, dtype=torch.float64).pin_memory() for _ in range(ring)], [torch.cuda.Event() for _ in range(ring)])
-    return _RINGS[key]
 
 
 STOP_MESSAGES = {0: "maximum number of iterations reached", 1: "gtol reached", 2: "no further decrease (damping exhausted)", 3: "ftol reached", 4: "xtol reached",
@@ -419,7 +411,22 @@ def _lm_loop_device(ne: BlockedNormalEquations, ps0: np.ndarray, *, max_iter, ft
         flags = torch.zeros(2, dtype=torch.int32, device=dev)          # [stop, accepted]
         stats_dev = torch.zeros(10, dtype=torch.float64, device=dev)
         ring = 4
-        stats_host, done = _stats_ring(torch, dev, ring)   # page-locked: allocated once per device, not per solve (hipHostMalloc costs ~0.2 ms)
+        # page-locked, allocated once per solver state, not per solve (hipHostMalloc costs ~0.2 ms) — and not shared between states: a
+        # speculative trial one solve leaves behind still writes its read-back while the next solve may already run
+        stats_host = ne.__dict__.get("_stats_host")
+        if stats_host is None:
+            stats_host = ne._stats_host = [torch.zeros(10, dtype=torch.float64).pin_memory() for _ in range(ring)]
+        # the final state (gradient | solution | sum r^2) is written into this page-locked buffer by the trial that ends the loop, before
+        # that trial's read-back: the host returns without a copy of its own and without waiting for the speculative trial to drain
+        n_free = int(ne.free_idx.numel())
+        result_host = ne.__dict__.get("_result_host")
+        if result_host is None or result_host.numel() != 2 * n_free + 1:
+            result_host = ne._result_host = torch.zeros(2 * n_free + 1, dtype=torch.float64).pin_memory()
+        result_view = result_host.numpy()
+        result_view[-1] = np.nan
+        pending = ne.__dict__.pop("_drain_event", None)
+        if pending is not None:
+            pending.synchronize()              # the speculative trial the previous solve left behind has written its (void) read-back
         ne.build(ps, 0)
         history = []                       # the first entry — the starting cost — comes with the first trial's read-back (no sync of its own)
 
@@ -433,6 +440,7 @@ def _lm_loop_device(ne: BlockedNormalEquations, ps0: np.ndarray, *, max_iter, ft
             b.ctrl, b.stop_flag, b.accept_flag = ctrl.data_ptr(), flags.data_ptr(), flags.data_ptr() + 4
             b.stats, b.stats_host = stats_dev.data_ptr(), stats_host[k % ring].data_ptr()
             b.spd_algorithm = SPD_ALGORITHMS[ne.spd_algorithm]
+            b.free_idx, b.n_free, b.result_host = ne.free_idx.data_ptr(), n_free, result_host.data_ptr()
             return b
 
         # The read-back of trial k lands in page-locked memory the device writes directly (lm_accept_kernel: word 9, the trial's number —
@@ -495,12 +503,19 @@ def _lm_loop_device(ne: BlockedNormalEquations, ps0: np.ndarray, *, max_iter, ft
                     enqueue(queued)
                     queued += 1
                 continue
-            if code != 0 and read >= queued:
-                break
-        # gradient, solution and cost in ONE read-back (g and the cost sit behind the blocks of the packed state: [A | B | C | g | cost])
-        n_free, g0 = int(ne.free_idx.numel()), ne.packed[0].numel() - 1 - ne.n_params
-        out = torch.cat([ne.packed[0][g0: g0 + ne.n_params][ne.free_idx], ps[ne.free_idx], ne.packed[0][-1:]]).cpu().numpy()
-        g, x, cost = out[:n_free], out[n_free: 2 * n_free].copy(), 0.5 * float(out[-1])
+            if code != 0:
+                break                               # the speculative trial behind this one drains on its own (ten empty launches)
+        if read < queued:                           # ... and the next solve on this state waits for that before it reuses the read-back ring
+            ne._drain_event = torch.cuda.Event()
+            ne._drain_event.record()
+        if code not in (0, 9) and not np.isnan(result_view[-1]):
+            out = result_view.copy()           # written by the trial that raised the stop code (lm_decide_kernel), complete before its read-back
+        else:
+            # gradient, solution and cost in ONE read-back (g and the cost sit behind the blocks of the packed state: [A | B | C | g | cost])
+            torch.cuda.current_stream().synchronize()
+            g0 = ne.packed[0].numel() - 1 - ne.n_params
+            out = torch.cat([ne.packed[0][g0: g0 + ne.n_params][ne.free_idx], ps[ne.free_idx], ne.packed[0][-1:]]).cpu().numpy()
+        g, x, cost = out[:n_free].copy(), out[n_free: 2 * n_free].copy(), 0.5 * float(out[-1])
         if not history:
             history.append(cost)
     return DeviceLMResult(x=x, cost=cost, grad=g, optimality=float(np.max(np.abs(g))) if g.size else 0.0, nit=it, nfev=nfev,
