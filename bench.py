@@ -273,12 +273,17 @@ def self_launch(n_ranks: int, argv, script=None, python=None, extra_env=None) ->
     proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
     for raw in proc.stdout:
         txt = raw.rstrip("\n")
+        # rank 0's JSON object, also when another rank's (or a library's) unterminated output shares its line: the ranks write to ONE pipe
         is_line = False
-        if txt.startswith("{"):
+        at = txt.find('{"')
+        if at >= 0:
             try:
-                is_line = isinstance(json.loads(txt), dict)
+                is_line = isinstance(json.loads(txt[at:]), dict)
             except ValueError:
                 pass
+        if is_line and at > 0:
+            print(txt[:at], file=sys.stderr, flush=True)
+            txt = txt[at:]
         print(txt, file=sys.stdout if is_line else sys.stderr, flush=True)
     return proc.wait()
 

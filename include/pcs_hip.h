@@ -199,9 +199,10 @@ int pcs_normal_blocks_device(pcs_engine *h, const double *d_param_str, double *d
  *                      d_ps_in / d_ps_out (both or neither) also the trial parameter string d_ps_out = d_ps_in + d_delta.
  *   pcs_lm_decide      the accept / reject decision of the trial on the device: predicted reduction 0.5 (lambda d'D d - g'd), actual
  *                      reduction 0.5 (cost_old - cost_new), gain ratio, *d_lambda <- the next damping (x 1/3 | 1 | 2 by the ratio, x 4
- *                      on a rejected or failed step), *d_status <- 0, and d_stats[8] = {accepted (-1: bit 2 of *d_status was set — the dense solve
+ *                      on a rejected or failed step), *d_status <- 0, and d_stats[12] = {accepted (-1: bit 2 of *d_status was set — the dense solve
  *                      did not complete, the trial is void), max |g|, relative cost drop, |step|,
- *                      |x| over the free parameters, new sum r^2, old sum r^2, lambda used} — the one vector the host reads per trial. */
+ *                      |x| over the free parameters, new sum r^2, old sum r^2, lambda used, 0, 0, 0, the next lambda} — the one vector the host reads per trial
+ *                      ([8] .. [10] are the stop code, the trial number and the current state of the device-steered loop, pcs_lm_trial). */
 int pcs_schur_prepare(pcs_engine *h, double *d_packed, const uint8_t *d_fixed, const double *d_lambda, double *d_linvt, double *d_u,
                       double *d_V, double *d_S, double *d_rhs, double *d_dvec, double *d_gm, int32_t *d_status, void *stream);
 int pcs_schur_finish(pcs_engine *h, const double *d_linvt, const double *d_u, const double *d_w, const double *d_xlead, const uint8_t *d_fixed,
@@ -209,40 +210,61 @@ int pcs_schur_finish(pcs_engine *h, const double *d_linvt, const double *d_u, co
 int pcs_lm_decide(pcs_engine *h, const double *d_cost_old, const double *d_cost_new, const double *d_dvec, const double *d_gm, const double *d_delta,
                   const double *d_ps, const uint8_t *d_fixed, int32_t *d_status, double *d_lambda, double *d_stats, void *stream);
 
-/* One whole LM trial in ONE call (round 4) — the device-steered form of the loop optimisation_handling.py:88-98 leaves to scipy.
- * Queues, on `stream`: the damped Schur step from packed_cur at *lambda (pcs_schur_prepare, pcs_schur_syrk, pcs_dense_spd_solve_algo,
- * pcs_schur_vtx, pcs_schur_finish: delta and ps_new = ps_cur + delta), the blocked normal equations at ps_new into packed_new, the
- * decision (pcs_lm_decide's arithmetic + the loop's termination rules from `ctrl`), the copy packed_new -> packed_cur, ps_new ->
- * ps_cur when the trial was accepted, and a 10-double read-back into stats_host (page-locked; may be NULL).  Every kernel of the
- * sequence first reads *stop_flag and does nothing when it is set, so a caller may queue the NEXT trial before it has seen this
- * one's verdict: the GPU never waits for the host between trials.
- *   ctrl (9 doubles, device): [0] stop code, 0 = running (1 gtol reached before the step, 2 `ctrl[7]` consecutive rejections, 3 ftol,
+/* One whole LM trial per call — the device-steered form of the loop optimisation_handling.py:88-98 leaves to scipy.
+ * The loop keeps TWO states (packed normal equations + parameter string each); flags[2] names the current one, the other receives the
+ * trial.  pcs_lm_trial_build queues, on `stream`: the damped Schur step from the current state at *lambda (pcs_schur_prepare,
+ * pcs_schur_syrk, pcs_dense_spd_solve_algo, pcs_schur_vtx, pcs_schur_finish: delta and the trial string = current string + delta) and
+ * the blocked normal equations at the trial string into the trial state.  pcs_lm_trial_finish queues the decision (pcs_lm_decide's
+ * arithmetic + the loop's termination rules from `ctrl`), which makes an accepted trial the current state by flipping flags[2] (no
+ * copy), and writes the 12-double read-back into stats_host (page-locked; may be NULL).  pcs_lm_trial = both.  A loop over observation
+ * shards (one process per GPU) queues its all-reduce of the trial state BETWEEN the two halves, on the same stream (RCCL: stream-
+ * ordered, no host synchronisation); because that collective is queued on a fixed address, such a loop sets
+ * PCS_LM_FIXED_TRIAL_BUFFER: state 0 stays current, trials are built into state 1 and an accepted one is copied over state 0.
+ * Every kernel of the sequence first reads flags[0] and does nothing when it is set, so a caller may queue the NEXT trial before it has
+ * seen this one's verdict: the GPU never waits for the host between trials.
+ *   ctrl (12 doubles, device): [0] stop code, 0 = running (1 gtol reached before the step, 2 `ctrl[7]` consecutive rejections, 3 ftol,
  *        4 xtol, 5 `ctrl[3]` accepted steps, 9 the one-launch dense solve gave up — set spd_algorithm = PCS_SPD_LAUNCHES, clear ctrl[0] and
- *        *stop_flag and queue the trial again), [1] consecutive rejections, [2] accepted steps, [3] iteration limit, [4] ftol, [5] xtol,
- *        [6] gtol, [7] rejection limit, [8] trials decided
- *   stats (10 doubles, device): pcs_lm_decide's eight, [8] the stop code after this trial, [9] the trial's number (ctrl[8]) or -1 for a
- *        launch that found the flag raised (nothing was computed; everything else in `stats` is then stale).
- * All pointers are device memory except stats_host; sizes as for the entry points named above. */
+ *        flags[0] and queue the trial again), [1] consecutive rejections, [2] accepted steps, [3] iteration limit, [4] ftol, [5] xtol,
+ *        [6] gtol, [7] rejection limit, [8] trials decided, [9] the factor a rejection applies to lambda before the first accepted step
+ *        (0 = 4, as after it), [10], [11] reserved
+ *   stats (12 doubles, device): pcs_lm_decide's eight, [8] the stop code after this trial, [9] the trial's number (ctrl[8]) or -1 for a
+ *        launch that found the flag raised (nothing was computed; everything else in `stats` is then stale), [10] the current state
+ *        after this trial (0 / 1), [11] lambda for the next trial.
+ *   PCS_LM_VOTES: every rank writes "my dense solve gave up" (0 / 1) into the word behind the trial state's packed buffer (hence
+ *        pcs_normal_layout's length + 1), the loop's all-reduce sums it with the blocks, and the decision voids the trial on EVERY
+ *        rank when the sum is positive — the ranks repeat it together.
+ * All pointers are device memory except stats_host / result_host; sizes as for the entry points named above.  After the loop has ended
+ * the buffers may only be touched on `stream` (the speculative trial behind the end is still draining). */
+#define PCS_LM_FIXED_TRIAL_BUFFER 1
+#define PCS_LM_VOTES 2
 typedef struct pcs_lm_buffers {
-    double *packed_cur, *packed_new;      /* [A | B | C | g | cost] of the current and of the trial state (pcs_normal_layout) */
+    double *packed[2];                    /* the two states: [A | B | C | g | cost | votes] (pcs_normal_layout's length + 1), 16-byte aligned */
+    double *ps[2];                        /* their parameter strings, n_params each */
+    int32_t *flags;                       /* 4 words: [0] stop, [1] the last trial was accepted, [2] the current state, [3] unused */
     const uint8_t *fixed;
     double *lambda;
     double *linvt, *u, *V, *S, *rhs, *dvec, *gm;   /* pcs_schur_prepare's outputs */
     int32_t *status;
     double *xlead, *w, *spd_work;         /* n_lead | n_trail | pcs_dense_spd_work_len(n_lead) */
-    double *delta, *ps_cur, *ps_new;      /* n_params each */
+    double *delta;                        /* n_params */
     double *ctrl;
-    int32_t *stop_flag, *accept_flag;
     double *stats;
     double *stats_host;
     int32_t spd_algorithm;                /* PCS_SPD_* */
+    int32_t mode;                         /* PCS_LM_* bits */
     /* optional: when the loop ends with this trial (stop code != 0), the final state — gradient and parameters at the n_free indices
      * free_idx (device, int64), then sum r^2 — goes to result_host (page-locked, mapped; 2 n_free + 1 doubles) BEFORE the read-back of
      * the trial: a host that polls stats_host[9] needs no further copy and no synchronisation to return the solution */
     const int64_t *free_idx;
     int64_t n_free;
     double *result_host;
+    /* engine option "deterministic": workspace of the ordered S -= V V' (pcs_schur_syrk_work_len(n_lead, n_trail) doubles; may be NULL
+     * when that is 0) */
+    double *syrk_work;
+    int64_t syrk_work_len;
 } pcs_lm_buffers;
+int pcs_lm_trial_build(pcs_engine *h, const pcs_lm_buffers *b, void *stream);
+int pcs_lm_trial_finish(pcs_engine *h, const pcs_lm_buffers *b, void *stream);
 int pcs_lm_trial(pcs_engine *h, const pcs_lm_buffers *b, void *stream);
 
 /* The two products of the Schur step around the dense solve, on raw device pointers (float64, row-major):
@@ -255,6 +277,13 @@ int pcs_lm_trial(pcs_engine *h, const pcs_lm_buffers *b, void *stream);
 int pcs_schur_syrk(int device, int64_t n_lead, int64_t n_trail, const double *d_V, int64_t ldv, double *d_S, int64_t lds, const double *d_u,
                    double *d_rhs, void *stream);
 int pcs_schur_vtx(int device, int64_t n_lead, int64_t n_trail, const double *d_V, int64_t ldv, const double *d_x, double *d_w, void *stream);
+/* pcs_schur_syrk with an ORDER: the partial products of a K split are stored to d_work (pcs_schur_syrk_work_len(n_lead, n_trail) doubles;
+ * 0 = this size is not split and d_work is not touched) and subtracted split by split by a second kernel — the same bits on every run
+ * and on every rank of a sharded solve (the reference's consumer is deterministic: scipy on one thread, optimisation_handling.py:88-98).
+ * What engine option "deterministic" makes pcs_lm_trial_build use. */
+int64_t pcs_schur_syrk_work_len(int64_t n_lead, int64_t n_trail);
+int pcs_schur_syrk_ordered(int device, int64_t n_lead, int64_t n_trail, const double *d_V, int64_t ldv, double *d_S, int64_t lds, const double *d_u,
+                           double *d_rhs, double *d_work, int64_t work_doubles, void *stream);
 
 /* S x = rhs for a dense symmetric positive definite S (float64, n x n row-major with row stride ld, LOWER triangle read and
  * overwritten by its Cholesky factor): the reduced system of the Schur step above — what optimisation_handling.py:88-98 leaves to
@@ -275,6 +304,12 @@ int64_t pcs_dense_spd_work_len(int64_t n);
 int pcs_dense_spd_solve_algo(int device, int64_t n, double *d_S, int64_t ld, const double *d_rhs, double *d_x, double *d_work, int32_t *d_status, void *stream,
                              int algorithm);
 int pcs_dense_spd_solve(int device, int64_t n, double *d_S, int64_t ld, const double *d_rhs, double *d_x, double *d_work, int32_t *d_status, void *stream);
+/* The same with the one-launch form's time limit spelled out: every wait of a workgroup for a hand-over gives up after timeout_us
+ * microseconds (1 .. 60 000 000; the other entry points use 250 000), sets bit 2 of *d_status and lets the whole grid drain.  Inside an LM
+ * trial (pcs_lm_trial*) the limit is the engine option "spd_timeout_us".  A caller that sees bit 2 repeats the solve with
+ * PCS_SPD_LAUNCHES on the ORIGINAL matrix (the abandoned launch has overwritten part of the lower triangle). */
+int pcs_dense_spd_solve_opts(int device, int64_t n, double *d_S, int64_t ld, const double *d_rhs, double *d_x, double *d_work, int32_t *d_status, void *stream,
+                             int algorithm, int64_t timeout_us);
 
 /* Which entry of H / g / cost every accumulator register of the normal-equations kernel stands for (host function, no
  * GPU needed): out[m][lane][r][2], m < 2 MFMAs, lane < 64, r < 4 registers = the two local column ids (index into

@@ -22,10 +22,16 @@ DTYPE_IDS = {"f64": 0, "f32": 1, "mixed": 2}   # mixed: FP64 arithmetic, FP32 re
 # every symbol include/pcs_hip.h declares: name -> (restype, argtypes)
 _P = c_void_p
 class LmBuffers(ctypes.Structure):
-    """include/pcs_hip.h pcs_lm_buffers: the device buffers of one LM trial (pcs_lm_trial)."""
-    _fields_ = [(n, c_void_p) for n in ("packed_cur", "packed_new", "fixed", "lam", "linvt", "u", "V", "S", "rhs", "dvec", "gm", "status", "xlead", "w", "spd_work",
-                                        "delta", "ps_cur", "ps_new", "ctrl", "stop_flag", "accept_flag", "stats", "stats_host")] + [
-        ("spd_algorithm", ctypes.c_int32), ("free_idx", c_void_p), ("n_free", ctypes.c_int64), ("result_host", c_void_p)]
+    """include/pcs_hip.h pcs_lm_buffers: the device buffers of one LM trial (pcs_lm_trial_build / pcs_lm_trial_finish)."""
+    _fields_ = [("packed", c_void_p * 2), ("ps", c_void_p * 2)] + [
+        (n, c_void_p) for n in ("flags", "fixed", "lam", "linvt", "u", "V", "S", "rhs", "dvec", "gm", "status", "xlead", "w", "spd_work", "delta", "ctrl", "stats",
+                                "stats_host")] + [
+        ("spd_algorithm", ctypes.c_int32), ("mode", ctypes.c_int32), ("free_idx", c_void_p), ("n_free", ctypes.c_int64), ("result_host", c_void_p),
+        ("syrk_work", c_void_p), ("syrk_work_len", ctypes.c_int64)]
+
+
+LM_FIXED_TRIAL_BUFFER, LM_VOTES = 1, 2   # include/pcs_hip.h PCS_LM_*
+LM_STATS = 12                            # doubles in a trial's read-back (and in the control block)
 
 
 SYMBOLS = {
@@ -59,11 +65,16 @@ SYMBOLS = {
     "pcs_schur_finish": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pcs_lm_decide": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pcs_lm_trial": (c_int, [_P, _P, _P]),
+    "pcs_lm_trial_build": (c_int, [_P, _P, _P]),
+    "pcs_lm_trial_finish": (c_int, [_P, _P, _P]),
     "pcs_schur_syrk": (c_int, [c_int, c_int64, c_int64, _P, c_int64, _P, c_int64, _P, _P, _P]),
     "pcs_schur_vtx": (c_int, [c_int, c_int64, c_int64, _P, c_int64, _P, _P, _P]),
+    "pcs_schur_syrk_work_len": (c_int64, [c_int64, c_int64]),
+    "pcs_schur_syrk_ordered": (c_int, [c_int, c_int64, c_int64, _P, c_int64, _P, c_int64, _P, _P, _P, c_int64, _P]),
     "pcs_dense_spd_work_len": (c_int64, [c_int64]),
     "pcs_dense_spd_solve": (c_int, [c_int, c_int64, _P, c_int64, _P, _P, _P, _P, _P]),
     "pcs_dense_spd_solve_algo": (c_int, [c_int, c_int64, _P, c_int64, _P, _P, _P, _P, _P, c_int]),
+    "pcs_dense_spd_solve_opts": (c_int, [c_int, c_int64, _P, c_int64, _P, _P, _P, _P, _P, c_int, c_int64]),
     "pcs_normal_descriptors": (c_int, [c_int, c_int, c_int, POINTER(c_int32)]),
     "pcs_genchain_create": (c_int, [POINTER(_P), c_char_p, c_int, c_int, c_int, POINTER(c_int64), POINTER(c_int32), c_int, POINTER(c_int64), c_int64, c_int64,
                                     c_int64, c_int64, c_int64, c_int64, c_int, c_int]),

@@ -27,6 +27,7 @@ from __future__ import annotations
 import hashlib
 import os
 import subprocess
+import uuid
 from ctypes import POINTER, byref, c_double, c_float, c_int32, c_int64, c_uint64, c_void_p
 from dataclasses import dataclass, field
 from pathlib import Path
@@ -64,6 +65,7 @@ class BlockInfo:
     device_fun: str = ""
     device_jac: str = ""
     cpp_name: str = ""
+    templated: bool = False    # user SOURCE with ``template = True``: its ``inp`` is the detection's template point (afb:138, afb:374-375)
 
 
 @dataclass
@@ -91,7 +93,8 @@ class ChainSpec:
 
     @property
     def uses_template(self) -> bool:
-        return self.blocks[-1].kind == "template_points"
+        # the reference feeds template[key] to whatever block sits last when that block says template = True (afb:138, afb:374-375, afb:582)
+        return self.blocks[-1].kind == "template_points" or self.blocks[-1].templated
 
     @property
     def user_blocks(self) -> list:
@@ -142,6 +145,10 @@ class ChainSpec:
                     raise bad(f"user block {name}: n_params >= 1, num_out >= 1, num_inp >= 0 expected")
                 info.uidx, info.device_fun, info.device_jac = user_id, str(b.device_fun), str(b.device_jac)
                 info.cpp_name = f"{''.join(ch if ch.isalnum() else '_' for ch in name)}_{user_id}"
+                info.templated = bool(getattr(b, "template", False))
+                if info.templated and (pos != len(names) - 1 or info.nin != 0):
+                    raise bad(f"user block {name} says template = True: only the LAST block receives the template point, and it is a source (num_inp = 0) "
+                              "— its `inp` then holds the three coordinates of the detection's template point (afb:374-375)")
                 user_id += 1
             elif kind == "template_points":
                 info.nin = 0
@@ -220,6 +227,9 @@ def emit_source(spec: ChainSpec) -> str:
             fwd.append(f"double x{i}[3], E{i}[9]; pcs::rigid_fwd<JAC>(c.slab({b.slab}, {_LINK_CPP[b.link]}), {x_in}, x{i}, E{i});")
         elif b.kind == "user":
             inp = x_in if b.nin > 0 else "nullptr"
+            if b.templated:   # a templated source: inp = template[key] (three doubles), like `inp[:3] = t_data[int(datum[2])]` (afb:374-375)
+                fwd.append(f"double xt{i}[3]; {{ const double *tp = c.tpoint(); xt{i}[0] = tp[0]; xt{i}[1] = tp[1]; xt{i}[2] = tp[2]; }}")
+                inp = f"xt{i}"
             fwd.append(f"double x{i}[{b.nout}]; const double *p{i} = c.user({b.uidx}, {_LINK_CPP[b.link]}, {b.n_params}); user::{b.cpp_name}::fun(p{i}, {inp}, x{i});")
         elif b.kind == "projection":
             fwd.append(f"double Ap[18], Ax[2][3]; pcs::project_generic<JAC>(c.intr(), {x_in}[0], {x_in}[1], {x_in}[2], u, v, Ap, Ax);")
@@ -235,7 +245,7 @@ def emit_source(spec: ChainSpec) -> str:
             if prev is None:
                 rule.append("const double Sid[2][2] = {{1.0, 0.0}, {0.0, 1.0}};")
                 prev = "Sid"
-            inp = f"x{i + 1}" if b.nin > 0 else "nullptr"
+            inp = f"x{i + 1}" if b.nin > 0 else (f"xt{i}" if b.templated else "nullptr")
             rule.append(f"double Jb{i}[{b.nout * (b.n_params + b.nin)}]; user::{b.cpp_name}::jac(p{i}, {inp}, Jb{i});")
             rule.append(f"double S{i}[2][{nin}]; pcs::chain_user<P, {cols[i]}, {b.n_params}, {b.nin}, {b.nout}>({prev}, Jb{i}, J, S{i});")
         elif b.kind == "rigid":
@@ -315,10 +325,20 @@ def _compile_with_hiprtc(src_text: str, out: Path) -> str | None:
         code = ctypes.create_string_buffer(n.value)
         if rtc.hiprtcGetCode(prog, code) != 0:
             return "hiprtcGetCode failed"
-        out.write_bytes(code.raw[: n.value])
+        _publish(out, code.raw[: n.value])
         return None
     finally:
         rtc.hiprtcDestroyProgram(ctypes.byref(prog))
+
+
+def _publish(out: Path, data: bytes | None = None, tmp: Path | None = None) -> None:
+    """Put a finished code object under its cache name in ONE step: several ranks (torchrun, `bench.py --gpus N`) may compile the
+    same chain at first use, and `compile_chain` returns as soon as the name exists — so a name must never point at a file somebody
+    is still writing.  The bytes go to a private name in the same directory first; `os.replace` is atomic."""
+    if tmp is None:
+        tmp = out.with_name(f".{out.name}.{os.getpid()}.{uuid.uuid4().hex[:8]}.tmp")
+        tmp.write_bytes(data)
+    os.replace(tmp, out)
 
 
 def compile_chain(spec: ChainSpec, verbose: bool = False) -> Path:
@@ -329,29 +349,39 @@ def compile_chain(spec: ChainSpec, verbose: bool = False) -> Path:
     if out.exists():
         return out
     CACHE.mkdir(exist_ok=True)
-    src = out.with_suffix(".hip")
+    unique = f"{os.getpid()}.{uuid.uuid4().hex[:8]}"
+    src = out.with_name(f".{out.stem}.{unique}.hip")      # private to this process until the object is published
     text = emit_source(spec)
     src.write_text(text)
-    which = os.environ.get("PCS_CHAIN_COMPILER", "auto")
-    log = None
-    if which in ("auto", "hiprtc"):
-        log = _compile_with_hiprtc(text, out)
-        if log is None:
-            if verbose:
-                print(f"hiprtc: {out}", flush=True)
-            return out
-        if which == "hiprtc":
-            raise RuntimeError(f"hiprtc failed compiling the chain {' + '.join(spec.names)}:\n{log}")
-    cmd = [os.environ.get("HIPCC", "hipcc"), "--genco", "--offload-arch=gfx950", "-O3", "-std=c++17", FP_CONTRACT, f"-I{CSRC}", str(src), "-o", str(out)]
-    if verbose:
-        print(" ".join(cmd), flush=True)
     try:
-        proc = subprocess.run(cmd, capture_output=True, text=True)
-    except FileNotFoundError as e:
-        raise RuntimeError(f"no compiler for the chain {' + '.join(spec.names)}: hiprtc said `{log}`, and hipcc is not installed ({e})") from None
-    if proc.returncode != 0 or not out.exists():
-        raise RuntimeError(f"hipcc failed compiling the chain {' + '.join(spec.names)}:\n{proc.stderr[-2000:]}")
-    return out
+        which = os.environ.get("PCS_CHAIN_COMPILER", "auto")
+        log = None
+        if which in ("auto", "hiprtc"):
+            log = _compile_with_hiprtc(text, out)
+            if log is None:
+                src.replace(out.with_suffix(".hip"))
+                if verbose:
+                    print(f"hiprtc: {out}", flush=True)
+                return out
+            if which == "hiprtc":
+                raise RuntimeError(f"hiprtc failed compiling the chain {' + '.join(spec.names)}:\n{log}")
+        tmp = out.with_name(f".{out.name}.{unique}.tmp")
+        cmd = [os.environ.get("HIPCC", "hipcc"), "--genco", "--offload-arch=gfx950", "-O3", "-std=c++17", FP_CONTRACT, f"-I{CSRC}", str(src), "-o", str(tmp)]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        try:
+            proc = subprocess.run(cmd, capture_output=True, text=True)
+        except FileNotFoundError as e:
+            raise RuntimeError(f"no compiler for the chain {' + '.join(spec.names)}: hiprtc said `{log}`, and hipcc is not installed ({e})") from None
+        if proc.returncode != 0 or not tmp.exists():
+            raise RuntimeError(f"hipcc failed compiling the chain {' + '.join(spec.names)}:\n{proc.stderr[-2000:]}")
+        _publish(out, tmp=tmp)
+        src.replace(out.with_suffix(".hip"))
+        return out
+    finally:
+        for leftover in (src, out.with_name(f".{out.name}.{unique}.tmp")):   # a failed compile leaves nothing behind
+            if leftover.exists():
+                leftover.unlink()
 
 
 def block_param_inds(spec: ChainSpec, lay: dict, det_idx: np.ndarray) -> np.ndarray:

@@ -75,6 +75,10 @@ __device__ __forceinline__ double cp_ld(const double *p) { return __hip_atomic_l
 __device__ __forceinline__ void cp_st(double *p, const double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }   // global_store_dwordx2 sc1
 __device__ __forceinline__ int cp_ldi(const int32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// The abort word and the clock are looked at every 64th poll of a wait — and at EVERY poll when the time limit is below 10 us (tests set
+// 1 us to force the give-up path: the shortest hand-over between two workgroups takes longer than that).
+__device__ __forceinline__ bool cp_check_now(const CholPersistArgs &a, const int spins) { return (spins & 63) == 0 || a.timeout_ticks < 1000; }
+
 // lane 0 of the calling wave: spin until flags[word] >= target; false = the launch is being abandoned
 __device__ __forceinline__ bool cp_spin(const CholPersistArgs &a, const int word, const int target) {
     if (cp_ldi(a.flags + word) >= target) return true;
@@ -82,7 +86,7 @@ __device__ __forceinline__ bool cp_spin(const CholPersistArgs &a, const int word
     for (int spins = 1;; ++spins) {
         __builtin_amdgcn_s_sleep(1);
         if (cp_ldi(a.flags + word) >= target) return true;
-        if ((spins & 63) == 0 && (cp_ldi(a.flags + CP_ABORT) >= 0 || (int64_t)(wall_clock64() - t0) > a.timeout_ticks)) {
+        if (cp_check_now(a, spins) && (cp_ldi(a.flags + CP_ABORT) >= 0 || (int64_t)(wall_clock64() - t0) > a.timeout_ticks)) {
             __hip_atomic_store(a.flags + CP_ABORT, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             atomicOr(a.status, 4);
             return false;
@@ -99,7 +103,7 @@ __device__ __forceinline__ bool cp_wait_wave(const CholPersistArgs &a, const int
 // between two polls of a DATA word by one wave: a short sleep; every 64th time the abort word and the clock.  false = abandon the launch
 __device__ __forceinline__ bool cp_poll_again(const CholPersistArgs &a, const uint64_t t0, const int spins, const int lane) {
     __builtin_amdgcn_s_sleep(1);
-    if (spins & 63) return true;
+    if (!cp_check_now(a, spins)) return true;
     int give_up = 0;
     if (lane == 0 && (cp_ldi(a.flags + CP_ABORT) >= 0 || (int64_t)(wall_clock64() - t0) > a.timeout_ticks)) {
         __hip_atomic_store(a.flags + CP_ABORT, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -154,7 +158,7 @@ __device__ __forceinline__ bool cp_fetch_polled(const CholPersistArgs &a, double
         const bool pending = cp_is_fill(vp) || (i != j && cp_is_fill(vq));
         if (!__syncthreads_or(pending)) return true;
         __builtin_amdgcn_s_sleep(1);
-        if ((spins & 63) == 0) {
+        if (cp_check_now(a, spins)) {
             int give_up = 0;
             if (tid == 0 && (cp_ldi(a.flags + CP_ABORT) >= 0 || (int64_t)(wall_clock64() - t0) > a.timeout_ticks)) {
                 __hip_atomic_store(a.flags + CP_ABORT, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -658,12 +662,10 @@ inline hipError_t cp_launch(const int64_t n, double *d_S, const int64_t ld, cons
     // prefilled: an earlier kernel on `s` has set the workspace to the fill value (schur_trail_lead_kernel in an LM trial)
     hipError_t e = prefilled ? hipSuccess : hipMemsetAsync(d_work, 0xFF, sizeof(double) * (size_t)cp_work_doubles(nb), s);
     if (e != hipSuccess) return e;
-    static bool attr_set = false;   // one code object per process: the attribute sticks to the function
-    if (!attr_set) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(chol_persist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)cp_lds_bytes(CP_MAX_SLOTS));
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    // more than 64 KB of dynamic LDS needs the attribute, and it belongs to the function object of the CURRENT device (the caller has set
+    // it): set it before every launch — microseconds, and right for a process that solves on several devices or from several threads
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(chol_persist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)cp_lds_bytes(CP_MAX_SLOTS));
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(chol_persist_kernel, dim3((unsigned)G), dim3(256), lds, s, a);
     return hipGetLastError();
 }

@@ -165,8 +165,12 @@ __global__ void normal_prologue_kernel(const double *__restrict__ prm, T *__rest
                                        T *__restrict__ points, int n_cams, int n_imgs, int n_keys, int64_t extr_off,
                                        int64_t pose_off, int64_t point_off, int has_pose, int copy_points, int prep_blocks,
                                        double *__restrict__ Hm, int64_t n_h, double *__restrict__ g, int64_t n_g, double *__restrict__ cost,
-                                       const int32_t *__restrict__ stop) {
+                                       const int32_t *__restrict__ stop, const int32_t *__restrict__ sel = nullptr, int64_t alt_prm = 0, int64_t alt_out = 0) {
     if (stop && *stop) return;   // a build queued behind the end of an LM loop (ba_schur.hpp PCS_STOP_GUARD)
+    if (sel && *sel) {           // LM loop with two states: the trial state is the other pair (string, packed buffer) — ba_schur.hpp SchurArgs::sel
+        prm += alt_prm;
+        Hm += alt_out; g += alt_out; cost += alt_out;
+    }
     if ((int)blockIdx.x < prep_blocks) {
         slab_prep_element((int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)prep_blocks * blockDim.x, prm, cam_slab, pose_slab, points, n_cams,
                           n_imgs, n_keys, extr_off, pose_off, point_off, has_pose, copy_points);

@@ -74,6 +74,15 @@ struct NormalArgs {
     int64_t n_params;
     int32_t tiles_per_wave;
     const int32_t *stop;   // optional device word: non-zero = do nothing (a build queued behind the end of an LM loop, ba_schur.hpp)
+    // LM loop with two packed states (ba_schur.hpp SchurArgs::sel): H, HB, HC, g, cost above are where the TRIAL state goes while state 0
+    // is current; when *sel != 0 the trial state is the other buffer, `alt` doubles further on (alt may be negative)
+    const int32_t *sel;
+    int64_t alt;
+    // Deterministic mode (csrc/ba_reduce.hpp): instead of adding a finished run's accumulators to H / g / cost with atomics, the kernel
+    // stores them raw into slot seg_base[workgroup] + (flushes this wave has done) of `part` — NM * 256 doubles per slot, register (m, r)
+    // of lane l at (m * 4 + r) * 64 + l — and an ordered second pass sums the slots.  NULL = atomics.
+    double *part;
+    const int32_t *seg_base;
     int32_t debug;  // profiling switches (results are wrong while set): 2 no flush atomics, 8 no MFMA phase, 16 no evaluation,
                     // 32 run boundaries ignored, 64 no LDS image writes, 128 flush = clear only; host side: 256 / 512 / 1024 skip the shared /
                     // (cam, key) / (image, key) pass
@@ -227,7 +236,8 @@ __global__ __launch_bounds__(64, 2) void ba_normal_mfma_kernel(const NormalArgs 
 #pragma unroll
         for (int r = 0; r < 4; ++r) ent[m][r] = entry_descriptor<CHAIN, PASS>(m, lane, r, tg);
     // lanes 0-4: the five output pointers (A, B, C, g, cost)
-    const uint64_t out_ptr = lane == 1 ? (uint64_t)a.HB : lane == 2 ? (uint64_t)a.HC : lane == 3 ? (uint64_t)a.g : lane == 4 ? (uint64_t)a.cost : (uint64_t)a.H;
+    const int64_t out_shift = (a.sel && *a.sel) ? 8 * a.alt : 0;   // bytes: which of the two packed states receives this build
+    const uint64_t out_ptr = (lane == 1 ? (uint64_t)a.HB : lane == 2 ? (uint64_t)a.HC : lane == 3 ? (uint64_t)a.g : lane == 4 ? (uint64_t)a.cost : (uint64_t)a.H) + (uint64_t)out_shift;
     const int ptr_lo = (int)(uint32_t)out_ptr, ptr_hi = (int)(uint32_t)(out_ptr >> 32);
     int base_tab = lane == 12 ? a.ldA : lane == 13 ? a.ldB : lane == 14 ? a.tb : 0;
     d4v acc[NM];
@@ -239,8 +249,21 @@ __global__ __launch_bounds__(64, 2) void ba_normal_mfma_kernel(const NormalArgs 
 
     // Add the finished entries to H / g / cost.  `everything` = false (PASS_SHARED, image changed but not the
     // camera): only entries that involve a pose column are flushed and cleared.
+    int64_t seg = a.part ? a.seg_base[blockIdx.x] : 0;   // deterministic mode: the slot of this wave's next flush
     auto flush = [&](const bool everything) {
         if (run_a < 0) return;
+        if (a.part) {   // deterministic mode: the whole tile, raw, to its slot (coalesced 512-byte stores); every flush is a complete one
+            double *slot = a.part + seg * (NM * 256) + lane;
+#pragma unroll
+            for (int m = 0; m < NM; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    slot[(m * 4 + r) * 64] = acc[m][r];
+                    acc[m][r] = 0.0;
+                }
+            ++seg;
+            return;
+        }
         if (a.debug & 128) {   // profiling: clear the finished entries, no look-ups, no atomics
 #pragma unroll
             for (int m = 0; m < NM; ++m)
@@ -546,6 +569,7 @@ __global__ __launch_bounds__(64, 3) void ba_normal_imgkey_kernel(const NormalArg
     using I4 = __attribute__((ext_vector_type(4))) int;
     using D2 = __attribute__((ext_vector_type(2))) double;
     I4 *runs = reinterpret_cast<I4 *>(lds_image + IK_RUNS);
+    const int64_t out_shift = (a.sel && *a.sel) ? a.alt : 0;   // doubles: which of the two packed states receives this build (NormalArgs::sel)
 
     const int li = lane & 15, lq = lane >> 4;
     // B operand at k-step s: P[4 s + q][j]; lanes whose column does not exist read a valid slot, result unused
@@ -667,7 +691,7 @@ __global__ __launch_bounds__(64, 3) void ba_normal_imgkey_kernel(const NormalArg
             // pose rows x point columns: inside B when the points are the trailing group (blocked layout), else inside the dense H
             const bool in_b = a.trail_group == 3;
             const int64_t ldh = in_b ? (int64_t)a.ldB : a.n_params;
-            double *Hrow = (in_b ? a.HB : a.H) + ((int64_t)a.pose_off + 6 * mine.y) * ldh + (in_b ? 0 : a.point_off) + 3 * mine.z;
+            double *Hrow = (in_b ? a.HB : a.H) + out_shift + ((int64_t)a.pose_off + 6 * mine.y) * ldh + (in_b ? 0 : a.point_off) + 3 * mine.z;
             auto emit = [&](double *ptr, const double val) {
                 if (live && val != 0.0) unsafeAtomicAdd(ptr, val);
             };

@@ -42,7 +42,16 @@ struct SchurArgs {
     uint64_t *fill;             // optional (schur_trail_lead_kernel): fill_n words to set to all-ones — the hand-over workspace of the one-launch
     int64_t fill_n;             // Cholesky that follows in the same trial (ba_chol_persist.hpp), instead of a memset launch of its own
     int32_t trail_blocks;       // schur_trail_lead_kernel: the first trail_blocks workgroups take the trailing entities
+    // Round 5: an LM loop keeps TWO packed states and a device word that says which one is current (lm_decide_kernel flips it when a
+    // trial is accepted — no copy).  A, B, C, g above are the regions of state 0; when *sel != 0 they are `alt` doubles further on.
+    const int32_t *sel;
+    int64_t alt;
 };
+// the packed regions of the CURRENT state (see SchurArgs::sel)
+__device__ __forceinline__ SchurArgs schur_current(SchurArgs a) {
+    if (a.sel && *a.sel) { a.A += a.alt; a.B += a.alt; a.C += a.alt; a.g += a.alt; }
+    return a;
+}
 // Every kernel of an LM trial starts with this: the host queues trial t + 1 before it has read the verdict of trial t
 // (pcs_lm_trial), and lm_decide_kernel raises the flag when the loop is over — what was queued behind it then drains as no-ops.
 #define PCS_STOP_GUARD(a) do { if ((a).stop && *(a).stop) return; } while (0)
@@ -134,8 +143,9 @@ __device__ __forceinline__ void schur_trail_body(const SchurArgs &a, const int b
 
 // One lane = one tb-chunk of one leading row: V[r, e, :] = b L_e^-T with b = the masked B[r, e, :].
 template <int TB>
-__global__ __launch_bounds__(256) void schur_v_kernel(const SchurArgs a) {
-    PCS_STOP_GUARD(a);
+__global__ __launch_bounds__(256) void schur_v_kernel(const SchurArgs a0) {
+    PCS_STOP_GUARD(a0);
+    const SchurArgs a = schur_current(a0);
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= a.n_lead * a.n_ent) return;
     const int64_t r = t / a.n_ent, e = t - r * a.n_ent;
@@ -204,8 +214,9 @@ __device__ __forceinline__ void schur_lead_body(const SchurArgs &a, const int bl
 // (schur_trail_body), the others write S, rhs and the damping diagonal tile by tile (schur_lead_body); every workgroup takes a
 // share of the optional fill (the hand-over workspace of the one-launch Cholesky that follows in an LM trial).
 template <int TB>
-__global__ __launch_bounds__(256) void schur_trail_lead_kernel(const SchurArgs a) {
-    PCS_STOP_GUARD(a);
+__global__ __launch_bounds__(256) void schur_trail_lead_kernel(const SchurArgs a0) {
+    PCS_STOP_GUARD(a0);
+    const SchurArgs a = schur_current(a0);
     {
         const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
         for (int64_t i = t; i < a.fill_n; i += (int64_t)gridDim.x * blockDim.x) a.fill[i] = ~0ull;
@@ -231,6 +242,11 @@ struct SchurSyrkArgs {
     double *rhs;         // n_lead
     int32_t n_lead, n_trail, ldv, lds, ksplit, kchunk;   // kchunk: columns per split (multiple of 64)
     const int32_t *stop;
+    // Ordered mode (engine option "deterministic"): with K split, a workgroup does not add its partial tile to S with atomics but stores
+    // it to ws[(split * tiles + tile) * TW * TW + row * TW + column] (and its share of V u to ws_rhs[split * n_lead + row]);
+    // schur_syrk_reduce_kernel then subtracts the splits in order.  NULL = atomics.
+    double *ws, *ws_rhs;
+    int32_t tiles;
 };
 constexpr int SYRK_LD = 65;   // odd: a quarter wave reads 16 rows, 16 different bank pairs (68: 4-way conflicts)
 using schur_d4 = __attribute__((ext_vector_type(4))) double;
@@ -290,7 +306,9 @@ __global__ __launch_bounds__(256) void schur_syrk_kernel(const SchurSyrkArgs a) 
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int gi = bi * 32 + i0 + (lane >> 4) + 4 * r, gj = bj * 32 + j0 + (lane & 15);
-        if (gi < a.n_lead && gj <= gi) {
+        if (a.ksplit > 1 && a.ws) {
+            a.ws[((int64_t)kc * a.tiles + t) * 1024 + (i0 + (lane >> 4) + 4 * r) * 32 + j0 + (lane & 15)] = acc[r];
+        } else if (gi < a.n_lead && gj <= gi) {
             double *dst = a.S + (int64_t)gi * a.lds + gj;
             if (a.ksplit == 1) *dst -= acc[r];
             else unsafeAtomicAdd(dst, -acc[r]);
@@ -303,6 +321,7 @@ __global__ __launch_bounds__(256) void schur_syrk_kernel(const SchurSyrkArgs a) 
         const int gi = bi * 32 + (tid >> 3);
         if ((tid & 7) == 0 && gi < a.n_lead) {
             if (a.ksplit == 1) a.rhs[gi] += dot;
+            else if (a.ws) a.ws_rhs[(int64_t)kc * a.n_lead + gi] = dot;
             else unsafeAtomicAdd(a.rhs + gi, dot);
         }
     }
@@ -401,7 +420,9 @@ __global__ __launch_bounds__(256) void schur_syrk64_kernel(const SchurSyrkArgs a
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int gi = bi * 64 + i0 + 16 * x + (lane >> 4) + 4 * r, gj = bj * 64 + j0 + 16 * y + (lane & 15);
-                if (gi < a.n_lead && gj <= gi) {
+                if (a.ksplit > 1 && a.ws) {
+                    a.ws[((int64_t)kc * a.tiles + blockIdx.x / a.ksplit) * 4096 + (i0 + 16 * x + (lane >> 4) + 4 * r) * 64 + j0 + 16 * y + (lane & 15)] = acc[x][y][r];
+                } else if (gi < a.n_lead && gj <= gi) {
                     double *dst = a.S + (int64_t)gi * a.lds + gj;
                     if (a.ksplit == 1) *dst -= acc[x][y][r];
                     else unsafeAtomicAdd(dst, -acc[x][y][r]);
@@ -413,7 +434,35 @@ __global__ __launch_bounds__(256) void schur_syrk64_kernel(const SchurSyrkArgs a
         const int gi = bi * 64 + (tid >> 2);
         if ((tid & 3) == 0 && gi < a.n_lead) {
             if (a.ksplit == 1) a.rhs[gi] += dot;
+            else if (a.ws) a.ws_rhs[(int64_t)kc * a.n_lead + gi] = dot;
             else unsafeAtomicAdd(a.rhs + gi, dot);
+        }
+    }
+}
+
+// Ordered mode: S -= sum over the K splits of a tile's partial products, rhs += sum of the partial V u, split 0 first.  One workgroup per
+// tile of the lower triangle, TW = 32 or 64 (the form that produced the partials).
+template <int TW>
+__global__ __launch_bounds__(256) void schur_syrk_reduce_kernel(const SchurSyrkArgs a) {
+    PCS_STOP_GUARD(a);
+    const int tid = threadIdx.x, t = blockIdx.x;
+    int bi = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);   // t -> (bi, bj), 0 <= bj <= bi
+    while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
+    while (bi * (bi + 1) / 2 > t) --bi;
+    const int bj = t - bi * (bi + 1) / 2;
+    for (int e = tid; e < TW * TW; e += 256) {
+        const int gi = bi * TW + e / TW, gj = bj * TW + e % TW;
+        if (gi >= a.n_lead || gj > gi) continue;
+        double sum = 0.0;
+        for (int kc = 0; kc < a.ksplit; ++kc) sum += a.ws[((int64_t)kc * a.tiles + t) * (TW * TW) + e];
+        a.S[(int64_t)gi * a.lds + gj] -= sum;
+    }
+    if (bi == bj && a.u && tid < TW) {
+        const int gi = bi * TW + tid;
+        if (gi < a.n_lead) {
+            double sum = 0.0;
+            for (int kc = 0; kc < a.ksplit; ++kc) sum += a.ws_rhs[(int64_t)kc * a.n_lead + gi];
+            a.rhs[gi] += sum;
         }
     }
 }
@@ -465,12 +514,24 @@ struct SchurBackArgs {
     double *ps_out;                     // ... and where the trial string ps_in + delta goes
     int64_t n_lead, n_ent, trail_off;
     const int32_t *stop;
+    // LM loop with two states (SchurArgs::sel): ps_in / ps_out are the strings of state 0 / state 1; when *sel != 0 they swap roles
+    const int32_t *sel;
+    // optional: vote[0] (state 0 is current) or vote[vote_alt] (state 1 is current) <- 1.0 when bit 2 of *status is set (the one-launch
+    // dense solve gave up), else 0.0.  The word sits behind the TRIAL state's packed buffer, so a sharded loop's all-reduce of that buffer
+    // carries it: every rank learns that SOME rank's step is void (lm_decide_kernel) and all of them repeat the trial together.
+    double *vote;
+    int64_t vote_alt;
+    const int32_t *status;
 };
 
 template <int TB>
-__global__ __launch_bounds__(256) void schur_back_kernel(const SchurBackArgs a) {
-    PCS_STOP_GUARD(a);
+__global__ __launch_bounds__(256) void schur_back_kernel(const SchurBackArgs a0) {
+    PCS_STOP_GUARD(a0);
+    SchurBackArgs a = a0;
+    const bool flipped = a.sel && *a.sel;
+    if (flipped && a.ps_out) { a.ps_in = a0.ps_out; a.ps_out = const_cast<double *>(a0.ps_in); }
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0 && a.vote) a.vote[flipped ? a.vote_alt : 0] = (a.status && (*a.status & 4)) ? 1.0 : 0.0;
     if (t < a.n_lead) {
         const double d = a.fixed[t] ? 0.0 : a.xl[t];
         a.delta[t] = d;
@@ -500,36 +561,56 @@ __global__ __launch_bounds__(256) void schur_back_kernel(const SchurBackArgs a) 
 // Round 4: with a control block (`ctrl`) the kernel also applies the loop's TERMINATION rules (gtol before the step, ftol / xtol
 // after an accepted one, the limit of consecutive rejections, the iteration limit) and raises `*stop_flag`: the host no longer has
 // to read a verdict before it may queue the next trial — whatever it queued speculatively starts with PCS_STOP_GUARD.
+// Round 5: the loop keeps two states (packed normal equations + parameter string each) and `*sel` names the current one; an
+// accepted trial becomes the current state by FLIPPING that word (round 4 copied 6.5 MB on rig-32, 42 MB on rig-32-self, in a launch
+// of its own), and the trial's read-back goes to the host's page-locked buffer from here.
 //   ctrl[0] stop code (0 = running; 1 gtol, 2 damping exhausted, 3 ftol, 4 xtol, 5 iteration limit, 9 = the dense solve gave up: host must
 //           repeat the trial)   [1] consecutive rejections   [2] accepted steps   [3] iteration limit   [4] ftol [5] xtol [6] gtol
 //           [7] rejection limit   [8] trials decided so far
+//           [9] factor applied to lambda by a rejection BEFORE the first accepted step (0 = the classic 4): a start far from the
+//               solution needs orders of magnitude more damping than the default initial value, not five rejections' worth of x 4
 struct LmDecideArgs {
-    const double *cost_old, *cost_new;     // sum r^2 of the current state and of the trial state
-    const double *dvec, *gm, *delta, *ps;  // n_params each: damping diagonal, masked gradient, step, CURRENT parameter string
+    // &packed[s][n_packed - 1] of the two states: [0] sum r^2, [1] the void votes of the ranks (schur_back_kernel, with use_votes),
+    // [-n_params .. -1] J^T r.  State *sel (0 without sel) is the current one, the other holds the trial.
+    const double *tail[2];
+    const double *ps2[2];                   // the two parameter strings, same roles
+    int32_t *sel;
+    const double *dvec, *gm, *delta;        // n_params each: damping diagonal, masked gradient, step
     const uint8_t *fixed;
     int32_t *status;                        // != 0: the step is invalid (a factorisation failed); cleared here for the next solve
     double *lambda;                         // in: the damping the step was computed with; out: the next one
-    double *stats;                          // out[10]: accepted (-1: the trial is void, see below), max |g|, relative cost drop, |step|, |x|, new sum r^2,
-                                            // old sum r^2, lambda used, stop code after this trial, trial number (-1: a no-op launch behind a raised flag)
+    double *stats;                          // out[12]: accepted (-1: the trial is void, see below), max |g|, relative cost drop, |step|, |x|, new sum r^2,
+                                            // old sum r^2, lambda used, stop code after this trial, trial number (-1: a no-op launch behind a raised flag),
+                                            // the current state after this trial (0 / 1), lambda for the next trial
     int64_t n_params;
     double *ctrl;                           // optional control block (see above)
     int32_t *stop_flag;                     // with ctrl: the word PCS_STOP_GUARD reads
-    int32_t *accept_flag;                   // with ctrl: 1 when this trial was accepted (lm_accept_kernel copies the trial state over the current one)
+    int32_t *accept_flag;                   // with ctrl: 1 when this trial was accepted
+    int32_t use_votes;                      // tail[trial][1] > 0: some rank's dense solve gave up — the trial is void on EVERY rank
+    int32_t keep_sel;                       // 1: an accepted trial does not flip *sel (the caller copies the trial state over the current one:
+                                            // lm_accept_kernel — a sharded loop builds into a FIXED buffer, the one its all-reduce was queued on)
     // optional (with ctrl): when this trial ends the loop, the final state goes to result (mapped page-locked host memory):
     // g[free_idx] | ps[free_idx] | sum r^2 of the state the loop ends in (the trial's if accepted, else the current one)
-    const double *g_cur, *g_new, *ps_new;
     const int64_t *free_idx;
     int64_t n_free;
     double *result;
+    double *stats_host;                     // optional: the 12 numbers again, in mapped page-locked host memory; word 9 is written last
 };
+constexpr int LM_STATS = 12;
 
 __global__ __launch_bounds__(1024) void lm_decide_kernel(const LmDecideArgs a) {
     __shared__ double red[4][1024];
     const int tid = threadIdx.x;
     if (a.ctrl && a.ctrl[0] != 0.0) {   // queued behind the end of the loop: nothing to decide
-        if (tid == 0) { a.stats[9] = -1.0; *a.accept_flag = 0; }
+        if (tid == 0) {
+            a.stats[9] = -1.0;
+            *a.accept_flag = 0;
+            if (a.stats_host) a.stats_host[9] = -1.0;
+        }
         return;
     }
+    const int cur = a.sel ? (*a.sel != 0 ? 1 : 0) : 0, tri = 1 - cur;
+    const double *ps = a.ps2[cur];
     double gd = 0.0, dd = 0.0, gmax = 0.0, xx = 0.0, ss = 0.0;
     for (int64_t i = tid; i < a.n_params; i += 1024) {
         const double d = a.delta[i], g = a.gm[i];
@@ -537,7 +618,7 @@ __global__ __launch_bounds__(1024) void lm_decide_kernel(const LmDecideArgs a) {
         dd += a.dvec[i] * d * d;
         gmax = fmax(gmax, fabs(g));
         ss += d * d;
-        if (!a.fixed[i]) xx += a.ps[i] * a.ps[i];
+        if (!a.fixed[i]) xx += ps[i] * ps[i];
     }
     // five reductions through LDS (sum, sum, max, sum, sum): four arrays, the fifth reuses the first after a barrier
     red[0][tid] = gd; red[1][tid] = dd; red[2][tid] = gmax; red[3][tid] = xx;
@@ -560,7 +641,7 @@ __global__ __launch_bounds__(1024) void lm_decide_kernel(const LmDecideArgs a) {
         __syncthreads();
     }
     if (tid == 0) {
-        const double lam = *a.lambda, c_old = *a.cost_old, c_new = *a.cost_new;
+        const double lam = *a.lambda, c_old = a.tail[cur][0], c_new = a.tail[tri][0];
         const double pred = 0.5 * (lam * s_dd - s_gd);
         const double actual = 0.5 * (c_old - c_new);
         const int st = *a.status;
@@ -570,9 +651,12 @@ __global__ __launch_bounds__(1024) void lm_decide_kernel(const LmDecideArgs a) {
         const double factor = rho > 0.75 ? 1.0 / 3.0 : rho > 0.25 ? 1.0 : 2.0;
         const double rel_drop = actual / (0.5 * c_old), step_norm = sqrt(red[0][0]), x_norm = sqrt(s_xx);
         double code = 0.0;
-        const bool void_trial = (st & 4) != 0;   // the dense solve did not complete (ba_chol_persist.hpp's time limit): the host repeats the trial
+        // the dense solve did not complete (ba_chol_persist.hpp's time limit) — here, or on some rank of a sharded loop: the host repeats the trial
+        const bool void_trial = (st & 4) != 0 || (a.use_votes && a.tail[tri][1] > 0.0);
+        double grow = 4.0;
         if (a.ctrl) {
             double *c = a.ctrl;
+            if (c[2] == 0.0 && c[9] > 1.0) grow = c[9];
             if (void_trial) { code = 9.0; acc = false; }
             else if (s_gmax <= c[6]) { code = 1.0; acc = false; }             // the state BEFORE this step was already stationary: the step is dropped
             else if (acc) {
@@ -592,8 +676,11 @@ __global__ __launch_bounds__(1024) void lm_decide_kernel(const LmDecideArgs a) {
             *a.accept_flag = acc ? 1 : 0;
             *a.stop_flag = code != 0.0 ? 1 : 0;
         }
-        if (!void_trial && code != 1.0) *a.lambda = acc ? fmax(lam * factor, 1e-12) : lam * 4.0;
+        const double lam_next = (!void_trial && code != 1.0) ? (acc ? fmax(lam * factor, 1e-12) : lam * grow) : lam;
+        *a.lambda = lam_next;
         *a.status = 0;
+        const int now = (acc && a.sel && !a.keep_sel) ? tri : cur;           // the state the next trial starts from
+        if (a.sel) *a.sel = now;
         a.stats[0] = void_trial ? -1.0 : acc ? 1.0 : 0.0;
         a.stats[1] = s_gmax;
         a.stats[2] = rel_drop;
@@ -602,37 +689,44 @@ __global__ __launch_bounds__(1024) void lm_decide_kernel(const LmDecideArgs a) {
         a.stats[5] = c_new;
         a.stats[6] = c_old;
         a.stats[7] = lam;
+        a.stats[10] = (double)now;
+        a.stats[11] = lam_next;
         red[1][0] = code;                    // for the other threads: does the loop end here, and in which state
         red[1][1] = acc ? 1.0 : 0.0;
         red[1][2] = acc ? c_new : c_old;
     }
-    if (!a.ctrl || !a.result) return;
+    if (!a.ctrl) return;
     __syncthreads();
-    if (red[1][0] == 0.0) return;
-    const bool acc = red[1][1] != 0.0;
-    const double *g = acc ? a.g_new : a.g_cur, *ps = acc ? a.ps_new : a.ps;
-    for (int64_t i = tid; i < a.n_free; i += 1024) {
-        const int64_t k = a.free_idx[i];
-        a.result[i] = g[k];
-        a.result[a.n_free + i] = ps[k];
+    if (a.result && red[1][0] != 0.0) {      // the loop ends here: gradient, solution and cost of the final state for the host
+        const int fin = red[1][1] != 0.0 ? tri : cur;
+        const double *g = a.tail[fin] - a.n_params, *pf = a.ps2[fin];
+        for (int64_t i = tid; i < a.n_free; i += 1024) {
+            const int64_t k = a.free_idx[i];
+            a.result[i] = g[k];
+            a.result[a.n_free + i] = pf[k];
+        }
+        __threadfence_system();              // every thread's stores are out before ...
+        __syncthreads();
+        if (tid == 0) {                      // ... the word the host takes for "the final state is there"
+            a.result[2 * a.n_free] = red[1][2];
+            __threadfence_system();
+        }
     }
-    if (tid == 0) a.result[2 * a.n_free] = red[1][2];
+    // the trial's read-back straight into the host's page-locked buffer (no copy launch; a host that polls word 9 needs no event)
+    if (tid == 0 && a.stats_host) {
+#pragma unroll
+        for (int i = 0; i < LM_STATS; ++i)
+            if (i != 9) a.stats_host[i] = a.stats[i];
+        __threadfence_system();
+        a.stats_host[9] = a.stats[9];        // the trial's number — what a polling host waits for — goes last
+    }
 }
 
-// An accepted trial becomes the current state: packed[trial] -> packed[current], trial parameter string -> current one.  Always
-// queued (the host does not know the verdict yet); copies only when lm_decide_kernel has set the accept flag — 6.5 MB on rig-32.
-// Also carries the trial's ten numbers to the host.
+// Sharded loops only (LmDecideArgs::keep_sel): the build writes into the FIXED buffer its all-reduce was queued on, so an accepted
+// trial is copied over the current state: packed[1] -> packed[0], string 1 -> string 0.  Always queued (the host does not know the
+// verdict yet); copies only when lm_decide_kernel has set the accept flag.
 __global__ __launch_bounds__(256) void lm_accept_kernel(const int32_t *__restrict__ accept_flag, const double *__restrict__ packed_new, double *__restrict__ packed_cur,
-                                                        const int64_t n_packed, const double *__restrict__ ps_new, double *__restrict__ ps_cur, const int64_t n_params,
-                                                        const double *__restrict__ stats, double *__restrict__ stats_host) {
-    // the trial's read-back (lm_decide_kernel's ten numbers) into the host's page-locked buffer: visible to the host when this launch
-    // has completed at the latest — no copy launch behind it, and a host that polls word 9 needs no event either
-    if (stats_host && blockIdx.x == 0 && threadIdx.x == 0) {   // [9] — the trial's number, what a polling host waits for — goes last
-#pragma unroll
-        for (int i = 0; i < 9; ++i) stats_host[i] = stats[i];
-        __threadfence_system();
-        stats_host[9] = stats[9];
-    }
+                                                        const int64_t n_packed, const double *__restrict__ ps_new, double *__restrict__ ps_cur, const int64_t n_params) {
     if (*accept_flag == 0) return;
     using D2 = __attribute__((ext_vector_type(2))) double;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (int64_t)gridDim.x * blockDim.x;

@@ -26,6 +26,7 @@
 #include "ba_kernels.hpp"
 #include "ba_matfree.hpp"
 #include "ba_normal.hpp"
+#include "ba_reduce.hpp"
 #include "ba_schur.hpp"
 #include "ba_dense_chol.hpp"
 #include "ba_chol_persist.hpp"
@@ -152,6 +153,25 @@ struct pcs_engine {
     int64_t fuse_prep_max_n = 250000;
     int64_t tiles_per_wg = 0;  // 0 = derive from wgs_per_cu
     size_t lds_limit = 160 * 1024;
+    // time limit of every wait inside the one-launch dense solve of an LM trial (csrc/ba_chol_persist.hpp); option "spd_timeout_us"
+    int64_t spd_timeout_us = 250000;
+    // option "deterministic": every sum of the normal equations and of the Schur step is taken in an order the table and the launch
+    // geometry fix (csrc/ba_reduce.hpp) instead of with f64 atomics in arrival order: two runs — and the ranks of a sharded loop — compute
+    // the same bits
+    int deterministic = 0;
+    // host copies of the visiting orders (shared pass of a scattered table, (cam, key) pass): the deterministic mode's tables are built from them
+    std::vector<int32_t> h_order, h_order_ck;
+    // static tables + workspaces of the ordered second pass, per MFMA pass (0 shared, 1 (cam, key)); built at the first deterministic
+    // build for the launch geometry in use, rebuilt when the table or the geometry changes
+    struct DetPass {
+        int64_t n = -1;
+        int64_t tpw = 0;
+        int32_t n_seg = 0, n_lr = 0, n_grp = 0, n_ent = 0, n_waves = 0;
+        int32_t *d_idx = nullptr;      // one allocation: seg_base | lr_ptr | lr_segs | lr_ka | lr_kb | grp_ptr | cam_ptr | ent_ptr | ent_runs
+        int64_t off[9] = {};
+        double *d_work = nullptr;      // one allocation: part | Q | G
+        int64_t work_off[3] = {};
+    } det[2];
 };
 
 // `done` is recorded LAZILY where that is safe (round 3): an event record is a packet of its own between two launches, and a
@@ -209,6 +229,14 @@ static int ring_read(pcs_engine *h, int64_t i, float *prep_ms, float *eval_ms) {
 }
 
 static int64_t padded_points(int64_t n_keys) { return (n_keys * 3 + 3) & ~(int64_t)3; }
+
+static void free_det_tables(pcs_engine *h) {
+    for (auto &d : h->det) {
+        if (d.d_idx) (void)hipFree(d.d_idx);
+        if (d.d_work) (void)hipFree(d.d_work);
+        d = pcs_engine::DetPass{};
+    }
+}
 
 extern "C" {
 
@@ -625,6 +653,7 @@ int pcs_destroy(pcs_engine *h) {
     for (auto &t : h->d_sorted)
         for (void *b : t)
             if (b) (void)hipFree(b);
+    free_det_tables(h);
     if (h->h_param) (void)hipHostFree(h->h_param);
     for (auto &e : h->ev)
         if (e) (void)hipEventDestroy(e);
@@ -686,6 +715,9 @@ static int upload_detections(pcs_engine *h, std::vector<int32_t> &cam, std::vect
         }
     h->jac_capacity = h->resid_capacity = h->data_capacity = 0;
     h->nnz = -1;
+    free_det_tables(h);
+    h->h_order.clear();
+    h->h_order_ck.clear();
     if (n == 0) return PCS_OK;
     // index word: cam | image | key bit fields when they fit 32 bits (12 -> 4 bytes per detection), else three arrays
     auto bits_for = [](int64_t count) { int b = 0; while (((int64_t)1 << b) < count) ++b; return b; };
@@ -723,6 +755,7 @@ static int upload_detections(pcs_engine *h, std::vector<int32_t> &cam, std::vect
         });
         HIPCHK(hipMalloc(&h->d_order, sizeof(int32_t) * n));
         HIPCHK(hipMemcpy(h->d_order, order.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice));
+        h->h_order.swap(order);
     }
     h->n = n;
     return PCS_OK;
@@ -825,6 +858,14 @@ int pcs_set_option(pcs_engine *h, const char *key, int64_t value) {
         h->ev_ring = value;
         h->ev_count = 0;
         h->events_valid = false;
+    } else if (!strcmp(key, "deterministic")) {
+        if (value < 0 || value > 1) return fail(PCS_ERR_ARG, "deterministic must be 0 or 1");
+        h->deterministic = (int)value;
+    } else if (!strcmp(key, "spd_timeout_us")) {
+        // how long a workgroup of the one-launch dense solve waits for a hand-over before it abandons the launch (status bit 2, LM stop
+        // code 9: the trial is repeated with the launch-per-column form).  Tests set it to 1 us to force that path.
+        if (value < 1 || value > 60000000) return fail(PCS_ERR_ARG, "spd_timeout_us must be in [1, 60000000]");
+        h->spd_timeout_us = value;
     } else if (!strcmp(key, "tiles_per_wg")) {
         if (value < 0 || value > (1 << 20)) return fail(PCS_ERR_ARG, "tiles_per_wg out of range");
         h->tiles_per_wg = value;
@@ -1067,6 +1108,7 @@ static int build_point_orders(pcs_engine *h) {
             int32_t **dst = pass == 0 ? &h->d_order_ck : &h->d_order_ik;
             HIPCHK(hipMalloc(dst, sizeof(int32_t) * n));
             HIPCHK(hipMemcpy(*dst, order.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice));
+            if (pass == 0) h->h_order_ck = order;
         }
     }
     // the table in each visiting order: the shared pass of a scattered table, the (cam, key) pass, the (image, key) pass (which
@@ -1090,6 +1132,128 @@ static int build_point_orders(pcs_engine *h) {
     return PCS_OK;
 }
 
+// ---- deterministic mode: the static tables of the ordered second pass (csrc/ba_reduce.hpp) ---------------------------------------------
+// For MFMA pass `pass` (0 shared, 1 (cam, key)) walked with `tpw` tiles per wave: segments = maximal stretches of detections inside one
+// run and one wave; logical runs = the segments of one key pair (one stretch in a sorted table; several when a pair re-appears);
+// groups = up to RED_RUNS_PER_GROUP logical runs of one camera; per camera its groups, per entity (image / key) its runs in camera order.
+static int ensure_det_tables(pcs_engine *h, int pass, int64_t tpw) {
+    pcs_engine::DetPass &D = h->det[pass];
+    if (D.n == h->n && D.tpw == tpw && D.d_idx) return PCS_OK;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(wait_done_host(h));
+    if (D.d_idx) (void)hipFree(D.d_idx);
+    if (D.d_work) (void)hipFree(D.d_work);
+    D = pcs_engine::DetPass{};
+    const int64_t n = h->n;
+    const bool has_pose = h->chain != PCS_CHAIN_FREE;
+    const std::vector<int32_t> *order = nullptr;
+    if (pass == PASS_SHARED) { if (h->d_order) order = &h->h_order; }
+    else order = &h->h_order_ck;
+    if (order && (int64_t)order->size() != n) return fail(PCS_ERR_STATE, "deterministic mode: the host copy of a visiting order is missing");
+    auto key_of = [&](int64_t d, int32_t &ka, int32_t &kb) {
+        const int64_t i = order ? (*order)[d] : d;
+        ka = h->h_cam[i];
+        kb = pass == PASS_SHARED ? (has_pose ? h->h_img[i] : 0) : h->h_key[i];
+    };
+    const int64_t per_wave = tpw * TILE;
+    const int64_t n_waves = (n + per_wave - 1) / per_wave;
+    std::vector<int32_t> seg_base((size_t)n_waves), seg_ka, seg_kb;
+    {
+        int32_t pa = -1, pb = -1;
+        for (int64_t d = 0; d < n; ++d) {
+            int32_t ka, kb;
+            key_of(d, ka, kb);
+            const bool wave_start = d % per_wave == 0;
+            if (wave_start) seg_base[(size_t)(d / per_wave)] = (int32_t)seg_ka.size();
+            if (wave_start || ka != pa || kb != pb) {
+                if (seg_ka.size() >= (size_t)INT32_MAX - 1) return fail(PCS_ERR_ARG, "deterministic mode: too many segments");
+                seg_ka.push_back(ka);
+                seg_kb.push_back(kb);
+            }
+            pa = ka;
+            pb = kb;
+        }
+    }
+    const int64_t n_seg = (int64_t)seg_ka.size();
+    // logical runs: segments sorted by (ka, kb), table order inside one pair
+    std::vector<int32_t> lr_segs((size_t)n_seg);
+    for (int64_t i = 0; i < n_seg; ++i) lr_segs[(size_t)i] = (int32_t)i;
+    std::stable_sort(lr_segs.begin(), lr_segs.end(), [&](int32_t x, int32_t y) {
+        return seg_ka[x] != seg_ka[y] ? seg_ka[x] < seg_ka[y] : seg_kb[x] < seg_kb[y];
+    });
+    // the free chain's shared pass has one run per camera and owns camera-level entries only: a long run may be cut into pieces
+    const bool may_split = pass == PASS_SHARED && !has_pose;
+    std::vector<int32_t> lr_ptr, lr_ka, lr_kb;
+    for (int64_t i = 0; i < n_seg; ++i) {
+        const int32_t sgm = lr_segs[(size_t)i];
+        const bool fresh = i == 0 || seg_ka[sgm] != lr_ka.back() || seg_kb[sgm] != lr_kb.back() ||
+                           (may_split && i - lr_ptr.back() >= RED_SPLIT_SEGS);
+        if (fresh) {
+            lr_ptr.push_back((int32_t)i);
+            lr_ka.push_back(seg_ka[sgm]);
+            lr_kb.push_back(seg_kb[sgm]);
+        }
+    }
+    const int64_t n_lr = (int64_t)lr_ka.size();
+    lr_ptr.push_back((int32_t)n_seg);
+    std::vector<int32_t> grp_ptr, cam_ptr((size_t)h->n_cams + 1, 0);
+    for (int64_t r = 0; r < n_lr; ++r) {
+        const bool fresh = r == 0 || lr_ka[(size_t)r] != lr_ka[(size_t)r - 1] || r - grp_ptr.back() >= RED_RUNS_PER_GROUP;
+        if (fresh) {
+            grp_ptr.push_back((int32_t)r);
+            ++cam_ptr[(size_t)lr_ka[(size_t)r] + 1];
+        }
+    }
+    const int64_t n_grp = (int64_t)grp_ptr.size();
+    grp_ptr.push_back((int32_t)n_lr);
+    for (int64_t c = 0; c < h->n_cams; ++c) cam_ptr[(size_t)c + 1] += cam_ptr[(size_t)c];
+    const bool has_ent = pass == PASS_CAMKEY || has_pose;
+    const int64_t n_ent = !has_ent ? 0 : pass == PASS_SHARED ? h->n_imgs : h->n_keys;
+    std::vector<int32_t> ent_ptr((size_t)n_ent + 1, 0), ent_runs(has_ent ? (size_t)n_lr : 0);
+    if (has_ent) {
+        for (int64_t r = 0; r < n_lr; ++r) ++ent_ptr[(size_t)lr_kb[(size_t)r] + 1];
+        for (int64_t e = 0; e < n_ent; ++e) ent_ptr[(size_t)e + 1] += ent_ptr[(size_t)e];
+        std::vector<int32_t> fill(ent_ptr.begin(), ent_ptr.end() - 1);
+        for (int64_t r = 0; r < n_lr; ++r) ent_runs[(size_t)fill[(size_t)lr_kb[(size_t)r]]++] = (int32_t)r;   // runs are sorted by camera: camera order per entity
+    }
+    const std::vector<int32_t> *parts[9] = {&seg_base, &lr_ptr, &lr_segs, &lr_ka, &lr_kb, &grp_ptr, &cam_ptr, &ent_ptr, &ent_runs};
+    int64_t total = 0;
+    for (int i = 0; i < 9; ++i) {
+        D.off[i] = total;
+        total += ((int64_t)parts[i]->size() + 3) & ~(int64_t)3;
+    }
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipMalloc(&D.d_idx, sizeof(int32_t) * std::max<int64_t>(total, 4)));
+    for (int i = 0; i < 9; ++i)
+        if (!parts[i]->empty()) HIPCHK(hipMemcpy(D.d_idx + D.off[i], parts[i]->data(), sizeof(int32_t) * parts[i]->size(), hipMemcpyHostToDevice));
+    const int nm = (pass == PASS_SHARED && has_pose) ? 2 : 1;
+    D.work_off[0] = 0;
+    D.work_off[1] = n_seg * nm * 256;
+    D.work_off[2] = D.work_off[1] + n_lr * RED_Q;
+    HIPCHK(hipMalloc(&D.d_work, sizeof(double) * (size_t)(D.work_off[2] + n_grp * RED_G + 2)));
+    D.n = n; D.tpw = tpw;
+    D.n_seg = (int32_t)n_seg; D.n_lr = (int32_t)n_lr; D.n_grp = (int32_t)n_grp; D.n_ent = (int32_t)n_ent; D.n_waves = (int32_t)n_waves;
+    return PCS_OK;
+}
+
+template <int CHAIN, int PASS>
+static hipError_t launch_reduce_p(const NormalArgs &a, const ReduceArgs &ra, hipStream_t s) {
+    if (ra.n_grp > 0) hipLaunchKernelGGL((normal_reduce_runs_kernel<CHAIN, PASS>), dim3((unsigned)((ra.n_grp + 3) / 4)), dim3(256), 0, s, a, ra);
+    const int blocks = (PASS == PASS_SHARED ? ra.n_cams + 1 : 0) + (ra.n_ent + 2) / 3;
+    if (blocks > 0) hipLaunchKernelGGL((normal_reduce_final_kernel<CHAIN, PASS>), dim3((unsigned)blocks), dim3(256), 0, s, a, ra);
+    return hipGetLastError();
+}
+static hipError_t launch_reduce(int chain, int pass, const NormalArgs &a, const ReduceArgs &ra, hipStream_t s) {
+    if (pass == PASS_SHARED) {
+        switch (chain) {
+            case CHAIN_TEMPLATE: return launch_reduce_p<CHAIN_TEMPLATE, PASS_SHARED>(a, ra, s);
+            case CHAIN_SELF: return launch_reduce_p<CHAIN_SELF, PASS_SHARED>(a, ra, s);
+            default: return launch_reduce_p<CHAIN_FREE, PASS_SHARED>(a, ra, s);
+        }
+    }
+    return chain == CHAIN_SELF ? launch_reduce_p<CHAIN_SELF, PASS_CAMKEY>(a, ra, s) : launch_reduce_p<CHAIN_FREE, PASS_CAMKEY>(a, ra, s);
+}
+
 // The blocked layout of J^T J (NormalArgs, ba_normal.hpp): where the parameter string splits into leading part and trailing group.
 struct BlockLayout {
     int64_t n_lead, n_trail, n_ent, trail_off;
@@ -1109,7 +1273,10 @@ static BlockLayout block_layout(const pcs_engine *h) {
 
 // slab_prep + the normal-equations passes on `s`; d_prm holds the parameter string; outputs are zeroed here.
 // blocked: d_H points at the packed [A | B | C] (contiguous), see pcs_normal_blocks_device.
-static int enqueue_normal(pcs_engine *h, const double *d_prm, double *d_H, double *d_g, double *d_cost, hipStream_t s, bool blocked = false, const int32_t *d_stop = nullptr) {
+// d_sel (LM loop with two states, ba_schur.hpp SchurArgs::sel): when *d_sel != 0 the string is read alt_prm doubles and the outputs are written
+// alt_out doubles further on.
+static int enqueue_normal(pcs_engine *h, const double *d_prm, double *d_H, double *d_g, double *d_cost, hipStream_t s, bool blocked = false, const int32_t *d_stop = nullptr,
+                          const int32_t *d_sel = nullptr, int64_t alt_prm = 0, int64_t alt_out = 0) {
     if (h->n <= 0) return fail(PCS_ERR_STATE, "no detections set");
     if (h->n > INT32_MAX) return fail(PCS_ERR_ARG, "normal equations: tables beyond 2^31 rows are not supported (visiting orders are int32)");
     if (h->chain == PCS_CHAIN_TEMPLATE && !h->have_template) return fail(PCS_ERR_STATE, "template points not set");
@@ -1126,7 +1293,7 @@ static int enqueue_normal(pcs_engine *h, const double *d_prm, double *d_H, doubl
     HIPCHK(hipSetDevice(h->device));
     int rc0 = ensure_point_orders(h);
     if (rc0) return rc0;
-    if (d_stop && reinterpret_cast<uintptr_t>(d_H) % 16) return fail(PCS_ERR_ARG, "normal equations behind a stop flag need a 16-byte aligned buffer");
+    if ((d_stop || d_sel) && (reinterpret_cast<uintptr_t>(d_H) % 16 || alt_out % 2)) return fail(PCS_ERR_ARG, "normal equations behind a stop flag / state selector need 16-byte aligned buffers");
     if (reinterpret_cast<uintptr_t>(d_H) % 16 == 0) {   // slab_prep and the zeroing of the outputs in one launch
         HIPCHK(order_after_done(h, s));
         const int has_pose = h->chain != PCS_CHAIN_FREE, copy_points = h->chain != PCS_CHAIN_TEMPLATE;
@@ -1137,7 +1304,7 @@ static int enqueue_normal(pcs_engine *h, const double *d_prm, double *d_H, doubl
         const int zero_blocks = (int)std::min<int64_t>((n_h / 2 + 63) / 64 + 1, (int64_t)h->n_cu * 32);
         hipLaunchKernelGGL(normal_prologue_kernel, dim3((unsigned)(prep_blocks + zero_blocks)), dim3(64), 0, s, d_prm, (double *)h->d_cam_slab,
                            (double *)h->d_pose_slab, (double *)h->d_points, (int)h->n_cams, (int)h->n_imgs, (int)h->n_keys, h->extr_off,
-                           h->pose_off, h->point_off, has_pose, copy_points, prep_blocks, d_H, n_h, d_g, h->n_params, d_cost, d_stop);
+                           h->pose_off, h->point_off, has_pose, copy_points, prep_blocks, d_H, n_h, d_g, h->n_params, d_cost, d_stop, d_sel, alt_prm, alt_out);
         HIPCHK(hipGetLastError());
         h->linearized = true;
     } else {
@@ -1163,6 +1330,7 @@ static int enqueue_normal(pcs_engine *h, const double *d_prm, double *d_H, doubl
     a.n_params = h->n_params;
     a.debug = h->normal_debug;
     a.stop = d_stop;
+    a.sel = d_sel; a.alt = alt_out;
     // every wave walks a contiguous range of tiles, so its register accumulators survive across tiles.  One-wave
     // workgroups; the LDS image (22.9 KB for 22 columns x 64 rows) allows 7 per CU, and exactly one resident round of
     // waves is fastest (92 us against 105 us with two rounds on rig-32, profiles/r02/sweeps.md).
@@ -1197,7 +1365,13 @@ static int enqueue_normal(pcs_engine *h, const double *d_prm, double *d_H, doubl
             }
         }
         hipError_t e;
-        if (pass == PASS_IMGKEY && h->normal_imgkey_product) {
+        a.part = nullptr; a.seg_base = nullptr;
+        if (pass == PASS_IMGKEY && h->deterministic) {
+            // this pass keeps its atomics: a run is at most n_cams long, so with n_cams <= 64 no address gets more than two contributions
+            // (csrc/ba_reduce.hpp) — beyond that the order of three could show in the last bit
+            if (h->n_cams > 64) return fail(PCS_ERR_ARG, "deterministic mode: the (image, key) pass of the self chain supports at most 64 cameras (%lld)", (long long)h->n_cams);
+        }
+        if (pass == PASS_IMGKEY && (h->normal_imgkey_product || h->deterministic)) {
             // 7 KB of LDS and 167 VGPRs per wave: 12 resident per CU.  The kernel waits on dependent loads and on its
             // atomics, so short waves (one or two tiles each, 48 per CU) that keep every slot refilled are fastest
             // (59 / 56 / 55 / 59 us for 12 / 24 / 48 / 96 per CU at N = 1e6, profiles/r02/sweeps.md)
@@ -1208,7 +1382,25 @@ static int enqueue_normal(pcs_engine *h, const double *d_prm, double *d_H, doubl
             // the shared pass's image (22.9 KB) allows 7 waves per CU; the (cam, key) pass's (19.8 KB) allows 8 = two per SIMD,
             // 65.5 against 70.0 us on rig-32-self (profiles/r02/sweeps.md)
             const dim3 grid = geometry(h->wgs_per_cu > 0 ? h->wgs_per_cu : pass == PASS_CAMKEY ? 8 : 7, (h->wgs_per_cu > 0 || a.n_tiles < 1024) ? 1 : 2);
-            e = launch_normal(h->chain, pass, h->normal_rows, a, grid, s);
+            if (h->deterministic) {   // the kernel stores its finished accumulators per segment, an ordered second pass sums them (csrc/ba_reduce.hpp)
+                const int rc = ensure_det_tables(h, pass, a.tiles_per_wave);
+                if (rc) return rc;
+                const pcs_engine::DetPass &D = h->det[pass];
+                if ((int64_t)grid.x != D.n_waves) return fail(PCS_ERR_STATE, "deterministic mode: launch geometry and segment table disagree");
+                a.part = D.d_work + D.work_off[0];
+                a.seg_base = D.d_idx + D.off[0];
+                e = launch_normal(h->chain, pass, h->normal_rows, a, grid, s);
+                if (e == hipSuccess) {
+                    ReduceArgs ra{};
+                    ra.part = a.part; ra.Q = D.d_work + D.work_off[1]; ra.G = D.d_work + D.work_off[2];
+                    ra.lr_ptr = D.d_idx + D.off[1]; ra.lr_segs = D.d_idx + D.off[2]; ra.lr_ka = D.d_idx + D.off[3]; ra.lr_kb = D.d_idx + D.off[4];
+                    ra.grp_ptr = D.d_idx + D.off[5]; ra.cam_ptr = D.d_idx + D.off[6]; ra.ent_ptr = D.d_idx + D.off[7]; ra.ent_runs = D.d_idx + D.off[8];
+                    ra.n_lr = D.n_lr; ra.n_grp = D.n_grp; ra.n_cams = (int32_t)h->n_cams; ra.n_ent = D.n_ent;
+                    e = launch_reduce(h->chain, pass, a, ra, s);
+                }
+            } else {
+                e = launch_normal(h->chain, pass, h->normal_rows, a, grid, s);
+            }
         }
         if (e != hipSuccess) return fail(PCS_ERR_HIP, "normal-equations kernel launch failed: %s", hipGetErrorString(e));
     }
@@ -1661,9 +1853,10 @@ int pcs_normal_blocks_device(pcs_engine *h, const double *d_param_str, double *d
 
 static int enqueue_schur_prepare(pcs_engine *h, double *d_packed, const uint8_t *d_fixed, const double *d_lambda, double *d_linvt, double *d_u,
                                  double *d_V, double *d_S, double *d_rhs, double *d_dvec, double *d_gm, int32_t *d_status, hipStream_t s, const int32_t *d_stop,
-                                 double *d_fill = nullptr, int64_t fill_n = 0) {
+                                 double *d_fill = nullptr, int64_t fill_n = 0, const int32_t *d_sel = nullptr, int64_t alt = 0) {
     const BlockLayout L = block_layout(h);
     SchurArgs a{};
+    a.sel = d_sel; a.alt = alt;
     a.fill = reinterpret_cast<uint64_t *>(d_fill); a.fill_n = d_fill ? fill_n : 0;
     a.A = d_packed; a.B = d_packed + L.a_len(); a.C = a.B + L.b_len(); a.g = a.C + L.c_len();
     a.fixed = d_fixed; a.lambda = d_lambda;
@@ -1702,16 +1895,20 @@ int pcs_lm_decide(pcs_engine *h, const double *d_cost_old, const double *d_cost_
         return fail(PCS_ERR_ARG, "pcs_lm_decide: bad arguments");
     HIPCHK(hipSetDevice(h->device));
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
-    LmDecideArgs a{d_cost_old, d_cost_new, d_dvec, d_gm, d_delta, d_ps, d_fixed, d_status, d_lambda, d_stats, h->n_params, nullptr, nullptr, nullptr};
+    LmDecideArgs a{};
+    a.tail[0] = d_cost_old; a.tail[1] = d_cost_new; a.ps2[0] = a.ps2[1] = d_ps;
+    a.dvec = d_dvec; a.gm = d_gm; a.delta = d_delta; a.fixed = d_fixed; a.status = d_status; a.lambda = d_lambda; a.stats = d_stats; a.n_params = h->n_params;
     hipLaunchKernelGGL(lm_decide_kernel, dim3(1), dim3(1024), 0, s, a);
     HIPCHK(hipGetLastError());
     return PCS_OK;
 }
 
 static int enqueue_schur_finish(pcs_engine *h, const double *d_linvt, const double *d_u, const double *d_w, const double *d_xlead, const uint8_t *d_fixed,
-                                double *d_delta, const double *d_ps_in, double *d_ps_out, hipStream_t s, const int32_t *d_stop) {
+                                double *d_delta, const double *d_ps_in, double *d_ps_out, hipStream_t s, const int32_t *d_stop, const int32_t *d_sel = nullptr,
+                                double *d_vote = nullptr, int64_t vote_alt = 0, const int32_t *d_status = nullptr) {
     const BlockLayout L = block_layout(h);
     SchurBackArgs a{};
+    a.sel = d_sel; a.vote = d_vote; a.vote_alt = vote_alt; a.status = d_status;
     a.linvt = d_linvt; a.u = d_u; a.w = d_w; a.xl = d_xlead; a.fixed = d_fixed; a.delta = d_delta;
     a.ps_in = d_ps_in; a.ps_out = d_ps_out;
     a.n_lead = L.n_lead; a.n_ent = L.n_ent; a.trail_off = L.trail_off;
@@ -1739,38 +1936,83 @@ int64_t pcs_dense_spd_work_len(int64_t n) {   // launch-per-column form: inverse
 }
 
 static int device_cu_count(int device);
-static int enqueue_schur_syrk(int64_t n_lead, int64_t n_trail, const double *d_V, int64_t ldv, double *d_S, int64_t lds, const double *d_u, double *d_rhs,
-                              hipStream_t s, const int32_t *d_stop) {
+// launch geometry of S -= V V' (csrc/ba_schur.hpp): tile width, tiles of the lower triangle, K split.  `ordered` = the partial sums of a
+// split go through a workspace and are subtracted in order (deterministic mode) instead of meeting in atomics.
+struct SyrkGeometry { bool big; int64_t tw, tiles, ksplit, kchunk; };
+static SyrkGeometry syrk_geometry(int64_t n_lead, int64_t n_trail, bool ordered) {
     // 64 x 64 tiles once 32 x 32 ones alone would fill the chip twice over (their operand traffic, not the matrix cores, is the bound then:
     // rig-32-self 175 us -> ~100 us); PCS_SYRK_TILE=32 / 64 forces one form (A/B)
     static const int forced = getenv("PCS_SYRK_TILE") ? atoi(getenv("PCS_SYRK_TILE")) : 0;
     const int64_t nb32 = (n_lead + 31) / 32;
-    const bool big = forced == 64 || (forced != 32 && nb32 * (nb32 + 1) / 2 >= 1024);
-    const int64_t tw = big ? 64 : 32;
-    const int64_t nb = (n_lead + tw - 1) / tw, tiles = nb * (nb + 1) / 2;
+    SyrkGeometry g{};
+    g.big = forced == 64 || (forced != 32 && nb32 * (nb32 + 1) / 2 >= 1024);
+    g.tw = g.big ? 64 : 32;
+    const int64_t nb = (n_lead + g.tw - 1) / g.tw;
+    g.tiles = nb * (nb + 1) / 2;
     // split K until ~512 workgroups exist (rig-32: 120 tiles x 5; the 2e4-point free chain: 21 tiles x 25 of 60 000 columns)
-    int64_t ksplit = std::min<int64_t>((512 + tiles - 1) / tiles, (n_trail + 127) / 128);
+    int64_t ksplit = std::min<int64_t>((512 + g.tiles - 1) / g.tiles, (n_trail + 127) / 128);
     ksplit = std::max<int64_t>(1, ksplit);
     int64_t kchunk = ((n_trail + ksplit - 1) / ksplit + 63) / 64 * 64;
     ksplit = (n_trail + kchunk - 1) / kchunk;
-    if (big) {
+    if (g.big) {
         // 64 x 64 tiles run two workgroups per CU: split K so that the workgroups fill whole rounds of the resident ones — the cost of a
-        // split = rounds x (columns per workgroup + ~64 columns' worth of ramp and atomics); rig-32-self: 378 tiles x 4 = 2.95 rounds
+        // split = rounds x (columns per workgroup + ~64 columns' worth of ramp and atomics); rig-32-self: 378 tiles x 4 = 2.95 rounds.
+        // Ordered mode: every split also writes and re-reads a 32 KB partial tile (rig-32-self: 50 MB per solve for four splits) —
+        // priced as 192 more columns per split, which leaves large systems unsplit (378 tiles x 1: 1.5 rounds' worth, ~15 % slower).
         int dev = 0;
         const int cus = hipGetDevice(&dev) == hipSuccess && device_cu_count(dev) > 0 ? device_cu_count(dev) : 256;
         const int64_t slots = 2 * (int64_t)cus;
         int64_t best = INT64_MAX;
         for (int64_t ks = 1; ks <= std::max<int64_t>(1, n_trail / 128); ++ks) {
             const int64_t kc = ((n_trail + ks - 1) / ks + 63) / 64 * 64, real = (n_trail + kc - 1) / kc;
-            const int64_t cost = (tiles * real + slots - 1) / slots * (kc + 64);
+            const int64_t cost = (g.tiles * real + slots - 1) / slots * (kc + 64 + ((ordered && real > 1) ? 192 : 0));
             if (cost < best) { best = cost; ksplit = real; kchunk = kc; }
         }
     }
-    SchurSyrkArgs a{d_V, d_S, d_u, d_rhs, (int32_t)n_lead, (int32_t)n_trail, (int32_t)ldv, (int32_t)lds, (int32_t)ksplit, (int32_t)kchunk, d_stop};
-    if (big) hipLaunchKernelGGL(schur_syrk64_kernel, dim3((unsigned)(tiles * ksplit)), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(schur_syrk_kernel, dim3((unsigned)(tiles * ksplit)), dim3(256), 0, s, a);
+    g.ksplit = ksplit; g.kchunk = kchunk;
+    return g;
+}
+// doubles of the ordered mode's workspace (0: the product is not split, nothing is needed)
+static int64_t syrk_work_doubles(int64_t n_lead, int64_t n_trail) {
+    const SyrkGeometry g = syrk_geometry(n_lead, n_trail, true);
+    return g.ksplit > 1 ? g.ksplit * (g.tiles * g.tw * g.tw + n_lead) : 0;
+}
+
+static int enqueue_schur_syrk(int64_t n_lead, int64_t n_trail, const double *d_V, int64_t ldv, double *d_S, int64_t lds, const double *d_u, double *d_rhs,
+                              hipStream_t s, const int32_t *d_stop, double *d_ws = nullptr, int64_t ws_doubles = 0) {
+    const bool ordered = d_ws != nullptr;
+    const SyrkGeometry g = syrk_geometry(n_lead, n_trail, ordered);
+    if (ordered && g.ksplit > 1 && ws_doubles < g.ksplit * (g.tiles * g.tw * g.tw + n_lead))
+        return fail(PCS_ERR_ARG, "pcs_schur_syrk: the ordered mode needs a workspace of %lld doubles (pcs_schur_syrk_work_len), got %lld",
+                    (long long)(g.ksplit * (g.tiles * g.tw * g.tw + n_lead)), (long long)ws_doubles);
+    SchurSyrkArgs a{d_V, d_S, d_u, d_rhs, (int32_t)n_lead, (int32_t)n_trail, (int32_t)ldv, (int32_t)lds, (int32_t)g.ksplit, (int32_t)g.kchunk, d_stop};
+    a.ws = (ordered && g.ksplit > 1) ? d_ws : nullptr;
+    a.ws_rhs = a.ws ? d_ws + g.ksplit * g.tiles * g.tw * g.tw : nullptr;
+    a.tiles = (int32_t)g.tiles;
+    if (g.big) hipLaunchKernelGGL(schur_syrk64_kernel, dim3((unsigned)(g.tiles * g.ksplit)), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(schur_syrk_kernel, dim3((unsigned)(g.tiles * g.ksplit)), dim3(256), 0, s, a);
     HIPCHK(hipGetLastError());
+    if (a.ws) {
+        if (g.big) hipLaunchKernelGGL(schur_syrk_reduce_kernel<64>, dim3((unsigned)g.tiles), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(schur_syrk_reduce_kernel<32>, dim3((unsigned)g.tiles), dim3(256), 0, s, a);
+        HIPCHK(hipGetLastError());
+    }
     return PCS_OK;
+}
+
+int64_t pcs_schur_syrk_work_len(int64_t n_lead, int64_t n_trail) {
+    if (n_lead <= 0 || n_trail < 0) return -1;
+    return syrk_work_doubles(n_lead, n_trail);
+}
+
+int pcs_schur_syrk_ordered(int device, int64_t n_lead, int64_t n_trail, const double *d_V, int64_t ldv, double *d_S, int64_t lds, const double *d_u,
+                           double *d_rhs, double *d_work, int64_t work_doubles, void *stream) {
+    if (n_lead <= 0 || n_lead > (1 << 15) || n_trail < 0 || n_trail > (1ll << 30) || ldv < n_trail || lds < n_lead || !d_S || (n_trail && !d_V) || (d_u && !d_rhs) || !d_work)
+        return fail(PCS_ERR_ARG, "pcs_schur_syrk_ordered: bad arguments");
+    if (device < 0 || device >= pcs_device_count()) return fail(PCS_ERR_NODEVICE, "pcs_schur_syrk_ordered: device %d not available", device);
+    if (n_trail == 0) return PCS_OK;
+    HIPCHK(hipSetDevice(device));
+    return enqueue_schur_syrk(n_lead, n_trail, d_V, ldv, d_S, lds, d_u, d_rhs, (hipStream_t)stream, nullptr, d_work, work_doubles);
 }
 
 int pcs_schur_syrk(int device, int64_t n_lead, int64_t n_trail, const double *d_V, int64_t ldv, double *d_S, int64_t lds, const double *d_u,
@@ -1809,7 +2051,7 @@ int pcs_dense_spd_solve(int device, int64_t n, double *d_S, int64_t ld, const do
 }
 
 static int enqueue_dense_spd(int device, int64_t n, double *d_S, int64_t ld, const double *d_rhs, double *d_x, double *d_work, int32_t *d_status, void *stream,
-                             int algorithm, const int32_t *d_stop, bool prefilled = false);
+                             int algorithm, const int32_t *d_stop, bool prefilled = false, int64_t timeout_us = 250000);
 
 // does a solve of size n with this algorithm request take the ONE persistent launch (csrc/ba_chol_persist.hpp)?  Wherever its tiles fit
 // the chip's LDS: n <= 1 984 on 256 CUs
@@ -1823,8 +2065,14 @@ int pcs_dense_spd_solve_algo(int device, int64_t n, double *d_S, int64_t ld, con
     return enqueue_dense_spd(device, n, d_S, ld, d_rhs, d_x, d_work, d_status, stream, algorithm, nullptr);
 }
 
+int pcs_dense_spd_solve_opts(int device, int64_t n, double *d_S, int64_t ld, const double *d_rhs, double *d_x, double *d_work, int32_t *d_status, void *stream,
+                             int algorithm, int64_t timeout_us) {
+    if (timeout_us < 1 || timeout_us > 60000000) return fail(PCS_ERR_ARG, "pcs_dense_spd_solve_opts: timeout_us must be in [1, 60000000]");
+    return enqueue_dense_spd(device, n, d_S, ld, d_rhs, d_x, d_work, d_status, stream, algorithm, nullptr, false, timeout_us);
+}
+
 static int enqueue_dense_spd(int device, int64_t n, double *d_S, int64_t ld, const double *d_rhs, double *d_x, double *d_work, int32_t *d_status, void *stream,
-                             int algorithm, const int32_t *d_stop, bool prefilled) {
+                             int algorithm, const int32_t *d_stop, bool prefilled, int64_t timeout_us) {
     constexpr int NB = 32;
     if (n <= 0 || n > (1 << 15) || ld < n || !d_S || !d_rhs || !d_x || !d_work || !d_status) return fail(PCS_ERR_ARG, "pcs_dense_spd_solve: bad arguments");
     if (algorithm != PCS_SPD_AUTO && algorithm != PCS_SPD_LAUNCHES && algorithm != PCS_SPD_ONE_LAUNCH) return fail(PCS_ERR_ARG, "pcs_dense_spd_solve: unknown algorithm %d", algorithm);
@@ -1833,7 +2081,7 @@ static int enqueue_dense_spd(int device, int64_t n, double *d_S, int64_t ld, con
     if (algorithm == PCS_SPD_ONE_LAUNCH && !cp_fits(n, device_cu_count(device)))
         return fail(PCS_ERR_ARG, "pcs_dense_spd_solve: n = %lld does not fit the one-launch form on %d compute units", (long long)n, device_cu_count(device));
     if (dense_spd_is_one_launch(device, n, algorithm)) {
-        HIPCHK(cp_launch(n, d_S, ld, d_rhs, d_x, d_work, d_status, device_cu_count(device), (hipStream_t)stream, 0.25, nullptr, d_stop, prefilled));
+        HIPCHK(cp_launch(n, d_S, ld, d_rhs, d_x, d_work, d_status, device_cu_count(device), (hipStream_t)stream, 1.0e-6 * (double)timeout_us, nullptr, d_stop, prefilled));
         return PCS_OK;
     }
     hipStream_t s = (hipStream_t)stream;   // NULL = the default stream
@@ -1875,32 +2123,43 @@ static int enqueue_dense_spd(int device, int64_t n, double *d_S, int64_t ld, con
     return PCS_OK;
 }
 
-// One whole Levenberg-Marquardt trial, queued in one call: damped Schur step from packed_cur at *lambda (+ the trial parameter
-// string), normal equations at the trial string into packed_new, the decision INCLUDING the loop's termination rules, the copy of an
-// accepted trial over the current state, and the read-back of the ten numbers the host follows the loop with.  Every kernel starts
-// with PCS_STOP_GUARD on b->stop_flag, so the host may queue trial t + 1 before it has read the verdict of trial t.
-int pcs_lm_trial(pcs_engine *h, const pcs_lm_buffers *b, void *stream) {
-    if (!h || !b || !b->packed_cur || !b->packed_new || !b->fixed || !b->lambda || !b->linvt || !b->u || !b->V || !b->S || !b->rhs || !b->dvec || !b->gm ||
-        !b->status || !b->xlead || !b->w || !b->spd_work || !b->delta || !b->ps_cur || !b->ps_new || !b->ctrl || !b->stop_flag || !b->accept_flag || !b->stats)
-        return fail(PCS_ERR_ARG, "pcs_lm_trial: bad arguments");
-    if (reinterpret_cast<uintptr_t>(b->packed_cur) % 16 || reinterpret_cast<uintptr_t>(b->packed_new) % 16) return fail(PCS_ERR_ARG, "pcs_lm_trial: the packed buffers must be 16-byte aligned");
+// One whole Levenberg-Marquardt trial in two halves (round 5; pcs_lm_trial = both): BUILD = the damped Schur step from the current state at
+// *lambda (+ the trial parameter string) and the normal equations at the trial string into the other state's packed buffer; FINISH = the
+// decision INCLUDING the loop's termination rules, the state flip of an accepted trial and the read-back of the twelve numbers the host
+// follows the loop with.  A sharded loop puts its all-reduce of the trial state between the two, on the same stream.  Every kernel starts
+// with PCS_STOP_GUARD on flags[0], so the host may queue trial t + 1 before it has read the verdict of trial t.
+static int lm_check(pcs_engine *h, const pcs_lm_buffers *b, const char *who) {
+    if (!h || !b || !b->packed[0] || !b->packed[1] || !b->ps[0] || !b->ps[1] || !b->flags || !b->fixed || !b->lambda || !b->linvt || !b->u || !b->V || !b->S || !b->rhs ||
+        !b->dvec || !b->gm || !b->status || !b->xlead || !b->w || !b->spd_work || !b->delta || !b->ctrl || !b->stats)
+        return fail(PCS_ERR_ARG, "%s: bad arguments", who);
+    if (reinterpret_cast<uintptr_t>(b->packed[0]) % 16 || reinterpret_cast<uintptr_t>(b->packed[1]) % 16) return fail(PCS_ERR_ARG, "%s: the packed buffers must be 16-byte aligned", who);
+    if (b->mode & ~(PCS_LM_FIXED_TRIAL_BUFFER | PCS_LM_VOTES)) return fail(PCS_ERR_ARG, "%s: unknown mode bits", who);
+    return PCS_OK;
+}
+
+int pcs_lm_trial_build(pcs_engine *h, const pcs_lm_buffers *b, void *stream) {
+    int rc = lm_check(h, b, "pcs_lm_trial_build");
+    if (rc) return rc;
     HIPCHK(hipSetDevice(h->device));
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
     const BlockLayout L = block_layout(h);
-    const int32_t *stop = b->stop_flag;
+    const int32_t *stop = b->flags, *sel = b->flags + 2;
+    const int64_t alt_pk = b->packed[1] - b->packed[0], alt_ps = b->ps[1] - b->ps[0];   // doubles from state 0 to state 1
     // the one-launch Cholesky wants its hand-over workspace at the fill value: schur_trail_lead_kernel sets it on the way (one launch fewer)
     const bool prefill = L.n_lead > 0 && dense_spd_is_one_launch(h->device, L.n_lead, b->spd_algorithm);
-    int rc = enqueue_schur_prepare(h, b->packed_cur, b->fixed, b->lambda, b->linvt, b->u, b->V, b->S, b->rhs, b->dvec, b->gm, b->status, s, stop,
-                                   prefill ? b->spd_work : nullptr, prefill ? cp_work_doubles((L.n_lead + 31) / 32) : 0);
+    rc = enqueue_schur_prepare(h, b->packed[0], b->fixed, b->lambda, b->linvt, b->u, b->V, b->S, b->rhs, b->dvec, b->gm, b->status, s, stop,
+                               prefill ? b->spd_work : nullptr, prefill ? cp_work_doubles((L.n_lead + 31) / 32) : 0, sel, alt_pk);
     if (rc) return rc;
     const int64_t ldv = std::max<int64_t>(1, L.n_trail);
     if (L.n_trail > 0 && L.n_lead > 0) {
-        rc = enqueue_schur_syrk(L.n_lead, L.n_trail, b->V, ldv, b->S, L.n_lead, b->u, b->rhs, s, stop);
+        if (h->deterministic && !b->syrk_work && syrk_work_doubles(L.n_lead, L.n_trail) > 0)
+            return fail(PCS_ERR_ARG, "pcs_lm_trial_build: deterministic mode needs pcs_lm_buffers.syrk_work (pcs_schur_syrk_work_len doubles)");
+        rc = enqueue_schur_syrk(L.n_lead, L.n_trail, b->V, ldv, b->S, L.n_lead, b->u, b->rhs, s, stop, h->deterministic ? b->syrk_work : nullptr, b->syrk_work_len);
         if (rc) return rc;
     }
     const double *w = b->u;
     if (L.n_lead > 0) {
-        rc = enqueue_dense_spd(h->device, L.n_lead, b->S, L.n_lead, b->rhs, b->xlead, b->spd_work, b->status, s, b->spd_algorithm, stop, prefill);
+        rc = enqueue_dense_spd(h->device, L.n_lead, b->S, L.n_lead, b->rhs, b->xlead, b->spd_work, b->status, s, b->spd_algorithm, stop, prefill, h->spd_timeout_us);
         if (rc) return rc;
         if (L.n_trail > 0) {
             launch_schur_vtx(b->V, b->xlead, b->w, (int)L.n_lead, (int)L.n_trail, (int)ldv, stop, s);
@@ -1908,38 +2167,70 @@ int pcs_lm_trial(pcs_engine *h, const pcs_lm_buffers *b, void *stream) {
             w = b->w;
         }
     }
-    rc = enqueue_schur_finish(h, b->linvt, b->u, w, b->xlead, b->fixed, b->delta, b->ps_cur, b->ps_new, s, stop);
-    if (rc) return rc;
     const int64_t n_packed = L.a_len() + L.b_len() + L.c_len() + h->n_params + 1;
-    double *g_new = b->packed_new + L.a_len() + L.b_len() + L.c_len();
-    rc = enqueue_normal(h, b->ps_new, b->packed_new, g_new, g_new + h->n_params, s, true, stop);
+    // the step, the trial string (ps[1] while state 0 is current) and this rank's vote behind the TRIAL state's packed buffer
+    rc = enqueue_schur_finish(h, b->linvt, b->u, w, b->xlead, b->fixed, b->delta, b->ps[0], b->ps[1], s, stop, sel,
+                              (b->mode & PCS_LM_VOTES) ? b->packed[1] + n_packed : nullptr, -alt_pk, b->status);
     if (rc) return rc;
-    LmDecideArgs a{b->packed_cur + n_packed - 1, b->packed_new + n_packed - 1, b->dvec, b->gm, b->delta, b->ps_cur, b->fixed, b->status, b->lambda, b->stats,
-                   h->n_params, b->ctrl, b->stop_flag, b->accept_flag};
+    if (h->n == 0) {
+        // a rank whose observation shard is empty (ceil(N / world) rows per rank can leave the last ranks without any) contributes zeros
+        // to the all-reduce of the trial state; the vote word behind it stays
+        if (!(b->mode & PCS_LM_FIXED_TRIAL_BUFFER)) return fail(PCS_ERR_STATE, "no detections set");
+        HIPCHK(hipMemsetAsync(b->packed[1], 0, sizeof(double) * (size_t)n_packed, s));
+        return PCS_OK;
+    }
+    double *g_new = b->packed[1] + L.a_len() + L.b_len() + L.c_len();
+    return enqueue_normal(h, b->ps[1], b->packed[1], g_new, g_new + h->n_params, s, true, stop, sel, -alt_ps, -alt_pk);
+}
+
+int pcs_lm_trial_finish(pcs_engine *h, const pcs_lm_buffers *b, void *stream) {
+    int rc = lm_check(h, b, "pcs_lm_trial_finish");
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    const BlockLayout L = block_layout(h);
+    const int64_t n_packed = L.a_len() + L.b_len() + L.c_len() + h->n_params + 1;
+    const bool fixed_buffer = (b->mode & PCS_LM_FIXED_TRIAL_BUFFER) != 0;
+    LmDecideArgs a{};
+    a.tail[0] = b->packed[0] + n_packed - 1; a.tail[1] = b->packed[1] + n_packed - 1;
+    a.ps2[0] = b->ps[0]; a.ps2[1] = b->ps[1];
+    a.sel = b->flags + 2;
+    a.dvec = b->dvec; a.gm = b->gm; a.delta = b->delta; a.fixed = b->fixed; a.status = b->status; a.lambda = b->lambda; a.stats = b->stats;
+    a.n_params = h->n_params;
+    a.ctrl = b->ctrl; a.stop_flag = b->flags; a.accept_flag = b->flags + 1;
+    a.use_votes = (b->mode & PCS_LM_VOTES) ? 1 : 0;
+    a.keep_sel = fixed_buffer ? 1 : 0;
     if (b->result_host && b->free_idx && b->n_free > 0) {   // the final state straight into the host's mapped buffer when this trial ends the loop
         double *result_mapped = nullptr;
         if (hipHostGetDevicePointer(reinterpret_cast<void **>(&result_mapped), b->result_host, 0) == hipSuccess && result_mapped) {
-            a.g_cur = b->packed_cur + n_packed - 1 - h->n_params; a.g_new = g_new; a.ps_new = b->ps_new;
             a.free_idx = b->free_idx; a.n_free = b->n_free; a.result = result_mapped;
         } else {
             (void)hipGetLastError();
         }
     }
-    hipLaunchKernelGGL(lm_decide_kernel, dim3(1), dim3(1024), 0, s, a);
-    HIPCHK(hipGetLastError());
-    const int copy_blocks = (int)std::min<int64_t>((n_packed / 2 + 255) / 256 + 1, (int64_t)h->n_cu * 8);
-    // the read-back: lm_accept_kernel writes the ten numbers straight into the page-locked buffer when the device can address it (no
+    // the read-back: lm_decide_kernel writes the twelve numbers straight into the page-locked buffer when the device can address it (no
     // copy launch); a buffer that is not mapped gets an asynchronous copy
     double *stats_mapped = nullptr;
     if (b->stats_host && hipHostGetDevicePointer(reinterpret_cast<void **>(&stats_mapped), b->stats_host, 0) != hipSuccess) {
         (void)hipGetLastError();
         stats_mapped = nullptr;
     }
-    hipLaunchKernelGGL(lm_accept_kernel, dim3((unsigned)copy_blocks), dim3(256), 0, s, (const int32_t *)b->accept_flag, (const double *)b->packed_new, b->packed_cur, n_packed,
-                       (const double *)b->ps_new, b->ps_cur, h->n_params, (const double *)b->stats, stats_mapped);
+    a.stats_host = stats_mapped;
+    hipLaunchKernelGGL(lm_decide_kernel, dim3(1), dim3(1024), 0, s, a);
     HIPCHK(hipGetLastError());
-    if (b->stats_host && !stats_mapped) HIPCHK(hipMemcpyAsync(b->stats_host, b->stats, sizeof(double) * 10, hipMemcpyDeviceToHost, s));
+    if (b->stats_host && !stats_mapped) HIPCHK(hipMemcpyAsync(b->stats_host, b->stats, sizeof(double) * LM_STATS, hipMemcpyDeviceToHost, s));
+    if (fixed_buffer) {   // sharded loop: the trial state sits in the buffer the all-reduce was queued on — an accepted one is copied over the current state
+        const int copy_blocks = (int)std::min<int64_t>((n_packed / 2 + 255) / 256 + 1, (int64_t)h->n_cu * 8);
+        hipLaunchKernelGGL(lm_accept_kernel, dim3((unsigned)copy_blocks), dim3(256), 0, s, (const int32_t *)(b->flags + 1), (const double *)b->packed[1], b->packed[0], n_packed,
+                           (const double *)b->ps[1], b->ps[0], h->n_params);
+        HIPCHK(hipGetLastError());
+    }
     return PCS_OK;
+}
+
+int pcs_lm_trial(pcs_engine *h, const pcs_lm_buffers *b, void *stream) {
+    const int rc = pcs_lm_trial_build(h, b, stream);
+    return rc ? rc : pcs_lm_trial_finish(h, b, stream);
 }
 
 int pcs_normal_equations(pcs_engine *h, const double *param_str, double *H, double *g, double *cost) {

@@ -15,10 +15,12 @@ Two ways to get the LM step from the GPU: ``"pcg"`` — Jacobi-preconditioned CG
 J^T (J v) products (~150 passes over the detections per step, parameter-sized traffic only); and
 ``"cholesky"`` — one pass of csrc/ba_normal.hpp builds J^T J, J^T r and the cost in BLOCKED form
 ([A | B | C]: leading x leading, leading x trailing, block-diagonal trailing group) and the damped system is
-reduced by the Schur complement of the trailing group (csrc/ba_schur.hpp + one library GEMM + a dense Cholesky
-of the leading size).  That loop is device-resident (round 3): parameter string, step, damping, gain ratio and
-the accept / reject decision live in HBM, and the host reads ONE small vector per trial step to steer the loop.
-The sharded form all-reduces the packed [A | B | C | g | cost].
+reduced by the Schur complement of the trailing group (csrc/ba_schur.hpp: the block parts and both products on the FP64
+matrix cores; csrc/ba_chol_persist.hpp: the dense Cholesky of the leading size in one persistent launch) — HIP kernels only; the
+vendor-library variants kept for A/B until round 4 live in tools/library_solver.py.  That loop is device-resident: parameter
+string, step, damping, gain ratio, the accept / reject decision AND the termination rules live in HBM, the host reads ONE small
+vector per trial to follow it.  The sharded form all-reduces the packed [A | B | C | g | cost | votes] once per trial — on the
+solver's stream between the two halves of a trial when the collective is RCCL (no host synchronisation), through the host for gloo.
 
 ``as_linear_operator()`` exposes J as a scipy LinearOperator (matvec / rmatvec) for callers that
 want scipy's own solvers without materialising J.
@@ -120,6 +122,7 @@ def pcg(apply_a, b, m_inv, tol: float, max_iter: int):
     return x, it
 
 
+LAM_GROW0 = 1e3             # factor a rejected trial applies to lambda before the first accepted step (lm_solve)
 LEAD_LIMIT = 16384          # leading parameters up to which lm_solve(linear_solver="auto") takes the Schur / Cholesky step (S: 2 GB)
 BLOCKED_BYTES_LIMIT = 16e9  # and total bytes of the two packed buffers + V
 
@@ -140,82 +143,19 @@ def blocked_fits(engine) -> bool:
     return n_lead <= LEAD_LIMIT and 8.0 * (2 * lay["packed_len"] + n_lead * n_trail + n_lead ** 2) <= BLOCKED_BYTES_LIMIT
 
 
-class NormalEquations:
-    """H = J^T J, g = J^T r and sum r^2 restricted to the free parameters, built by one pass of the
-    block-reduced kernel (csrc/ba_normal.hpp) and kept on the GPU as torch tensors.
-
-    ``reduce_fn`` (optional, sharded detections) sums a float64 vector across ranks; it receives the packed
-    [H_ff, g_f, cost] — the "all-reduce of the small result instead of an all-gather of J" of SURVEY 8 f2.
-    A callable with attribute ``on_device = True`` is handed the CUDA tensor itself (RCCL), otherwise a
-    NumPy copy."""
+class BlockedNormalEquations:
+    """J^T J in blocked form + the Schur-complement step, all on the device (engine.normal_blocks_device,
+    engine.schur_prepare / schur_finish; include/pcs_hip.h).  Two packed states (current, trial): in the device-steered loop a
+    device word says which is which and an accepted trial flips it (include/pcs_hip.h pcs_lm_buffers)."""
 
     def __init__(self, engine, unfixed=None, reduce_fn=None):
         import torch
 
-        self.torch = torch
-        self.eng = engine
-        mask = np.ones(engine.n_params, dtype=bool) if unfixed is None else np.asarray(unfixed, dtype=bool)
-        if mask.shape[0] != engine.n_params:
-            raise ValueError("mask must have one entry per parameter")
-        self.free = np.flatnonzero(mask)
-        self.n_free = self.free.shape[0]
-        self.reduce_fn = reduce_fn
-        dev = torch.device("cuda", engine.device)
-        n = engine.n_params
-        self._H = torch.empty((n, n), dtype=torch.float64, device=dev)
-        self._g = torch.empty(n, dtype=torch.float64, device=dev)
-        self._c = torch.empty(1, dtype=torch.float64, device=dev)
-        self._idx = torch.from_numpy(self.free).to(dev)
-        self._all_free = self.n_free == n
-        self.schur = trailing_block_structure(engine.chain, engine.n_cams, engine.n_imgs, engine.n_keys, mask)
-        self._perm = self._inv_perm = None
-
-    def build(self, param_str):
-        """-> (H_ff (n_free, n_free) symmetric CUDA tensor, g_f CUDA tensor, sum r^2 float)."""
-        torch = self.torch
-        with torch.cuda.device(self._H.device):
-            stream = torch.cuda.current_stream().cuda_stream
-            if self.eng.n == 0:   # empty shard: zeros, but the all-reduce below still happens (see JacobianOperator)
-                self._H.zero_(); self._g.zero_(); self._c.zero_()
-            else:
-                self.eng.normal_equations_device(param_str, self._H.data_ptr(), self._g.data_ptr(), self._c.data_ptr(), stream)
-            U = self._H if self._all_free else self._H[self._idx][:, self._idx]
-            g = self._g if self._all_free else self._g[self._idx]
-            U, g, c = reduce_normal_equations(U, g, self._c, self.reduce_fn)
-            Hs = torch.triu(U) + torch.triu(U, 1).T   # the kernel writes the upper triangle only
-            return Hs, g.clone(), float(c.item())
-
-    def solve(self, Hs, g, lam, d):
-        """delta of (H + lam diag(d)) delta = -g; None if the damped matrix is not positive definite."""
-        if self.schur is None:
-            return cholesky_step(Hs, g, lam, d)
-        n_lead, block, perm = self.schur
-        if perm is None:
-            return schur_cholesky_step(Hs, g, lam, d, n_lead, block)
-        if self._perm is None:
-            self._perm = self.torch.from_numpy(perm).to(Hs.device)
-            self._inv_perm = self.torch.argsort(self._perm)
-        p = self._perm
-        delta = schur_cholesky_step(Hs[p][:, p], g[p], lam, d[p], n_lead, block)
-        return None if delta is None else delta[self._inv_perm]
-
-
-class BlockedNormalEquations:
-    """J^T J in blocked form + the Schur-complement step, all on the device (engine.normal_blocks_device,
-    engine.schur_prepare / schur_finish; include/pcs_hip.h).  Two packed buffers (current state, trial state) so that an
-    accepted trial becomes the current state by swapping indices."""
-
-    def __init__(self, engine, unfixed=None, reduce_fn=None, dense_solver: str = "hip"):
-        """``dense_solver``: 'hip' = the blocked Cholesky + substitution kernels of csrc/ba_dense_chol.hpp for the reduced system,
-        'rocsolver' = torch.linalg.cholesky_ex + cholesky_solve (kept for A/B: 1.6 ms against 0.3 ms at n = 480)."""
-        import torch
-
-        if dense_solver not in ("hip", "rocsolver"):
-            raise ValueError("dense_solver must be 'hip' or 'rocsolver'")
-        self.torch, self.eng, self.reduce_fn, self.dense_solver = torch, engine, reduce_fn, dense_solver
+        self.torch, self.eng, self.reduce_fn = torch, engine, reduce_fn
         lay = engine.normal_layout()
         self.n_lead, self.n_trail, self.tb, self.n_params = lay["n_lead"], lay["n_trail"], lay["tb"], lay["n_params"]
         self.n_ent = self.n_trail // self.tb
+        self.n_packed = lay["packed_len"]            # [A | B | C | g | cost]; one more word behind it: the ranks' void votes
         mask = np.ones(self.n_params, dtype=bool) if unfixed is None else np.asarray(unfixed, dtype=bool)
         if mask.shape[0] != self.n_params:
             raise ValueError("mask must have one entry per parameter")
@@ -223,7 +163,8 @@ class BlockedNormalEquations:
         self.n_free = self.free.shape[0]
         dev = self.dev = torch.device("cuda", engine.device)
         f64 = dict(dtype=torch.float64, device=dev)
-        self.packed = [torch.empty(lay["packed_len"], **f64) for _ in range(2)]
+        n_alloc = self.n_packed + 1 + ((self.n_packed + 1) & 1)     # an even number of doubles: both states 16-byte aligned in any allocator
+        self.packed = [torch.zeros(n_alloc, **f64)[: self.n_packed + 1] for _ in range(2)]
         self.fixed = torch.from_numpy((~mask).astype(np.uint8)).to(dev)
         self.free_idx = torch.from_numpy(self.free).to(dev)
         self.linvt = torch.empty(max(1, self.n_ent * self.tb * self.tb), **f64)
@@ -241,19 +182,24 @@ class BlockedNormalEquations:
         self.xl = torch.empty(self.n_lead, **f64)
         self.w = torch.empty(max(1, self.n_trail), **f64)
         self.chol_work = torch.empty(dense_spd_work_len(self.n_lead), **f64)
-        self._cons = None   # sharded loop only: the ranks' consensus step (n_params + 1)
+        from .engine import schur_syrk_work_len
+
+        # the ordered S -= V V' of the engine's deterministic mode parks the partial products of its K split here (0: not split)
+        self.syrk_work_len = schur_syrk_work_len(self.n_lead, self.n_trail) if self.n_trail else 0
+        self.syrk_work = torch.empty(max(1, self.syrk_work_len), **f64)
+        self._cons = None   # sharded host-steered loop only: the ranks' consensus step (n_params + 2)
         self.spd_algorithm = "auto"   # 'launches' after a one-launch solve ran out of time (another process held the compute units)
 
     def cost(self, slot):
-        return self.packed[slot][-1]
+        return self.packed[slot][self.n_packed - 1]
 
     @contextlib.contextmanager
     def on_stream(self):
-        """The solver mixes torch operations (GEMM, GEMV) with kernels launched through the C ABI; both must land on ONE
-        stream handle.  torch's default stream is the NULL handle, which the C ABI can only name as ``hipStreamLegacy`` — two
-        spellings the runtime is not guaranteed to order against each other in both directions.  So whenever the caller is on
-        the default stream the work moves to a stream of this object (ordered after what the caller queued, and the caller's
-        later work after ours); a caller that already runs on a real stream keeps it."""
+        """Kernels launched through the C ABI and the few torch operations around them (copies, the collective of a sharded loop)
+        must land on ONE stream handle.  torch's default stream is the NULL handle, which the C ABI can only name as
+        ``hipStreamLegacy`` — two spellings the runtime is not guaranteed to order against each other in both directions.  So
+        whenever the caller is on the default stream the work moves to a stream of this object (ordered after what the caller
+        queued, and the caller's later work after ours); a caller that already runs on a real stream keeps it."""
         torch = self.torch
         cur = torch.cuda.current_stream(self.dev)
         if cur.cuda_stream != 0:
@@ -264,86 +210,77 @@ class BlockedNormalEquations:
             yield self.stream.cuda_stream
         cur.wait_stream(self.stream)
 
+    def reduce(self, buf):
+        """Sum ``buf`` (a packed state incl. its vote word) over the ranks, in place: stream-ordered on the device when the
+        callable says ``on_device`` (RCCL), through the host otherwise (gloo)."""
+        if self.reduce_fn is None:
+            return
+        if getattr(self.reduce_fn, "on_device", False):
+            self.reduce_fn(buf)
+        else:
+            buf.copy_(self.torch.from_numpy(np.asarray(self.reduce_fn(buf.cpu().numpy()), dtype=np.float64)))
+
     def build(self, ps, slot: int):
         """packed[slot] <- [A | B | C | g | cost] at the device parameter string ``ps`` (+ the sum over the ranks)."""
-        torch = self.torch
         buf = self.packed[slot]
         with self.on_stream() as stream:
             if self.eng.n == 0:   # empty shard: zeros, but the all-reduce below still happens (see JacobianOperator)
-                buf.zero_()
+                buf[: self.n_packed].zero_()
             else:
                 self.eng.normal_blocks_device(ps.data_ptr(), buf.data_ptr(), stream)
-            if self.reduce_fn is not None:
-                if getattr(self.reduce_fn, "on_device", False):
-                    self.reduce_fn(buf)
-                else:
-                    buf.copy_(torch.from_numpy(self.reduce_fn(buf.cpu().numpy())))
+            self.reduce(buf)
 
     def solve(self, slot: int, lam, ps=None, ps_out=None):
         """Enqueue the damped step (H + lam diag(H)) delta = -g for the state in packed[slot]: ``self.delta`` (n_params,
         parameter-string order, 0 where fixed) and — given the current parameter string ``ps`` — the trial string
         ``ps_out = ps + delta``.  Device work only; ``self.status`` becomes non-zero when a factorisation fails."""
-        torch = self.torch
         with self.on_stream() as stream:
             self.eng.schur_prepare(self.packed[slot].data_ptr(), self.fixed.data_ptr(), lam.data_ptr(), self.linvt.data_ptr(), self.u.data_ptr(),
                                    self.V.data_ptr(), self.S.data_ptr(), self.rhs.data_ptr(), self.dvec.data_ptr(), self.gm.data_ptr(),
                                    self.status.data_ptr(), stream)
             ldv = self.V.shape[1]
-            if self.dense_solver == "hip":
-                # S = A + lam D - V V' (lower triangle), rhs = -g_l + V u: MFMA kernel of csrc/ba_schur.hpp; S x_l = rhs: blocked
-                # Cholesky + substitutions (csrc/ba_dense_chol.hpp); w = V' x_l
-                from .engine import dense_spd_solve, schur_syrk, schur_vtx
+            # S = A + lam D - V V' (lower triangle), rhs = -g_l + V u: MFMA kernel of csrc/ba_schur.hpp; S x_l = rhs: blocked
+            # Cholesky + substitutions (csrc/ba_chol_persist.hpp / ba_dense_chol.hpp); w = V' x_l
+            from .engine import dense_spd_solve, schur_syrk, schur_vtx
 
-                xl = self.xl
-                if self.n_trail:
-                    schur_syrk(self.eng.device, self.n_lead, self.n_trail, self.V.data_ptr(), ldv, self.S.data_ptr(), self.n_lead,
-                               self.u.data_ptr(), self.rhs.data_ptr(), stream)
-                dense_spd_solve(self.eng.device, self.n_lead, self.S.data_ptr(), self.n_lead, self.rhs.data_ptr(), xl.data_ptr(),
-                                self.chol_work.data_ptr(), self.status.data_ptr(), stream, algorithm=self.spd_algorithm)
-                if self.n_trail:
-                    schur_vtx(self.eng.device, self.n_lead, self.n_trail, self.V.data_ptr(), ldv, xl.data_ptr(), self.w.data_ptr(), stream)
-                    w = self.w
-                else:
-                    w = self.u
-            else:                                            # the library path, kept for A/B: rocBLAS GEMM / GEMV + rocSOLVER through torch
-                if self.n_trail:
-                    V = self.V[:, : self.n_trail]
-                    self.S.addmm_(V, V.T, alpha=-1.0)
-                    self.rhs.addmv_(V, self.u[: self.n_trail])
-                L, info = torch.linalg.cholesky_ex(self.S)   # `info` stays on the device
-                xl = torch.cholesky_solve(self.rhs.unsqueeze(1), L).squeeze(1)
-                self.status.bitwise_or_((info != 0).to(torch.int32) * 2)
-                w = torch.mv(self.V[:, : self.n_trail].T, xl) if self.n_trail else self.u
+            xl = self.xl
+            if self.n_trail:
+                det = bool(self.eng.option("deterministic", 0))
+                schur_syrk(self.eng.device, self.n_lead, self.n_trail, self.V.data_ptr(), ldv, self.S.data_ptr(), self.n_lead,
+                           self.u.data_ptr(), self.rhs.data_ptr(), stream, work=self.syrk_work.data_ptr() if det else None, work_len=self.syrk_work_len)
+            dense_spd_solve(self.eng.device, self.n_lead, self.S.data_ptr(), self.n_lead, self.rhs.data_ptr(), xl.data_ptr(),
+                            self.chol_work.data_ptr(), self.status.data_ptr(), stream, algorithm=self.spd_algorithm,
+                            timeout_us=self.eng.option("spd_timeout_us", None))
+            if self.n_trail:
+                schur_vtx(self.eng.device, self.n_lead, self.n_trail, self.V.data_ptr(), ldv, xl.data_ptr(), self.w.data_ptr(), stream)
+                w = self.w
+            else:
+                w = self.u
             self.eng.schur_finish(self.linvt.data_ptr(), self.u.data_ptr(), w.data_ptr(), xl.data_ptr(), self.fixed.data_ptr(), self.delta.data_ptr(),
                                   ps.data_ptr() if ps is not None else 0, ps_out.data_ptr() if ps is not None else 0, stream)
-            if self.reduce_fn is not None and ps is not None:
-                self._consensus_step(ps, ps_out)
         return self.delta
 
     def _consensus_step(self, ps, ps_out):
-        """Sharded loop: every rank has solved the SAME all-reduced system, but schur_syrk_kernel sums its K splits with f64
-        atomics in arrival order (csrc/ba_schur.hpp), so the steps agree to the last bits only — enough for one rank to meet
-        xtol, or to take the other branch of the gain-ratio rule, while its peers enter the next all-reduce (a hang).  The
-        ranks therefore adopt ONE step: the mean of theirs, from one more all-reduce of n_params + 1 doubles (the extra entry
-        counts the ranks; an all-reduce delivers the same bits to every rank).  From here on — trial string, build, all-reduced
-        blocks, decision, damping — every rank computes on identical inputs with order-deterministic kernels."""
+        """Sharded host-steered loop WITHOUT the engine's deterministic mode: every rank has solved the SAME all-reduced system, but
+        schur_syrk_kernel sums its K splits with f64 atomics in arrival order (csrc/ba_schur.hpp), so the steps agree to the last
+        bits only — enough for one rank to meet xtol, or to take the other branch of the gain-ratio rule, while its peers enter the
+        next all-reduce (a hang).  The ranks therefore adopt ONE step: the mean of theirs, from one more all-reduce of
+        n_params + 1 doubles (the extra entry counts the ranks; an all-reduce delivers the same bits to every rank).  With
+        ``set_option('deterministic', 1)`` the steps are bit-identical and this collective is not needed."""
         torch = self.torch
         if self._cons is None:
             self._cons = torch.empty(self.n_params + 1, dtype=torch.float64, device=self.dev)
         buf = self._cons
         buf[:-1].copy_(self.delta)
         buf[-1] = 1.0
-        if getattr(self.reduce_fn, "on_device", False):
-            self.reduce_fn(buf)
-        else:
-            buf.copy_(torch.from_numpy(np.asarray(self.reduce_fn(buf.cpu().numpy()), dtype=np.float64)))
+        self.reduce(buf)
         torch.div(buf[:-1], buf[-1], out=self.delta)
         torch.add(ps, self.delta, out=ps_out)
 
     def decide(self, cur: int, new: int, ps, lam, stats):
         """The accept / reject decision of the trial state packed[new] against packed[cur] on the device (pcs_lm_decide):
-        updates ``lam`` in place, clears ``status`` and fills ``stats`` (8 doubles) — what the host reads once per trial."""
-        last = 8 * (self.packed[0].numel() - 1)
+        updates ``lam`` in place, clears ``status`` and fills ``stats`` (12 doubles) — what the host reads once per trial."""
+        last = 8 * (self.n_packed - 1)
         with self.on_stream() as stream:
             self.eng.lm_decide(self.packed[cur].data_ptr() + last, self.packed[new].data_ptr() + last, self.dvec.data_ptr(), self.gm.data_ptr(),
                                self.delta.data_ptr(), ps.data_ptr(), self.fixed.data_ptr(), self.status.data_ptr(), lam.data_ptr(), stats.data_ptr(),
@@ -358,17 +295,15 @@ class BlockedNormalEquations:
     def gradient(self, slot: int, lam=None):
         """masked J^T r of the state in packed[slot] (free entries), as NumPy — one read-back, used once at the end.  g sits in the
         packed buffer right behind the blocks ([A | B | C | g | cost]); no solve is needed to read it."""
-        g0 = self.packed[slot].numel() - 1 - self.n_params
+        g0 = self.n_packed - 1 - self.n_params
         return self.packed[slot][g0: g0 + self.n_params][self.free_idx].cpu().numpy()
 
 
-def _lm_solve_blocked(ne: BlockedNormalEquations, ps0: np.ndarray, *, max_iter, ftol, xtol, gtol, lam0, verbose):
+def _lm_solve_blocked(ne: BlockedNormalEquations, ps0: np.ndarray, *, max_iter, ftol, xtol, gtol, lam0, lam_grow0, verbose):
     """The device-resident loop behind ``lm_solve(..., linear_solver='cholesky')``.  Per trial step the host enqueues
-    solve (+ trial parameter string) -> build -> decision and then reads ONE 8-vector
-        [accepted, max |g| before the step, relative cost drop, |step|, |x|, new sum r^2, old sum r^2, lambda used]
-    to steer the loop; x, lambda, the gain ratio and both states stay in HBM."""
-    torch = ne.torch
-    dev = ne.dev
+    step (+ trial parameter string) -> build -> decision and then reads ONE small vector
+        [accepted, max |g| before the step, relative cost drop, |step|, |x|, new sum r^2, old sum r^2, lambda used, ...]
+    to follow the loop; x, lambda, the gain ratio and both states stay in HBM."""
     # For the duration of the loop the engine records neither the start / stop events of every build (pcs_last_kernel_ms) nor its
     # ordering event after every enqueue on this solver's stream (the stream lives as long as `ne`; "lazy_done_event" = 2 records
     # when somebody waits): each record is a packet between two launches, three of them cost a trial ~17 us (rocprofv3 trace).
@@ -377,160 +312,192 @@ def _lm_solve_blocked(ne: BlockedNormalEquations, ps0: np.ndarray, *, max_iter, 
     eng.set_option("timing_every", 0)
     eng.set_option("lazy_done_event", 2)
     try:
-        loop = _lm_loop_blocked if ne.reduce_fn is not None else _lm_loop_device   # sharded: the all-reduce sits between build and decision
-        return loop(ne, ps0, max_iter=max_iter, ftol=ftol, xtol=xtol, gtol=gtol, lam0=lam0, verbose=verbose)
+        # The device steers the loop wherever the collective (if any) is stream-ordered: one GPU, or RCCL on the solver's stream.
+        # A host-staged collective (gloo) needs the host between build and decision anyway: host-steered loop.
+        device_steered = ne.reduce_fn is None or getattr(ne.reduce_fn, "on_device", False)
+        loop = _lm_loop_device if device_steered else _lm_loop_blocked
+        return loop(ne, ps0, max_iter=max_iter, ftol=ftol, xtol=xtol, gtol=gtol, lam0=lam0, lam_grow0=lam_grow0, verbose=verbose)
     finally:
         eng.set_option("lazy_done_event", saved[1])   # flushes the pending record while the stream exists
         eng.set_option("timing_every", saved[0])
 
 
-
-
 STOP_MESSAGES = {0: "maximum number of iterations reached", 1: "gtol reached", 2: "no further decrease (damping exhausted)", 3: "ftol reached", 4: "xtol reached",
                  5: "maximum number of iterations reached"}
 STOP_STATUS = {0: 0, 1: 1, 2: 2, 3: 3, 4: 4, 5: 0}
+REJECTION_LIMIT = 12      # consecutive rejected trials before the loop gives up ("damping exhausted")
 
 
-def _lm_loop_device(ne: BlockedNormalEquations, ps0: np.ndarray, *, max_iter, ftol, xtol, gtol, lam0, verbose):
-    """The single-GPU loop, steered by the DEVICE (round 4): one ``pcs_lm_trial`` call queues a whole trial — step, build at the trial
-    string, the decision WITH the termination rules, the copy of an accepted trial over the current state, a 10-double read-back — and
-    every kernel of it starts by reading a stop word.  The host therefore queues trial t + 1 BEFORE it reads the verdict of trial t:
-    the GPU never idles between trials (38-53 us per trial on rig-32, profiles/r04/lm_trace_rig32.log), and when the loop ends the one
-    speculative trial behind it drains as ten empty launches.  Same rules and the same results as `_lm_loop_blocked`."""
-    from ._capi import LmBuffers
+def _lm_loop_device(ne: BlockedNormalEquations, ps0: np.ndarray, *, max_iter, ftol, xtol, gtol, lam0, lam_grow0, verbose):
+    """The loop the DEVICE steers: one trial = the step, the build at the trial string, the decision WITH the termination rules and
+    the state flip of an accepted trial, a 12-double read-back into page-locked memory — and every kernel of it starts by reading a
+    stop word.  The host therefore queues trial t + 1 BEFORE it reads the verdict of trial t: the GPU never idles between trials
+    (38-53 us per trial on rig-32 in the host-steered form, profiles/r04/lm_trace_rig32.log), and when the loop ends the one
+    speculative trial behind it drains as empty launches.
+
+    Sharded over ranks with a stream-ordered collective (RCCL; ``reduce_fn.on_device``): the same loop with the all-reduce of the
+    trial state queued between the two halves of a trial (pcs_lm_trial_build / pcs_lm_trial_finish) — no host synchronisation
+    either.  The collective is queued on a fixed address, so the trial is always built into packed[1] and an accepted one is copied
+    over packed[0] (PCS_LM_FIXED_TRIAL_BUFFER); the ranks decide on identical all-reduced blocks with order-deterministic kernels
+    (the engine's deterministic mode is switched on for the loop), so every rank walks the same path without a consensus
+    collective, and a dense solve that gives up on ONE rank voids the trial on all of them (PCS_LM_VOTES)."""
+    from ._capi import LM_FIXED_TRIAL_BUFFER, LM_STATS, LM_VOTES, LmBuffers
     from .engine import SPD_ALGORITHMS
 
     torch = ne.torch
     dev = ne.dev
-    with torch.cuda.device(dev), torch.cuda.stream(ne.stream):
-        stream = ne.stream.cuda_stream
-        ps = torch.from_numpy(np.ascontiguousarray(ps0, dtype=np.float64)).to(dev)
-        ps_new = torch.empty_like(ps)
-        lam = torch.full((1,), float(lam0), dtype=torch.float64, device=dev)
-        ctrl = torch.tensor([0.0, 0.0, 0.0, float(max_iter), ftol, xtol, gtol, 12.0, 0.0], dtype=torch.float64, device=dev)
-        flags = torch.zeros(2, dtype=torch.int32, device=dev)          # [stop, accepted]
-        stats_dev = torch.zeros(10, dtype=torch.float64, device=dev)
-        ring = 4
-        # page-locked, allocated once per solver state, not per solve (hipHostMalloc costs ~0.2 ms) — and not shared between states: a
-        # speculative trial one solve leaves behind still writes its read-back while the next solve may already run
-        stats_host = ne.__dict__.get("_stats_host")
-        if stats_host is None:
-            stats_host = ne._stats_host = [torch.zeros(10, dtype=torch.float64).pin_memory() for _ in range(ring)]
-        # the final state (gradient | solution | sum r^2) is written into this page-locked buffer by the trial that ends the loop, before
-        # that trial's read-back: the host returns without a copy of its own and without waiting for the speculative trial to drain
-        n_free = int(ne.free_idx.numel())
-        result_host = ne.__dict__.get("_result_host")
-        if result_host is None or result_host.numel() != 2 * n_free + 1:
-            result_host = ne._result_host = torch.zeros(2 * n_free + 1, dtype=torch.float64).pin_memory()
-        result_view = result_host.numpy()
-        result_view[-1] = np.nan
-        pending = ne.__dict__.pop("_drain_event", None)
-        if pending is not None:
-            pending.synchronize()              # the speculative trial the previous solve left behind has written its (void) read-back
-        ne.build(ps, 0)
-        history = []                       # the first entry — the starting cost — comes with the first trial's read-back (no sync of its own)
+    sharded = ne.reduce_fn is not None
+    eng = ne.eng
+    saved_det = eng.option("deterministic", 0)
+    if sharded and not saved_det:
+        eng.set_option("deterministic", 1)
+    try:
+        with torch.cuda.device(dev), torch.cuda.stream(ne.stream):
+            stream = ne.stream.cuda_stream
+            ps = [torch.from_numpy(np.ascontiguousarray(ps0, dtype=np.float64)).to(dev), None]
+            ps[1] = torch.empty_like(ps[0])
+            lam = torch.full((1,), float(lam0), dtype=torch.float64, device=dev)
+            ctrl = torch.tensor([0.0, 0.0, 0.0, float(max_iter), ftol, xtol, gtol, float(REJECTION_LIMIT), 0.0, float(lam_grow0), 0.0, 0.0],
+                                dtype=torch.float64, device=dev)
+            flags = torch.zeros(4, dtype=torch.int32, device=dev)          # [stop, accepted, current state, -]
+            stats_dev = torch.zeros(LM_STATS, dtype=torch.float64, device=dev)
+            ring = 4
+            # page-locked, allocated once per solver state, not per solve (hipHostMalloc costs ~0.2 ms) — and not shared between states: a
+            # speculative trial one solve leaves behind still writes its read-back while the next solve may already run
+            stats_host = ne.__dict__.get("_stats_host")
+            if stats_host is None:
+                stats_host = ne._stats_host = [torch.zeros(LM_STATS, dtype=torch.float64).pin_memory() for _ in range(ring)]
+            # the final state (gradient | solution | sum r^2) is written into this page-locked buffer by the trial that ends the loop, before
+            # that trial's read-back: the host returns without a copy of its own and without waiting for the speculative trial to drain
+            n_free = int(ne.free_idx.numel())
+            result_host = ne.__dict__.get("_result_host")
+            if result_host is None or result_host.numel() != 2 * n_free + 1:
+                result_host = ne._result_host = torch.zeros(2 * n_free + 1, dtype=torch.float64).pin_memory()
+            result_view = result_host.numpy()
+            result_view[-1] = np.nan
+            pending = ne.__dict__.pop("_drain_event", None)
+            if pending is not None:
+                pending.synchronize()              # the speculative trial the previous solve left behind has written its (void) read-back
+            ne.build(ps[0], 0)
+            history = []                       # the first entry — the starting cost — comes with the first trial's read-back (no sync of its own)
 
-        def buffers(k):
-            b = LmBuffers()
-            b.packed_cur, b.packed_new = ne.packed[0].data_ptr(), ne.packed[1].data_ptr()
-            b.fixed, b.lam = ne.fixed.data_ptr(), lam.data_ptr()
-            b.linvt, b.u, b.V, b.S, b.rhs, b.dvec, b.gm = (t.data_ptr() for t in (ne.linvt, ne.u, ne.V, ne.S, ne.rhs, ne.dvec, ne.gm))
-            b.status, b.xlead, b.w, b.spd_work = ne.status.data_ptr(), ne.xl.data_ptr(), ne.w.data_ptr(), ne.chol_work.data_ptr()
-            b.delta, b.ps_cur, b.ps_new = ne.delta.data_ptr(), ps.data_ptr(), ps_new.data_ptr()
-            b.ctrl, b.stop_flag, b.accept_flag = ctrl.data_ptr(), flags.data_ptr(), flags.data_ptr() + 4
-            b.stats, b.stats_host = stats_dev.data_ptr(), stats_host[k % ring].data_ptr()
-            b.spd_algorithm = SPD_ALGORITHMS[ne.spd_algorithm]
-            b.free_idx, b.n_free, b.result_host = ne.free_idx.data_ptr(), n_free, result_host.data_ptr()
-            return b
+            def buffers(k):
+                b = LmBuffers()
+                b.packed[0], b.packed[1] = ne.packed[0].data_ptr(), ne.packed[1].data_ptr()
+                b.ps[0], b.ps[1] = ps[0].data_ptr(), ps[1].data_ptr()
+                b.flags, b.fixed, b.lam = flags.data_ptr(), ne.fixed.data_ptr(), lam.data_ptr()
+                b.linvt, b.u, b.V, b.S, b.rhs, b.dvec, b.gm = (t.data_ptr() for t in (ne.linvt, ne.u, ne.V, ne.S, ne.rhs, ne.dvec, ne.gm))
+                b.status, b.xlead, b.w, b.spd_work = ne.status.data_ptr(), ne.xl.data_ptr(), ne.w.data_ptr(), ne.chol_work.data_ptr()
+                b.delta, b.ctrl = ne.delta.data_ptr(), ctrl.data_ptr()
+                b.stats, b.stats_host = stats_dev.data_ptr(), stats_host[k % ring].data_ptr()
+                b.spd_algorithm = SPD_ALGORITHMS[ne.spd_algorithm]
+                b.mode = (LM_FIXED_TRIAL_BUFFER | LM_VOTES) if sharded else 0
+                b.free_idx, b.n_free, b.result_host = ne.free_idx.data_ptr(), n_free, result_host.data_ptr()
+                b.syrk_work, b.syrk_work_len = ne.syrk_work.data_ptr(), ne.syrk_work_len
+                return b
 
-        # The read-back of trial k lands in page-locked memory the device writes directly (lm_accept_kernel: word 9, the trial's number —
-        # or -1 for a launch that found the stop flag raised —, last).  The host waits for THAT word instead of an event: an event record
-        # between two trials cost the GPU 5.6 us of idling per trial (the one gap in profiles/r04/lm_trace_*.log).
-        views = [t.numpy() for t in stats_host]
+            # The read-back of trial k lands in page-locked memory the device writes directly (lm_decide_kernel: word 9, the trial's number —
+            # or -1 for a launch that found the stop flag raised —, last).  The host waits for THAT word instead of an event: an event record
+            # between two trials cost the GPU 5.6 us of idling per trial (the one gap in profiles/r04/lm_trace_*.log).
+            views = [t.numpy() for t in stats_host]
 
-        def enqueue(k):
-            views[k % ring][9] = np.nan
-            ne.eng.lm_trial(buffers(k), stream)
+            def enqueue(k):
+                views[k % ring][9] = np.nan
+                b = buffers(k)
+                if sharded:   # the trial state is all-reduced between the two halves, on this stream: nothing waits for the host
+                    eng.lm_trial_build(b, stream)
+                    ne.reduce(ne.packed[1])
+                    eng.lm_trial_finish(b, stream)
+                else:
+                    eng.lm_trial(b, stream)
 
-        def wait_for(k):
-            v = views[k % ring]
-            t_end = time.perf_counter() + 30.0
-            spins = 0
-            while np.isnan(v[9]):
-                spins += 1
-                if spins & 1023 == 0:
-                    if time.perf_counter() > t_end:
-                        raise RuntimeError("device LM loop: no read-back within 30 s")
-                    time.sleep(0)
-            return v.copy()
+            def wait_for(k):
+                v = views[k % ring]
+                t_end = time.perf_counter() + 30.0
+                spins = 0
+                while np.isnan(v[9]):
+                    spins += 1
+                    if spins & 1023 == 0:
+                        if time.perf_counter() > t_end:
+                            raise RuntimeError("device LM loop: no read-back within 30 s")
+                        time.sleep(0)
+                return v.copy()
 
-        code, nfev, n_lin, it = 0, 1, 0, 0
-        limit = 12 * max_iter + 16          # every accepted step is preceded by fewer than 12 rejections
-        queued = 0
-        enqueue(queued)
-        queued += 1
-        read = 0
-        while read < limit:
-            if code == 0 and queued < limit:   # speculate: the next trial goes out before this one's verdict is read
+            code, nfev, n_lin, it = 0, 1, 0, 0
+            limit = REJECTION_LIMIT * max_iter + 16          # every accepted step is preceded by fewer than REJECTION_LIMIT rejections
+            queued = read = 0
+            if max_iter > 0:
                 enqueue(queued)
                 queued += 1
-            st = wait_for(read)
-            read += 1
-            if st[9] < 0:                       # a launch that found the flag raised: nothing happened
-                if read >= queued:
-                    break
-                continue
-            n_lin += 1
-            nfev += 1
-            if not history:
-                history.append(0.5 * float(st[6]))
-            if verbose:
-                print(f"  trial {int(st[9])}: lam {st[7]:.2e} cost {0.5 * st[6]:.6e} -> {0.5 * st[5]:.6e} accepted {bool(st[0] > 0)} stop {int(st[8])}")
-            if st[0] > 0:
-                it += 1
-                history.append(0.5 * float(st[5]))
-            code = int(st[8])
-            if code == 9:   # the one-launch dense solve gave up waiting: repeat the trial with the launch-per-column form
-                torch.cuda.current_stream().synchronize()      # whatever was queued behind it has drained as no-ops
-                ne.spd_algorithm = "launches"
-                ctrl[0] = 0.0
-                flags.zero_()
-                nfev -= 1
-                n_lin -= 1
-                code = 0
-                read = queued                                   # forget the drained launches
-                if queued < limit:
+            else:
+                code = 5
+            while code == 0 and read < limit:
+                if queued < limit:                 # speculate: the next trial goes out before this one's verdict is read
                     enqueue(queued)
                     queued += 1
-                continue
-            if code != 0:
-                break                               # the speculative trial behind this one drains on its own (ten empty launches)
-        if read < queued:                           # ... and the next solve on this state waits for that before it reuses the read-back ring
-            ne._drain_event = torch.cuda.Event()
-            ne._drain_event.record()
-        if code not in (0, 9) and not np.isnan(result_view[-1]):
-            out = result_view.copy()           # written by the trial that raised the stop code (lm_decide_kernel), complete before its read-back
-        else:
-            # gradient, solution and cost in ONE read-back (g and the cost sit behind the blocks of the packed state: [A | B | C | g | cost])
-            torch.cuda.current_stream().synchronize()
-            g0 = ne.packed[0].numel() - 1 - ne.n_params
-            out = torch.cat([ne.packed[0][g0: g0 + ne.n_params][ne.free_idx], ps[ne.free_idx], ne.packed[0][-1:]]).cpu().numpy()
-        g, x, cost = out[:n_free].copy(), out[n_free: 2 * n_free].copy(), 0.5 * float(out[-1])
-        if not history:
-            history.append(cost)
+                st = wait_for(read)
+                read += 1
+                if st[9] < 0:                       # a launch that found the flag raised: nothing happened
+                    if read >= queued:
+                        break
+                    continue
+                n_lin += 1
+                nfev += 1
+                if not history:
+                    history.append(0.5 * float(st[6]))
+                if verbose:
+                    print(f"  trial {int(st[9])}: lam {st[7]:.2e} cost {0.5 * st[6]:.6e} -> {0.5 * st[5]:.6e} accepted {bool(st[0] > 0)} stop {int(st[8])}")
+                if st[0] > 0:
+                    it += 1
+                    history.append(0.5 * float(st[5]))
+                code = int(st[8])
+                if code == 9:   # the one-launch dense solve gave up waiting (on this rank or on a peer): repeat the trial with the launch-per-column form
+                    torch.cuda.current_stream().synchronize()      # whatever was queued behind it has drained as no-ops
+                    ne.spd_algorithm = "launches"
+                    ctrl[0] = 0.0
+                    flags[:2].zero_()                               # stop and accept; the current-state word stays
+                    nfev -= 1
+                    n_lin -= 1
+                    code = 0
+                    read = queued                                   # forget the drained launches
+                    if queued < limit:
+                        enqueue(queued)
+                        queued += 1
+            if read < queued:                           # the speculative trial behind the end drains on its own (empty launches) ...
+                ne._drain_event = torch.cuda.Event()    # ... and the next solve on this state waits for that before it reuses the read-back ring
+                ne._drain_event.record()
+            if code not in (0, 9) and max_iter > 0 and not np.isnan(result_view[-1]):
+                out = result_view.copy()           # written by the trial that raised the stop code (lm_decide_kernel), complete before its read-back
+            else:
+                # gradient, solution and cost in ONE read-back (g and the cost sit behind the blocks of the packed state: [A | B | C | g | cost])
+                torch.cuda.current_stream().synchronize()
+                cur = int(flags[2].item())
+                g0 = ne.n_packed - 1 - ne.n_params
+                out = torch.cat([ne.packed[cur][g0: g0 + ne.n_params][ne.free_idx], ps[cur][ne.free_idx], ne.packed[cur][ne.n_packed - 1: ne.n_packed]]).cpu().numpy()
+            g, x, cost = out[:n_free].copy(), out[n_free: 2 * n_free].copy(), 0.5 * float(out[-1])
+            if not history:
+                history.append(cost)
+    finally:
+        if sharded and not saved_det:
+            eng.set_option("deterministic", 0)
     return DeviceLMResult(x=x, cost=cost, grad=g, optimality=float(np.max(np.abs(g))) if g.size else 0.0, nit=it, nfev=nfev,
                           n_jtjv=n_lin, status=STOP_STATUS.get(code, 0), message=STOP_MESSAGES.get(code, f"stopped ({code})"), history=history)
 
 
-def _lm_loop_blocked(ne: BlockedNormalEquations, ps0: np.ndarray, *, max_iter, ftol, xtol, gtol, lam0, verbose):
+def _lm_loop_blocked(ne: BlockedNormalEquations, ps0: np.ndarray, *, max_iter, ftol, xtol, gtol, lam0, lam_grow0, verbose):
+    """The host-steered loop: what a sharded solve takes when its collective goes through the host (gloo).  Same rules as the
+    device-steered loop (the decision itself is pcs_lm_decide on the device).  Every rank decides on the same all-reduced blocks;
+    whether a rank's one-launch dense solve gave up is all-reduced with them (the word behind the packed state), so the ranks repeat
+    a void trial TOGETHER; without the engine's deterministic mode they also adopt one consensus step per trial."""
     torch = ne.torch
     dev = ne.dev
+    deterministic = bool(ne.eng.option("deterministic", 0))
     with torch.cuda.device(dev), torch.cuda.stream(ne.stream):     # one real stream for torch operations and C-ABI kernels alike
         ps = torch.from_numpy(np.ascontiguousarray(ps0, dtype=np.float64)).to(dev)
         ps_new = torch.empty_like(ps)
         lam = torch.full((1,), float(lam0), dtype=torch.float64, device=dev)
-        stats_dev = torch.zeros(8, dtype=torch.float64, device=dev)
-        stats_host = torch.zeros(8, dtype=torch.float64).pin_memory()
+        stats_dev = torch.zeros(12, dtype=torch.float64, device=dev)
+        stats_host = torch.zeros(12, dtype=torch.float64).pin_memory()
         verdict = torch.cuda.Event()
         cur, new = 0, 1
         ne.build(ps, cur)
@@ -539,22 +506,33 @@ def _lm_loop_blocked(ne: BlockedNormalEquations, ps0: np.ndarray, *, max_iter, f
         nfev, n_lin = 1, 0
         status, message = 0, "maximum number of iterations reached"
         it = 0
+        any_accepted = False
         for it in range(1, max_iter + 1):
             accepted = False
             stop = False
-            for _retry in range(12):   # damping retries
+            retry = 0
+            while retry < REJECTION_LIMIT:   # damping retries
                 ne.solve(cur, lam, ps, ps_new)
+                if ne.reduce_fn is not None:
+                    if not deterministic:
+                        ne._consensus_step(ps, ps_new)
+                    ne.packed[new][ne.n_packed] = (ne.status[0] & 4).to(torch.float64)     # this rank's vote: "my dense solve gave up"
                 n_lin += 1
-                ne.build(ps_new, new)
+                ne.build(ps_new, new)                                                        # the all-reduce sums the votes with the blocks
+                if ne.reduce_fn is not None:
+                    ne.status.bitwise_or_((ne.packed[new][ne.n_packed: ne.n_packed + 1] > 0).to(torch.int32) * 4)
                 nfev += 1
                 ne.decide(cur, new, ps, lam, stats_dev)
-                stats_host.copy_(stats_dev, non_blocking=True)   # the ONE read-back of the trial: 64 bytes into page-locked memory
+                stats_host.copy_(stats_dev, non_blocking=True)   # the ONE read-back of the trial: 96 bytes into page-locked memory
                 verdict.record()
                 verdict.synchronize()
                 stats = stats_host.numpy().copy()
-                if stats[0] < 0:   # the one-launch dense solve gave up waiting (status bit 2): nothing of this trial is valid —
-                    ne.spd_algorithm = "launches"   # repeat it with the launch-per-column form (the decision left the damping alone)
+                if stats[0] < 0:   # the one-launch dense solve gave up waiting on SOME rank (status bit 2): nothing of this trial is valid —
+                    ne.spd_algorithm = "launches"   # every rank repeats it with the launch-per-column form (the decision left the damping alone)
+                    nfev -= 1
+                    n_lin -= 1
                     continue
+                retry += 1
                 gmax = float(stats[1])
                 if verbose:
                     print(f"  it {it}: lam {stats[7]:.2e} cost {0.5 * stats[6]:.6e} -> {0.5 * stats[5]:.6e} accepted {bool(stats[0])}")
@@ -562,12 +540,14 @@ def _lm_loop_blocked(ne: BlockedNormalEquations, ps0: np.ndarray, *, max_iter, f
                     status, message, stop = 1, "gtol reached", True
                     break
                 if stats[0] > 0:
-                    accepted = True
+                    accepted = any_accepted = True
                     ps, ps_new = ps_new, ps
                     cur, new = new, cur
                     history.append(0.5 * float(stats[5]))
                     rel_drop, step_norm, x_norm = float(stats[2]), float(stats[3]), float(stats[4])
                     break
+                if not any_accepted and lam_grow0 > 1.0:   # a rejection before the first accepted step: the device rule multiplied by 4
+                    lam.mul_(lam_grow0 / 4.0)
             if stop:
                 break
             if not accepted:
@@ -584,93 +564,6 @@ def _lm_loop_blocked(ne: BlockedNormalEquations, ps0: np.ndarray, *, max_iter, f
         cost = 0.5 * float(ne.cost(cur).item())
     return DeviceLMResult(x=x, cost=cost, grad=g, optimality=float(np.max(np.abs(g))) if g.size else 0.0, nit=it, nfev=nfev,
                           n_jtjv=n_lin, status=status, message=message, history=history)
-
-
-def reduce_normal_equations(U, g, c, reduce_fn):
-    """Sum one rank's (J^T J, J^T r, cost) torch tensors over the ranks with ONE collective on the packed
-    buffer.  ``reduce_fn`` with ``on_device = True`` receives the tensor itself (RCCL on a CUDA tensor, see
-    sharding.allreduce_sum_tensor_fn), otherwise a NumPy copy (sharding.allreduce_sum_fn, gloo)."""
-    if reduce_fn is None:
-        return U, g, c
-    import torch
-
-    m = g.shape[0]
-    packed = torch.cat([U.reshape(-1), g, c.reshape(1)])
-    if getattr(reduce_fn, "on_device", False):
-        packed = reduce_fn(packed)
-    else:
-        packed = torch.from_numpy(reduce_fn(packed.cpu().numpy())).to(U.device)
-    return packed[: m * m].view(m, m), packed[m * m: m * m + m], packed[-1:]
-
-
-def cholesky_step(Hs, g, lam, d):
-    """Damped normal equations by Cholesky on torch tensors (rocSOLVER on a CUDA tensor)."""
-    import torch
-
-    L, info = torch.linalg.cholesky_ex(Hs + torch.diag(lam * d))
-    if int(info.item()) != 0:
-        return None
-    return torch.cholesky_solve(-g.unsqueeze(1), L).squeeze(1)
-
-
-def schur_cholesky_step(Hs, g, lam, d, n_lead: int, block: int):
-    """The same step through the Schur complement of the trailing parameter group.
-
-    The free parameters are ordered [leading | trailing]; the trailing group (the per-image poses of the
-    template chain, the per-key points of the self / free chains) consists of ``block``-sized sets that
-    never share a detection, so its part of J^T J is block diagonal:  H = [[A, B], [B^T, C]],
-    C = diag(C_1 .. C_m).  Eliminating it leaves a dense system of the leading size only
-    (480 instead of 1 680 unknowns on rig-32):
-        (A_d - B C_d^-1 B^T) x_a = -g_a + B C_d^-1 g_c,      x_c = -C_d^-1 (g_c + B^T x_a)
-    with A_d, C_d the damped blocks.  Returns None when a factorisation fails."""
-    import torch
-
-    n = Hs.shape[0]
-    m = (n - n_lead) // block
-    if m == 0 or n_lead == 0:
-        return cholesky_step(Hs, g, lam, d)
-    A = Hs[:n_lead, :n_lead] + torch.diag(lam * d[:n_lead])
-    B = Hs[:n_lead, n_lead:]                                           # (n_lead, m * block)
-    Ct = Hs[n_lead:, n_lead:].reshape(m, block, m, block)
-    C = Ct.diagonal(dim1=0, dim2=2).permute(2, 0, 1)                  # (m, block, block) diagonal blocks
-    C = C + torch.diag_embed(lam * d[n_lead:].reshape(m, block))
-    Lc, info_c = torch.linalg.cholesky_ex(C)
-    if int(info_c.max().item()) != 0:
-        return None
-    Cinv = torch.cholesky_inverse(Lc)
-    BCinv = torch.einsum("amk,mkl->aml", B.reshape(n_lead, m, block), Cinv).reshape(n_lead, m * block)
-    S = A - BCinv @ B.T
-    rhs = -g[:n_lead] + BCinv @ g[n_lead:]
-    Ls, info_s = torch.linalg.cholesky_ex(S)
-    if int(info_s.item()) != 0:
-        return None
-    xa = torch.cholesky_solve(rhs.unsqueeze(1), Ls).squeeze(1)
-    t = (g[n_lead:] + B.T @ xa).reshape(m, block)
-    xc = -torch.einsum("mkl,ml->mk", Cinv, t).reshape(-1)
-    return torch.cat([xa, xc])
-
-
-def trailing_block_structure(chain: str, n_cams: int, n_imgs: int, n_keys: int, mask):
-    """(n_lead, block, perm) for schur_cholesky_step, or None if there is nothing to eliminate.
-    template: poses (6 per image) trail the cameras; self / free: points (3 per key) trail everything
-    else.  Sets that are only partly free (single point coordinates fixed by the self-calibration gauge,
-    sbh:153-158) are moved to the leading group: ``perm`` is that reordering of the free-parameter vector
-    (None when it is the identity)."""
-    mask = np.asarray(mask, dtype=bool)
-    block = 6 if chain == "template" else 3
-    start = 15 * n_cams if chain in ("template", "free") else 15 * n_cams + 6 * n_imgs
-    sets = mask[start:].reshape(-1, block)
-    whole = sets.all(axis=1)
-    if not whole.any() or not (mask[:start].any() or (sets.any(axis=1) & ~whole).any()):
-        return None
-    free_pos = np.cumsum(mask) - 1                       # full index -> position in the free vector
-    trailing = np.repeat(whole, block)
-    full_idx = np.arange(mask.shape[0])
-    lead_full = np.concatenate([full_idx[:start][mask[:start]], (full_idx[start:])[mask[start:] & ~trailing]])
-    trail_full = (full_idx[start:])[trailing]
-    perm = free_pos[np.concatenate([lead_full, trail_full])]
-    n_lead = lead_full.shape[0]
-    return n_lead, block, (None if np.array_equal(perm, np.arange(perm.shape[0])) else perm)
 
 
 @dataclass
@@ -742,24 +635,28 @@ class _CholeskyStep:
 
 
 def lm_solve(handler, x0, *, max_iter: int = 50, ftol: float = 1e-8, xtol: float = 1e-8, gtol: float = 1e-8,
-             cg_tol: float = 1e-3, cg_max_iter: int = 200, lam0: float | None = None, reduce_fn=None, verbose: int = 0,
+             cg_tol: float = 1e-3, cg_max_iter: int = 200, lam0: float | None = None, lam_grow0: float | None = None, reduce_fn=None, verbose: int = 0,
              operator=None, linear_solver: str = "auto") -> DeviceLMResult:
     """Levenberg-Marquardt (Marquardt scaling D = diag(J^T J)) for a pycamset_amd handler.  The damped
     normal equations are solved by Jacobi-PCG on matrix-free J^T J products (``linear_solver='pcg'``) or
     by a Cholesky factorisation of the block-reduced J^T J (``'cholesky'``).  Every quantity that depends
     on the detections is computed by the HIP engine.  ``operator`` replaces the engine-backed
-    JacobianOperator / NormalEquations (used by the CPU tests of this driver).
+    JacobianOperator (used by the CPU tests of this driver).
 
     ``lam0``: the initial damping (Nielsen's tau: lambda multiplies D).  ``None`` = 1e-6 with the exact (Cholesky) step, 1e-3 with
     PCG.  The reference's solver — scipy ``least_squares(method='trf')``, optimisation_handling.py:88-98 — starts with the plain
     Gauss-Newton step whenever that lies inside its first trust region, which it does from a calibration's starting values; 1e-3 and
     the update lambda <- lambda max(1/3, 1 - (2 rho - 1)^3) need nine accepted steps on rig-32 to get the damping out of the way,
-    1e-6 five (scipy: four evaluations), to the same cost.  A rejected trial multiplies lambda by 2, 4, 8, ...: five of them take
-    1e-6 to 3e-2."""
+    1e-6 five (scipy: four evaluations), to the same cost.  Every rejected trial multiplies lambda by 4 (host and device rule alike;
+    at most REJECTION_LIMIT = 12 in a row) — except BEFORE the first accepted step, where a rejection multiplies it by ``lam_grow0``
+    (default LAM_GROW0 = 1e3): a start far from the solution (PnP poses tens of pixels off, two poses swapped) needs orders of magnitude
+    more damping than 1e-6, and x 4 per rejected evaluation would spend five evaluations to get to 1e-3 (DESIGN section 4 has the
+    table).  ``max_iter <= 0`` evaluates the start and returns it."""
     if linear_solver not in ("auto", "pcg", "cholesky"):
         raise ValueError("linear_solver must be 'auto', 'pcg' or 'cholesky'")
     op_fun = handler.op_fun
     lam0_exact, lam0_pcg = (1e-6, 1e-3) if lam0 is None else (float(lam0), float(lam0))
+    grow0 = LAM_GROW0 if lam_grow0 is None else float(lam_grow0)
     if operator is None:
         dd = handler._flat_detections()
         eng = op_fun._engine_for(dd)
@@ -778,7 +675,7 @@ def lm_solve(handler, x0, *, max_iter: int = 50, ftol: float = 1e-8, xtol: float
                 ne = cache[key] = BlockedNormalEquations(eng, mask, reduce_fn=reduce_fn)
             ne.spd_algorithm = "auto"
             ps0 = op_fun.build_param_list(*handler.get_bundle_adjustment_inputs(np.array(x0, dtype=np.float64)))
-            return _lm_solve_blocked(ne, ps0, max_iter=max_iter, ftol=ftol, xtol=xtol, gtol=gtol, lam0=lam0_exact, verbose=verbose)
+            return _lm_solve_blocked(ne, ps0, max_iter=max_iter, ftol=ftol, xtol=xtol, gtol=gtol, lam0=lam0_exact, lam_grow0=grow0, verbose=verbose)
         operator = JacobianOperator(eng, handler._jac_mask(), reduce_fn=reduce_fn)
     elif linear_solver == "auto":
         linear_solver = "cholesky" if hasattr(operator, "build") else "pcg"
@@ -793,18 +690,19 @@ def lm_solve(handler, x0, *, max_iter: int = 50, ftol: float = 1e-8, xtol: float
     history = [0.5 * st["sumsq"]]
     status, message = 0, "maximum number of iterations reached"
     it = 0
+    any_accepted = False
     for it in range(1, max_iter + 1):
         if float(np.max(np.abs(st["g"]))) <= gtol:
             status, message = 1, "gtol reached"
             break
         accepted = False
-        for retry in range(12):  # damping retries
+        for retry in range(REJECTION_LIMIT):  # damping retries
             if retry:
                 step.restore(st)
             delta, k, pred = step.solve(st, lam)
             n_lin += k
             if delta is None:   # damped matrix not positive definite: more damping
-                lam *= 4.0
+                lam *= 4.0 if any_accepted else max(grow0, 4.0)
                 continue
             x_new = x + delta
             st_new = step.evaluate(param_str(x_new))
@@ -814,14 +712,14 @@ def lm_solve(handler, x0, *, max_iter: int = 50, ftol: float = 1e-8, xtol: float
             if verbose:
                 print(f"  it {it}: lam {lam:.2e} lin {k} cost {0.5 * st['sumsq']:.6e} -> {0.5 * st_new['sumsq']:.6e} rho {rho:.3f}")
             if np.isfinite(st_new["sumsq"]) and actual > 0:
-                accepted = True
+                accepted = any_accepted = True
                 step_norm, x_norm = float(np.linalg.norm(delta)), float(np.linalg.norm(x))
                 rel_drop = actual / (0.5 * st["sumsq"])
                 x, st = x_new, st_new
                 lam = max(lam * (1.0 / 3.0 if rho > 0.75 else 1.0 if rho > 0.25 else 2.0), 1e-12)
                 history.append(0.5 * st["sumsq"])
                 break
-            lam *= 4.0
+            lam *= 4.0 if any_accepted else max(grow0, 4.0)
         if not accepted:
             step.restore(st)
             status, message = 2, "no further decrease (damping exhausted)"

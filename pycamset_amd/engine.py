@@ -7,7 +7,7 @@ All arithmetic happens in the HIP kernels behind the C ABI; nothing here compute
 from __future__ import annotations
 
 import ctypes
-import sys
+import weakref
 from ctypes import POINTER, byref, c_double, c_float, c_int32, c_int64, c_uint8, c_void_p
 
 import numpy as np
@@ -52,23 +52,33 @@ def pinned_empty(shape, dtype=np.float64) -> np.ndarray:
     return np.frombuffer(buf, dtype=dtype, count=n).reshape(shape)
 
 
-def _ring_counts(bufs: list, idx: int) -> tuple[int, int]:
-    """Reference counts of ring buffer ``bufs[idx]`` and of the array its views hang on.  Views of a buffer
-    (``a.reshape(-1)``, a ``csr_array`` built on one) do not reference the buffer itself but the array NumPy collapses
-    their ``base`` chain to — ``a.base``, the ``frombuffer`` array of ``pinned_empty`` — so both are counted.  The buffer
-    is fetched from the list in here, so the numbers do not depend on the caller's frames."""
-    a = bufs[idx]
-    base = a.base
-    return sys.getrefcount(a), (sys.getrefcount(base) if base is not None else 0)
+class _PinnedSlot:
+    """One page-locked block of an output ring and the LEASE on it (round 5; rounds 3-4 counted references with
+    ``sys.getrefcount``).  ``lease()`` hands the block out as a fresh NumPy array; NumPy hangs every view derived from that array —
+    ``a.reshape(-1)``, slices, a ``csr_array`` built on one, ``torch.from_numpy(a)``, a ``memoryview(a)`` — on ONE root array (the
+    ``base`` chain collapses to it), and a ``weakref.finalize`` on that root ends the lease when the last of them has gone.  The ring
+    keeps no reference to the root, so nothing about frames, temporaries or interpreter versions enters the decision; a holder that
+    keeps only a raw address (``a.ctypes.data`` handed to a C library or queued on a stream) must keep the array too, as with any
+    NumPy buffer — or call ``release`` semantics explicitly by dropping it when the consumer is done."""
 
+    def __init__(self, shape, dtype=np.float64):
+        self.shape = tuple(int(x) for x in np.atleast_1d(shape))
+        self.dtype = np.dtype(dtype)
+        self.count = int(np.prod(self.shape)) if self.shape else 1
+        self.nbytes = max(1, self.count) * self.dtype.itemsize
+        self.block = _PinnedBlock(self.nbytes)
+        self.leased = False
 
-_IDLE_COUNTS = _ring_counts([np.frombuffer(bytearray(16), dtype=np.float64).reshape(1, 2)], 0)   # a buffer nobody else holds
+    def _end(self):
+        self.leased = False
 
-
-def _still_held(bufs: list, idx: int) -> bool:
-    """True when something besides the ring references ring buffer ``bufs[idx]`` or any view of it."""
-    n_a, n_base = _ring_counts(bufs, idx)
-    return n_a > _IDLE_COUNTS[0] or n_base > _IDLE_COUNTS[1]
+    def lease(self) -> np.ndarray:
+        buf = (ctypes.c_char * self.nbytes).from_address(self.block.ptr.value)
+        buf._pcs_owner = self.block          # the memory outlives the ring (and the engine) for as long as somebody holds the array
+        root = np.frombuffer(buf, dtype=self.dtype, count=self.count)
+        self.leased = True
+        weakref.finalize(root, self._end)
+        return root.reshape(self.shape)      # a view: its base is `root`, like every view the caller derives from it
 
 
 def _stream_arg(stream):
@@ -164,29 +174,24 @@ class Engine:
         return p
 
     def _out(self, name: str, shape, pinned_ring: int):
-        """Output array: fresh pageable memory, or the next buffer of a ring of ``pinned_ring`` page-locked
-        buffers.  A ring buffer is only reused once nobody else references it, so every array handed out stays
-        valid for as long as it is held — reference semantics either way.
-
-        What counts as "held": Python references to the array or to anything NumPy hangs on it — views
-        (``j.reshape(-1)``, slices), a ``scipy.sparse.csr_array`` built on it, ``torch.from_numpy(j)``
-        (tests/test_gpu_parity.py covers these).  What does NOT: a raw address taken from it (``j.ctypes.data``,
-        a pointer handed to a C library or queued on a stream) or a ``memoryview`` of the underlying ctypes block —
-        keep the array itself alive for as long as such a pointer is in use, as with any NumPy buffer."""
+        """Output array: fresh pageable memory, or the next block of a ring of ``pinned_ring`` page-locked blocks.  A block is only
+        handed out again once its LEASE has ended (``_PinnedSlot``): every array handed out stays valid for as long as it — or any
+        view NumPy derives from it: ``j.reshape(-1)``, slices, a ``scipy.sparse.csr_array`` built on it, ``torch.from_numpy(j)``, a
+        ``memoryview(j)`` — is held (tests/test_gpu_parity.py covers these): reference semantics either way, like the reference's
+        fresh array per call (afb:561).  What a lease cannot see is a raw address taken from the array (``j.ctypes.data``, a pointer
+        handed to a C library or queued on a stream): keep the array itself alive for as long as such a pointer is in use."""
         if pinned_ring <= 0:
             return np.empty(shape)
-        ring = self._rings.setdefault((name, tuple(shape), pinned_ring), {"bufs": [], "count": 0})
+        ring = self._rings.setdefault((name, tuple(shape), pinned_ring), {"slots": [], "count": 0})
         idx = ring["count"] % pinned_ring
         ring["count"] += 1
-        if idx >= len(ring["bufs"]):
-            ring["bufs"].append(pinned_empty(shape))
-        elif _still_held(ring["bufs"], idx):
-            # Somebody still holds this buffer (or a view of it: `j.reshape(-1)`, a csr_array wrapping it — every view
-            # keeps its base alive, so the base's reference count says so): the reference hands out a fresh array per
-            # call (afb:561) and a kept Jacobian must never change under its owner.  The slot gets a new page-locked
-            # buffer; the old one lives on with its holder and is freed with it.
-            ring["bufs"][idx] = pinned_empty(shape)
-        return ring["bufs"][idx]
+        if idx >= len(ring["slots"]):
+            ring["slots"].append(_PinnedSlot(shape))
+        elif ring["slots"][idx].leased:
+            # Somebody still holds this block: a kept Jacobian must never change under its owner.  The slot gets a new page-locked
+            # block; the old one lives on with its holder and is freed with it.
+            ring["slots"][idx] = _PinnedSlot(shape)
+        return ring["slots"][idx].lease()
 
     def eval(self, param_str, want_resid: bool = True, want_jac: bool = True, pinned_ring: int = 0):
         """-> (resid (N,2) | None, jac (2N,P) | None), float64 NumPy."""
@@ -306,11 +311,18 @@ class Engine:
                                   _stream_arg(stream)))
 
     def lm_trial(self, buffers, stream=None):
-        """One whole LM trial (step, build at the trial string, decision with the termination rules, accept copy, read-back) in one
-        call; ``buffers`` = a filled ``_capi.LmBuffers`` (include/pcs_hip.h pcs_lm_buffers)."""
-        import ctypes
-
+        """One whole LM trial (step, build at the trial string, decision with the termination rules and the state flip, read-back) in
+        one call; ``buffers`` = a filled ``_capi.LmBuffers`` (include/pcs_hip.h pcs_lm_buffers)."""
         check(lib().pcs_lm_trial(self._h, ctypes.byref(buffers), _stream_arg(stream)))
+
+    def lm_trial_build(self, buffers, stream=None):
+        """First half of a trial: the damped step and the normal equations at the trial string (a sharded loop all-reduces the
+        trial state after this, on the same stream)."""
+        check(lib().pcs_lm_trial_build(self._h, ctypes.byref(buffers), _stream_arg(stream)))
+
+    def lm_trial_finish(self, buffers, stream=None):
+        """Second half: decision, termination rules, state flip (or copy, PCS_LM_FIXED_TRIAL_BUFFER), read-back."""
+        check(lib().pcs_lm_trial_finish(self._h, ctypes.byref(buffers), _stream_arg(stream)))
 
     # -- evaluation: device buffers -----------------------------------------------------------
     def eval_device(self, param_str, d_resid: int | None, d_jac: int | None, stream: int | None = None):
@@ -378,21 +390,38 @@ SPD_ALGORITHMS = {"auto": 0, "launches": 1, "one_launch": 2}   # include/pcs_hip
 
 
 def dense_spd_solve(device: int, n: int, d_S: int, ld: int, d_rhs: int, d_x: int, d_work: int, d_status: int, stream: int | None = None,
-                    algorithm: str = "auto"):
+                    algorithm: str = "auto", timeout_us: int | None = None):
     """S x = rhs on the device (raw float64 device addresses, the lower triangle of S becomes its Cholesky factor).
     ``algorithm``: 'one_launch' = the persistent kernel of csrc/ba_chol_persist.hpp, 'launches' = one launch per block column
     (csrc/ba_dense_chol.hpp), 'auto' = the first where it fits.  ``d_work``: ``dense_spd_work_len(n)`` doubles; status bit 1
-    (value 2): a pivot was not positive, bit 2 (value 4): the one-launch form gave up waiting.  ``stream=None`` queues on the
-    default stream."""
+    (value 2): a pivot was not positive, bit 2 (value 4): the one-launch form gave up waiting (``timeout_us`` per wait, default
+    250 000: the launch drains, S is partly overwritten — solve again from the original matrix with 'launches').  ``stream=None``
+    queues on the default stream."""
     s = c_void_p(0) if stream is None else _stream_arg(stream)
+    if timeout_us is not None:
+        check(lib().pcs_dense_spd_solve_opts(int(device), int(n), c_void_p(d_S), int(ld), c_void_p(d_rhs), c_void_p(d_x), c_void_p(d_work), c_void_p(d_status), s,
+                                             SPD_ALGORITHMS[algorithm], int(timeout_us)))
+        return
     check(lib().pcs_dense_spd_solve_algo(int(device), int(n), c_void_p(d_S), int(ld), c_void_p(d_rhs), c_void_p(d_x), c_void_p(d_work), c_void_p(d_status), s,
                                          SPD_ALGORITHMS[algorithm]))
 
 
-def schur_syrk(device: int, n_lead: int, n_trail: int, d_V: int, ldv: int, d_S: int, lds: int, d_u: int | None, d_rhs: int | None, stream: int | None = None):
-    """S -= V V' (lower triangle) and, with ``d_u``, rhs += V u on the device (csrc/ba_schur.hpp; raw float64 device addresses)."""
+def schur_syrk(device: int, n_lead: int, n_trail: int, d_V: int, ldv: int, d_S: int, lds: int, d_u: int | None, d_rhs: int | None, stream: int | None = None,
+               work: int | None = None, work_len: int = 0):
+    """S -= V V' (lower triangle) and, with ``d_u``, rhs += V u on the device (csrc/ba_schur.hpp; raw float64 device addresses).
+    ``work`` (a device buffer of ``schur_syrk_work_len`` doubles): the ordered form — the partial sums of the K split are subtracted
+    in a fixed order instead of meeting in atomics."""
     s = c_void_p(0) if stream is None else _stream_arg(stream)
+    if work:
+        check(lib().pcs_schur_syrk_ordered(int(device), int(n_lead), int(n_trail), c_void_p(d_V), int(ldv), c_void_p(d_S), int(lds), c_void_p(d_u or 0), c_void_p(d_rhs or 0),
+                                           c_void_p(work), int(work_len), s))
+        return
     check(lib().pcs_schur_syrk(int(device), int(n_lead), int(n_trail), c_void_p(d_V), int(ldv), c_void_p(d_S), int(lds), c_void_p(d_u or 0), c_void_p(d_rhs or 0), s))
+
+
+def schur_syrk_work_len(n_lead: int, n_trail: int) -> int:
+    """Doubles of the workspace ``schur_syrk(..., work=...)`` needs for the ordered (deterministic) product; 0 = not split."""
+    return int(lib().pcs_schur_syrk_work_len(int(n_lead), int(n_trail)))
 
 
 def schur_vtx(device: int, n_lead: int, n_trail: int, d_V: int, ldv: int, d_x: int, d_w: int, stream: int | None = None):

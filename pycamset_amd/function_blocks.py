@@ -91,7 +91,23 @@ class device_function_block(abstract_function_block):
     pasted into the chain's translation unit (pycamset_amd/chain_compiler.py) next to the built-in blocks and chained by the
     same rule S <- S . d out / d inp.  A first block must have ``num_out = 2`` (the pixel), neighbours must agree
     (``num_inp`` of a block = ``num_out`` of the next), the last block is a source.  As in the reference, blocks that share
-    one ``param_type`` OBJECT share one parameter group (afb:160-163)."""
+    one ``param_type`` OBJECT share one parameter group (afb:160-163).
+
+    A TEMPLATED source (round 5) — ``template = True`` on the LAST block, ``num_inp = 0`` — receives the detection's template point
+    as ``inp`` (three doubles), exactly like the reference's ``inp[:3] = t_data[int(datum[2])]`` (afb:138, afb:374-375, afb:582;
+    shipped example: ``template_points``, fbi:188-211): a per-image similarity or a board-flex model of the calibration target is
+    written like this::
+
+        class board_flex(device_function_block):            # out = [sx X + tx, sy Y + ty, Z + k (X^2 + Y^2)], one set per image
+            template = True
+            num_inp, num_out, array_memory = 0, 3, 0
+            params = param_type(key_type.PER_IMG, 5)
+            device_fun = "out[0] = params[0] * inp[0] + params[2]; out[1] = params[1] * inp[1] + params[3];" \
+                         " out[2] = inp[2] + params[4] * (inp[0] * inp[0] + inp[1] * inp[1]);"
+            device_jac = "for (int i = 0; i < 15; ++i) out[i] = 0.0; out[0] = inp[0]; out[2] = 1.0; out[6] = inp[1]; out[8] = 1.0;" \
+                         " out[14] = inp[0] * inp[0] + inp[1] * inp[1];"
+
+        op_fun = projection() + extrinsic3D() + rigidTform3d() + board_flex()     # loss_fn(param_str, template)"""
     device_fun: str = ""
     device_jac: str = ""
 

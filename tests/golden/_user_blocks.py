@@ -1,7 +1,7 @@
 """User-written function blocks on the REFERENCE's own ABC (TEST INFRASTRUCTURE, build container only).
 
 The reference's extension point is ``abstract_function_block`` (abstract_function_blocks.py:689-775): a user subclasses it,
-gives ``num_inp`` / ``num_out`` / ``params`` and the two numba bodies, and composes the block with ``+``.  These two blocks are
+gives ``num_inp`` / ``num_out`` / ``params`` and the two numba bodies, and composes the block with ``+``.  These blocks are
 written by this repo (they are not reference code) and exist to pin pycamset_amd's counterpart of that extension point —
 ``function_blocks.device_function_block``, whose bodies are HIP device code — to what the reference's own code generator
 makes of the same mathematics: ``make_golden.py --only round4`` imports this module from inside the temporary copy of the
@@ -86,3 +86,36 @@ class division_projection(abstract_function_block):
         output[8 + 5] = vx * iz
         output[8 + 6] = vy * iz
         output[8 + 7] = -(x * vx + y * vy) * iz
+
+
+# the reference declares its shipped blocks' bodies with this signature string (function_block_implementations.py:11); a templated
+# source written after the pattern of `template_points` (fbi:188-211) uses it too
+ftemplate = "void(float64[::1],float64[::1],float64[::1],float64[::1])"
+
+
+class board_flex(abstract_function_block):
+    """A TEMPLATED user source (round 5): the reference hands `template[key]` to whatever block sits last when that block says
+    ``template = True`` (afb:138, afb:374-375, afb:582).  One flex model of the calibration board per image, params =
+    [sx, sy, tx, ty, k]:  out = [sx X + tx, sy Y + ty, Z + k (X^2 + Y^2)]  with (X, Y, Z) the template point."""
+    template = True
+    num_inp = 0
+    num_out = 3
+    params = param_type(key_type.PER_IMG, 5)
+    array_memory = 0
+
+    @staticmethod
+    @njit(ftemplate, cache=True)
+    def compute_fun(params, inp, output, memory):
+        output[0] = params[0] * inp[0] + params[2]
+        output[1] = params[1] * inp[1] + params[3]
+        output[2] = inp[2] + params[4] * (inp[0] * inp[0] + inp[1] * inp[1])
+
+    @staticmethod
+    @njit(ftemplate, cache=True)
+    def compute_jac(params, inp, output, memory):
+        output[:15] = 0
+        output[0] = inp[0]
+        output[2] = 1
+        output[5 + 1] = inp[1]
+        output[5 + 3] = 1
+        output[10 + 4] = inp[0] * inp[0] + inp[1] * inp[1]

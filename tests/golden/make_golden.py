@@ -515,6 +515,10 @@ USER_CHAINS = {
     "user_cam_scale": ("projection", "cam_scale", "extrinsic3D", "template_points"),
     "user_division": ("division_projection", "extrinsic3D", "rigidTform3d", "free_point"),
 }
+USER_CHAINS_R5 = {
+    # round 5: a user block as a TEMPLATED source (template = True on the last block: it receives template[key], afb:374-375)
+    "user_board_flex": ("projection", "extrinsic3D", "rigidTform3d", "board_flex"),
+}
 
 
 def user_block_level(mods, ub, rig, names, seed=6):
@@ -539,7 +543,9 @@ def user_block_level(mods, ub, rig, names, seed=6):
             slabs.append(rig.poses)
         elif n == "free_point":
             slabs.append(rig.points)
-    template = rig.points if names[-1] == "template_points" else None
+        elif n == "board_flex":   # per image [sx, sy, tx, ty, k]: a board that is nearly rigid
+            slabs.append(np.concatenate([rng.uniform(0.97, 1.03, (rig.n_imgs, 2)), rng.normal(0.0, 2e-3, (rig.n_imgs, 2)), rng.normal(0.0, 0.5, (rig.n_imgs, 1))], axis=1))
+    template = rig.points if getattr(blocks[-1], "template", False) else None
     param_str = op.build_param_list(*slabs)
     unfixed = rng.random(param_str.shape[0]) > 0.3
     call = (lambda f: f(param_str, template)) if template is not None else (lambda f: f(param_str))
@@ -553,6 +559,18 @@ def user_block_level(mods, ub, rig, names, seed=6):
     out["data_masked"], out["indices_masked"], out["indptr_masked"] = np.array(d), np.array(c), np.array(rp)
     out["block_param_inds"] = np.array(op.get_block_param_inds(rig.detections, 1, unthreaded=True)).astype(np.int64)
     return out
+
+
+def round5_vectors(mods):
+    """A user block as a TEMPLATED source through the reference's generator (round-4 review, "what's missing" 1)."""
+    import importlib
+
+    ub = importlib.import_module("_user_blocks")
+    small = synthetic.tiny_rig(seed=35, n_cams=3, n_imgs=5, n_keys=8, visibility=0.85)
+    for tag, names in USER_CHAINS_R5.items():
+        res = user_block_level(mods, ub, small, names, seed=7)
+        np.savez_compressed(HERE / f"{tag}.npz", **res)
+        print(tag, "P", res["block_param_inds"].shape[1], "nnz", res["data_all"].shape, "max |resid|", float(np.max(np.abs(res["resid"]))))
 
 
 def round4_vectors(mods):
@@ -573,10 +591,14 @@ def main():
     import _refload
 
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", choices=["round1", "round2", "round3", "round4"], default=None, help="regenerate one group of fixtures only")
+    ap.add_argument("--only", choices=["round1", "round2", "round3", "round4", "round5"], default=None, help="regenerate one group of fixtures only")
     args = ap.parse_args()
     with _refload.reference_modules() as mods:
         ch, fb, th, sbh, fph, TargetDetection = mods.ch, mods.fb, mods.th, mods.sbh, mods.fph, mods.TargetDetection
+        if args.only in (None, "round5"):
+            round5_vectors(mods)
+        if args.only == "round5":
+            return
         if args.only in (None, "round4"):
             round4_vectors(mods)
         if args.only == "round4":

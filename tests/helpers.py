@@ -70,7 +70,7 @@ def describe(rep):
 
 
 def user_blocks(fb):
-    """The two user blocks of tests/golden/_user_blocks.py (written there on the reference's ABC) as device code."""
+    """The user blocks of tests/golden/_user_blocks.py (written there on the reference's ABC) as device code."""
 
     class cam_scale(fb.device_function_block):
         num_inp, num_out = 3, 3
@@ -98,4 +98,17 @@ def user_blocks(fb):
         const double vx = -2.0 * params[2] * params[4] * x * y * d2, vy = params[2] * (d - 2.0 * params[4] * y * y * d2);
         out[8 + 5] = vx * iz; out[8 + 6] = vy * iz; out[8 + 7] = -(x * vx + y * vy) * iz;"""
 
-    return {"cam_scale": cam_scale, "division_projection": division_projection}
+    class board_flex(fb.device_function_block):
+        # a TEMPLATED source: template = True on the last block -> `inp` is the detection's template point (afb:374-375)
+        template = True
+        num_inp, num_out, array_memory = 0, 3, 0
+        params = fb.param_type(fb.key_type.PER_IMG, 5)
+        device_fun = """out[0] = params[0] * inp[0] + params[2];
+        out[1] = params[1] * inp[1] + params[3];
+        out[2] = inp[2] + params[4] * (inp[0] * inp[0] + inp[1] * inp[1]);"""
+        device_jac = """for (int q = 0; q < 15; ++q) out[q] = 0.0;
+        out[0] = inp[0]; out[2] = 1.0;
+        out[5 + 1] = inp[1]; out[5 + 3] = 1.0;
+        out[10 + 4] = inp[0] * inp[0] + inp[1] * inp[1];"""
+
+    return {"cam_scale": cam_scale, "division_projection": division_projection, "board_flex": board_flex}

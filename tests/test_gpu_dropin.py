@@ -338,7 +338,7 @@ def test_blocked_normal_equations_and_schur_step(chain):
         d_ps = torch.from_numpy(ps).cuda()
         ne.build(d_ps, 0)
         torch.cuda.synchronize()
-        pk = ne.packed[0].cpu().numpy()
+        pk = ne.packed[0][: ne.n_packed].cpu().numpy()          # one more word behind it: the ranks' void votes
         A = pk[: nl * nl].reshape(nl, nl)
         B = pk[nl * nl: nl * nl + nl * nt].reshape(nl, nt)
         C = pk[nl * nl + nl * nt: nl * nl + nl * nt + nt * tb].reshape(-1, tb, tb)
@@ -373,6 +373,31 @@ def test_blocked_normal_equations_and_schur_step(chain):
             assert np.max(np.abs(x - x_ref)) <= 1e-8 * np.max(np.abs(x_ref)), (chain, lam_v, np.max(np.abs(x - x_ref)), np.max(np.abs(x_ref)))
             pred_ref = 0.5 * (lam_v * np.sum(d * x_ref * x_ref) - np.dot(g * mask, x_ref))
             assert abs(float(pred.item()) - pred_ref) <= 1e-8 * abs(pred_ref)
+        # deterministic mode: the blocked build and the whole step hold the same bits on every run, and the values of the atomics build
+        e.set_option("deterministic", 1)
+        lam = torch.full((1,), 1e-3, dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        runs = []
+        for _ in range(3):
+            ne.build(d_ps, 1)
+            torch.cuda.synchronize()
+            built = ne.packed[1][: ne.n_packed].cpu().numpy()      # before the step: the solve masks B in place (fixed rows / columns -> 0)
+            delta = ne.solve(1, lam, d_ps, d_trial)
+            torch.cuda.synchronize()
+            runs.append((built, delta.cpu().numpy().copy()))
+        assert all(np.array_equal(runs[0][0], r[0]) and np.array_equal(runs[0][1], r[1]) for r in runs[1:])
+        pk1 = runs[0][0]
+        nb_ = nl * nl + nl * nt + nt * tb
+        Hd1 = np.zeros((n, n))
+        Hd1[:nl, :nl] = np.triu(pk1[: nl * nl].reshape(nl, nl))
+        Hd1[:nl, nl:] = pk1[nl * nl: nl * nl + nl * nt].reshape(nl, nt)
+        C1 = pk1[nl * nl + nl * nt: nb_].reshape(-1, tb, tb)
+        for k in range(C1.shape[0]):
+            Hd1[nl + k * tb: nl + (k + 1) * tb, nl + k * tb: nl + (k + 1) * tb] = C1[k]
+        Hd1 = Hd1 + np.triu(Hd1, 1).T
+        assert np.max(np.abs(Hd1 - Hd) / scale) <= 1e-10
+        assert np.max(np.abs(pk1[nb_: nb_ + n] - g_ref)) <= 1e-10 * np.max(np.abs(g_ref)) and abs(pk1[nb_ + n] - c_ref) <= 1e-10 * c_ref
+        e.set_option("deterministic", 0)
         e.close()
 
 
@@ -459,6 +484,19 @@ def test_block_reduced_normal_equations_match_the_oracle_jacobian(chain, dtype):
             e.set_option("normal_imgkey_product", 0)
             H4, _, _ = e.normal_equations(ps)
             assert np.max(np.abs(H4 - H_ref) / np.where(scale > 0, scale, 1.0)) <= tol, name
+            e.set_option("normal_imgkey_product", 1)
+        # deterministic mode (round 5, csrc/ba_reduce.hpp): no sum in arrival order — the same matrix, and the same BITS on every build,
+        # for every table order (a scattered table is walked through sorted copies; "runs-of-7" repeats (camera, image) pairs)
+        e.set_option("deterministic", 1)
+        builds = [e.normal_equations(ps, symmetric=False) for _ in range(3)]
+        assert all(np.array_equal(builds[0][0], b[0]) and np.array_equal(builds[0][1], b[1]) and builds[0][2] == b[2] for b in builds[1:]), name
+        Hu8, g8, c8 = builds[0]
+        assert np.all(np.tril(Hu8, -1) == 0)
+        H8 = Hu8 + np.triu(Hu8, 1).T
+        assert np.max(np.abs(H8 - H_ref) / np.where(scale > 0, scale, 1.0)) <= tol, name
+        assert np.all(H8[H_ref == 0] == 0), "structural zeros stay zero"
+        assert np.max(np.abs(g8 - g_ref)) <= tol_r * np.max(np.abs(g_ref)) and abs(c8 - c_ref) <= tol_r * c_ref, name
+        e.set_option("deterministic", 0)
         e.close()
 
 
@@ -494,6 +532,108 @@ def test_device_lm_reaches_the_scipy_solution(chain):
     assert np.max(np.abs(op.jtjv(v) - Jc.T @ (Jc @ v))) <= 1e-9 * np.max(np.abs(Jc.T @ (Jc @ v)))
     L = op.as_linear_operator()
     assert L.shape == Jc.shape and np.max(np.abs(L @ v - Jc @ v)) <= 1e-9 * np.max(np.abs(Jc @ v))
+
+
+def _ring8_small_handler(chain="template"):
+    rig = synthetic.make_rig("ring-8-small", 8, 12, synthetic.charuco_points(9, 8.0), seed=21, visibility=0.8)
+    names = [f"cam_{i}" for i in range(rig.n_cams)]
+    cls = handlers.TemplateBundleHandler if chain == "template" else handlers.SelfBundleHandler
+    h = cls(DuckCamset(rig.n_cams), DuckTarget(rig.points), TargetDetection(names, rig.detections),
+            fixed_params={"cam_0": {"ext": rig.extr_true[0].copy()}}, options={"verbosity": 0})
+    bp = h.bundlePrimitive
+    parts = [rig.intr[bp.intr_unfixed].ravel(), rig.extr[bp.extr_unfixed].ravel(), rig.poses[bp.poses_unfixed].ravel()]
+    if chain == "self":
+        parts.append(rig.points.ravel()[bp.bdpt_unfixed])
+    return rig, h, np.concatenate(parts)
+
+
+def test_device_lm_repeats_a_void_trial_with_the_launch_per_column_solve():
+    """The recovery path of the one-launch dense solve inside the LM loop: with a 1 us time limit the persistent
+    Cholesky gives up in the first trial (status bit 2 -> stop code 9), the loop drains what it queued behind it, switches the
+    solver state to the launch-per-column form and repeats the trial — same message, same cost as a run that used that form from
+    the start, and the solver state says so afterwards."""
+    from pycamset_amd.device_solver import lm_solve
+    _, h, x0 = _ring8_small_handler()
+    ref = lm_solve(h, x0.copy(), max_iter=30)
+    eng = h.op_fun.engine
+    ne = next(iter(eng.__dict__["_blocked_solvers"].values()))
+    assert ne.spd_algorithm == "auto"
+    eng.set_option("spd_timeout_us", 1)
+    try:
+        res = lm_solve(h, x0.copy(), max_iter=30)
+    finally:
+        eng.set_option("spd_timeout_us", 250000)
+    assert ne.spd_algorithm == "launches"
+    assert res.message == ref.message and res.nit == ref.nit and res.nfev == ref.nfev, (res.message, ref.message, res.nfev, ref.nfev)
+    assert abs(res.cost - ref.cost) <= 1e-9 * ref.cost and np.max(np.abs(res.x - ref.x)) <= 1e-7 * np.max(np.abs(ref.x))
+    again = lm_solve(h, x0.copy(), max_iter=30)          # the next solve starts with the one-launch form again
+    assert ne.spd_algorithm == "auto" and abs(again.cost - ref.cost) <= 1e-9 * ref.cost
+    assert lm_solve(h, x0.copy(), max_iter=0).nfev == 1  # max_iter = 0: the start is evaluated and returned, no trial is queued
+
+
+@pytest.mark.parametrize("chain", ["template", "self"])
+def test_device_steered_loop_with_a_stream_ordered_collective(chain):
+    """The sharded form of the device-steered loop on ONE rank: ``reduce_fn.on_device`` (what RCCL is) makes lm_solve queue
+    pcs_lm_trial_build -> the collective on the solver's stream -> pcs_lm_trial_finish per trial, with the trial built into the
+    fixed buffer the collective was queued on and the ranks' void votes summed with the blocks.  The stand-in collective is an
+    in-stream operation that leaves the sum of ONE rank unchanged, so the solve must reproduce the single-GPU one — and it must never
+    synchronise with the host between build and decision (the calls are counted: one per trial + one for the start)."""
+    import torch
+    from pycamset_amd.device_solver import lm_solve
+    _, h, x0 = _ring8_small_handler(chain)
+    one = lm_solve(h, x0.copy(), max_iter=30)
+    calls = []
+
+    def in_stream_sum(t):
+        calls.append((t.data_ptr(), t.numel(), torch.cuda.current_stream().cuda_stream))
+        t.mul_(1.0)                                      # stream-ordered, like dist.all_reduce on the current stream
+        return t
+
+    in_stream_sum.on_device = True
+    res = lm_solve(h, x0.copy(), max_iter=30, reduce_fn=in_stream_sum)
+    assert res.message == one.message and res.nit == one.nit, (res.message, one.message)
+    assert abs(res.cost - one.cost) <= 1e-9 * one.cost and np.max(np.abs(res.x - one.x)) <= 1e-7 * np.max(np.abs(one.x))
+    eng = h.op_fun.engine
+    ne = [v for v in eng.__dict__["_blocked_solvers"].values() if v.reduce_fn is in_stream_sum][0]
+    # the start state goes into packed[0]; every trial's collective is queued on packed[1] (a fixed address), on the solver's stream
+    assert calls[0][0] == ne.packed[0].data_ptr() and {c[0] for c in calls[1:]} == {ne.packed[1].data_ptr()}
+    assert all(c[1] == ne.n_packed + 1 and c[2] == ne.stream.cuda_stream for c in calls)
+    assert res.nfev <= len(calls) <= res.nfev + 1        # one per evaluation (+ the speculative trial behind the end)
+
+
+def _config_handler(number, chain):
+    rig = synthetic.config_rig(number)
+    names = [f"cam_{i}" for i in range(rig.n_cams)]
+    cls = {"template": handlers.TemplateBundleHandler, "self": handlers.SelfBundleHandler, "free": handlers.FreePointBundleHandler}[chain]
+    h = cls(DuckCamset(rig.n_cams), DuckTarget(rig.points), TargetDetection(names, rig.detections),
+            fixed_params={"cam_0": {"ext": rig.extr_true[0].copy()}}, options={"verbosity": 0})
+    bp = h.bundlePrimitive
+    parts = [rig.intr[bp.intr_unfixed].ravel(), rig.extr[bp.extr_unfixed].ravel()]
+    if chain != "free":
+        parts.append(rig.poses[bp.poses_unfixed].ravel())
+    if chain != "template":
+        parts.append(rig.points.ravel()[bp.bdpt_unfixed])
+    return rig, h, np.concatenate(parts)
+
+
+@pytest.mark.parametrize("number,chain", [(3, "template"), (2, "template"), (1, "self"), (1, "free")])
+def test_deterministic_mode_repeats_a_solve_bit_for_bit(number, chain):
+    """with ``set_option('deterministic', 1)`` no sum of the solve is taken in arrival order — the run-boundary
+    flush of the normal equations goes through per-segment partials and an ordered second pass (csrc/ba_reduce.hpp), the K split of
+    S -= V V' through a workspace — so two solves of the same problem return the same BITS (the reference's path is deterministic
+    for a given thread count: afb:281-288, afb:356-387), and the same cost as the atomics build."""
+    from pycamset_amd.device_solver import lm_solve
+    _, h, x0 = _config_handler(number, chain)
+    plain = lm_solve(h, x0.copy(), max_iter=8)
+    eng = h.op_fun.engine
+    eng.set_option("deterministic", 1)
+    try:
+        a = lm_solve(h, x0.copy(), max_iter=8)
+        b = lm_solve(h, x0.copy(), max_iter=8)
+    finally:
+        eng.set_option("deterministic", 0)
+    assert np.array_equal(a.x, b.x) and np.array_equal(a.grad, b.grad) and a.cost == b.cost and a.history == b.history and (a.nit, a.nfev) == (b.nit, b.nfev)
+    assert abs(a.cost - plain.cost) <= 1e-8 * plain.cost and a.message == plain.message, (a.cost, plain.cost, a.message, plain.message)
 
 
 # ---- round 3: chains as data (pycamset_amd/chain_compiler.py + csrc/ba_generic.hpp) -------------------------------------
@@ -600,7 +740,7 @@ def test_generated_chain_options_counts_shared_groups_and_errors():
     assert r3.shape == (det.shape[0], 2)
 
 
-@pytest.mark.parametrize("tag", ["user_cam_scale", "user_division"])
+@pytest.mark.parametrize("tag", ["user_cam_scale", "user_division", "user_board_flex"])
 def test_user_blocks_match_the_reference_code_generator(golden_dir, tag):
     """The reference's extension point on the GPU (afb:689-775): chains with USER-written blocks — a per-camera isotropic scale
     between `projection` and `extrinsic3D`; a division-model projection REPLACING `projection` — evaluated by the reference's
@@ -614,7 +754,10 @@ def test_user_blocks_match_the_reference_code_generator(golden_dir, tag):
     op = fb.optimisation_function([ub[n]() if n in ub else getattr(fb, n)() for n in names])
     assert op.chain == "generated"
     det, ps = g["detections"], g["param_str"]
-    tm = (g["points"],) if names[-1] == "template_points" else ()
+    # template[key] goes to whatever block sits last when that block says template = True (afb:138, afb:374-375): the shipped
+    # template_points, or — round 5 — a user source (board_flex: one flex model of the board per image)
+    tm = (g["points"],) if op.templated else ()
+    assert op.templated == (names[-1] in ("template_points", "board_flex"))
     assert np.array_equal(op.build_param_list(*[g[f"slab_{i}"] for i in range(len(names))]), ps)
     r = op.make_full_loss_fn(det, 2)(ps, *tm)
     H.assert_resid_close(r, g["resid"].reshape(r.shape), det[:, 3:])
@@ -694,6 +837,47 @@ def test_generated_chain_products_and_device_lm_reach_the_scipy_solution(golden_
     assert res.cost <= ref.cost * (1 + 1e-3), (res.cost, ref.cost)
     assert abs(0.5 * np.sum(loss_fn(res.x) ** 2) - res.cost) <= 1e-9 * res.cost
     assert res.cost < 0.05 * res.history[0]
+
+
+def test_templated_user_source_through_the_device_lm(golden_dir):
+    """a user block as a TEMPLATED source through `lm_solve` (handlers.ChainProblem): the board-flex model of
+    tests/golden/_user_blocks.py — `projection + extrinsic3D + rigidTform3d + board_flex`, template[key] as the source's input —
+    ends where scipy.optimize.least_squares on the same closures ends, from a start off the truth; a block that says
+    template = True anywhere but last, or with inputs, is refused with the reason."""
+    from pycamset_amd import function_blocks as fb
+    from pycamset_amd.device_solver import lm_solve
+    ub = H.user_blocks(fb)
+    rig = synthetic.make_rig("flex-lm", 4, 10, synthetic.charuco_points(7, 8.0), seed=62, visibility=0.9)
+    det = rig.detections
+    rng = np.random.default_rng(6)
+    op = fb.projection() + fb.extrinsic3D() + fb.rigidTform3d() + ub["board_flex"]()
+    assert op.chain == "generated" and op.templated
+    flex = np.concatenate([rng.uniform(0.98, 1.02, (rig.n_imgs, 2)), rng.normal(0, 1e-3, (rig.n_imgs, 2)), rng.normal(0, 0.3, (rig.n_imgs, 1))], axis=1)
+    ps_true = op.build_param_list(rig.intr_true, rig.extr_true, rig.poses_true, flex)
+    uv = op.make_full_loss_fn(det, 1)(ps_true, rig.points) + det[:, 3:]
+    det = det.copy()
+    det[:, 3:] = uv + rng.normal(0, 0.3, uv.shape)
+    op = fb.projection() + fb.extrinsic3D() + fb.rigidTform3d() + ub["board_flex"]()
+    fix_ext = np.ones((rig.n_cams, 6), dtype=bool)
+    fix_ext[0] = False                                                   # gauge: camera 0 stays where it is
+    free_flex = np.zeros((rig.n_imgs, 5), dtype=bool)
+    free_flex[:, 4] = True                                               # the bend of every image is estimated; scale and shift are redundant with the pose
+    start = [rig.intr_true * (1 + 1e-3 * rng.standard_normal(rig.intr_true.shape)), rig.extr_true + 1e-3 * rng.standard_normal(rig.extr_true.shape),
+             rig.poses_true + 1e-3 * rng.standard_normal(rig.poses_true.shape), flex.copy()]
+    start[1][0] = rig.extr_true[0]
+    start[3][:, 4] = 0.0                                                 # a flat board as the first guess
+    prob = handlers.ChainProblem(op, det, start, template=rig.points, unfixed=[None, fix_ext, None, free_flex])
+    loss_fn, jac_fn = prob.make_loss_fun(), prob.make_loss_jac()
+    ref = least_squares(loss_fn, prob.x0.copy(), jac=jac_fn, x_scale="jac", max_nfev=40)
+    res = lm_solve(prob, prob.x0.copy(), max_iter=40)
+    assert res.history == sorted(res.history, reverse=True)
+    assert res.cost <= ref.cost * (1 + 1e-3), (res.cost, ref.cost)
+    assert abs(0.5 * np.sum(loss_fn(res.x) ** 2) - res.cost) <= 1e-9 * res.cost
+    assert res.cost < 0.05 * res.history[0]
+    k_est = prob.get_bundle_adjustment_inputs(res.x)[3][:, 4]
+    assert np.max(np.abs(k_est - flex[:, 4])) < 0.15, (k_est, flex[:, 4])            # the bends are recovered from a flat start
+    with pytest.raises(NotImplementedError, match="template = True"):
+        (fb.projection() + ub["board_flex"]() + fb.free_point()).chain
 
 
 def test_generated_kernel_for_the_template_chain_against_the_hand_fused_one(capsys):
@@ -833,6 +1017,39 @@ def test_dense_spd_solve_against_numpy(n, algorithm):
         assert int(status.item()) == 0 and np.max(np.abs(d_x.cpu().numpy() - x_ref)) <= tol * np.max(np.abs(x_ref))
 
 
+@pytest.mark.parametrize("n", [480, 1680])
+def test_one_launch_spd_solve_gives_up_and_drains(n):
+    """The persistent Cholesky's escape hatch (csrc/ba_chol_persist.hpp "Safety"): with a time limit of 1 us per wait — no hand-over
+    between workgroups is that fast — a workgroup abandons the launch, bit 2 of the status is set, EVERY workgroup leaves at its next
+    wait (the call returns: the grid has drained), and the same workspace then solves the system with the default limit."""
+    import torch
+    from pycamset_amd.engine import dense_spd_solve, dense_spd_work_len
+    rng = np.random.default_rng(n)
+    G = rng.standard_normal((n, n + 5))
+    S = G @ G.T + 1e-3 * np.eye(n)
+    rhs = rng.standard_normal(n)
+    x_ref = np.linalg.solve(S, rhs)
+    d_rhs, d_x = torch.from_numpy(rhs).cuda(), torch.empty(n, dtype=torch.float64, device="cuda")
+    work = torch.empty(dense_spd_work_len(n), dtype=torch.float64, device="cuda")
+    status = torch.zeros(1, dtype=torch.int32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    dS = torch.from_numpy(np.tril(S)).cuda()
+    dense_spd_solve(0, n, dS.data_ptr(), n, d_rhs.data_ptr(), d_x.data_ptr(), work.data_ptr(), status.data_ptr(), stream, algorithm="one_launch", timeout_us=1)
+    torch.cuda.synchronize()                                               # returns: no workgroup is left spinning
+    assert int(status.item()) & 4, int(status.item())
+    status.zero_()
+    dS = torch.from_numpy(np.tril(S)).cuda()                               # the abandoned launch has overwritten part of the triangle
+    dense_spd_solve(0, n, dS.data_ptr(), n, d_rhs.data_ptr(), d_x.data_ptr(), work.data_ptr(), status.data_ptr(), stream, algorithm="one_launch")
+    torch.cuda.synchronize()
+    assert int(status.item()) == 0
+    import scipy.linalg as sla
+    x_lapack = sla.cho_solve(sla.cho_factor(S, lower=True), rhs)
+    tol = max(1e-9, 20 * np.max(np.abs(x_lapack - x_ref)) / np.max(np.abs(x_ref)))
+    assert np.max(np.abs(d_x.cpu().numpy() - x_ref)) <= tol * np.max(np.abs(x_ref))
+    with pytest.raises(Exception):
+        dense_spd_solve(0, n, dS.data_ptr(), n, d_rhs.data_ptr(), d_x.data_ptr(), work.data_ptr(), status.data_ptr(), stream, timeout_us=0)
+
+
 @pytest.mark.parametrize("n_lead,n_trail", [(480, 1200), (45, 18), (100, 7), (180, 20001), (33, 64), (1, 3), (1100, 257), (1680, 1458)])
 def test_schur_syrk_and_vtx_against_numpy(n_lead, n_trail):
     """csrc/ba_schur.hpp: S -= V V' on the lower triangle (the upper one must stay as it was), rhs += V u and w = V' x against
@@ -861,6 +1078,20 @@ def test_schur_syrk_and_vtx_against_numpy(n_lead, n_trail):
     assert np.array_equal(got[up], S0[up])
     assert np.max(np.abs(drhs.cpu().numpy() - (rhs0 + Vr @ u))) <= 1e-12 * (1.0 + np.max(np.abs(Vr @ u)))
     assert np.max(np.abs(dw.cpu().numpy() - Vr.T @ x)) <= 1e-12 * (1.0 + np.max(np.abs(Vr.T @ x)))
+    # the ORDERED form (engine option "deterministic"): the partial products of the K split go through a workspace and are subtracted
+    # split by split — same values, and the same BITS every time
+    from pycamset_amd.engine import schur_syrk_work_len
+    wl = schur_syrk_work_len(n_lead, n_trail)
+    work = torch.empty(max(1, wl), dtype=torch.float64, device="cuda")
+    outs = []
+    for _ in range(3):
+        dS2, drhs2 = torch.from_numpy(S0.copy()).cuda(), torch.from_numpy(rhs0.copy()).cuda()
+        schur_syrk(0, n_lead, n_trail, dV.data_ptr(), ldv, dS2.data_ptr(), n_lead, du.data_ptr(), drhs2.data_ptr(), stream, work=work.data_ptr(), work_len=wl)
+        torch.cuda.synchronize()
+        outs.append((dS2.cpu().numpy(), drhs2.cpu().numpy()))
+    assert all(np.array_equal(outs[0][0], o[0]) and np.array_equal(outs[0][1], o[1]) for o in outs[1:])
+    assert np.max(np.abs(outs[0][0][lo] - ref[lo]) / scale[lo]) <= 1e-13 and np.array_equal(outs[0][0][up], S0[up])
+    assert np.max(np.abs(outs[0][1] - (rhs0 + Vr @ u))) <= 1e-12 * (1.0 + np.max(np.abs(Vr @ u)))
 
 
 def test_free_point_chain_with_2e4_points_solves_through_the_schur_path():

@@ -518,6 +518,26 @@ def test_pinned_output_ring(Engine):
         again.append(jn.ctypes.data)
         del jn
     assert len(set(again[2:])) <= 2
+    # holders that are not NumPy arrays keep the lease too (round 5: leases, not reference counts): a torch tensor sharing the
+    # memory, a memoryview, a csr_array built on a reshape
+    import torch
+    from scipy.sparse import csr_array as _csr
+    j1 = e.eval(ps, pinned_ring=2)[1]
+    a1, t1 = j1.ctypes.data, torch.from_numpy(j1)
+    j2 = e.eval(ps, pinned_ring=2)[1]
+    a2, m2 = j2.ctypes.data, memoryview(j2)
+    j3 = e.eval(ps, pinned_ring=2)[1]
+    a3 = j3.ctypes.data
+    c3 = _csr((j3.reshape(-1)[:6], np.arange(6) % 3, np.array([0, 3, 6])), shape=(2, 3))
+    del j1, j2, j3
+    held = []
+    for _ in range(5):
+        jn = e.eval(ps * 1.002, pinned_ring=2)[1]
+        held.append(jn.ctypes.data)
+        del jn
+    assert not ({a1, a2, a3} & set(held))
+    assert np.array_equal(t1.numpy(), j0) and np.array_equal(np.asarray(m2), j0) and np.array_equal(c3.data, j0.reshape(-1)[:6])
+    del t1, m2, c3
     # the compacted data array goes through the same ring
     nnz = e.set_unfixed(np.arange(ps.shape[0]) % 3 != 0)
     _, d0 = e.eval_compact(ps)

@@ -124,6 +124,19 @@ def _worker(rank, world, port, out_dir, backend="gloo"):
         assert abs(chol.cost - one.cost) <= 1e-5 * one.cost, (chol.cost, one.cost)
         dist.all_gather_object(gathered, chol.x)
         assert all(np.array_equal(gathered[0], g) for g in gathered)
+        # ONE rank's one-launch dense solve gives up (1 us time limit on rank 1 only): the verdict travels with the all-reduced blocks,
+        # so EVERY rank voids that trial, switches to the launch-per-column solve and repeats it — nobody adopts a garbage step and
+        # nobody is left alone in a collective (the retry used to be decided per rank)
+        eng_shard = h_shard.op_fun._engine_for(h_shard._flat_detections())
+        if rank == 1:
+            eng_shard.set_option("spd_timeout_us", 1)
+        void = lm_solve(h_shard, x0.copy(), max_iter=20, reduce_fn=mat_reduce, linear_solver="cholesky")
+        eng_shard.set_option("spd_timeout_us", 250000)
+        ne_shard = next(iter(eng_shard.__dict__["_blocked_solvers"].values()))
+        assert ne_shard.spd_algorithm == "launches", (rank, ne_shard.spd_algorithm)
+        assert abs(void.cost - chol.cost) <= 1e-9 * chol.cost and (void.nit, void.nfev) == (chol.nit, chol.nfev), (void.cost, chol.cost, void.nfev, chol.nfev)
+        dist.all_gather_object(gathered, void.x)
+        assert all(np.array_equal(gathered[0], g) for g in gathered)
 
         # (4) self-calibration sharded: the global feature-visibility mask keeps the x layout identical
         vis = np.isin(np.arange(rig.n_keys), det[:, 2])

@@ -171,7 +171,7 @@ def _worker_normal_eq(rank, world, port, out_dir):
 
         # block-reduced form: every rank's (J^T J, J^T r, cost) packed into ONE all-reduce, both flavours of reduce_fn
         import torch
-        from pycamset_amd.device_solver import reduce_normal_equations, schur_cholesky_step, cholesky_step, trailing_block_structure
+        from tools.library_solver import reduce_normal_equations, schur_cholesky_step, cholesky_step, trailing_block_structure
         free = np.flatnonzero(mask)
         Jm, Jf = op.eng.J[:, free], full.eng.J[:, free]
         H_full, g_full, c_full = (Jf.T @ Jf).toarray(), Jf.T @ full.eng.r, float(full.eng.r @ full.eng.r)
@@ -255,7 +255,7 @@ def test_bench_launches_its_own_ranks(capfd):
     rc, out, err = _capture_self_launch(capfd, 3, ["--gpus", "3", "--steps", "5"])
     assert rc == 0, err
     lines = [ln for ln in out.splitlines() if ln.strip()]
-    assert len(lines) == 1, out
+    assert len(lines) == 1, (out, err[-3000:])
     line = json.loads(lines[0])
     assert line["n_gpus"] == 3 and line["sum"] == 6.0 and line["argv"] == ["--gpus", "3", "--steps", "5"]
     assert "noise from rank 0" in err and "noise from rank 2" in err

@@ -16,6 +16,7 @@ from pycamset_amd import handlers, synthetic
 from pycamset_amd.detections import TargetDetection
 from pycamset_amd.device_solver import BlockedNormalEquations, lm_solve
 from pycamset_amd.engine import schur_syrk, schur_vtx
+from tools.library_solver import library_schur_solve
 
 
 class _Camset:
@@ -91,9 +92,7 @@ def main():
         g, w = timed(fn)
         print(f"  {name:34s} {g:9.1f} | {w:9.1f}")
     ne.build(ps, 0)
-    ne.dense_solver = "rocsolver"          # leaves ne.S = the reduced matrix (the HIP solver factors it in place)
-    ne.solve(0, lam)
-    ne.dense_solver = "hip"
+    library_schur_solve(ne, 0, lam)        # leaves ne.S = the reduced matrix (the HIP solver factors it in place)
     S0 = ne.S.clone()
     S0 = torch.tril(S0) + torch.tril(S0, -1).T
     g, w = timed(lambda: torch.linalg.cholesky_ex(S0))
@@ -119,11 +118,9 @@ def main():
     print(f"  {'pcs_dense_spd_solve (HIP)':34s} {g - g0:9.1f} | {w:9.1f}   (incl. a {g0:.1f} us copy of S in the host figure)")
     err = float((ne.xl - xl).abs().max() / xl.abs().max())
     print(f"  HIP solve vs rocSOLVER solution: max rel diff {err:.2e}")
-    for ds in ("hip", "rocsolver"):
-        ne.dense_solver = ds
-        g, w = timed(lambda: ne.solve(0, lam))
+    for ds, fn in (("hip", lambda: ne.solve(0, lam)), ("rocsolver", lambda: library_schur_solve(ne, 0, lam))):
+        g, w = timed(fn)
         print(f"  {'solve() as a whole, ' + ds:34s} {g:9.1f} | {w:9.1f}")
-    ne.dense_solver = "hip"
     # one trial of the loop, section by section (host wall with a synchronize after each section)
     def wall(fn, reps=10):
         fn(); torch.cuda.synchronize()
@@ -133,7 +130,7 @@ def main():
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / reps * 1e6
     ps_new = torch.empty_like(ps)
-    stats = torch.zeros(8, dtype=torch.float64, device="cuda")
+    stats = torch.zeros(12, dtype=torch.float64, device="cuda")
     ne.build(ps, 1)
 
     def decide():
