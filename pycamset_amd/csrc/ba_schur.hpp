@@ -42,6 +42,7 @@ struct SchurArgs {
     uint64_t *fill;             // optional (schur_trail_lead_kernel): fill_n words to set to all-ones — the hand-over workspace of the one-launch
     int64_t fill_n;             // Cholesky that follows in the same trial (ba_chol_persist.hpp), instead of a memset launch of its own
     int32_t trail_blocks;       // schur_trail_lead_kernel: the first trail_blocks workgroups take the trailing entities
+    int32_t ent_chunks;         // schur_prep_kernel (ba_lm_fused.hpp): its first trail_blocks workgroups = ent_chunks entity chunks x row blocks of V
     // Round 5: an LM loop keeps TWO packed states and a device word that says which one is current (lm_decide_kernel flips it when a
     // trial is accepted — no copy).  A, B, C, g above are the regions of state 0; when *sel != 0 they are `alt` doubles further on.
     const int32_t *sel;
@@ -56,11 +57,10 @@ __device__ __forceinline__ SchurArgs schur_current(SchurArgs a) {
 // (pcs_lm_trial), and lm_decide_kernel raises the flag when the loop is over — what was queued behind it then drains as no-ops.
 #define PCS_STOP_GUARD(a) do { if ((a).stop && *(a).stop) return; } while (0)
 
-// One lane = one trailing entity (workgroup `block` of the trailing part of schur_trail_lead_kernel).
+// Entity e: C_e + lambda D_e = L L', L^-T -> `linvt_out` (TB x TB, row-major; global memory or LDS), and — when `publish` — the entity's
+// part of dvec / gm / u and the status bit (the fused kernel factors an entity once per block of leading rows and publishes once).
 template <int TB>
-__device__ __forceinline__ void schur_trail_body(const SchurArgs &a, const int block) {
-    const int64_t e = (int64_t)block * blockDim.x + threadIdx.x;
-    if (e >= a.n_ent) return;
+__device__ __forceinline__ void schur_trail_entity(const SchurArgs &a, const int64_t e, double *linvt_out, const bool publish) {
     const double lam = *a.lambda;
     const double *Ce = a.C + e * TB * TB;
     const int64_t col0 = a.trail_off + e * TB;
@@ -83,8 +83,10 @@ __device__ __forceinline__ void schur_trail_body(const SchurArgs &a, const int b
 #pragma unroll
     for (int i = 0; i < TB; ++i) {
         const double d = fx[i] ? 0.0 : fmax(M[i][i], 1e-300);
-        a.dvec[col0 + i] = d;
-        a.gm[col0 + i] = gv[i];
+        if (publish) {
+            a.dvec[col0 + i] = d;
+            a.gm[col0 + i] = gv[i];
+        }
         M[i][i] += lam * d;
     }
     // Cholesky M = L L' (lower triangle of M becomes L).  1 / sqrt(s) from the hardware estimate + one third-order step (full double
@@ -114,7 +116,7 @@ __device__ __forceinline__ void schur_trail_body(const SchurArgs &a, const int b
             M[i][j] = t * il;
         }
     }
-    if (!ok) atomicOr(a.status, 1);
+    if (!ok && publish) atomicOr(a.status, 1);
     // Linv = L^-1 (lower), column by column; u = Linv g
     double Li[TB][TB];
 #pragma unroll
@@ -132,13 +134,18 @@ __device__ __forceinline__ void schur_trail_body(const SchurArgs &a, const int b
         double t = 0.0;
 #pragma unroll
         for (int k = 0; k <= i; ++k) t += Li[i][k] * gv[k];
-        a.u[e * TB + i] = t;
+        if (publish) a.u[e * TB + i] = t;
     }
-    double *out = a.linvt + e * TB * TB;   // L^-T[i][j] = Linv[j][i]
 #pragma unroll
-    for (int i = 0; i < TB; ++i)
+    for (int i = 0; i < TB; ++i)   // L^-T[i][j] = Linv[j][i]
 #pragma unroll
-        for (int j = 0; j < TB; ++j) out[i * TB + j] = Li[j][i];
+        for (int j = 0; j < TB; ++j) linvt_out[i * TB + j] = Li[j][i];
+}
+// One lane = one trailing entity (workgroup `block` of the trailing part of schur_trail_lead_kernel).
+template <int TB>
+__device__ __forceinline__ void schur_trail_body(const SchurArgs &a, const int block) {
+    const int64_t e = (int64_t)block * blockDim.x + threadIdx.x;
+    if (e < a.n_ent) schur_trail_entity<TB>(a, e, a.linvt + e * TB * TB, true);
 }
 
 // One lane = one tb-chunk of one leading row: V[r, e, :] = b L_e^-T with b = the masked B[r, e, :].

@@ -28,6 +28,7 @@
 #include "ba_normal.hpp"
 #include "ba_reduce.hpp"
 #include "ba_schur.hpp"
+#include "ba_lm_fused.hpp"
 #include "ba_dense_chol.hpp"
 #include "ba_chol_persist.hpp"
 #include "ba_triangulate.hpp"
@@ -159,6 +160,7 @@ struct pcs_engine {
     // geometry fix (csrc/ba_reduce.hpp) instead of with f64 atomics in arrival order: two runs — and the ranks of a sharded loop — compute
     // the same bits
     int deterministic = 0;
+    int fused_trial = 1;   // option: pcs_lm_trial_build uses schur_prep_kernel / schur_finish_kernel (csrc/ba_lm_fused.hpp); 0 = the separate launches (A/B)
     // host copies of the visiting orders (shared pass of a scattered table, (cam, key) pass): the deterministic mode's tables are built from them
     std::vector<int32_t> h_order, h_order_ck;
     // static tables + workspaces of the ordered second pass, per MFMA pass (0 shared, 1 (cam, key)); built at the first deterministic
@@ -858,6 +860,8 @@ int pcs_set_option(pcs_engine *h, const char *key, int64_t value) {
         h->ev_ring = value;
         h->ev_count = 0;
         h->events_valid = false;
+    } else if (!strcmp(key, "fused_trial")) {
+        h->fused_trial = value != 0;
     } else if (!strcmp(key, "deterministic")) {
         if (value < 0 || value > 1) return fail(PCS_ERR_ARG, "deterministic must be 0 or 1");
         h->deterministic = (int)value;
@@ -1276,7 +1280,7 @@ static BlockLayout block_layout(const pcs_engine *h) {
 // d_sel (LM loop with two states, ba_schur.hpp SchurArgs::sel): when *d_sel != 0 the string is read alt_prm doubles and the outputs are written
 // alt_out doubles further on.
 static int enqueue_normal(pcs_engine *h, const double *d_prm, double *d_H, double *d_g, double *d_cost, hipStream_t s, bool blocked = false, const int32_t *d_stop = nullptr,
-                          const int32_t *d_sel = nullptr, int64_t alt_prm = 0, int64_t alt_out = 0) {
+                          const int32_t *d_sel = nullptr, int64_t alt_prm = 0, int64_t alt_out = 0, bool skip_prologue = false) {
     if (h->n <= 0) return fail(PCS_ERR_STATE, "no detections set");
     if (h->n > INT32_MAX) return fail(PCS_ERR_ARG, "normal equations: tables beyond 2^31 rows are not supported (visiting orders are int32)");
     if (h->chain == PCS_CHAIN_TEMPLATE && !h->have_template) return fail(PCS_ERR_STATE, "template points not set");
@@ -1294,7 +1298,10 @@ static int enqueue_normal(pcs_engine *h, const double *d_prm, double *d_H, doubl
     int rc0 = ensure_point_orders(h);
     if (rc0) return rc0;
     if ((d_stop || d_sel) && (reinterpret_cast<uintptr_t>(d_H) % 16 || alt_out % 2)) return fail(PCS_ERR_ARG, "normal equations behind a stop flag / state selector need 16-byte aligned buffers");
-    if (reinterpret_cast<uintptr_t>(d_H) % 16 == 0) {   // slab_prep and the zeroing of the outputs in one launch
+    if (skip_prologue) {   // the caller's previous kernel has prepared the slabs and zeroed the outputs (schur_finish_kernel, csrc/ba_lm_fused.hpp)
+        HIPCHK(order_after_done(h, s));
+        h->linearized = true;
+    } else if (reinterpret_cast<uintptr_t>(d_H) % 16 == 0) {   // slab_prep and the zeroing of the outputs in one launch
         HIPCHK(order_after_done(h, s));
         const int has_pose = h->chain != PCS_CHAIN_FREE, copy_points = h->chain != PCS_CHAIN_TEMPLATE;
         int64_t threads = slab_prep_threads(h->n_cams, h->n_imgs, has_pose);
@@ -2123,6 +2130,61 @@ static int enqueue_dense_spd(int device, int64_t n, double *d_S, int64_t ld, con
     return PCS_OK;
 }
 
+// The fused forms of the trial's small kernels (csrc/ba_lm_fused.hpp).
+static int enqueue_schur_prep_fused(pcs_engine *h, const pcs_lm_buffers *b, hipStream_t s, const int32_t *d_stop, const int32_t *d_sel, int64_t alt,
+                                    double *d_fill, int64_t fill_n) {
+    const BlockLayout L = block_layout(h);
+    SchurArgs a{};
+    a.sel = d_sel; a.alt = alt;
+    a.fill = reinterpret_cast<uint64_t *>(d_fill); a.fill_n = d_fill ? fill_n : 0;
+    a.A = b->packed[0]; a.B = a.A + L.a_len(); a.C = a.B + L.b_len(); a.g = a.C + L.c_len();
+    a.fixed = b->fixed; a.lambda = b->lambda;
+    a.linvt = b->linvt; a.u = b->u; a.V = b->V; a.S = b->S; a.rhs = b->rhs; a.dvec = b->dvec; a.gm = b->gm; a.status = b->status;
+    a.n_lead = L.n_lead; a.n_trail = L.n_trail; a.n_ent = L.n_ent; a.trail_off = L.trail_off;
+    a.stop = d_stop;
+    const int epb = prep_epb(L.tb);
+    const int64_t ent_chunks = (L.n_ent + epb - 1) / epb, row_chunks = std::max<int64_t>(1, (L.n_lead + PREP_RPB - 1) / PREP_RPB);
+    const int64_t nbt = (L.n_lead + 31) / 32;
+    a.ent_chunks = (int32_t)ent_chunks;
+    a.trail_blocks = (int32_t)(ent_chunks * row_chunks);
+    const int64_t grid = ent_chunks * row_chunks + nbt * nbt;
+    if (grid <= 0) return PCS_OK;
+    if (grid > INT32_MAX) return fail(PCS_ERR_ARG, "pcs_lm_trial_build: the system is too large for one launch of the Schur preparation");
+    if (L.tb == 6) hipLaunchKernelGGL(schur_prep_kernel<6>, dim3((unsigned)grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(schur_prep_kernel<3>, dim3((unsigned)grid), dim3(256), 0, s, a);
+    HIPCHK(hipGetLastError());
+    return PCS_OK;
+}
+
+static int enqueue_schur_finish_fused(pcs_engine *h, const pcs_lm_buffers *b, hipStream_t s, const int32_t *d_stop, const int32_t *d_sel, int64_t alt_pk,
+                                      int64_t n_packed) {
+    const BlockLayout L = block_layout(h);
+    SchurFinishArgs a{};
+    a.V = b->V; a.xl = b->xlead; a.n_lead = (int32_t)L.n_lead; a.n_trail = (int32_t)L.n_trail; a.ldv = (int32_t)std::max<int64_t>(1, L.n_trail);
+    a.linvt = b->linvt; a.u = b->u; a.fixed = b->fixed; a.delta = b->delta; a.ps_in = b->ps[0]; a.ps_out = b->ps[1];
+    a.n_ent = L.n_ent; a.trail_off = L.trail_off;
+    a.stop = d_stop; a.sel = d_sel;
+    a.vote = (b->mode & PCS_LM_VOTES) ? b->packed[1] + n_packed : nullptr; a.vote_alt = -alt_pk; a.status = b->status;
+    a.cam_slab = (double *)h->d_cam_slab; a.pose_slab = (double *)h->d_pose_slab; a.points = (double *)h->d_points;
+    a.n_cams = (int32_t)h->n_cams; a.n_imgs = (int32_t)h->n_imgs; a.n_keys = (int32_t)h->n_keys;
+    a.has_pose = h->chain != PCS_CHAIN_FREE; a.copy_points = h->chain != PCS_CHAIN_TEMPLATE;
+    a.extr_off = h->extr_off; a.pose_off = h->pose_off; a.point_off = h->point_off;
+    a.Hm = b->packed[1]; a.n_h = L.a_len() + L.b_len() + L.c_len(); a.g = a.Hm + a.n_h; a.n_g = h->n_params; a.cost = a.g + h->n_params; a.alt_out = -alt_pk;
+    const int ecb = finish_ecb(L.tb);
+    const int64_t w_blocks = (L.n_ent + ecb - 1) / ecb;
+    const bool lead_poses = a.has_pose && h->pose_off < L.trail_off;
+    const int64_t lead_threads = std::max<int64_t>(L.n_lead, (int64_t)h->n_cams * CAM_STRIDE + (lead_poses ? (int64_t)h->n_imgs * POSE_STRIDE : 0));
+    const int64_t lead_blocks = std::max<int64_t>(1, (lead_threads + 1023) / 1024);
+    const int64_t zero_blocks = std::min<int64_t>((a.n_h / 2 + 1023) / 1024 + 1, (int64_t)h->n_cu * 4);
+    a.w_blocks = (int32_t)w_blocks; a.lead_blocks = (int32_t)lead_blocks;
+    const int64_t grid = w_blocks + lead_blocks + zero_blocks;
+    if (grid > INT32_MAX) return fail(PCS_ERR_ARG, "pcs_lm_trial_build: the system is too large for one launch of the step's completion");
+    if (L.tb == 6) hipLaunchKernelGGL(schur_finish_kernel<6>, dim3((unsigned)grid), dim3(1024), 0, s, a);
+    else hipLaunchKernelGGL(schur_finish_kernel<3>, dim3((unsigned)grid), dim3(1024), 0, s, a);
+    HIPCHK(hipGetLastError());
+    return PCS_OK;
+}
+
 // One whole Levenberg-Marquardt trial in two halves (round 5; pcs_lm_trial = both): BUILD = the damped Schur step from the current state at
 // *lambda (+ the trial parameter string) and the normal equations at the trial string into the other state's packed buffer; FINISH = the
 // decision INCLUDING the loop's termination rules, the state flip of an accepted trial and the read-back of the twelve numbers the host
@@ -2147,8 +2209,12 @@ int pcs_lm_trial_build(pcs_engine *h, const pcs_lm_buffers *b, void *stream) {
     const int64_t alt_pk = b->packed[1] - b->packed[0], alt_ps = b->ps[1] - b->ps[0];   // doubles from state 0 to state 1
     // the one-launch Cholesky wants its hand-over workspace at the fill value: schur_trail_lead_kernel sets it on the way (one launch fewer)
     const bool prefill = L.n_lead > 0 && dense_spd_is_one_launch(h->device, L.n_lead, b->spd_algorithm);
-    rc = enqueue_schur_prepare(h, b->packed[0], b->fixed, b->lambda, b->linvt, b->u, b->V, b->S, b->rhs, b->dvec, b->gm, b->status, s, stop,
-                               prefill ? b->spd_work : nullptr, prefill ? cp_work_doubles((L.n_lead + 31) / 32) : 0, sel, alt_pk);
+    // fused: the two launches in front of the matrix products as one, the three behind the dense solve as one (csrc/ba_lm_fused.hpp); they
+    // need every trailing entity to have leading rows to ride on and the normal equations' prologue to be theirs to replace
+    const bool fused = h->fused_trial && L.n_lead > 0 && L.n_ent > 0 && h->n > 0;
+    if (fused) rc = enqueue_schur_prep_fused(h, b, s, stop, sel, alt_pk, prefill ? b->spd_work : nullptr, prefill ? cp_work_doubles((L.n_lead + 31) / 32) : 0);
+    else rc = enqueue_schur_prepare(h, b->packed[0], b->fixed, b->lambda, b->linvt, b->u, b->V, b->S, b->rhs, b->dvec, b->gm, b->status, s, stop,
+                                    prefill ? b->spd_work : nullptr, prefill ? cp_work_doubles((L.n_lead + 31) / 32) : 0, sel, alt_pk);
     if (rc) return rc;
     const int64_t ldv = std::max<int64_t>(1, L.n_trail);
     if (L.n_trail > 0 && L.n_lead > 0) {
@@ -2157,17 +2223,24 @@ int pcs_lm_trial_build(pcs_engine *h, const pcs_lm_buffers *b, void *stream) {
         rc = enqueue_schur_syrk(L.n_lead, L.n_trail, b->V, ldv, b->S, L.n_lead, b->u, b->rhs, s, stop, h->deterministic ? b->syrk_work : nullptr, b->syrk_work_len);
         if (rc) return rc;
     }
+    const int64_t n_packed = L.a_len() + L.b_len() + L.c_len() + h->n_params + 1;
     const double *w = b->u;
     if (L.n_lead > 0) {
         rc = enqueue_dense_spd(h->device, L.n_lead, b->S, L.n_lead, b->rhs, b->xlead, b->spd_work, b->status, s, b->spd_algorithm, stop, prefill, h->spd_timeout_us);
         if (rc) return rc;
-        if (L.n_trail > 0) {
+        if (L.n_trail > 0 && !fused) {
             launch_schur_vtx(b->V, b->xlead, b->w, (int)L.n_lead, (int)L.n_trail, (int)ldv, stop, s);
             HIPCHK(hipGetLastError());
             w = b->w;
         }
     }
-    const int64_t n_packed = L.a_len() + L.b_len() + L.c_len() + h->n_params + 1;
+    double *g_new = b->packed[1] + L.a_len() + L.b_len() + L.c_len();
+    if (fused) {
+        // w = V' x_l, the back substitution, the step, the trial string, this rank's vote, the slabs at the trial string and the zeroed trial state
+        rc = enqueue_schur_finish_fused(h, b, s, stop, sel, alt_pk, n_packed);
+        if (rc) return rc;
+        return enqueue_normal(h, b->ps[1], b->packed[1], g_new, g_new + h->n_params, s, true, stop, sel, -alt_ps, -alt_pk, true);
+    }
     // the step, the trial string (ps[1] while state 0 is current) and this rank's vote behind the TRIAL state's packed buffer
     rc = enqueue_schur_finish(h, b->linvt, b->u, w, b->xlead, b->fixed, b->delta, b->ps[0], b->ps[1], s, stop, sel,
                               (b->mode & PCS_LM_VOTES) ? b->packed[1] + n_packed : nullptr, -alt_pk, b->status);
@@ -2179,7 +2252,6 @@ int pcs_lm_trial_build(pcs_engine *h, const pcs_lm_buffers *b, void *stream) {
         HIPCHK(hipMemsetAsync(b->packed[1], 0, sizeof(double) * (size_t)n_packed, s));
         return PCS_OK;
     }
-    double *g_new = b->packed[1] + L.a_len() + L.b_len() + L.c_len();
     return enqueue_normal(h, b->ps[1], b->packed[1], g_new, g_new + h->n_params, s, true, stop, sel, -alt_ps, -alt_pk);
 }
 

@@ -528,7 +528,8 @@ def test_pinned_output_ring(Engine):
     a2, m2 = j2.ctypes.data, memoryview(j2)
     j3 = e.eval(ps, pinned_ring=2)[1]
     a3 = j3.ctypes.data
-    c3 = _csr((j3.reshape(-1)[:6], np.arange(6) % 3, np.array([0, 3, 6])), shape=(2, 3))
+    idx3, ptr3 = e.csr_structure()                # the whole data array, like the handlers' jac_fn (a csr_array built on a SMALL slice of a
+    c3 = _csr((j3.reshape(-1), idx3, ptr3), shape=(2 * rig.n_det, ps.shape[0]))   # large array copies it: scipy prunes such views)
     del j1, j2, j3
     held = []
     for _ in range(5):
@@ -536,7 +537,8 @@ def test_pinned_output_ring(Engine):
         held.append(jn.ctypes.data)
         del jn
     assert not ({a1, a2, a3} & set(held))
-    assert np.array_equal(t1.numpy(), j0) and np.array_equal(np.asarray(m2), j0) and np.array_equal(c3.data, j0.reshape(-1)[:6])
+    assert np.array_equal(t1.numpy(), j0) and np.array_equal(np.asarray(m2), j0) and np.array_equal(c3.data, j0.reshape(-1))
+    assert c3.data.ctypes.data == a3              # the csr_array wraps the page-locked block itself
     del t1, m2, c3
     # the compacted data array goes through the same ring
     nnz = e.set_unfixed(np.arange(ps.shape[0]) % 3 != 0)

@@ -16,7 +16,7 @@ for a, b in zip(idx[:-1], idx[1:]):
     seg = rows[a + 1: b + 1]
     busy = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in seg) / 1e3
     segs.append((len(seg), busy, a, b))
-segs = [g for g in segs if g[0] >= 8] or segs   # whole trials only (lm_profile.py also times lm_decide on its own)
+segs = [g for g in segs if g[0] >= 5] or segs   # whole trials only (lm_profile.py also times lm_decide on its own); the fused trial has 6 launches
 count = max(set(n for n, _, _, _ in segs), key=[n for n, _, _, _ in segs].count)
 cand = sorted((busy, a, b) for n, busy, a, b in segs if n == count)
 _, a, b = cand[len(cand) // 2]
