@@ -226,7 +226,7 @@ int pcs_lm_decide(pcs_engine *h, const double *d_cost_old, const double *d_cost_
  *        4 xtol, 5 `ctrl[3]` accepted steps, 9 the one-launch dense solve gave up — set spd_algorithm = PCS_SPD_LAUNCHES, clear ctrl[0] and
  *        flags[0] and queue the trial again), [1] consecutive rejections, [2] accepted steps, [3] iteration limit, [4] ftol, [5] xtol,
  *        [6] gtol, [7] rejection limit, [8] trials decided, [9] the factor a rejection applies to lambda before the first accepted step
- *        (0 = 4, as after it), [10], [11] reserved
+ *        (0 = 4, as after it), [10], [11] a gain ratio above ctrl[10] multiplies lambda by ctrl[11] instead of 1/3 (0 = off)
  *   stats (12 doubles, device): pcs_lm_decide's eight, [8] the stop code after this trial, [9] the trial's number (ctrl[8]) or -1 for a
  *        launch that found the flag raised (nothing was computed; everything else in `stats` is then stale), [10] the current state
  *        after this trial (0 / 1), [11] lambda for the next trial.

@@ -49,6 +49,26 @@ __global__ __launch_bounds__(256) void schur_prep_kernel(const SchurArgs a0) {
     const int ec = (int)blockIdx.x % a.ent_chunks, rc = (int)blockIdx.x / a.ent_chunks;
     const int64_t e0 = (int64_t)ec * EPB;
     const bool publish = rc == 0;
+    // this thread's (row, entity) pieces of B, requested BEFORE the factorisation: their latency (and that of the fixed-parameter bytes)
+    // passes while the first EPB lanes factor
+    constexpr int NQ = PREP_RPB * EPB / 256;
+    double bv[NQ][TB];
+    int fx[NQ];   // bit j: entry j is masked (its row or its column is a fixed parameter); bit 30: the piece exists
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi) {
+        const int q = tid + 256 * qi, el = q % EPB;
+        const int64_t r = (int64_t)rc * PREP_RPB + q / EPB, e = e0 + el;
+        const bool have = r < a.n_lead && e < a.n_ent;
+        const double *Bp = a.B + (have ? r * a.n_trail + e * TB : 0);
+        const bool row_fixed = have && a.fixed[r] != 0;
+        int f = have ? (1 << 30) : 0;
+#pragma unroll
+        for (int jj = 0; jj < TB; ++jj) {
+            bv[qi][jj] = have ? Bp[jj] : 0.0;
+            if (have && (row_fixed || a.fixed[a.trail_off + e * TB + jj])) f |= 1 << jj;
+        }
+        fx[qi] = f;
+    }
     if (tid < EPB && e0 + tid < a.n_ent) schur_trail_entity<TB>(a, e0 + tid, Lt + tid * LT, publish);
     __syncthreads();
     if (publish) {
@@ -57,31 +77,31 @@ __global__ __launch_bounds__(256) void schur_prep_kernel(const SchurArgs a0) {
             if (e0 + el < a.n_ent) a.linvt[(e0 + el) * TB * TB + k] = Lt[el * LT + k];
         }
     }
-    for (int q = tid; q < PREP_RPB * EPB; q += 256) {
-        const int el = q % EPB;
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi) {
+        if (!(fx[qi] & (1 << 30))) continue;
+        const int q = tid + 256 * qi, el = q % EPB;
         const int64_t r = (int64_t)rc * PREP_RPB + q / EPB, e = e0 + el;
-        if (r >= a.n_lead || e >= a.n_ent) continue;
-        double *Bp = a.B + r * a.n_trail + e * TB;
         double b[TB];
         bool touched = false;
-        const bool row_fixed = a.fixed[r] != 0;
 #pragma unroll
-        for (int j = 0; j < TB; ++j) {
-            b[j] = Bp[j];
-            if ((row_fixed || a.fixed[a.trail_off + e * TB + j]) && b[j] != 0.0) { b[j] = 0.0; touched = true; }
+        for (int jj = 0; jj < TB; ++jj) {
+            b[jj] = bv[qi][jj];
+            if ((fx[qi] >> jj & 1) && b[jj] != 0.0) { b[jj] = 0.0; touched = true; }
         }
-        if (touched) {
+        if (touched) {   // B is masked in place (rows / columns of fixed parameters -> 0), as schur_v_kernel does
+            double *Bp = a.B + r * a.n_trail + e * TB;
 #pragma unroll
-            for (int j = 0; j < TB; ++j) Bp[j] = b[j];
+            for (int jj = 0; jj < TB; ++jj) Bp[jj] = b[jj];
         }
         const double *L = Lt + el * LT;
         double *Vp = a.V + r * a.n_trail + e * TB;
 #pragma unroll
-        for (int j = 0; j < TB; ++j) {
-            double s = 0.0;
+        for (int jj = 0; jj < TB; ++jj) {
+            double sum = 0.0;
 #pragma unroll
-            for (int i = 0; i <= j; ++i) s += b[i] * L[i * TB + j];
-            Vp[j] = s;
+            for (int ii = 0; ii <= jj; ++ii) sum += b[ii] * L[ii * TB + jj];
+            Vp[jj] = sum;
         }
     }
 }

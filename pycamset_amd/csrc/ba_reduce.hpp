@@ -9,7 +9,7 @@
 //      ((cam, image) / (cam, key)) and inside one wave's tile range — raw, 512 bytes per register index, into its own slot of a
 //      workspace.  Which segment a flush belongs to is static: the table and the launch geometry fix it (`seg_base[wave]` + the
 //      number of flushes the wave has done), so the host builds every index structure below ONCE per table;
-//   2. normal_reduce_runs_kernel: one wave per GROUP of logical runs of one camera.  Per run it sums the run's segments in table
+//   2. normal_reduce_runs_kernel: one workgroup per GROUP of up to four logical runs of one camera, one wave per run.  Per run it sums the run's segments in table
 //      order and sorts the entries by what they still have to meet:
 //        RUN  one camera-level and one entity-level column (camera x pose, camera x point): complete — stored to H;
 //        ENT  entity-level columns only (pose x pose, pose x r; point x point, point x r): the entity's other cameras are
@@ -74,40 +74,24 @@ struct ReduceArgs {
     int32_t n_lr, n_grp, n_cams, n_ent;
 };
 
-// where an owned entry of a run goes: the flush of ba_normal_mfma_kernel, spelled out with 64-bit offsets (entry_descriptor's fields)
-template <int PASS>
-__device__ __forceinline__ double *reduce_entry_address(const NormalArgs &a, const int d, const int ka, const int kb, const int64_t shift) {
-    const int cam = PASS == PASS_IMGKEY ? 0 : ka;
-    const int img = PASS == PASS_SHARED ? kb : ka;
-    const int key = kb;
-    const int tg = a.trail_group;
-    const int64_t base[4] = {9 * (int64_t)cam, a.extr_off + 6 * (int64_t)cam, a.pose_off + 6 * (int64_t)img, a.point_off + 3 * (int64_t)key};
-    const int64_t ent_idx = tg == 2 ? img : key;
-    auto tab = [&](const int e) -> int64_t {   // doubles (the kernel's table holds bytes)
-        if (e < 4) return (int64_t)a.ldA * base[e];
-        if (e < 8) return (int64_t)a.ldB * base[e - 4];
-        if (e == 8) return (int64_t)a.tb * a.tb * ent_idx;
-        if (e == 12) return a.ldA;
-        if (e == 13) return a.ldB;
-        if (e == 14) return a.tb;
-        if (e >= 16 && e < 20) return base[e - 16] - ((e - 16) == tg ? a.trail_off : 0);
-        if (e >= 24 && e < 28) return base[e - 24];
-        return 0;
-    };
-    const int oR = d & 15, oC = (d >> 4) & 15, eRow = (d >> 8) & 31, eCol = (d >> 13) & 31, eLd = (d >> 18) & 31, ePtr = (d >> 23) & 15;
-    double *p = ePtr == 0 ? a.H : ePtr == 1 ? a.HB : ePtr == 2 ? a.HC : ePtr == 3 ? a.g : a.cost;
-    return p + shift + tab(eRow) + tab(eCol) + (int64_t)oR * tab(eLd) + oC;
-}
-
-// Step 2 of the header comment: four waves per workgroup, one group each.
+// Step 2 of the header comment.  One workgroup per group, one WAVE per logical run (round 5, second version: the first walked the
+// group's runs one after the other — three levels of dependent loads per run, 29 us on rig-32 with 1.6 waves per SIMD):
+//   level 1  the run's record (segment range, keys): uniform loads;
+//   level 2  the ids of its segments, one per lane (up to 64 in one request);
+//   level 3  the segments' slots, four in flight, summed in table order.
+// RUN entries go straight to H: their destination is  P + (rb[gR] + oR) ld + cb + oC  with P, ld, cb, rb[] wave-uniform per run and
+// gR, oR, oC static per register (entry_descriptor's fields; same address as the flush of ba_normal_mfma_kernel).  ENT entries are
+// parked in Q[run]; CAM entries meet the group's other runs in LDS and are summed in run order into G[group].
 template <int CHAIN, int PASS>
 __global__ __launch_bounds__(256) void normal_reduce_runs_kernel(const NormalArgs a, const ReduceArgs ra) {
     if (a.stop && *a.stop) return;
     constexpr int NM = normal_mfmas(CHAIN, PASS);
-    const int lane = threadIdx.x & 63;
-    const int g = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
-    if (g >= ra.n_grp) return;
+    constexpr int E = PASS == PASS_SHARED ? 2 : 3;
+    __shared__ double cam_stage[RED_RUNS_PER_GROUP][RED_G];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = blockIdx.x;
     const int64_t shift = (a.sel && *a.sel) ? a.alt : 0;
+    const int r0 = ra.grp_ptr[g], nr = ra.grp_ptr[g + 1] - r0;
     int ent[NM][4], rd[NM][4];
 #pragma unroll
     for (int m = 0; m < NM; ++m)
@@ -116,42 +100,66 @@ __global__ __launch_bounds__(256) void normal_reduce_runs_kernel(const NormalArg
             ent[m][r] = entry_descriptor<CHAIN, PASS>(m, lane, r, a.trail_group);
             rd[m][r] = reduce_descriptor<CHAIN, PASS>(m, lane, r);
         }
-    double cam_acc[NM][4];
-#pragma unroll
-    for (int m = 0; m < NM; ++m)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) cam_acc[m][r] = 0.0;
-    const int r0 = ra.grp_ptr[g], r1 = ra.grp_ptr[g + 1];
-    for (int run = r0; run < r1; ++run) {
+    if (wave < nr) {
+        const int run = r0 + wave;
+        const int k0 = __builtin_amdgcn_readfirstlane(ra.lr_ptr[run]), nseg = __builtin_amdgcn_readfirstlane(ra.lr_ptr[run + 1]) - k0;
+        const int ka = __builtin_amdgcn_readfirstlane(ra.lr_ka[run]), kb = __builtin_amdgcn_readfirstlane(ra.lr_kb[run]);
+        const int sid_lane = lane < nseg ? ra.lr_segs[k0 + lane] : 0;
         double acc[NM][4];
 #pragma unroll
         for (int m = 0; m < NM; ++m)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[m][r] = 0.0;
-        const int k0 = ra.lr_ptr[run], k1 = ra.lr_ptr[run + 1];
-        for (int k = k0; k < k1; ++k) {   // the run's segments, in table order
-            const double *p = ra.part + (int64_t)ra.lr_segs[k] * (NM * 256) + lane;
+        for (int t = 0; t < nseg; t += 4) {   // four slots in flight; added in table order (a missing one adds +0.0)
+            double v[4][NM][4];
 #pragma unroll
-            for (int m = 0; m < NM; ++m)
+            for (int u = 0; u < 4; ++u) {
+                const bool have = t + u < nseg;   // uniform
+                int sid = 0;
+                if (have) sid = t + u < 64 ? __builtin_amdgcn_readlane(sid_lane, (t + u) & 63) : __builtin_amdgcn_readfirstlane(ra.lr_segs[k0 + t + u]);
+                const double *p = ra.part + (int64_t)sid * (NM * 256) + lane;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[m][r] += p[(m * 4 + r) * 64];
+                for (int m = 0; m < NM; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[u][m][r] = have ? p[(m * 4 + r) * 64] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int m = 0; m < NM; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[m][r] += v[u][m][r];
         }
-        const int ka = ra.lr_ka[run], kb = ra.lr_kb[run];
+        // the run's destination in H (wave-uniform part)
+        const bool ent_trails = a.trail_group == E;
+        double *P = (ent_trails ? a.HB : a.H) + shift;
+        const int64_t ld = ent_trails ? a.ldB : a.ldA;
+        const int64_t cb = ent_trails ? (int64_t)a.tb * kb : (E == 2 ? a.pose_off + 6 * (int64_t)kb : a.point_off + 3 * (int64_t)kb);
+        const int64_t rb0 = 9 * (int64_t)ka, rb1 = a.extr_off + 6 * (int64_t)ka;
 #pragma unroll
         for (int m = 0; m < NM; ++m)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int cls = rd[m][r] & 3, pos = rd[m][r] >> 2;
-                if (cls == RED_RUN) *reduce_entry_address<PASS>(a, ent[m][r], ka, kb, shift) = acc[m][r];
-                else if (cls == RED_ENT) ra.Q[(int64_t)run * RED_Q + pos] = acc[m][r];
-                else if (cls == RED_CAM) cam_acc[m][r] += acc[m][r];
+                const int d = ent[m][r], cls = rd[m][r] & 3, pos = rd[m][r] >> 2;
+                if (cls == RED_RUN) {
+                    const int gR = (d >> 8) & 3, oR = d & 15, oC = (d >> 4) & 15;
+                    P[((gR ? rb1 : rb0) + oR) * ld + cb + oC] = acc[m][r];
+                } else if (cls == RED_ENT) {
+                    ra.Q[(int64_t)run * RED_Q + pos] = acc[m][r];
+                } else if (cls == RED_CAM) {
+                    cam_stage[wave][pos] = acc[m][r];
+                }
             }
     }
-#pragma unroll
-    for (int m = 0; m < NM; ++m)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if ((rd[m][r] & 3) == RED_CAM) ra.G[(int64_t)g * RED_G + (rd[m][r] >> 2)] = cam_acc[m][r];
+    if (PASS != PASS_SHARED) return;   // the (cam, key) pass owns no camera-level entries (uniform: no barrier is skipped by part of a workgroup)
+    __syncthreads();
+    {
+        const int p = threadIdx.x, la = p >> 4, lb = p & 15;
+        if (!((p < 240 && la <= lb && lb < 15) || (p >= 240 && p <= 255))) return;   // positions no register owns
+        double s = 0.0;
+        for (int w = 0; w < nr; ++w) s += cam_stage[w][p];
+        ra.G[(int64_t)g * RED_G + p] = s;
+    }
 }
 
 // Step 3.  Grid: [n_cams camera workgroups | 1 cost workgroup] (shared pass only) + ceil(n_ent / 3) entity workgroups.
@@ -171,7 +179,13 @@ __global__ __launch_bounds__(256) void normal_reduce_final_kernel(const NormalAr
         const bool is_h = p < 240 && la <= lb && lb < 15, is_g = p >= 240 && p < 255;
         if (g0 == g1 || !(is_h || is_g)) return;          // a camera without detections keeps the prologue's zeros
         double s = 0.0;
-        for (int g = g0; g < g1; ++g) s += ra.G[(int64_t)g * RED_G + p];
+        for (int g = g0; g < g1; g += 8) {   // eight loads in flight, added in group order (a missing one adds +0.0)
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = g + u < g1 ? ra.G[(int64_t)(g + u) * RED_G + p] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
         auto col = [&](const int l) -> int64_t { return l < 9 ? 9 * (int64_t)c + l : a.extr_off + 6 * (int64_t)c + (l - 9); };
         if (is_h) a.H[shift + col(la) * a.ldA + col(lb)] = s;
         else a.g[shift + col(p - 240)] = s;
@@ -180,7 +194,13 @@ __global__ __launch_bounds__(256) void normal_reduce_final_kernel(const NormalAr
     if (HAS_CAM && (int)blockIdx.x == ra.n_cams) {        // the cost: every group's share, in a fixed tree
         __shared__ double red[256];
         double s = 0.0;
-        for (int g = tid; g < ra.n_grp; g += 256) s += ra.G[(int64_t)g * RED_G + 255];
+        for (int g = tid; g < ra.n_grp; g += 8 * 256) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = g + 256 * u < ra.n_grp ? ra.G[(int64_t)(g + 256 * u) * RED_G + 255] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
         red[tid] = s;
         __syncthreads();
         for (int h = 128; h > 0; h >>= 1) {
@@ -197,7 +217,16 @@ __global__ __launch_bounds__(256) void normal_reduce_final_kernel(const NormalAr
     const int k0 = ra.ent_ptr[e], k1 = ra.ent_ptr[e + 1];
     if (k0 == k1 || !(is_h || is_g)) return;
     double s = 0.0;
-    for (int k = k0; k < k1; ++k) s += ra.Q[(int64_t)ra.ent_runs[k] * RED_Q + p];
+    for (int k = k0; k < k1; k += 8) {   // eight loads in flight, added in camera order
+        int run[8];
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) run[u] = k + u < k1 ? ra.ent_runs[k + u] : -1;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = run[u] >= 0 ? ra.Q[(int64_t)run[u] * RED_Q + p] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
     const int64_t base = (E == 2 ? a.pose_off + 6 * (int64_t)e : a.point_off + 3 * (int64_t)e);
     if (is_g) a.g[shift + base + (p - 64)] = s;
     else if (a.trail_group == E) a.HC[shift + (int64_t)a.tb * a.tb * e + (int64_t)oR * a.tb + oC] = s;   // blocked layout, the entity is the trailing group

@@ -447,30 +447,37 @@ __global__ __launch_bounds__(256) void schur_syrk64_kernel(const SchurSyrkArgs a
     }
 }
 
-// Ordered mode: S -= sum over the K splits of a tile's partial products, rhs += sum of the partial V u, split 0 first.  One workgroup per
-// tile of the lower triangle, TW = 32 or 64 (the form that produced the partials).
+// Ordered mode: S -= sum over the K splits of a tile's partial products, rhs += sum of the partial V u, split 0 first.  One thread per
+// entry — TW * TW / 256 workgroups per tile of the lower triangle (TW = 32 or 64, the form that produced the partials) —, its loads
+// eight in flight, added in split order.
 template <int TW>
 __global__ __launch_bounds__(256) void schur_syrk_reduce_kernel(const SchurSyrkArgs a) {
     PCS_STOP_GUARD(a);
-    const int tid = threadIdx.x, t = blockIdx.x;
+    constexpr int PARTS = TW * TW / 256;
+    const int tid = threadIdx.x, t = blockIdx.x / PARTS, part = blockIdx.x % PARTS;
     int bi = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);   // t -> (bi, bj), 0 <= bj <= bi
     while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
     while (bi * (bi + 1) / 2 > t) --bi;
     const int bj = t - bi * (bi + 1) / 2;
-    for (int e = tid; e < TW * TW; e += 256) {
-        const int gi = bi * TW + e / TW, gj = bj * TW + e % TW;
-        if (gi >= a.n_lead || gj > gi) continue;
+    auto ordered_sum = [&](const double *src, const int64_t stride) {
         double sum = 0.0;
-        for (int kc = 0; kc < a.ksplit; ++kc) sum += a.ws[((int64_t)kc * a.tiles + t) * (TW * TW) + e];
-        a.S[(int64_t)gi * a.lds + gj] -= sum;
-    }
-    if (bi == bj && a.u && tid < TW) {
-        const int gi = bi * TW + tid;
-        if (gi < a.n_lead) {
-            double sum = 0.0;
-            for (int kc = 0; kc < a.ksplit; ++kc) sum += a.ws_rhs[(int64_t)kc * a.n_lead + gi];
-            a.rhs[gi] += sum;
+        for (int kc = 0; kc < a.ksplit; kc += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = kc + u < a.ksplit ? src[(int64_t)(kc + u) * stride] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) sum += v[u];
         }
+        return sum;
+    };
+    {
+        const int e = part * 256 + tid;
+        const int gi = bi * TW + e / TW, gj = bj * TW + e % TW;
+        if (gi < a.n_lead && gj <= gi) a.S[(int64_t)gi * a.lds + gj] -= ordered_sum(a.ws + (int64_t)t * (TW * TW) + e, (int64_t)a.tiles * (TW * TW));
+    }
+    if (bi == bj && part == 0 && a.u && tid < TW) {
+        const int gi = bi * TW + tid;
+        if (gi < a.n_lead) a.rhs[gi] += ordered_sum(a.ws_rhs + gi, a.n_lead);
     }
 }
 
@@ -576,6 +583,8 @@ __global__ __launch_bounds__(256) void schur_back_kernel(const SchurBackArgs a0)
 //           [7] rejection limit   [8] trials decided so far
 //           [9] factor applied to lambda by a rejection BEFORE the first accepted step (0 = the classic 4): a start far from the
 //               solution needs orders of magnitude more damping than the default initial value, not five rejections' worth of x 4
+//           [10], [11] a gain ratio above ctrl[10] multiplies lambda by ctrl[11] instead of 1/3 (0 = off): an accurate model lets the
+//               damping go quickly, so the loop can START with more of it ("damping policy")
 struct LmDecideArgs {
     // &packed[s][n_packed - 1] of the two states: [0] sum r^2, [1] the void votes of the ranks (schur_back_kernel, with use_votes),
     // [-n_params .. -1] J^T r.  State *sel (0 without sel) is the current one, the other holds the trial.
@@ -601,9 +610,10 @@ struct LmDecideArgs {
     const int64_t *free_idx;
     int64_t n_free;
     double *result;
-    double *stats_host;                     // optional: the 12 numbers again, in mapped page-locked host memory; word 9 is written last
+    double *stats_host;                     // optional: the 12 numbers again, in mapped page-locked host memory the host has filled with LM_SENTINEL
 };
 constexpr int LM_STATS = 12;
+// (the host side of the read-back protocol: pycamset_amd/device_solver.py LM_SENTINEL = a quiet NaN with a payload, 0x7FF8DEAD00000001)
 
 __global__ __launch_bounds__(1024) void lm_decide_kernel(const LmDecideArgs a) {
     __shared__ double red[4][1024];
@@ -612,12 +622,25 @@ __global__ __launch_bounds__(1024) void lm_decide_kernel(const LmDecideArgs a) {
         if (tid == 0) {
             a.stats[9] = -1.0;
             *a.accept_flag = 0;
-            if (a.stats_host) a.stats_host[9] = -1.0;
+            if (a.stats_host) {
+#pragma unroll
+                for (int i = 0; i < LM_STATS; ++i) a.stats_host[i] = -1.0;     // the host waits for all twelve words
+            }
         }
         return;
     }
     const int cur = a.sel ? (*a.sel != 0 ? 1 : 0) : 0, tri = 1 - cur;
     const double *ps = a.ps2[cur];
+    // the scalars of the decision, requested now: their latency passes behind the reductions (requested where they are used, thread 0
+    // waited for five dependent round trips after the last barrier: 9.5 us per decision on rig-32)
+    const double lam = *a.lambda, c_old = a.tail[cur][0], c_new = a.tail[tri][0];
+    const int st = *a.status;
+    const double votes = a.use_votes ? a.tail[tri][1] : 0.0;
+    double cv[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (a.ctrl) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) cv[i] = a.ctrl[i];
+    }
     double gd = 0.0, dd = 0.0, gmax = 0.0, xx = 0.0, ss = 0.0;
     for (int64_t i = tid; i < a.n_params; i += 1024) {
         const double d = a.delta[i], g = a.gm[i];
@@ -648,38 +671,35 @@ __global__ __launch_bounds__(1024) void lm_decide_kernel(const LmDecideArgs a) {
         __syncthreads();
     }
     if (tid == 0) {
-        const double lam = *a.lambda, c_old = a.tail[cur][0], c_new = a.tail[tri][0];
         const double pred = 0.5 * (lam * s_dd - s_gd);
         const double actual = 0.5 * (c_old - c_new);
-        const int st = *a.status;
         const bool ok = st == 0 && pred == pred && fabs(pred) < 1.0e300;
         const double rho = pred > 0.0 ? actual / pred : -1.0;
         bool acc = ok && c_new == c_new && fabs(c_new) < 1.0e300 && actual > 0.0;
-        const double factor = rho > 0.75 ? 1.0 / 3.0 : rho > 0.25 ? 1.0 : 2.0;
+        const double factor = (cv[10] > 0.0 && cv[11] > 0.0 && rho > cv[10]) ? cv[11] : rho > 0.75 ? 1.0 / 3.0 : rho > 0.25 ? 1.0 : 2.0;
         const double rel_drop = actual / (0.5 * c_old), step_norm = sqrt(red[0][0]), x_norm = sqrt(s_xx);
-        double code = 0.0;
+        double code = 0.0, trial_no = 0.0;
         // the dense solve did not complete (ba_chol_persist.hpp's time limit) — here, or on some rank of a sharded loop: the host repeats the trial
-        const bool void_trial = (st & 4) != 0 || (a.use_votes && a.tail[tri][1] > 0.0);
+        const bool void_trial = (st & 4) != 0 || votes > 0.0;
         double grow = 4.0;
         if (a.ctrl) {
             double *c = a.ctrl;
-            if (c[2] == 0.0 && c[9] > 1.0) grow = c[9];
+            if (cv[2] == 0.0 && cv[9] > 1.0) grow = cv[9];
             if (void_trial) { code = 9.0; acc = false; }
-            else if (s_gmax <= c[6]) { code = 1.0; acc = false; }             // the state BEFORE this step was already stationary: the step is dropped
+            else if (s_gmax <= cv[6]) { code = 1.0; acc = false; }             // the state BEFORE this step was already stationary: the step is dropped
             else if (acc) {
                 c[1] = 0.0;
-                c[2] += 1.0;
-                if (rel_drop <= c[4]) code = 3.0;
-                else if (step_norm <= c[5] * (c[5] + x_norm)) code = 4.0;
-                else if (c[2] >= c[3]) code = 5.0;
+                c[2] = cv[2] + 1.0;
+                if (rel_drop <= cv[4]) code = 3.0;
+                else if (step_norm <= cv[5] * (cv[5] + x_norm)) code = 4.0;
+                else if (cv[2] + 1.0 >= cv[3]) code = 5.0;
             } else {
-                c[1] += 1.0;
-                if (c[1] >= c[7]) code = 2.0;
+                c[1] = cv[1] + 1.0;
+                if (cv[1] + 1.0 >= cv[7]) code = 2.0;
             }
-            c[8] += 1.0;
+            trial_no = cv[8] + 1.0;
+            c[8] = trial_no;
             c[0] = code;
-            a.stats[8] = code;
-            a.stats[9] = c[8];
             *a.accept_flag = acc ? 1 : 0;
             *a.stop_flag = code != 0.0 ? 1 : 0;
         }
@@ -688,19 +708,20 @@ __global__ __launch_bounds__(1024) void lm_decide_kernel(const LmDecideArgs a) {
         *a.status = 0;
         const int now = (acc && a.sel && !a.keep_sel) ? tri : cur;           // the state the next trial starts from
         if (a.sel) *a.sel = now;
-        a.stats[0] = void_trial ? -1.0 : acc ? 1.0 : 0.0;
-        a.stats[1] = s_gmax;
-        a.stats[2] = rel_drop;
-        a.stats[3] = step_norm;
-        a.stats[4] = x_norm;
-        a.stats[5] = c_new;
-        a.stats[6] = c_old;
-        a.stats[7] = lam;
-        a.stats[10] = (double)now;
-        a.stats[11] = lam_next;
+        const double out[LM_STATS] = {void_trial ? -1.0 : acc ? 1.0 : 0.0, s_gmax, rel_drop, step_norm, x_norm, c_new, c_old, lam, code, trial_no, (double)now, lam_next};
+#pragma unroll
+        for (int i = 0; i < LM_STATS; ++i)
+            if (a.ctrl || (i != 8 && i != 9)) a.stats[i] = out[i];
         red[1][0] = code;                    // for the other threads: does the loop end here, and in which state
         red[1][1] = acc ? 1.0 : 0.0;
         red[1][2] = acc ? c_new : c_old;
+        // the trial's read-back straight into the host's page-locked buffer (no copy launch, no fence: the host has filled the twelve
+        // words with a NaN pattern no arithmetic produces and waits until none is left — the words may land in any order).  Not for the
+        // trial that ENDS the loop: its read-back follows the final state (below)
+        if (a.ctrl && a.stats_host && (code == 0.0 || !a.result)) {
+#pragma unroll
+            for (int i = 0; i < LM_STATS; ++i) a.stats_host[i] = out[i];
+        }
     }
     if (!a.ctrl) return;
     __syncthreads();
@@ -719,13 +740,10 @@ __global__ __launch_bounds__(1024) void lm_decide_kernel(const LmDecideArgs a) {
             __threadfence_system();
         }
     }
-    // the trial's read-back straight into the host's page-locked buffer (no copy launch; a host that polls word 9 needs no event)
-    if (tid == 0 && a.stats_host) {
+    // ... and only then the read-back of the trial that ended the loop: a host that has seen it finds the final state complete
+    if (tid == 0 && a.stats_host && a.result && red[1][0] != 0.0) {
 #pragma unroll
-        for (int i = 0; i < LM_STATS; ++i)
-            if (i != 9) a.stats_host[i] = a.stats[i];
-        __threadfence_system();
-        a.stats_host[9] = a.stats[9];        // the trial's number — what a polling host waits for — goes last
+        for (int i = 0; i < LM_STATS; ++i) a.stats_host[i] = a.stats[i];
     }
 }
 

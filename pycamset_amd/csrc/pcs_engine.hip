@@ -1242,7 +1242,8 @@ static int ensure_det_tables(pcs_engine *h, int pass, int64_t tpw) {
 
 template <int CHAIN, int PASS>
 static hipError_t launch_reduce_p(const NormalArgs &a, const ReduceArgs &ra, hipStream_t s) {
-    if (ra.n_grp > 0) hipLaunchKernelGGL((normal_reduce_runs_kernel<CHAIN, PASS>), dim3((unsigned)((ra.n_grp + 3) / 4)), dim3(256), 0, s, a, ra);
+    static_assert(RED_RUNS_PER_GROUP == 4, "one wave per run, four waves per workgroup");
+    if (ra.n_grp > 0) hipLaunchKernelGGL((normal_reduce_runs_kernel<CHAIN, PASS>), dim3((unsigned)ra.n_grp), dim3(256), 0, s, a, ra);
     const int blocks = (PASS == PASS_SHARED ? ra.n_cams + 1 : 0) + (ra.n_ent + 2) / 3;
     if (blocks > 0) hipLaunchKernelGGL((normal_reduce_final_kernel<CHAIN, PASS>), dim3((unsigned)blocks), dim3(256), 0, s, a, ra);
     return hipGetLastError();
@@ -1965,14 +1966,15 @@ static SyrkGeometry syrk_geometry(int64_t n_lead, int64_t n_trail, bool ordered)
         // 64 x 64 tiles run two workgroups per CU: split K so that the workgroups fill whole rounds of the resident ones — the cost of a
         // split = rounds x (columns per workgroup + ~64 columns' worth of ramp and atomics); rig-32-self: 378 tiles x 4 = 2.95 rounds.
         // Ordered mode: every split also writes and re-reads a 32 KB partial tile (rig-32-self: 50 MB per solve for four splits) —
-        // priced as 192 more columns per split, which leaves large systems unsplit (378 tiles x 1: 1.5 rounds' worth, ~15 % slower).
+        // priced as 48 more columns per split.  (Priced at 192 the model left rig-32-self unsplit: 378 workgroups of 1 458 columns on
+        // 512 slots took 172.7 us against 133.4 us for the four-way split with atomics, profiles/r05/lm_trace_rig32_self_form11.log.)
         int dev = 0;
         const int cus = hipGetDevice(&dev) == hipSuccess && device_cu_count(dev) > 0 ? device_cu_count(dev) : 256;
         const int64_t slots = 2 * (int64_t)cus;
         int64_t best = INT64_MAX;
         for (int64_t ks = 1; ks <= std::max<int64_t>(1, n_trail / 128); ++ks) {
             const int64_t kc = ((n_trail + ks - 1) / ks + 63) / 64 * 64, real = (n_trail + kc - 1) / kc;
-            const int64_t cost = (g.tiles * real + slots - 1) / slots * (kc + 64 + ((ordered && real > 1) ? 192 : 0));
+            const int64_t cost = (g.tiles * real + slots - 1) / slots * (kc + 64 + ((ordered && real > 1) ? 48 : 0));
             if (cost < best) { best = cost; ksplit = real; kchunk = kc; }
         }
     }
@@ -2000,8 +2002,8 @@ static int enqueue_schur_syrk(int64_t n_lead, int64_t n_trail, const double *d_V
     else hipLaunchKernelGGL(schur_syrk_kernel, dim3((unsigned)(g.tiles * g.ksplit)), dim3(256), 0, s, a);
     HIPCHK(hipGetLastError());
     if (a.ws) {
-        if (g.big) hipLaunchKernelGGL(schur_syrk_reduce_kernel<64>, dim3((unsigned)g.tiles), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL(schur_syrk_reduce_kernel<32>, dim3((unsigned)g.tiles), dim3(256), 0, s, a);
+        if (g.big) hipLaunchKernelGGL(schur_syrk_reduce_kernel<64>, dim3((unsigned)(g.tiles * 16)), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(schur_syrk_reduce_kernel<32>, dim3((unsigned)(g.tiles * 4)), dim3(256), 0, s, a);
         HIPCHK(hipGetLastError());
     }
     return PCS_OK;

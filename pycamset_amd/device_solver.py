@@ -122,7 +122,9 @@ def pcg(apply_a, b, m_inv, tol: float, max_iter: int):
     return x, it
 
 
+LAM0_EXACT = 1e-5           # initial damping of the exact (Cholesky) step; 1e-3 for the inexact PCG step (lm_solve's docstring has the why)
 LAM_GROW0 = 1e3             # factor a rejected trial applies to lambda before the first accepted step (lm_solve)
+LAM_FAST = (0.95, 0.1)      # a gain ratio above 0.95 multiplies lambda by 0.1 instead of 1/3: a model THAT accurate lets the damping go quickly
 LEAD_LIMIT = 16384          # leading parameters up to which lm_solve(linear_solver="auto") takes the Schur / Cholesky step (S: 2 GB)
 BLOCKED_BYTES_LIMIT = 16e9  # and total bytes of the two packed buffers + V
 
@@ -326,6 +328,7 @@ STOP_MESSAGES = {0: "maximum number of iterations reached", 1: "gtol reached", 2
                  5: "maximum number of iterations reached"}
 STOP_STATUS = {0: 0, 1: 1, 2: 2, 3: 3, 4: 4, 5: 0}
 REJECTION_LIMIT = 12      # consecutive rejected trials before the loop gives up ("damping exhausted")
+LM_SENTINEL = np.uint64(0x7FF8DEAD00000001)   # what a read-back slot holds until the device has written it (csrc/ba_schur.hpp lm_decide_kernel)
 
 
 def _lm_loop_device(ne: BlockedNormalEquations, ps0: np.ndarray, *, max_iter, ftol, xtol, gtol, lam0, lam_grow0, verbose):
@@ -357,7 +360,7 @@ def _lm_loop_device(ne: BlockedNormalEquations, ps0: np.ndarray, *, max_iter, ft
             ps = [torch.from_numpy(np.ascontiguousarray(ps0, dtype=np.float64)).to(dev), None]
             ps[1] = torch.empty_like(ps[0])
             lam = torch.full((1,), float(lam0), dtype=torch.float64, device=dev)
-            ctrl = torch.tensor([0.0, 0.0, 0.0, float(max_iter), ftol, xtol, gtol, float(REJECTION_LIMIT), 0.0, float(lam_grow0), 0.0, 0.0],
+            ctrl = torch.tensor([0.0, 0.0, 0.0, float(max_iter), ftol, xtol, gtol, float(REJECTION_LIMIT), 0.0, float(lam_grow0), LAM_FAST[0], LAM_FAST[1]],
                                 dtype=torch.float64, device=dev)
             flags = torch.zeros(4, dtype=torch.int32, device=dev)          # [stop, accepted, current state, -]
             stats_dev = torch.zeros(LM_STATS, dtype=torch.float64, device=dev)
@@ -396,13 +399,15 @@ def _lm_loop_device(ne: BlockedNormalEquations, ps0: np.ndarray, *, max_iter, ft
                 b.syrk_work, b.syrk_work_len = ne.syrk_work.data_ptr(), ne.syrk_work_len
                 return b
 
-            # The read-back of trial k lands in page-locked memory the device writes directly (lm_decide_kernel: word 9, the trial's number —
-            # or -1 for a launch that found the stop flag raised —, last).  The host waits for THAT word instead of an event: an event record
-            # between two trials cost the GPU 5.6 us of idling per trial (the one gap in profiles/r04/lm_trace_*.log).
+            # The read-back of trial k lands in page-locked memory the device writes directly (lm_decide_kernel; all twelve words are -1 for
+            # a launch that found the stop flag raised).  The host waits for THOSE words instead of an event — an event record between two
+            # trials cost the GPU 5.6 us of idling per trial (the one gap in profiles/r04/lm_trace_*.log) — and the device needs no fence
+            # between them: the host fills the slot with a NaN pattern no arithmetic produces and waits until none of it is left.
             views = [t.numpy() for t in stats_host]
+            raw = [v.view(np.uint64) for v in views]
 
             def enqueue(k):
-                views[k % ring][9] = np.nan
+                raw[k % ring][:] = LM_SENTINEL
                 b = buffers(k)
                 if sharded:   # the trial state is all-reduced between the two halves, on this stream: nothing waits for the host
                     eng.lm_trial_build(b, stream)
@@ -412,10 +417,10 @@ def _lm_loop_device(ne: BlockedNormalEquations, ps0: np.ndarray, *, max_iter, ft
                     eng.lm_trial(b, stream)
 
             def wait_for(k):
-                v = views[k % ring]
+                v, u = views[k % ring], raw[k % ring]
                 t_end = time.perf_counter() + 30.0
                 spins = 0
-                while np.isnan(v[9]):
+                while (u == LM_SENTINEL).any():
                     spins += 1
                     if spins & 1023 == 0:
                         if time.perf_counter() > t_end:
@@ -484,6 +489,14 @@ def _lm_loop_device(ne: BlockedNormalEquations, ps0: np.ndarray, *, max_iter, ft
                           n_jtjv=n_lin, status=STOP_STATUS.get(code, 0), message=STOP_MESSAGES.get(code, f"stopped ({code})"), history=history)
 
 
+def _gain_ratio(ne: BlockedNormalEquations, stats) -> float:
+    """actual / predicted reduction of the trial `stats` describes (host-steered loop; the device-steered one has it in the kernel)."""
+    torch = ne.torch
+    lam_used = float(stats[7])
+    pred = 0.5 * float((lam_used * torch.dot(ne.dvec, ne.delta * ne.delta) - torch.dot(ne.gm, ne.delta)).item())
+    return 0.5 * (float(stats[6]) - float(stats[5])) / pred if pred > 0 else -1.0
+
+
 def _lm_loop_blocked(ne: BlockedNormalEquations, ps0: np.ndarray, *, max_iter, ftol, xtol, gtol, lam0, lam_grow0, verbose):
     """The host-steered loop: what a sharded solve takes when its collective goes through the host (gloo).  Same rules as the
     device-steered loop (the decision itself is pcs_lm_decide on the device).  Every rank decides on the same all-reduced blocks;
@@ -541,6 +554,9 @@ def _lm_loop_blocked(ne: BlockedNormalEquations, ps0: np.ndarray, *, max_iter, f
                     break
                 if stats[0] > 0:
                     accepted = any_accepted = True
+                    # pcs_lm_decide applied the classic 1/3; a gain ratio above LAM_FAST[0] earns LAM_FAST[1] (the device-steered loop's rule)
+                    if _gain_ratio(ne, stats) > LAM_FAST[0]:
+                        lam.fill_(max(float(stats[7]) * LAM_FAST[1], 1e-12))
                     ps, ps_new = ps_new, ps
                     cur, new = new, cur
                     history.append(0.5 * float(stats[5]))
@@ -643,19 +659,20 @@ def lm_solve(handler, x0, *, max_iter: int = 50, ftol: float = 1e-8, xtol: float
     on the detections is computed by the HIP engine.  ``operator`` replaces the engine-backed
     JacobianOperator (used by the CPU tests of this driver).
 
-    ``lam0``: the initial damping (Nielsen's tau: lambda multiplies D).  ``None`` = 1e-6 with the exact (Cholesky) step, 1e-3 with
-    PCG.  The reference's solver — scipy ``least_squares(method='trf')``, optimisation_handling.py:88-98 — starts with the plain
-    Gauss-Newton step whenever that lies inside its first trust region, which it does from a calibration's starting values; 1e-3 and
-    the update lambda <- lambda max(1/3, 1 - (2 rho - 1)^3) need nine accepted steps on rig-32 to get the damping out of the way,
-    1e-6 five (scipy: four evaluations), to the same cost.  Every rejected trial multiplies lambda by 4 (host and device rule alike;
-    at most REJECTION_LIMIT = 12 in a row) — except BEFORE the first accepted step, where a rejection multiplies it by ``lam_grow0``
-    (default LAM_GROW0 = 1e3): a start far from the solution (PnP poses tens of pixels off, two poses swapped) needs orders of magnitude
-    more damping than 1e-6, and x 4 per rejected evaluation would spend five evaluations to get to 1e-3 (DESIGN section 4 has the
-    table).  ``max_iter <= 0`` evaluates the start and returns it."""
+    ``lam0``: the initial damping (Nielsen's tau: lambda multiplies D).  ``None`` = LAM0_EXACT = 1e-5 with the exact (Cholesky)
+    step, 1e-3 with PCG.  The reference's solver — scipy ``least_squares(method='trf')``, optimisation_handling.py:88-98 — starts with
+    the plain Gauss-Newton step whenever that lies inside its first trust region, which it does from a calibration's starting values;
+    round 3's 1e-3 with the update lambda <- lambda / 3 needs nine accepted steps on rig-32 to get the damping out of the way.  The
+    policy since round 5 (DESIGN section 4 has the table: near starts, 5 x / 10 x farther starts, two poses swapped, chains T and S):
+    start at 1e-5 and let an ACCURATE model shed damping fast — a gain ratio above LAM_FAST[0] = 0.95 multiplies lambda by 0.1, above
+    0.75 by 1/3, above 0.25 by 1, below by 2; every rejected trial multiplies it by 4 (host and device rule alike; at most
+    REJECTION_LIMIT = 12 in a row), a rejection BEFORE the first accepted step by ``lam_grow0`` (default LAM_GROW0 = 1e3).  1e-6 (round
+    4) is one evaluation faster from a near start and up to twice as slow from a far one: a nearly undamped step from 70 px away
+    overshoots into a region where five to eight trials are rejected in a row.  ``max_iter <= 0`` evaluates the start and returns it."""
     if linear_solver not in ("auto", "pcg", "cholesky"):
         raise ValueError("linear_solver must be 'auto', 'pcg' or 'cholesky'")
     op_fun = handler.op_fun
-    lam0_exact, lam0_pcg = (1e-6, 1e-3) if lam0 is None else (float(lam0), float(lam0))
+    lam0_exact, lam0_pcg = (LAM0_EXACT, 1e-3) if lam0 is None else (float(lam0), float(lam0))
     grow0 = LAM_GROW0 if lam_grow0 is None else float(lam_grow0)
     if operator is None:
         dd = handler._flat_detections()
@@ -716,7 +733,8 @@ def lm_solve(handler, x0, *, max_iter: int = 50, ftol: float = 1e-8, xtol: float
                 step_norm, x_norm = float(np.linalg.norm(delta)), float(np.linalg.norm(x))
                 rel_drop = actual / (0.5 * st["sumsq"])
                 x, st = x_new, st_new
-                lam = max(lam * (1.0 / 3.0 if rho > 0.75 else 1.0 if rho > 0.25 else 2.0), 1e-12)
+                fast = linear_solver != "pcg" and rho > LAM_FAST[0]    # exact steps only: less damping costs an inexact (CG) step iterations
+                lam = max(lam * (LAM_FAST[1] if fast else 1.0 / 3.0 if rho > 0.75 else 1.0 if rho > 0.25 else 2.0), 1e-12)
                 history.append(0.5 * st["sumsq"])
                 break
             lam *= 4.0 if any_accepted else max(grow0, 4.0)

@@ -19,12 +19,14 @@ Hd = torch.empty((n, n), dtype=torch.float64, device="cuda"); gd = torch.empty(n
 for arg in [x for x in sys.argv if x.startswith("--ikw=")]: sys.argv.remove(arg); e.set_option("normal_imgkey_wgs_per_cu", int(arg[6:]))
 for arg in [x for x in sys.argv if x.startswith("--sort=")]: sys.argv.remove(arg); e.set_option("normal_sort_tables", int(arg[7:]))
 if "--walk" in sys.argv: sys.argv.remove("--walk"); e.set_option("normal_imgkey_product", 0)
+import os
+if os.environ.get("PCS_NORMAL_DET", "0") == "1": e.set_option("deterministic", 1)   # the ordered build (csrc/ba_reduce.hpp)
 dbgs = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0]
 for dbg in dbgs:
   e.set_option("normal_debug", dbg)
   print("normal_debug", dbg)
   for rows in ([int(x) for x in sys.argv[4].split(",")] if len(sys.argv) > 4 else (64,)):
-    for wpc in [int(x) for x in (sys.argv[3].split(',') if len(sys.argv) > 3 else ['7', '14'])]:
+    for wpc in [int(x) for x in (sys.argv[3].split(',') if len(sys.argv) > 3 else ['0'])]:
         e.set_option("normal_rows", rows); e.set_option("wgs_per_cu", wpc)
         ks = []
         for _ in range(9):
