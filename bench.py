@@ -223,7 +223,7 @@ def lm_end_to_end(config: int, with_scipy: bool, scipy_nfev: int = 8):
     loss_fn = h.make_loss_fun(1)
     err = lambda r: float(np.mean(np.linalg.norm(np.asarray(r).reshape(-1, 2), axis=1)))  # noqa: E731
     out = {"workload": f"{rig.name}: {rig.n_det} detections, {x0.size} free parameters", "start_error_px": err(loss_fn(x0))}
-    lm_solve(h, x0.copy(), max_iter=2, linear_solver="cholesky")   # rocSOLVER start-up (~0.2 s, once per process)
+    lm_solve(h, x0.copy(), max_iter=2, linear_solver="cholesky")   # first-call set-up (solver workspace, visiting orders, page-locked read-back), once per engine
     t0 = time.perf_counter()
     dev = lm_solve(h, x0.copy(), max_iter=30, linear_solver="cholesky")
     out["device_lm"] = {"seconds": time.perf_counter() - t0, "iterations": dev.nit, "nfev": dev.nfev, "cost": dev.cost,

@@ -2063,7 +2063,9 @@ static int enqueue_dense_spd(int device, int64_t n, double *d_S, int64_t ld, con
                              int algorithm, const int32_t *d_stop, bool prefilled = false, int64_t timeout_us = 250000);
 
 // does a solve of size n with this algorithm request take the ONE persistent launch (csrc/ba_chol_persist.hpp)?  Wherever its tiles fit
-// the chip's LDS: n <= 1 984 on 256 CUs
+// the chip's LDS: n <= 1 984 on 256 CUs.  (Round 5 also tried ONE workgroup with the whole matrix in its LDS for n <= 160 — nothing to hand
+// over —: 110 us at n = 120 against the persistent kernel's 47: fourteen workgroups load, update and factor their tiles side by side, one
+// workgroup does it all in sequence.  Dropped.)
 static bool dense_spd_is_one_launch(int device, int64_t n, int algorithm) {
     static const bool env_launches = getenv("PCS_CHOL_LAUNCHES") != nullptr;   // A/B switch for whole runs
     return n > 0 && cp_fits(n, device_cu_count(device)) && (algorithm == PCS_SPD_ONE_LAUNCH || (algorithm == PCS_SPD_AUTO && !env_launches));
