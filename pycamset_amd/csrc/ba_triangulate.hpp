@@ -214,11 +214,10 @@ __device__ __forceinline__ double tri_rcp(const double x) {
     e = fma(-x, y, 1.0);
     return fma(y, e, y);
 }
-__device__ __forceinline__ double tri_rsq(const double x) {   // 1 / sqrt(x), x > 0
-    double y = __builtin_amdgcn_rsq(x);
-    y = y * (1.5 - 0.5 * x * y * y);
-    y = y * (1.5 - 0.5 * x * y * y);
-    return y;
+__device__ __forceinline__ double tri_rsq(const double x) {   // 1 / sqrt(x), x > 0: hardware estimate (~2^-26) + ONE third-order step,
+    const double y = __builtin_amdgcn_rsq(x);                   // y (1 + h / 2 + 3 h^2 / 8) with h = 1 - x y^2 (error ~ h^3: full double precision;
+    const double h = fma(-(x * y), y, 1.0);                     // ba_chol_persist.hpp's cp_rsqrt) — 6 instructions where two Newton steps took 9
+    return fma(y * h, fma(h, 0.375, 0.5), y);
 }
 
 __device__ __forceinline__ void undistort5_fast(const double u, const double v, const double *__restrict__ ct, double &uo, double &vo) {
@@ -256,20 +255,31 @@ __device__ __forceinline__ void view_rows_fast(const double *__restrict__ P, con
     }
 }
 
-// fold one row into the upper-triangular 4x4 factor: branch-free, one reciprocal square root per rotation
-__device__ __forceinline__ void givens_insert_fast(double (&R)[4][4], double (&row)[4]) {
+// Fold TWO rows into the upper-triangular 4 x 4 factor at once (round 5): per column k a 3-element Householder reflector on
+// (R_kk, row0_k, row1_k) — norm, ONE reciprocal square root and one reciprocal, then 7 multiply-adds per remaining column — where two
+// Givens folds spent two reciprocal square roots and 8 multiply-adds per column and row: ~110 instead of ~200 instructions per view
+// (profiles/r05/tri_sq_counters_a.json: the kernel issues 2 407 vector instructions per wave and is issue-bound to 52 %).  Backward
+// stable like the rotations (v_0 = a - alpha with alpha of the opposite sign of a: no cancellation); rows that are zero in a column
+// leave it untouched (also keeps 0 / 0 out of an empty factor), so an absent view changes nothing; the factor's diagonal may come out
+// negative, which the triangular solves do not mind.
+__device__ __forceinline__ void house2_insert(double (&R)[4][4], double (&r0)[4], double (&r1)[4]) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const double a = R[k][k], b = row[k];
-        const double h2 = a * a + b * b;
-        const bool rot = b != 0.0;                        // b == 0: the identity (also keeps 0 / 0 out of an empty factor)
-        const double ih = rot ? tri_rsq(h2) : 0.0;
-        const double c = rot ? a * ih : 1.0, s = b * ih;
+        const double a = R[k][k], b = r0[k], c = r1[k];
+        const double s2 = fma(c, c, b * b);
+        const bool skip = s2 == 0.0;
+        const double n2 = skip ? 1.0 : fma(a, a, s2);
+        const double inx = tri_rsq(n2), nx = n2 * inx;
+        const double alpha = (a >= 0.0) ? -nx : nx;
+        const double v0 = a - alpha;                                  // |v0| = |a| + nx
+        const double beta = skip ? 0.0 : tri_rcp(nx * fabs(v0));      // 2 / (v' v) = 1 / (nx |v0|)
+        R[k][k] = skip ? a : alpha;
 #pragma unroll
-        for (int j = k; j < 4; ++j) {
-            const double rk = R[k][j], rw = row[j];
-            R[k][j] = c * rk + s * rw;
-            row[j] = c * rw - s * rk;
+        for (int j = k + 1; j < 4; ++j) {
+            const double t = beta * fma(c, r1[j], fma(b, r0[j], v0 * R[k][j]));
+            R[k][j] = fma(-v0, t, R[k][j]);
+            r0[j] = fma(-b, t, r0[j]);
+            r1[j] = fma(-c, t, r1[j]);
         }
     }
 }
@@ -314,8 +324,7 @@ __global__ __launch_bounds__(256) void triangulate_reg_kernel(const int32_t *__r
             c1[k] = have ? c1[k] : 0.0;
         }
         ia[v] = have ? -inv_alpha : 0.0;   // 1 / E_i
-        givens_insert_fast(R, c0);
-        givens_insert_fast(R, c1);
+        house2_insert(R, c0, c1);
     }
     for (int64_t q = s0 + g + (int64_t)V * G; q < s1; q += G) {   // views beyond the registers: the scratch records of the first version
         const double *ct = cam_tab + (int64_t)cam[q] * TRI_CAM_STRIDE;
@@ -325,8 +334,7 @@ __global__ __launch_bounds__(256) void triangulate_reg_kernel(const int32_t *__r
         view_rows_fast(ct, uu, vv, inv_alpha, r, c0, c1);
         scr_r[q] = make_double4(r[0], r[1], r[2], r[3]);
         scr_al[q] = make_double2(-inv_alpha, 0.0);
-        givens_insert_fast(R, c0);
-        givens_insert_fast(R, c1);
+        house2_insert(R, c0, c1);
     }
     if constexpr (G > 1) {
         // merge the G private factors: after step `off` every lane holds the factor of its 2*off-lane block
@@ -338,9 +346,10 @@ __global__ __launch_bounds__(256) void triangulate_reg_kernel(const int32_t *__r
 #pragma unroll
                 for (int b = 0; b < 4; ++b) Rp[a][b] = (b >= a) ? __shfl_xor(R[a][b], off, G) : 0.0;
 #pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                double row[4] = {Rp[a][0], Rp[a][1], Rp[a][2], Rp[a][3]};
-                givens_insert_fast(R, row);
+            for (int a = 0; a < 4; a += 2) {   // the partner's rows two at a time
+                double row0[4] = {Rp[a][0], Rp[a][1], Rp[a][2], Rp[a][3]};
+                double row1[4] = {Rp[a + 1][0], Rp[a + 1][1], Rp[a + 1][2], Rp[a + 1][3]};
+                house2_insert(R, row0, row1);
             }
         }
         // the two partners of a step fold in opposite orders; all lanes adopt lane 0's copy

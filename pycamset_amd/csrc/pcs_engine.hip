@@ -449,7 +449,8 @@ int pcs_tri_run(pcs_triangulator *t, double *d_pts, void *stream) {
         else if (lanes == 8) PCS_TRI_LAUNCH_REG(8, 8);
         else if (lanes == 16) PCS_TRI_LAUNCH_REG(16, 8);
         else if (t->variant == 3) PCS_TRI_LAUNCH_REG(4, 8);
-        else PCS_TRI_LAUNCH_REG(4, 6);   // 24 views in registers at 161 VGPRs (three waves per SIMD): 51 us against 55 us for (4, 8)
+        else PCS_TRI_LAUNCH_REG(4, 6);   // 24 views in registers at 156 VGPRs (three waves per SIMD): 47 us against 52 us for (4, 8); (4, 3) — four waves
+                                         // per SIMD, 12 register views, the rest through the scratch records — 53 us, (4, 4) 49 us (profiles/r05/tri_bench_r05.log)
     }
 #undef PCS_TRI_LAUNCH_REG
 #undef PCS_TRI_LAUNCH
