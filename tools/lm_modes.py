@@ -41,6 +41,9 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--trace", action="store_true", help="one quiet solve per form only (for rocprofv3 --kernel-trace)")
     ap.add_argument("--forms", default="00,01,10,11", help="fused,deterministic pairs")
+    ap.add_argument("--stub-collective", action="store_true",
+                    help="solve through the SHARDED device-steered loop on one rank: reduce_fn = an in-stream operation that leaves the one rank's sum "
+                         "unchanged (what dist.all_reduce over RCCL is to the stream) — the trace then shows build -> collective -> decision without a gap")
     a = ap.parse_args()
     rig = synthetic.config_rig(a.config)
     cs = _Camset(rig.n_cams)
@@ -55,6 +58,12 @@ def main():
         parts.append(rig.points.ravel()[bp.bdpt_unfixed])
     x0 = np.concatenate(parts)
     h.make_loss_fun(1)
+    reduce_fn = None
+    if a.stub_collective:
+        def reduce_fn(t):
+            t.mul_(1.0)
+            return t
+        reduce_fn.on_device = True
     lm_solve(h, x0.copy(), max_iter=2)
     eng = h.op_fun.engine
     ne = BlockedNormalEquations(eng, h._jac_mask())
@@ -65,7 +74,7 @@ def main():
         eng.set_option("fused_trial", fused)
         eng.set_option("deterministic", det)
         if a.trace:
-            lm_solve(h, x0.copy(), max_iter=30)
+            lm_solve(h, x0.copy(), max_iter=30, reduce_fn=reduce_fn)
             torch.cuda.synchronize()
             continue
         with torch.cuda.stream(ne.stream):
@@ -82,7 +91,7 @@ def main():
         for _ in range(5):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            res = lm_solve(h, x0.copy(), max_iter=30)
+            res = lm_solve(h, x0.copy(), max_iter=30, reduce_fn=reduce_fn)
             best = min(best, time.perf_counter() - t0)
         print(f"  fused {fused} deterministic {det}: build {build_us:7.1f} us | lm_solve {best * 1e3:6.2f} ms for {res.nfev} evaluations "
               f"({best / res.nfev * 1e6:6.1f} us each), cost {res.cost:.9e}, {res.message}", flush=True)
