@@ -166,12 +166,12 @@ int pcs_matfree(pcs_engine *h, int op, const double *in, double *out, double *co
  * writing J:  H = J^T J  (n_params x n_params row-major, FULL parameter-string space, only the UPPER
  * triangle incl. the diagonal is written, the rest is zero),  g = J^T r  (n_params),  cost = r^T r.
  * float64 whatever the engine dtype.  The sums use f64 atomics: the last bits depend on arrival order.  The kernels address H
- * with 32-bit byte offsets: n_params <= PCS_NORMAL_MAX_PARAMS = 23170 (a 4.3 GB matrix); both entry points return
+ * with 32-bit offsets in doubles: n_params <= PCS_NORMAL_MAX_PARAMS = 65535 (a 34 GB matrix; 23170 until round 4); both entry points return
  * PCS_ERR_ARG beyond it, before anything is allocated.
  *   pcs_normal_equations         host buffers (engine-owned device scratch, blocking)
  *   pcs_normal_equations_device  device buffers of the caller, queued on `stream` (NULL = engine stream);
  *                                the call zeroes them first.  Observation shards: all-reduce H, g, cost. */
-#define PCS_NORMAL_MAX_PARAMS 23170
+#define PCS_NORMAL_MAX_PARAMS 65535
 int pcs_normal_equations(pcs_engine *h, const double *param_str, double *H, double *g, double *cost);
 int pcs_normal_equations_device(pcs_engine *h, const double *param_str, double *d_H, double *d_g, double *d_cost, void *stream);
 
@@ -182,7 +182,7 @@ int pcs_normal_equations_device(pcs_engine *h, const double *param_str, double *
  *     d_packed = [ A (n_lead x n_lead, upper triangle) | B (n_lead x n_trail) | C (n_trail / tb blocks of tb x tb, upper
  *                  triangle) | g (n_params) | cost (1) ]     float64, 16-byte aligned, zeroed by the call.
  * pcs_normal_layout: out5 = {n_lead, n_trail, tb, length of d_packed in doubles, n_params}.  The parameter string is read
- * from DEVICE memory (d_param_str), so an LM loop never stages it through the host.  Limits: each region below 4 GiB.
+ * from DEVICE memory (d_param_str), so an LM loop never stages it through the host.  Limits: each region below 2^32 doubles (32 GiB).
  * Observation shards: all-reduce d_packed.  Consumer: pycamset_amd/device_solver.py (reference consumer of J:
  * optimisation_handling.py:88-98). */
 int pcs_normal_layout(const pcs_engine *h, int64_t *out5);

@@ -151,14 +151,14 @@ __host__ __device__ __forceinline__ bool entry_kept(int m, int i, int j, int &sa
 // Descriptor of accumulator register r of lane `lane` of MFMA m (see the flush of ba_normal_mfma_kernel): where the entry goes.
 //   oR | oC << 4 | row entry << 8 | column entry << 13 | ld entry << 18 | pointer entry << 23 | owned << 27 | pose << 28
 // the "entries" being lanes of the look-up table the flush refreshes per run:
-//   lanes  0- 3  8 ldA base[g]            row offset of a leading group inside A
-//   lanes  4- 7  8 ldB base[g]            row offset of a leading group inside B
-//   lane   8     8 tb tb entity           the run's trailing block inside C        lanes 9, 15: zero
+//   lanes  0- 3  ldA base[g]              row offset of a leading group inside A
+//   lanes  4- 7  ldB base[g]              row offset of a leading group inside B
+//   lane   8     tb tb entity             the run's trailing block inside C        lanes 9, 15: zero
 //   lanes 12-14  ldA, ldB, tb             row lengths
-//   lanes 16-19  8 (base[g] - (g == trail_group ? trail_off : 0))   column offset: leading columns keep their
+//   lanes 16-19  base[g] - (g == trail_group ? trail_off : 0)   column offset: leading columns keep their
 //                parameter-string index, trailing ones are local to the trailing part
-//   lanes 24-27  8 base[g]                index into g (parameter-string order)
-// (bytes except the row lengths; every entry number fits its 5-bit field).  Pointer entries: 0 A, 1 B, 2 C, 3 g, 4 cost.
+//   lanes 24-27  base[g]                  index into g (parameter-string order)
+// (doubles; every entry number fits its 5-bit field).  Pointer entries: 0 A, 1 B, 2 C, 3 g, 4 cost.
 // Host-callable: tests/test_host_logic.py decodes these descriptors for sample runs and checks every owned entry against the
 // column pair pcs_normal_entry_map reports for it (pcs_normal_descriptors).
 template <int CHAIN, int PASS>
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(64, 2) void ba_normal_mfma_kernel(const NormalArgs 
     // across lanes (ds_bpermute) in a table the flush refreshes with v_writelane.  No selects: hipcc turned the select
     // chains of the first version into ~10 exec-mask branches per register (800 instructions and 80 branches per flush,
     // 12 us of the 92 at N = 1e6).
-    // (entry_descriptor above; A and B are addressed with 32-bit byte offsets: the host checks the sizes)
+    // (entry_descriptor above; A, B and C are addressed with 32-bit offsets in doubles: the host checks the sizes)
     const int tg = a.trail_group;
     int ent[NM][4];
 #pragma unroll
@@ -278,9 +278,11 @@ __global__ __launch_bounds__(64, 2) void ba_normal_mfma_kernel(const NormalArgs 
         const int base[4] = {9 * cam, (int)a.extr_off + 6 * cam, (int)a.pose_off + 6 * img, (int)a.point_off + 3 * key};
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const int b = __builtin_amdgcn_readfirstlane(base[g]);
-            const int rowA = 8 * a.ldA * b, rowB = 8 * a.ldB * b;
-            const int col = 8 * (b - (g == tg ? (int)a.trail_off : 0)), gi = 8 * b;
+            // the table holds offsets in DOUBLES (round 5; bytes before: a region ended at 4 GiB = 2^29 doubles — now 2^32 doubles = 32 GiB,
+            // checked by the host): unsigned 32-bit arithmetic, widened and shifted when the address is formed
+            const uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane(base[g]);
+            const int rowA = (int)((uint32_t)a.ldA * b), rowB = (int)((uint32_t)a.ldB * b);
+            const int col = (int)(b - (g == tg ? (uint32_t)a.trail_off : 0u)), gi = (int)b;
             asm("v_writelane_b32 %0, %1, %2" : "+v"(base_tab) : "s"(rowA), "n"(g));
             asm("v_writelane_b32 %0, %1, %2" : "+v"(base_tab) : "s"(rowB), "n"(4 + g));
             asm("v_writelane_b32 %0, %1, %2" : "+v"(base_tab) : "s"(col), "n"(16 + g));
@@ -288,7 +290,7 @@ __global__ __launch_bounds__(64, 2) void ba_normal_mfma_kernel(const NormalArgs 
         }
         {
             const int ent_idx = tg == 2 ? img : key;   // entity of the trailing group in this run
-            const int rowC = __builtin_amdgcn_readfirstlane(8 * a.tb * a.tb * ent_idx);
+            const int rowC = __builtin_amdgcn_readfirstlane((int)((uint32_t)(a.tb * a.tb) * (uint32_t)ent_idx));
             asm("v_writelane_b32 %0, %1, %2" : "+v"(base_tab) : "s"(rowC), "n"(8));
         }
         // all destinations first (5 lane look-ups per register, no branch in between, so their latencies overlap) ...
@@ -303,10 +305,10 @@ __global__ __launch_bounds__(64, 2) void ba_normal_mfma_kernel(const NormalArgs 
                 const uint32_t ld = (uint32_t)__builtin_amdgcn_ds_bpermute((d >> 16) & (31 << 2), base_tab);
                 const uint32_t off = (uint32_t)__builtin_amdgcn_ds_bpermute((d >> 6) & (31 << 2), base_tab) +
                                      (uint32_t)__builtin_amdgcn_ds_bpermute((d >> 11) & (31 << 2), base_tab) +
-                                     8u * ((uint32_t)(d & 15) * ld + (uint32_t)((d >> 4) & 15));
+                                     ((uint32_t)(d & 15) * ld + (uint32_t)((d >> 4) & 15));
                 const int psel = (d >> 21) & (7 << 2);
                 const uint64_t pb = ((uint64_t)(uint32_t)__builtin_amdgcn_ds_bpermute(psel, ptr_hi) << 32) | (uint32_t)__builtin_amdgcn_ds_bpermute(psel, ptr_lo);
-                dst[m][r] = pb + off;
+                dst[m][r] = pb + ((uint64_t)off << 3);
                 dsc[m][r] = d;
             }
         // ... then one predicated atomic per register

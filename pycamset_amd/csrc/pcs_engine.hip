@@ -1288,12 +1288,12 @@ static int enqueue_normal(pcs_engine *h, const double *d_prm, double *d_H, doubl
     if (h->chain == PCS_CHAIN_TEMPLATE && !h->have_template) return fail(PCS_ERR_STATE, "template points not set");
     const BlockLayout L = block_layout(h);
     if (!blocked) {
-        // the flush addresses H with 32-bit byte offsets: 8 n^2 < 2^32 (a 4.3 GB matrix)
-        if (h->n_params > PCS_NORMAL_MAX_PARAMS) return fail(PCS_ERR_ARG, "normal equations: more than %d parameters (dense H beyond 4 GiB) is not supported", PCS_NORMAL_MAX_PARAMS);
+        // the flush addresses H with 32-bit offsets in doubles: n^2 < 2^32 (a 34 GB matrix)
+        if (h->n_params > PCS_NORMAL_MAX_PARAMS) return fail(PCS_ERR_ARG, "normal equations: more than %d parameters (dense H beyond 32 GiB) is not supported", PCS_NORMAL_MAX_PARAMS);
     } else {
-        const int64_t lim = (int64_t)1 << 29;   // doubles per region: 32-bit byte offsets
+        const int64_t lim = (int64_t)1 << 32;   // doubles per region: 32-bit offsets in doubles (32 GiB; rounds 3-4: byte offsets, 4 GiB)
         if (L.a_len() >= lim || L.b_len() >= lim || L.c_len() >= lim)
-            return fail(PCS_ERR_ARG, "blocked normal equations: a region beyond 4 GiB (leading %lld, trailing %lld columns) is not supported; use pcs_matfree",
+            return fail(PCS_ERR_ARG, "blocked normal equations: a region beyond 32 GiB (leading %lld, trailing %lld columns) is not supported; use pcs_matfree",
                         (long long)L.n_lead, (long long)L.n_trail);
     }
     HIPCHK(hipSetDevice(h->device));
@@ -2314,7 +2314,7 @@ int pcs_normal_equations(pcs_engine *h, const double *param_str, double *H, doub
     if (!h || !param_str || !H || !g || !cost) return fail(PCS_ERR_ARG, "pcs_normal_equations: bad arguments");
     if (h->n <= 0) return fail(PCS_ERR_STATE, "no detections set");
     if (h->n_params > PCS_NORMAL_MAX_PARAMS)  // the same limit as enqueue_normal, checked BEFORE the scratch allocation
-        return fail(PCS_ERR_ARG, "pcs_normal_equations: %lld parameters make a dense J^T J of %.1f GB (limit %d parameters: 32-bit byte offsets); use pcs_matfree",
+        return fail(PCS_ERR_ARG, "pcs_normal_equations: %lld parameters make a dense J^T J of %.1f GB (limit %d parameters: 32-bit offsets); use pcs_matfree",
                     (long long)h->n_params, (double)h->n_params * (double)h->n_params * 8e-9, PCS_NORMAL_MAX_PARAMS);
     HIPCHK(hipSetDevice(h->device));
     const int64_t need = h->n_params * h->n_params + h->n_params + 1;  // H | g | cost in one scratch buffer

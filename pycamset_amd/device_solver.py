@@ -126,16 +126,16 @@ LAM0_EXACT = 1e-5           # initial damping of the exact (Cholesky) step; 1e-3
 LAM_GROW0 = 1e3             # factor a rejected trial applies to lambda before the first accepted step (lm_solve)
 LAM_FAST = (0.95, 0.1)      # a gain ratio above 0.95 multiplies lambda by 0.1 instead of 1/3: a model THAT accurate lets the damping go quickly
 LEAD_LIMIT = 16384          # leading parameters up to which lm_solve(linear_solver="auto") takes the Schur / Cholesky step (S: 2 GB)
-BLOCKED_BYTES_LIMIT = 16e9  # and total bytes of the two packed buffers + V
+BLOCKED_BYTES_LIMIT = 96e9  # and total bytes of the two packed buffers + V + S (a third of the part's 288 GB)
 
 
-REGION_LIMIT = 2 ** 29     # doubles per region of the packed buffer: the build addresses A, B and C with 32-bit byte offsets (pcs_engine.hip enqueue_normal)
+REGION_LIMIT = 2 ** 32     # doubles per region of the packed buffer: the build addresses A, B and C with 32-bit offsets in doubles (pcs_engine.hip enqueue_normal; 2^29 until round 4)
 
 
 def blocked_fits(engine) -> bool:
     """Can ``linear_solver='auto'`` take the blocked normal equations + Schur / Cholesky step on this engine?  False for generated
     chains (no block-reduced build: they use the products of csrc/ba_blockrow.hpp), for leading groups beyond LEAD_LIMIT, for
-    buffers beyond BLOCKED_BYTES_LIMIT and for any single region A / B / C of 2^29 doubles or more (the build would refuse it)."""
+    buffers beyond BLOCKED_BYTES_LIMIT and for any single region A / B / C of 2^32 doubles or more (the build would refuse it)."""
     if not hasattr(engine, "normal_layout"):
         return False
     lay = engine.normal_layout()

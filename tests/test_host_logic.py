@@ -561,12 +561,12 @@ def test_normal_equation_flush_descriptors_address_the_right_entries():
                     base = [9 * cam, extr_off + 6 * cam, pose_off + 6 * img, point_off + 3 * key]
                     tab = np.zeros(64, dtype=np.int64)
                     tab[12], tab[13], tab[14] = ldA, ldB, tb
-                    for g in range(4):
-                        tab[g] = 8 * ldA * base[g]
-                        tab[4 + g] = 8 * ldB * base[g]
-                        tab[16 + g] = 8 * (base[g] - (trail_off if g == tg else 0))
-                        tab[24 + g] = 8 * base[g]
-                    tab[8] = 8 * tb * tb * (img if tg == 2 else key)
+                    for g in range(4):          # offsets in doubles (round 5; bytes until round 4)
+                        tab[g] = ldA * base[g]
+                        tab[4 + g] = ldB * base[g]
+                        tab[16 + g] = base[g] - (trail_off if g == tg else 0)
+                        tab[24 + g] = base[g]
+                    tab[8] = tb * tb * (img if tg == 2 else key)
 
                     def glob(lc):
                         if lc < 9:
@@ -588,7 +588,7 @@ def test_normal_equation_flush_descriptors_address_the_right_entries():
                                     continue
                                 o_r, o_c = d & 15, (d >> 4) & 15
                                 e_row, e_col, e_ld, e_ptr = (d >> 8) & 31, (d >> 13) & 31, (d >> 18) & 31, (d >> 23) & 7
-                                off = (tab[e_row] + tab[e_col]) // 8 + o_r * tab[e_ld] + o_c
+                                off = tab[e_row] + tab[e_col] + o_r * tab[e_ld] + o_c
                                 if la == R and lb == R:
                                     want = (4, 0)
                                 elif R in (la, lb):
