@@ -439,6 +439,14 @@ int pcs_tri_set_cameras(pcs_triangulator *t, const double *proj, const double *i
 int pcs_tri_set_observations(pcs_triangulator *t, int64_t n_obs, const int32_t *cam, const double *uv, int64_t n_pts, const int64_t *start_inds);
 int pcs_tri_set_observations_device(pcs_triangulator *t, int64_t n_obs, const int32_t *d_cam, const double *d_uv, int64_t n_pts,
                                     const int64_t *d_start_inds);
+/* The grouping CameraSet.multi_cam_triangulate does in front of nb_triangulate_full (cameras/camera_set.py:371-378: two np.unique calls over
+ * the (image, key...) columns — which features are seen by more than one camera, their rows in table order, start indices in order of
+ * first appearance), on the device: n table rows as caller-owned device arrays (camera index, dense feature id in [0, n_features),
+ * measurement), grouped by feature like TargetDetection.get_data returns them -> the handle's current observations (pcs_tri_run next).
+ * *n_pts / *n_kept: features kept / their rows.  *grouped = 0 (nothing set): a feature's rows are not consecutive — group on the host
+ * (the reference's consecutive slices then mix features; the host mirror reproduces that).  One host synchronisation. */
+int pcs_tri_group_device(pcs_triangulator *t, int64_t n, const int32_t *d_cam, const int32_t *d_feat, const double *d_uv, int64_t n_features,
+                         int64_t *n_pts, int64_t *n_kept, int32_t *grouped, void *stream);
 int pcs_tri_run(pcs_triangulator *t, double *d_pts, void *stream);
 int pcs_tri_points(pcs_triangulator *t, double *pts);
 int pcs_tri_synchronize(pcs_triangulator *t, void *stream);

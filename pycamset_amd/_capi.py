@@ -106,6 +106,7 @@ SYMBOLS = {
     "pcs_tri_set_cameras": (c_int, [_P, POINTER(c_double), POINTER(c_double), POINTER(c_double)]),
     "pcs_tri_set_observations": (c_int, [_P, c_int64, POINTER(c_int32), POINTER(c_double), c_int64, POINTER(c_int64)]),
     "pcs_tri_set_observations_device": (c_int, [_P, c_int64, _P, _P, c_int64, _P]),
+    "pcs_tri_group_device": (c_int, [_P, c_int64, _P, _P, _P, c_int64, POINTER(c_int64), POINTER(c_int64), POINTER(c_int32), _P]),
     "pcs_tri_run": (c_int, [_P, _P, _P]),
     "pcs_tri_points": (c_int, [_P, POINTER(c_double)]),
     "pcs_tri_synchronize": (c_int, [_P, _P]),

@@ -462,4 +462,93 @@ __global__ __launch_bounds__(256) void tri_order_scatter_kernel(const int64_t *_
     order[pos] = (int32_t)j;
 }
 
+// ---- the grouping in front of the triangulation, on the device (round 5) ---------------------------------------------------------------------
+// CameraSet.multi_cam_triangulate (cameras/camera_set.py:371-378) finds, with two np.unique calls over the (image, key...) columns of the
+// detection table, the features seen by more than one camera, keeps their rows in table order and builds start_ind = cumulative counts
+// in order of first appearance; nb_triangulate_full then takes CONSECUTIVE rows per feature.  On a table grouped by feature (what
+// TargetDetection.get_data returns, and the only kind for which the reference's consecutive slices are one feature each) that is:
+//   count[f]  rows per feature (dense feature ids);  head[i] = row i starts a run of its feature;
+//   keep[i] = count[feature[i]] >= 2;  position among the kept rows and index of the kept run = an exclusive scan of (keep, keep & head);
+//   kept rows scattered in order, start[run] = position of the run's first row.
+// The host grouping took 0.37 s for 1e6 observations (NumPy's sort-based unique); this is four launches.  Whether the table IS grouped
+// (runs == features present) is checked on the device; the caller falls back to the host grouping — the reference's semantics for
+// any table — otherwise.
+struct TriGroupArgs {
+    const int32_t *cam, *feat;       // n rows: camera index, dense feature id in [0, n_features)
+    const double2 *uv;
+    int32_t *count;                  // n_features, zeroed
+    uint64_t *block_sums;            // one packed (kept rows | kept runs << 32) per 1024-row block; exclusive-scanned in place
+    int64_t *totals;                 // [0] kept rows, [1] kept runs, [2] runs in the table, [3] features present; zeroed
+    int32_t *cam_out;
+    double2 *uv_out;
+    int64_t *start;                  // kept runs + 1
+    int64_t n, n_features;
+    int32_t n_blocks;
+};
+constexpr int TRI_GROUP_BLOCK = 1024;
+
+__global__ __launch_bounds__(256) void tri_group_count_kernel(const TriGroupArgs a) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    const int32_t f = a.feat[i];
+    if (atomicAdd(a.count + f, 1) == 0) atomicAdd(reinterpret_cast<unsigned long long *>(a.totals + 3), 1ull);   // a feature's first row
+    if (i == 0 || a.feat[i - 1] != f) atomicAdd(reinterpret_cast<unsigned long long *>(a.totals + 2), 1ull);     // a run's first row
+}
+
+__device__ __forceinline__ uint64_t tri_group_flags(const TriGroupArgs &a, const int64_t i) {
+    if (i >= a.n) return 0;
+    const int32_t f = a.feat[i];
+    const bool keep = a.count[f] >= 2;
+    const bool head = i == 0 || a.feat[i - 1] != f;
+    return (keep ? 1ull : 0ull) | ((keep && head) ? (1ull << 32) : 0ull);
+}
+// workgroup-wide inclusive scan of one packed word per thread (1024 threads), through LDS
+__device__ __forceinline__ uint64_t tri_group_scan(uint64_t v, uint64_t *sm) {
+    const int tid = threadIdx.x;
+    sm[tid] = v;
+    __syncthreads();
+    for (int off = 1; off < TRI_GROUP_BLOCK; off <<= 1) {
+        const uint64_t add = tid >= off ? sm[tid - off] : 0;
+        __syncthreads();
+        sm[tid] += add;
+        __syncthreads();
+    }
+    return sm[tid];
+}
+__global__ __launch_bounds__(TRI_GROUP_BLOCK) void tri_group_blocksum_kernel(const TriGroupArgs a) {
+    __shared__ uint64_t sm[TRI_GROUP_BLOCK];
+    const uint64_t inc = tri_group_scan(tri_group_flags(a, (int64_t)blockIdx.x * TRI_GROUP_BLOCK + threadIdx.x), sm);
+    if (threadIdx.x == TRI_GROUP_BLOCK - 1) a.block_sums[blockIdx.x] = inc;
+}
+__global__ __launch_bounds__(TRI_GROUP_BLOCK) void tri_group_scan_sums_kernel(const TriGroupArgs a) {   // one workgroup: exclusive scan of the block sums
+    __shared__ uint64_t sm[TRI_GROUP_BLOCK];
+    uint64_t carry = 0;
+    for (int b0 = 0; b0 < a.n_blocks; b0 += TRI_GROUP_BLOCK) {
+        const int b = b0 + threadIdx.x;
+        const uint64_t v = b < a.n_blocks ? a.block_sums[b] : 0;
+        const uint64_t inc = tri_group_scan(v, sm);
+        if (b < a.n_blocks) a.block_sums[b] = carry + inc - v;
+        const uint64_t total = sm[TRI_GROUP_BLOCK - 1];
+        __syncthreads();
+        carry += total;
+    }
+    if (threadIdx.x == 0) {
+        a.totals[0] = (int64_t)(carry & 0xffffffffull);
+        a.totals[1] = (int64_t)(carry >> 32);
+        a.start[carry >> 32] = (int64_t)(carry & 0xffffffffull);   // start[n_runs] = kept rows
+    }
+}
+__global__ __launch_bounds__(TRI_GROUP_BLOCK) void tri_group_scatter_kernel(const TriGroupArgs a) {
+    __shared__ uint64_t sm[TRI_GROUP_BLOCK];
+    const int64_t i = (int64_t)blockIdx.x * TRI_GROUP_BLOCK + threadIdx.x;
+    const uint64_t fl = tri_group_flags(a, i);
+    const uint64_t exc = a.block_sums[blockIdx.x] + tri_group_scan(fl, sm) - fl;
+    if (fl & 1ull) {
+        const int64_t pos = (int64_t)(exc & 0xffffffffull);
+        a.cam_out[pos] = a.cam[i];
+        a.uv_out[pos] = a.uv[i];
+        if (fl >> 32) a.start[exc >> 32] = pos;
+    }
+}
+
 }  // namespace pcs

@@ -265,6 +265,9 @@ struct pcs_triangulator {
     // current problem (device pointers: handle-owned or the caller's)
     const int32_t *cur_cam = nullptr; const double *cur_uv = nullptr; const int64_t *cur_start = nullptr;
     int64_t n_obs = 0, n_pts = -1;
+    // the grouping in front of the triangulation (pcs_tri_group_device): per-feature counts, block sums of the scan, totals
+    int32_t *d_count = nullptr; uint64_t *d_block_sums = nullptr; int64_t *d_totals = nullptr;
+    int64_t count_capacity = 0, block_capacity = 0;
     int32_t *d_order = nullptr, *d_hist = nullptr;   // points by view count (built by the first run of a set of observations)
     int64_t order_capacity = 0;
     bool order_valid = false, sort_points = true;
@@ -326,7 +329,8 @@ int pcs_tri_destroy(pcs_triangulator *t) {
     (void)hipSetDevice(t->device);
     if (t->stream) (void)hipStreamSynchronize(t->stream);
     (void)tri_wait_done_host(t);   // a run on a caller stream may still read the tables
-    for (void *b : {(void *)t->d_tab, (void *)t->d_cam, (void *)t->d_uv, (void *)t->d_start, t->d_scr, t->d_scl, (void *)t->d_pts, (void *)t->d_order, (void *)t->d_hist})
+    for (void *b : {(void *)t->d_tab, (void *)t->d_cam, (void *)t->d_uv, (void *)t->d_start, t->d_scr, t->d_scl, (void *)t->d_pts, (void *)t->d_order, (void *)t->d_hist,
+                    (void *)t->d_count, (void *)t->d_block_sums, (void *)t->d_totals})
         if (b) (void)hipFree(b);
     if (t->e0) (void)hipEventDestroy(t->e0);
     if (t->e1) (void)hipEventDestroy(t->e1);
@@ -388,6 +392,68 @@ int pcs_tri_set_observations_device(pcs_triangulator *t, int64_t n_obs, const in
     if (!t || n_obs < 0 || n_pts < 0 || !d_start_inds || (n_obs > 0 && (!d_cam || !d_uv))) return fail(PCS_ERR_ARG, "pcs_tri_set_observations_device: bad arguments");
     t->cur_cam = d_cam; t->cur_uv = d_uv; t->cur_start = d_start_inds;   // caller-owned, not range-checked (stay on the device)
     t->n_obs = n_obs; t->n_pts = n_pts;
+    t->order_valid = false;
+    t->out_owned = false;
+    return PCS_OK;
+}
+
+// The grouping CameraSet.multi_cam_triangulate does in front of nb_triangulate_full (cameras/camera_set.py:371-378), on the device
+// (csrc/ba_triangulate.hpp, "the grouping in front of the triangulation"): from n table rows (camera, dense feature id, measurement;
+// caller-owned device arrays, the table grouped by feature) to the handle's current observations — the rows of features seen by at
+// least two cameras, in table order, and their start indices.  One host synchronisation (the counts).  *grouped = 0: the table is
+// NOT grouped by feature (a feature's rows are not consecutive): nothing was set, the caller groups on the host.
+int pcs_tri_group_device(pcs_triangulator *t, int64_t n, const int32_t *d_cam, const int32_t *d_feat, const double *d_uv, int64_t n_features,
+                         int64_t *n_pts, int64_t *n_kept, int32_t *grouped, void *stream) {
+    if (!t || n < 0 || n > INT32_MAX || n_features <= 0 || n_features > INT32_MAX || !n_pts || !n_kept || !grouped || (n > 0 && (!d_cam || !d_feat || !d_uv)))
+        return fail(PCS_ERR_ARG, "pcs_tri_group_device: bad arguments");
+    *n_pts = *n_kept = 0;
+    *grouped = 1;
+    HIPCHK(hipSetDevice(t->device));
+    hipStream_t s = stream ? (hipStream_t)stream : t->stream;
+    HIPCHK(tri_wait_done_host(t));   // a run queued on ANY stream may still read the observation copies this call overwrites
+    HIPCHK(hipStreamSynchronize(t->stream));
+    t->n_pts = -1;
+    if (n == 0) {
+        int rc0 = tri_grow((void **)&t->d_start, &t->pts_capacity, 1, sizeof(int64_t));
+        if (rc0) return rc0;
+        HIPCHK(hipMemsetAsync(t->d_start, 0, sizeof(int64_t), s));
+        HIPCHK(hipStreamSynchronize(s));
+        t->cur_cam = t->d_cam; t->cur_uv = t->d_uv; t->cur_start = t->d_start;
+        t->n_obs = 0; t->n_pts = 0; t->order_valid = false; t->out_owned = false;
+        return PCS_OK;
+    }
+    const int64_t n_blocks = (n + TRI_GROUP_BLOCK - 1) / TRI_GROUP_BLOCK;
+    int rc = tri_grow((void **)&t->d_cam, &t->obs_capacity, n, sizeof(int32_t));
+    if (rc) return rc;
+    rc = tri_grow((void **)&t->d_uv, &t->uv_capacity, n, 2 * sizeof(double));
+    if (rc) return rc;
+    rc = tri_grow((void **)&t->d_start, &t->pts_capacity, n / 2 + 2, sizeof(int64_t));
+    if (rc) return rc;
+    rc = tri_grow((void **)&t->d_count, &t->count_capacity, n_features, sizeof(int32_t));
+    if (rc) return rc;
+    rc = tri_grow((void **)&t->d_block_sums, &t->block_capacity, n_blocks, sizeof(uint64_t));
+    if (rc) return rc;
+    if (!t->d_totals) HIPCHK(hipMalloc(&t->d_totals, sizeof(int64_t) * 4));
+    HIPCHK(hipMemsetAsync(t->d_count, 0, sizeof(int32_t) * n_features, s));
+    HIPCHK(hipMemsetAsync(t->d_totals, 0, sizeof(int64_t) * 4, s));
+    TriGroupArgs a{d_cam, d_feat, reinterpret_cast<const double2 *>(d_uv), t->d_count, t->d_block_sums, t->d_totals, t->d_cam,
+                   reinterpret_cast<double2 *>(t->d_uv), t->d_start, n, n_features, (int32_t)n_blocks};
+    hipLaunchKernelGGL(tri_group_count_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(tri_group_blocksum_kernel, dim3((unsigned)n_blocks), dim3(TRI_GROUP_BLOCK), 0, s, a);
+    hipLaunchKernelGGL(tri_group_scan_sums_kernel, dim3(1), dim3(TRI_GROUP_BLOCK), 0, s, a);
+    hipLaunchKernelGGL(tri_group_scatter_kernel, dim3((unsigned)n_blocks), dim3(TRI_GROUP_BLOCK), 0, s, a);
+    HIPCHK(hipGetLastError());
+    int64_t totals[4];
+    HIPCHK(hipMemcpyAsync(totals, t->d_totals, sizeof totals, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (totals[2] != totals[3]) {   // more runs than features: some feature's rows are not consecutive
+        *grouped = 0;
+        return PCS_OK;
+    }
+    *n_kept = totals[0];
+    *n_pts = totals[1];
+    t->cur_cam = t->d_cam; t->cur_uv = t->d_uv; t->cur_start = t->d_start;
+    t->n_obs = totals[0]; t->n_pts = totals[1];
     t->order_valid = false;
     t->out_owned = false;
     return PCS_OK;

@@ -187,3 +187,51 @@ def test_triangulator_orders_runs_across_streams():
     assert np.array_equal(tri.points(), ref[:half])
     tri.close()
 
+
+
+@pytest.mark.parametrize("n_cams,vis", [(5, 0.45), (32, 0.3215)])
+def test_multi_cam_triangulate_groups_on_the_device(n_cams, vis):
+    """The front end of row f4 (cameras/camera_set.py:343-402, the array branch): which features are seen by more than one camera, their
+    rows in table order, start indices in order of first appearance — np.unique twice in the reference, four small launches here
+    (pcs_tri_group_device) — and then the triangulation.  Against the host grouping (group_reconstructable, itself pinned to the
+    reference's in tests/test_oracle_golden.py) followed by nb_triangulate_full: the same points bit for bit, single-view features
+    dropped, features with NO detection skipped, an empty table, and a table that is not grouped by feature (host fallback)."""
+    import torch
+    rig = synthetic.make_rig("tri-group", n_cams, 6, synthetic.ccube_points(6, 30.0), seed=70 + n_cams, visibility=vis, n_rings=2 if n_cams >= 4 else 1)
+    _, P, K, D = orc.legacy_inputs(rig.intr_true, rig.extr_true, rig.poses_true, rig.points)
+    d = rig.detections
+    d = d[np.lexsort((d[:, 0], d[:, 2], d[:, 1]))]                       # grouped by (image, key), cameras inside: TargetDetection.get_data's order
+    rec, start = hip_ch.group_reconstructable(d)
+    counts = np.unique(d[:, 1:3], axis=0, return_counts=True)[1]
+    assert start.shape[0] - 1 == int((counts >= 2).sum())
+    if n_cams == 5:
+        assert (counts == 1).any()                                       # some features are seen once and must be dropped
+    ref = hip_ch.nb_triangulate_full(rec, P, start, K, D)
+    pts = hip_ch.multi_cam_triangulate(d, P, K, D)
+    assert pts.shape == ref.shape and np.array_equal(pts, ref)
+    # the pieces: counts, kept rows and start indices of the device grouping
+    tri = hip_ch.Triangulator(n_cams)
+    tri.set_cameras(P, K, D)
+    feat = (d[:, 1].astype(np.int64) * rig.n_keys + d[:, 2].astype(np.int64)).astype(np.int32)
+    d_cam, d_feat, d_uv = (torch.from_numpy(x).cuda() for x in (d[:, 0].astype(np.int32), feat, np.ascontiguousarray(d[:, 3:])))
+    torch.cuda.synchronize()
+    n_pts, n_kept, grouped = tri.group_table_device(d.shape[0], d_cam.data_ptr(), d_feat.data_ptr(), d_uv.data_ptr(), rig.n_imgs * rig.n_keys)
+    assert grouped and (n_pts, n_kept) == (start.shape[0] - 1, rec.shape[0])
+    tri.run()
+    assert np.array_equal(tri.points(), ref)
+    # distortion off, like multi_cam_triangulate(distort=False)
+    assert np.array_equal(hip_ch.multi_cam_triangulate(d, P, K, D, distort=False), hip_ch.nb_triangulate_full(rec, P, start, K, np.zeros_like(D)))
+    # a table that is NOT grouped by feature (cam -> image -> key order): the device says so, the host grouping takes over — and that is
+    # the reference's own (consecutive-slice) semantics for such a table
+    dd = rig.detections                                                   # cam-major
+    feat2 = (dd[:, 1].astype(np.int64) * rig.n_keys + dd[:, 2].astype(np.int64)).astype(np.int32)
+    t_cam, t_feat, t_uv = (torch.from_numpy(x).cuda() for x in (dd[:, 0].astype(np.int32), feat2, np.ascontiguousarray(dd[:, 3:])))
+    torch.cuda.synchronize()
+    assert tri.group_table_device(dd.shape[0], t_cam.data_ptr(), t_feat.data_ptr(), t_uv.data_ptr(), rig.n_imgs * rig.n_keys)[2] is False
+    rec2, start2 = hip_ch.group_reconstructable(dd)
+    assert np.array_equal(hip_ch.multi_cam_triangulate(dd, P, K, D), hip_ch.nb_triangulate_full(rec2, P, start2, K, D))
+    # nothing to reconstruct
+    assert hip_ch.multi_cam_triangulate(d[:0], P, K, D).shape == (0, 3)
+    single = d[np.concatenate([[True], np.any(d[1:, 1:3] != d[:-1, 1:3], axis=1)])]      # one row per feature: no feature is seen twice
+    assert hip_ch.multi_cam_triangulate(single, P, K, D).shape == (0, 3)
+    tri.close()

@@ -46,6 +46,10 @@ for _ in range(20):  # (c) everything resident: the call is enqueue + synchroniz
 k = tri.last_kernel_ms()
 print(f"  handle, device in / device out:       kernel {k*1e3:8.1f} us   call {np.median(calls)*1e6:8.1f} us (median of 20) = {np.median(calls)*1e3/k:.2f} x kernel")
 assert np.array_equal(d_pts.cpu().numpy(), pts), "resident and host paths agree bit for bit"
+for _ in range(3):   # (d) the whole front end: grouping (device: pcs_tri_group_device) + triangulation from the detection table
+    t0 = time.perf_counter(); pts_fe = hc.multi_cam_triangulate(d, P, Kc, D); wall = time.perf_counter() - t0
+    print(f"  multi_cam_triangulate (table in, points out; grouping on the device): call {wall*1e3:8.2f} ms   (host grouping alone: {tg*1e3:.0f} ms)")
+assert np.array_equal(pts_fe, pts), "device grouping and host grouping give the same points"
 sel = np.arange(0, n_pts, 200)
 rows = np.concatenate([np.arange(start[j], start[j + 1]) for j in sel]); sst = np.append(0, np.cumsum(np.diff(start)[sel]))
 t0 = time.perf_counter(); ref = orc.triangulate_full(rec[rows], P, sst, Kc, D); tc = time.perf_counter() - t0
