@@ -316,9 +316,21 @@ def _lm_solve_blocked(ne: BlockedNormalEquations, ps0: np.ndarray, *, max_iter, 
     try:
         # The device steers the loop wherever the collective (if any) is stream-ordered: one GPU, or RCCL on the solver's stream.
         # A host-staged collective (gloo) needs the host between build and decision anyway: host-steered loop.
-        device_steered = ne.reduce_fn is None or getattr(ne.reduce_fn, "on_device", False)
+        # A sharded loop runs in the engine's deterministic mode — every rank computes the same bits from the all-reduced blocks, so
+        # no rank can take another branch than its peers — unless the engine cannot (the (image, key) pass of the self chain with more
+        # than 64 cameras keeps its atomics, csrc/ba_reduce.hpp): then the ranks adopt one consensus step per trial, host-steered.
+        sharded = ne.reduce_fn is not None
+        det_ok = not (eng.chain == "self" and eng.n_cams > DET_SELF_CAM_LIMIT)
+        device_steered = not sharded or (getattr(ne.reduce_fn, "on_device", False) and det_ok)
         loop = _lm_loop_device if device_steered else _lm_loop_blocked
-        return loop(ne, ps0, max_iter=max_iter, ftol=ftol, xtol=xtol, gtol=gtol, lam0=lam0, lam_grow0=lam_grow0, verbose=verbose)
+        saved_det = eng.option("deterministic", 0)
+        if sharded and det_ok and not saved_det:
+            eng.set_option("deterministic", 1)
+        try:
+            return loop(ne, ps0, max_iter=max_iter, ftol=ftol, xtol=xtol, gtol=gtol, lam0=lam0, lam_grow0=lam_grow0, verbose=verbose)
+        finally:
+            if sharded and det_ok and not saved_det:
+                eng.set_option("deterministic", 0)
     finally:
         eng.set_option("lazy_done_event", saved[1])   # flushes the pending record while the stream exists
         eng.set_option("timing_every", saved[0])
@@ -327,6 +339,7 @@ def _lm_solve_blocked(ne: BlockedNormalEquations, ps0: np.ndarray, *, max_iter, 
 STOP_MESSAGES = {0: "maximum number of iterations reached", 1: "gtol reached", 2: "no further decrease (damping exhausted)", 3: "ftol reached", 4: "xtol reached",
                  5: "maximum number of iterations reached"}
 STOP_STATUS = {0: 0, 1: 1, 2: 2, 3: 3, 4: 4, 5: 0}
+DET_SELF_CAM_LIMIT = 64          # the self chain's (image, key) pass is order-deterministic up to this many cameras (csrc/ba_reduce.hpp)
 REJECTION_LIMIT = 12      # consecutive rejected trials before the loop gives up ("damping exhausted")
 LM_SENTINEL = np.uint64(0x7FF8DEAD00000001)   # what a read-back slot holds until the device has written it (csrc/ba_schur.hpp lm_decide_kernel)
 
@@ -342,7 +355,7 @@ def _lm_loop_device(ne: BlockedNormalEquations, ps0: np.ndarray, *, max_iter, ft
     trial state queued between the two halves of a trial (pcs_lm_trial_build / pcs_lm_trial_finish) — no host synchronisation
     either.  The collective is queued on a fixed address, so the trial is always built into packed[1] and an accepted one is copied
     over packed[0] (PCS_LM_FIXED_TRIAL_BUFFER); the ranks decide on identical all-reduced blocks with order-deterministic kernels
-    (the engine's deterministic mode is switched on for the loop), so every rank walks the same path without a consensus
+    (`_lm_solve_blocked` switches the engine's deterministic mode on for a sharded loop), so every rank walks the same path without a consensus
     collective, and a dense solve that gives up on ONE rank voids the trial on all of them (PCS_LM_VOTES)."""
     from ._capi import LM_FIXED_TRIAL_BUFFER, LM_STATS, LM_VOTES, LmBuffers
     from .engine import SPD_ALGORITHMS
@@ -351,140 +364,133 @@ def _lm_loop_device(ne: BlockedNormalEquations, ps0: np.ndarray, *, max_iter, ft
     dev = ne.dev
     sharded = ne.reduce_fn is not None
     eng = ne.eng
-    saved_det = eng.option("deterministic", 0)
-    if sharded and not saved_det:
-        eng.set_option("deterministic", 1)
-    try:
-        with torch.cuda.device(dev), torch.cuda.stream(ne.stream):
-            stream = ne.stream.cuda_stream
-            ps = [torch.from_numpy(np.ascontiguousarray(ps0, dtype=np.float64)).to(dev), None]
-            ps[1] = torch.empty_like(ps[0])
-            lam = torch.full((1,), float(lam0), dtype=torch.float64, device=dev)
-            ctrl = torch.tensor([0.0, 0.0, 0.0, float(max_iter), ftol, xtol, gtol, float(REJECTION_LIMIT), 0.0, float(lam_grow0), LAM_FAST[0], LAM_FAST[1]],
-                                dtype=torch.float64, device=dev)
-            flags = torch.zeros(4, dtype=torch.int32, device=dev)          # [stop, accepted, current state, -]
-            stats_dev = torch.zeros(LM_STATS, dtype=torch.float64, device=dev)
-            ring = 4
-            # page-locked, allocated once per solver state, not per solve (hipHostMalloc costs ~0.2 ms) — and not shared between states: a
-            # speculative trial one solve leaves behind still writes its read-back while the next solve may already run
-            stats_host = ne.__dict__.get("_stats_host")
-            if stats_host is None:
-                stats_host = ne._stats_host = [torch.zeros(LM_STATS, dtype=torch.float64).pin_memory() for _ in range(ring)]
-            # the final state (gradient | solution | sum r^2) is written into this page-locked buffer by the trial that ends the loop, before
-            # that trial's read-back: the host returns without a copy of its own and without waiting for the speculative trial to drain
-            n_free = int(ne.free_idx.numel())
-            result_host = ne.__dict__.get("_result_host")
-            if result_host is None or result_host.numel() != 2 * n_free + 1:
-                result_host = ne._result_host = torch.zeros(2 * n_free + 1, dtype=torch.float64).pin_memory()
-            result_view = result_host.numpy()
-            result_view[-1] = np.nan
-            pending = ne.__dict__.pop("_drain_event", None)
-            if pending is not None:
-                pending.synchronize()              # the speculative trial the previous solve left behind has written its (void) read-back
-            ne.build(ps[0], 0)
-            history = []                       # the first entry — the starting cost — comes with the first trial's read-back (no sync of its own)
+    with torch.cuda.device(dev), torch.cuda.stream(ne.stream):
+        stream = ne.stream.cuda_stream
+        ps = [torch.from_numpy(np.ascontiguousarray(ps0, dtype=np.float64)).to(dev), None]
+        ps[1] = torch.empty_like(ps[0])
+        lam = torch.full((1,), float(lam0), dtype=torch.float64, device=dev)
+        ctrl = torch.tensor([0.0, 0.0, 0.0, float(max_iter), ftol, xtol, gtol, float(REJECTION_LIMIT), 0.0, float(lam_grow0), LAM_FAST[0], LAM_FAST[1]],
+                            dtype=torch.float64, device=dev)
+        flags = torch.zeros(4, dtype=torch.int32, device=dev)          # [stop, accepted, current state, -]
+        stats_dev = torch.zeros(LM_STATS, dtype=torch.float64, device=dev)
+        ring = 4
+        # page-locked, allocated once per solver state, not per solve (hipHostMalloc costs ~0.2 ms) — and not shared between states: a
+        # speculative trial one solve leaves behind still writes its read-back while the next solve may already run
+        stats_host = ne.__dict__.get("_stats_host")
+        if stats_host is None:
+            stats_host = ne._stats_host = [torch.zeros(LM_STATS, dtype=torch.float64).pin_memory() for _ in range(ring)]
+        # the final state (gradient | solution | sum r^2) is written into this page-locked buffer by the trial that ends the loop, before
+        # that trial's read-back: the host returns without a copy of its own and without waiting for the speculative trial to drain
+        n_free = int(ne.free_idx.numel())
+        result_host = ne.__dict__.get("_result_host")
+        if result_host is None or result_host.numel() != 2 * n_free + 1:
+            result_host = ne._result_host = torch.zeros(2 * n_free + 1, dtype=torch.float64).pin_memory()
+        result_view = result_host.numpy()
+        result_view[-1] = np.nan
+        pending = ne.__dict__.pop("_drain_event", None)
+        if pending is not None:
+            pending.synchronize()              # the speculative trial the previous solve left behind has written its (void) read-back
+        ne.build(ps[0], 0)
+        history = []                       # the first entry — the starting cost — comes with the first trial's read-back (no sync of its own)
 
-            def buffers(k):
-                b = LmBuffers()
-                b.packed[0], b.packed[1] = ne.packed[0].data_ptr(), ne.packed[1].data_ptr()
-                b.ps[0], b.ps[1] = ps[0].data_ptr(), ps[1].data_ptr()
-                b.flags, b.fixed, b.lam = flags.data_ptr(), ne.fixed.data_ptr(), lam.data_ptr()
-                b.linvt, b.u, b.V, b.S, b.rhs, b.dvec, b.gm = (t.data_ptr() for t in (ne.linvt, ne.u, ne.V, ne.S, ne.rhs, ne.dvec, ne.gm))
-                b.status, b.xlead, b.w, b.spd_work = ne.status.data_ptr(), ne.xl.data_ptr(), ne.w.data_ptr(), ne.chol_work.data_ptr()
-                b.delta, b.ctrl = ne.delta.data_ptr(), ctrl.data_ptr()
-                b.stats, b.stats_host = stats_dev.data_ptr(), stats_host[k % ring].data_ptr()
-                b.spd_algorithm = SPD_ALGORITHMS[ne.spd_algorithm]
-                b.mode = (LM_FIXED_TRIAL_BUFFER | LM_VOTES) if sharded else 0
-                b.free_idx, b.n_free, b.result_host = ne.free_idx.data_ptr(), n_free, result_host.data_ptr()
-                b.syrk_work, b.syrk_work_len = ne.syrk_work.data_ptr(), ne.syrk_work_len
-                return b
+        def buffers(k):
+            b = LmBuffers()
+            b.packed[0], b.packed[1] = ne.packed[0].data_ptr(), ne.packed[1].data_ptr()
+            b.ps[0], b.ps[1] = ps[0].data_ptr(), ps[1].data_ptr()
+            b.flags, b.fixed, b.lam = flags.data_ptr(), ne.fixed.data_ptr(), lam.data_ptr()
+            b.linvt, b.u, b.V, b.S, b.rhs, b.dvec, b.gm = (t.data_ptr() for t in (ne.linvt, ne.u, ne.V, ne.S, ne.rhs, ne.dvec, ne.gm))
+            b.status, b.xlead, b.w, b.spd_work = ne.status.data_ptr(), ne.xl.data_ptr(), ne.w.data_ptr(), ne.chol_work.data_ptr()
+            b.delta, b.ctrl = ne.delta.data_ptr(), ctrl.data_ptr()
+            b.stats, b.stats_host = stats_dev.data_ptr(), stats_host[k % ring].data_ptr()
+            b.spd_algorithm = SPD_ALGORITHMS[ne.spd_algorithm]
+            b.mode = (LM_FIXED_TRIAL_BUFFER | LM_VOTES) if sharded else 0
+            b.free_idx, b.n_free, b.result_host = ne.free_idx.data_ptr(), n_free, result_host.data_ptr()
+            b.syrk_work, b.syrk_work_len = ne.syrk_work.data_ptr(), ne.syrk_work_len
+            return b
 
-            # The read-back of trial k lands in page-locked memory the device writes directly (lm_decide_kernel; all twelve words are -1 for
-            # a launch that found the stop flag raised).  The host waits for THOSE words instead of an event — an event record between two
-            # trials cost the GPU 5.6 us of idling per trial (the one gap in profiles/r04/lm_trace_*.log) — and the device needs no fence
-            # between them: the host fills the slot with a NaN pattern no arithmetic produces and waits until none of it is left.
-            views = [t.numpy() for t in stats_host]
-            raw = [v.view(np.uint64) for v in views]
+        # The read-back of trial k lands in page-locked memory the device writes directly (lm_decide_kernel; all twelve words are -1 for
+        # a launch that found the stop flag raised).  The host waits for THOSE words instead of an event — an event record between two
+        # trials cost the GPU 5.6 us of idling per trial (the one gap in profiles/r04/lm_trace_*.log) — and the device needs no fence
+        # between them: the host fills the slot with a NaN pattern no arithmetic produces and waits until none of it is left.
+        views = [t.numpy() for t in stats_host]
+        raw = [v.view(np.uint64) for v in views]
 
-            def enqueue(k):
-                raw[k % ring][:] = LM_SENTINEL
-                b = buffers(k)
-                if sharded:   # the trial state is all-reduced between the two halves, on this stream: nothing waits for the host
-                    eng.lm_trial_build(b, stream)
-                    ne.reduce(ne.packed[1])
-                    eng.lm_trial_finish(b, stream)
-                else:
-                    eng.lm_trial(b, stream)
+        def enqueue(k):
+            raw[k % ring][:] = LM_SENTINEL
+            b = buffers(k)
+            if sharded:   # the trial state is all-reduced between the two halves, on this stream: nothing waits for the host
+                eng.lm_trial_build(b, stream)
+                ne.reduce(ne.packed[1])
+                eng.lm_trial_finish(b, stream)
+            else:
+                eng.lm_trial(b, stream)
 
-            def wait_for(k):
-                v, u = views[k % ring], raw[k % ring]
-                t_end = time.perf_counter() + 30.0
-                spins = 0
-                while (u == LM_SENTINEL).any():
-                    spins += 1
-                    if spins & 1023 == 0:
-                        if time.perf_counter() > t_end:
-                            raise RuntimeError("device LM loop: no read-back within 30 s")
-                        time.sleep(0)
-                return v.copy()
+        def wait_for(k):
+            v, u = views[k % ring], raw[k % ring]
+            t_end = time.perf_counter() + 30.0
+            spins = 0
+            while (u == LM_SENTINEL).any():
+                spins += 1
+                if spins & 1023 == 0:
+                    if time.perf_counter() > t_end:
+                        raise RuntimeError("device LM loop: no read-back within 30 s")
+                    time.sleep(0)
+            return v.copy()
 
-            code, nfev, n_lin, it = 0, 1, 0, 0
-            limit = REJECTION_LIMIT * max_iter + 16          # every accepted step is preceded by fewer than REJECTION_LIMIT rejections
-            queued = read = 0
-            if max_iter > 0:
+        code, nfev, n_lin, it = 0, 1, 0, 0
+        limit = REJECTION_LIMIT * max_iter + 16          # every accepted step is preceded by fewer than REJECTION_LIMIT rejections
+        queued = read = 0
+        if max_iter > 0:
+            enqueue(queued)
+            queued += 1
+        else:
+            code = 5
+        while code == 0 and read < limit:
+            if queued < limit:                 # speculate: the next trial goes out before this one's verdict is read
                 enqueue(queued)
                 queued += 1
-            else:
-                code = 5
-            while code == 0 and read < limit:
-                if queued < limit:                 # speculate: the next trial goes out before this one's verdict is read
+            st = wait_for(read)
+            read += 1
+            if st[9] < 0:                       # a launch that found the flag raised: nothing happened
+                if read >= queued:
+                    break
+                continue
+            n_lin += 1
+            nfev += 1
+            if not history:
+                history.append(0.5 * float(st[6]))
+            if verbose:
+                print(f"  trial {int(st[9])}: lam {st[7]:.2e} cost {0.5 * st[6]:.6e} -> {0.5 * st[5]:.6e} accepted {bool(st[0] > 0)} stop {int(st[8])}")
+            if st[0] > 0:
+                it += 1
+                history.append(0.5 * float(st[5]))
+            code = int(st[8])
+            if code == 9:   # the one-launch dense solve gave up waiting (on this rank or on a peer): repeat the trial with the launch-per-column form
+                torch.cuda.current_stream().synchronize()      # whatever was queued behind it has drained as no-ops
+                ne.spd_algorithm = "launches"
+                ctrl[0] = 0.0
+                flags[:2].zero_()                               # stop and accept; the current-state word stays
+                nfev -= 1
+                n_lin -= 1
+                code = 0
+                read = queued                                   # forget the drained launches
+                if queued < limit:
                     enqueue(queued)
                     queued += 1
-                st = wait_for(read)
-                read += 1
-                if st[9] < 0:                       # a launch that found the flag raised: nothing happened
-                    if read >= queued:
-                        break
-                    continue
-                n_lin += 1
-                nfev += 1
-                if not history:
-                    history.append(0.5 * float(st[6]))
-                if verbose:
-                    print(f"  trial {int(st[9])}: lam {st[7]:.2e} cost {0.5 * st[6]:.6e} -> {0.5 * st[5]:.6e} accepted {bool(st[0] > 0)} stop {int(st[8])}")
-                if st[0] > 0:
-                    it += 1
-                    history.append(0.5 * float(st[5]))
-                code = int(st[8])
-                if code == 9:   # the one-launch dense solve gave up waiting (on this rank or on a peer): repeat the trial with the launch-per-column form
-                    torch.cuda.current_stream().synchronize()      # whatever was queued behind it has drained as no-ops
-                    ne.spd_algorithm = "launches"
-                    ctrl[0] = 0.0
-                    flags[:2].zero_()                               # stop and accept; the current-state word stays
-                    nfev -= 1
-                    n_lin -= 1
-                    code = 0
-                    read = queued                                   # forget the drained launches
-                    if queued < limit:
-                        enqueue(queued)
-                        queued += 1
-            if read < queued:                           # the speculative trial behind the end drains on its own (empty launches) ...
-                ne._drain_event = torch.cuda.Event()    # ... and the next solve on this state waits for that before it reuses the read-back ring
-                ne._drain_event.record()
-            if code not in (0, 9) and max_iter > 0 and not np.isnan(result_view[-1]):
-                out = result_view.copy()           # written by the trial that raised the stop code (lm_decide_kernel), complete before its read-back
-            else:
-                # gradient, solution and cost in ONE read-back (g and the cost sit behind the blocks of the packed state: [A | B | C | g | cost])
-                torch.cuda.current_stream().synchronize()
-                cur = int(flags[2].item())
-                g0 = ne.n_packed - 1 - ne.n_params
-                out = torch.cat([ne.packed[cur][g0: g0 + ne.n_params][ne.free_idx], ps[cur][ne.free_idx], ne.packed[cur][ne.n_packed - 1: ne.n_packed]]).cpu().numpy()
-            g, x, cost = out[:n_free].copy(), out[n_free: 2 * n_free].copy(), 0.5 * float(out[-1])
-            if not history:
-                history.append(cost)
-    finally:
-        if sharded and not saved_det:
-            eng.set_option("deterministic", 0)
+        if read < queued:                           # the speculative trial behind the end drains on its own (empty launches) ...
+            ne._drain_event = torch.cuda.Event()    # ... and the next solve on this state waits for that before it reuses the read-back ring
+            ne._drain_event.record()
+        if code not in (0, 9) and max_iter > 0 and not np.isnan(result_view[-1]):
+            out = result_view.copy()           # written by the trial that raised the stop code (lm_decide_kernel), complete before its read-back
+        else:
+            # gradient, solution and cost in ONE read-back (g and the cost sit behind the blocks of the packed state: [A | B | C | g | cost])
+            torch.cuda.current_stream().synchronize()
+            cur = int(flags[2].item())
+            g0 = ne.n_packed - 1 - ne.n_params
+            out = torch.cat([ne.packed[cur][g0: g0 + ne.n_params][ne.free_idx], ps[cur][ne.free_idx], ne.packed[cur][ne.n_packed - 1: ne.n_packed]]).cpu().numpy()
+        g, x, cost = out[:n_free].copy(), out[n_free: 2 * n_free].copy(), 0.5 * float(out[-1])
+        if not history:
+            history.append(cost)
     return DeviceLMResult(x=x, cost=cost, grad=g, optimality=float(np.max(np.abs(g))) if g.size else 0.0, nit=it, nfev=nfev,
                           n_jtjv=n_lin, status=STOP_STATUS.get(code, 0), message=STOP_MESSAGES.get(code, f"stopped ({code})"), history=history)
 
@@ -501,7 +507,8 @@ def _lm_loop_blocked(ne: BlockedNormalEquations, ps0: np.ndarray, *, max_iter, f
     """The host-steered loop: what a sharded solve takes when its collective goes through the host (gloo).  Same rules as the
     device-steered loop (the decision itself is pcs_lm_decide on the device).  Every rank decides on the same all-reduced blocks;
     whether a rank's one-launch dense solve gave up is all-reduced with them (the word behind the packed state), so the ranks repeat
-    a void trial TOGETHER; without the engine's deterministic mode they also adopt one consensus step per trial."""
+    a void trial TOGETHER.  `_lm_solve_blocked` runs the loop in the engine's deterministic mode, where the ranks compute identical
+    steps; only where that mode is not available (self chain beyond 64 cameras) do they adopt one consensus step per trial."""
     torch = ne.torch
     dev = ne.dev
     deterministic = bool(ne.eng.option("deterministic", 0))
