@@ -91,6 +91,12 @@ SYMBOLS = {
     "pcs_genchain_set_blocks": (c_int, [_P, c_int, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32), POINTER(c_int64)]),
     "pcs_genchain_linearize": (c_int, [_P, POINTER(c_double)]),
     "pcs_genchain_matfree": (c_int, [_P, c_int, POINTER(c_double), POINTER(c_double), POINTER(c_double)]),
+    "pcs_genchain_normal_layout": (c_int, [_P, POINTER(c_int64)]),
+    "pcs_genchain_normal_blocks_device": (c_int, [_P, _P, _P, _P]),
+    "pcs_genchain_lm_trial": (c_int, [_P, _P, _P]),
+    "pcs_genchain_lm_trial_build": (c_int, [_P, _P, _P]),
+    "pcs_genchain_lm_trial_finish": (c_int, [_P, _P, _P]),
+    "pcs_genchain_set_option": (c_int, [_P, c_char_p, c_int64]),
     "pcs_genchain_device_buffers": (c_int, [_P, POINTER(_P), POINTER(_P)]),
     "pcs_genchain_synchronize": (c_int, [_P, _P]),
     "pcs_genchain_last_kernel_ms": (c_int, [_P, POINTER(c_float), POINTER(c_float)]),

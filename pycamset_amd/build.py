@@ -12,7 +12,7 @@ from pathlib import Path
 
 PKG = Path(__file__).resolve().parent
 SRC = PKG / "csrc" / "pcs_engine.hip"
-DEPS = [SRC, PKG / "csrc" / "ba_device.hpp", PKG / "csrc" / "ba_rtc_prelude.hpp", PKG / "csrc" / "ba_kernels.hpp", PKG / "csrc" / "ba_matfree.hpp", PKG / "csrc" / "ba_normal.hpp", PKG / "csrc" / "ba_schur.hpp", PKG / "csrc" / "ba_dense_chol.hpp", PKG / "csrc" / "ba_chol_persist.hpp", PKG / "csrc" / "ba_generic.hpp", PKG / "csrc" / "ba_blockrow.hpp", PKG / "csrc" / "pcs_genchain.inc",
+DEPS = [SRC, PKG / "csrc" / "ba_device.hpp", PKG / "csrc" / "ba_rtc_prelude.hpp", PKG / "csrc" / "ba_kernels.hpp", PKG / "csrc" / "ba_matfree.hpp", PKG / "csrc" / "ba_normal.hpp", PKG / "csrc" / "ba_schur.hpp", PKG / "csrc" / "ba_dense_chol.hpp", PKG / "csrc" / "ba_chol_persist.hpp", PKG / "csrc" / "ba_generic.hpp", PKG / "csrc" / "ba_blockrow.hpp", PKG / "csrc" / "ba_blockgram.hpp", PKG / "csrc" / "pcs_genchain.inc",
         PKG / "csrc" / "ba_triangulate.hpp", PKG.parent / "include" / "pcs_hip.h"]
 OUT = PKG / "libpcs_hip.so"
 

@@ -556,6 +556,60 @@ class ChainEngine:
         """(J^T r, sum r^2) at the linearisation point."""
         return self._matfree(self.OP_GRAD, None, self.n_params, want_cost=True)
 
+    # -- the exact LM step: dense normal equations + the device-steered trial (csrc/ba_blockgram.hpp; device_solver.BlockedNormalEquations) ----
+    lm_fixed_trial_buffer = True   # the generated kernel reads its string from a fixed address: trials are built at ps[1] into packed[1]
+    DENSE_OPTIONS = ("spd_timeout_us", "timing")
+
+    def dense_lm_supported(self) -> bool:
+        """Does the contraction of csrc/ba_blockgram.hpp take this chain?  FP64 block rows of at most 63 columns, n_params <= 65 535."""
+        return self.dtype == "f64" and self.P + 1 <= 64 and self.n_params <= 65535
+
+    def normal_layout(self) -> dict:
+        """{n_lead, n_trail, tb, packed_len, n_params} of the packed state [A | g | cost]: every parameter in the leading group, A dense."""
+        out = (c_int64 * 5)()
+        check(lib().pcs_genchain_normal_layout(self._h, out))
+        return dict(n_lead=int(out[0]), n_trail=int(out[1]), tb=int(out[2]), packed_len=int(out[3]), n_params=int(out[4]))
+
+    def normal_blocks_device(self, d_param_str: int, d_packed: int, stream: int | None = None):
+        """[J^T J | J^T r | sum r^2] at the DEVICE-resident parameter string; asynchronous, zeroes the buffer first."""
+        from .engine import _stream_arg
+
+        check(lib().pcs_genchain_normal_blocks_device(self._h, c_void_p(d_param_str), c_void_p(d_packed), _stream_arg(stream)))
+
+    def lm_trial(self, buffers, stream=None):
+        from .engine import _stream_arg
+
+        check(lib().pcs_genchain_lm_trial(self._h, byref(buffers), _stream_arg(stream)))
+
+    def lm_trial_build(self, buffers, stream=None):
+        from .engine import _stream_arg
+
+        check(lib().pcs_genchain_lm_trial_build(self._h, byref(buffers), _stream_arg(stream)))
+
+    def lm_trial_finish(self, buffers, stream=None):
+        from .engine import _stream_arg
+
+        check(lib().pcs_genchain_lm_trial_finish(self._h, byref(buffers), _stream_arg(stream)))
+
+    def set_option(self, key: str, value: int):
+        """Engine's option interface as far as the LM driver uses it: "spd_timeout_us" and "timing" reach the handle; "timing_every"
+        maps to "timing"; "lazy_done_event" has nothing to switch here; "deterministic" cannot be switched ON (the contraction of a
+        generated chain's block rows sums with atomics)."""
+        value = int(value)
+        if key == "deterministic":
+            if value:
+                raise NotImplementedError("generated chains have no order-deterministic normal equations (csrc/ba_blockgram.hpp sums with atomics)")
+        elif key == "timing_every":
+            check(lib().pcs_genchain_set_option(self._h, b"timing", int(value != 0)))
+        elif key in self.DENSE_OPTIONS:
+            check(lib().pcs_genchain_set_option(self._h, key.encode(), value))
+        elif key != "lazy_done_event":
+            raise ValueError(f"unknown option '{key}' for a generated chain")
+        self.__dict__.setdefault("_options", {})[key] = value
+
+    def option(self, key: str, default):
+        return self.__dict__.get("_options", {}).get(key, default)
+
     # -- static structure (integer work on the host, like the reference's afb:192-233, afb:465-489) -------------------------
     def block_param_inds(self) -> np.ndarray:
         if self._det is None:

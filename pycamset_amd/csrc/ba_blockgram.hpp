@@ -1,0 +1,166 @@
+// ba_blockgram.hpp — dense normal equations  [J^T J | J^T r | sum r^2]  of a GENERATED chain from its materialised block rows
+// (SURVEY 8 row f2 for generated chains; round 5).
+//
+// The three hand-fused chains build their blocked normal equations while they evaluate (ba_normal.hpp).  A generated chain — any
+// composition of the reference's function blocks, user blocks included (afb:290-419 / afb:492-652 generate its loss and Jacobian) —
+// has one kernel that writes dense block rows (ba_generic.hpp: 2N x P); until round 5 a Levenberg-Marquardt solve on it went through
+// conjugate gradients on the products of ba_blockrow.hpp with the host between every two of them.  This kernel makes the exact step
+// available: it contracts the block rows into the dense  A = J^T J  (upper triangle, n_params x n_params — a calibration's few hundred
+// to few thousand parameters), g = J^T r and the cost, in the packed layout [A | g | cost] that the Schur / Cholesky step
+// (ba_schur.hpp with an empty trailing group, ba_chol_persist.hpp) and the device-steered loop (lm_decide_kernel) already consume.
+//
+// Which global column a local column stands for is the reference's get_block_param_inds (afb:192-233) as a rule: block b covers local
+// columns [col0_b, col0_b + np_b) and its parameters of entity e (camera / image / key by link_b) start at start_b + np_b e.  In the
+// reference's table order (camera, then image, then key) a run of detections shares camera AND image, so every column that is not
+// linked to the key stands for ONE global column over the whole run: the host cuts the table into SEGMENTS (<= GRAM_SEG detections of
+// one (camera, image) pair), one wave contracts a segment on the FP64 matrix cores and flushes (P + 1)^2 / 2 sums:
+//   * operands straight from global memory in v_mfma_f64_16x16x4's layout: lane l holds element [row 4 s + l / 16][column 16 c + l % 16]
+//     of the segment's rows — four row pieces of 128 bytes per load instruction, no LDS staging; the residual rides along as column P
+//     (G[p][P] = g_p, G[P][P] = the cost), so one contraction yields all three outputs;
+//   * columns linked to the KEY (free points, per-point user parameters) differ from detection to detection: their products are
+//     taken per detection by the lanes (one detection each) and added one by one — (key columns) x P atomics per detection, only for
+//     chains that have such columns;
+//   * sums meet in f64 atomics on A / g / cost (zeroed by the caller): at most (P + 1)^2 / 2 per segment.
+// On MI355X an FP64 MFMA issues at the rate of the FP64 vector pipe (2 048 flop in 64 cycles); what the matrix cores save here is the
+// cross-lane reduction — 64 detections' products land summed in the accumulators.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "ba_blockrow.hpp"
+#include "ba_device.hpp"
+
+namespace pcs {
+
+constexpr int GRAM_SEG = 128;        // detections per segment at most (256 rows = 64 contraction steps)
+constexpr int GRAM_MAX_COLS = 64;    // P + 1 <= 64: four column blocks of 16
+
+struct BlockGramArgs {
+    DetTable tab;
+    const double *J;        // 2N x P dense block rows, u row then v row
+    const double *resid;    // N x 2
+    const int32_t *seg;     // n_seg x 4: first detection, count, camera, image
+    double *A, *g, *cost;   // n_params x n_params (upper triangle written), n_params, 1 — zeroed by the caller
+    int64_t n_params;
+    int32_t P, n_seg, n_blocks;
+    int32_t blk_col0[BLOCKROW_MAX_BLOCKS], blk_np[BLOCKROW_MAX_BLOCKS], blk_link[BLOCKROW_MAX_BLOCKS];   // link: 0 camera, 1 image, 2 key
+    int64_t blk_start[BLOCKROW_MAX_BLOCKS];
+    const int32_t *stop;    // optional LM stop word (ba_schur.hpp PCS_STOP_GUARD)
+};
+
+using gram_d4 = __attribute__((ext_vector_type(4))) double;
+
+// NB = column blocks of 16 covering the P + 1 columns (block rows + the residual column)
+template <int NB>
+__global__ __launch_bounds__(256) void blockrow_gram_kernel(const BlockGramArgs a) {
+    if (a.stop && *a.stop) return;
+    // per local column: base (global column of entity 0), multiplier (parameters per entity), link
+    __shared__ int64_t col_base[GRAM_MAX_COLS];
+    __shared__ int32_t col_mul[GRAM_MAX_COLS], col_link[GRAM_MAX_COLS];
+    if (threadIdx.x < GRAM_MAX_COLS) {
+        const int p = threadIdx.x;
+        int64_t base = 0;
+        int32_t mul = 0, link = -1;
+        for (int b = 0; b < a.n_blocks; ++b)
+            if (p >= a.blk_col0[b] && p < a.blk_col0[b] + a.blk_np[b]) { base = a.blk_start[b] + (p - a.blk_col0[b]); mul = a.blk_np[b]; link = a.blk_link[b]; }
+        col_base[p] = base; col_mul[p] = mul; col_link[p] = link;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int s_id = blockIdx.x * 4 + wave;
+    if (s_id >= a.n_seg) return;
+    const int first = a.seg[4 * s_id], count = a.seg[4 * s_id + 1], cam = a.seg[4 * s_id + 2], img = a.seg[4 * s_id + 3];
+    const int P = a.P;
+    const int64_t row0 = 2 * (int64_t)first, row_end = row0 + 2 * (int64_t)count;
+    const int lr = lane >> 4, lc = lane & 15;
+
+    // ---- the contraction: G = [J r]' [J r] over the segment's rows, upper column blocks -------------------------------------------
+    gram_d4 acc[NB][NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[i][j] = gram_d4{0.0, 0.0, 0.0, 0.0};
+    auto fetch = [&](const int64_t row, double (&v)[NB]) {
+        const bool in = row < row_end;
+#pragma unroll
+        for (int cb = 0; cb < NB; ++cb) {
+            const int col = 16 * cb + lc;
+            double x = 0.0;
+            if (in) {
+                if (col < P) x = a.J[row * P + col];
+                else if (col == P) x = a.resid[row];
+            }
+            v[cb] = x;
+        }
+    };
+    constexpr int UNROLL = 4;   // steps (16 rows) whose loads are in flight together
+    for (int64_t r = row0 + lr; r - lr < row_end; r += 4 * UNROLL) {
+        double v[UNROLL][NB];
+#pragma unroll
+        for (int t = 0; t < UNROLL; ++t) fetch(r + 4 * t, v[t]);
+#pragma unroll
+        for (int t = 0; t < UNROLL; ++t)
+#pragma unroll
+            for (int i = 0; i < NB; ++i)
+#pragma unroll
+                for (int j = i; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(v[t][i], v[t][j], acc[i][j], 0, 0, 0);
+    }
+
+    // ---- flush: acc[i][j][q] = G[16 i + lane / 16 + 4 q][16 j + lane % 16] ---------------------------------------------------------
+    auto gcol = [&](const int p, const int key) -> int64_t {
+        const int link = col_link[p];
+        return col_base[p] + (int64_t)col_mul[p] * (link == 0 ? cam : link == 1 ? img : key);
+    };
+    const int64_t n = a.n_params;
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int j = i; j < NB; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int p = 16 * i + lr + 4 * q, c = 16 * j + lc;
+                if (p > c || c > P) continue;
+                const double val = acc[i][j][q];
+                if (p == P) {   // (residual, residual)
+                    unsafeAtomicAdd(a.cost, val);
+                    continue;
+                }
+                if (col_link[p] == 2) continue;   // key-linked columns: per detection, below
+                const int64_t gp = gcol(p, 0);
+                if (c == P) {
+                    unsafeAtomicAdd(a.g + gp, val);
+                    continue;
+                }
+                if (col_link[c] == 2) continue;
+                const int64_t gc = gcol(c, 0);
+                unsafeAtomicAdd(a.A + (gp < gc ? gp * n + gc : gc * n + gp), val);
+            }
+
+    // ---- key-linked columns: one detection per lane ------------------------------------------------------------------------------
+    bool any_key = false;
+    for (int p = 0; p < P; ++p) any_key = any_key || col_link[p] == 2;
+    if (!any_key) return;
+    for (int d0 = 0; d0 < count; d0 += 64) {
+        const int d = d0 + lane;
+        if (d >= count) break;
+        const int64_t i = (int64_t)first + d;
+        int c_, im_, key;
+        load_indices(a.tab, i, c_, im_, key);
+        const double *ju = a.J + 2 * i * (int64_t)P, *jv = ju + P;
+        const double ru = a.resid[2 * i], rv = a.resid[2 * i + 1];
+        for (int p = 0; p < P; ++p) {
+            if (col_link[p] != 2) continue;
+            const double pu = ju[p], pv = jv[p];
+            const int64_t gp = gcol(p, key);
+            unsafeAtomicAdd(a.g + gp, pu * ru + pv * rv);
+            for (int c = 0; c < P; ++c) {
+                if (col_link[c] == 2 && c < p) continue;   // a pair of key-linked columns is taken once
+                const int64_t gc = gcol(c, key);
+                unsafeAtomicAdd(a.A + (gp < gc ? gp * n + gc : gc * n + gp), pu * ju[c] + pv * jv[c]);
+            }
+        }
+    }
+}
+
+}  // namespace pcs

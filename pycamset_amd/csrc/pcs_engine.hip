@@ -1926,10 +1926,9 @@ int pcs_normal_blocks_device(pcs_engine *h, const double *d_param_str, double *d
     return enqueue_normal(h, d_param_str, d_packed, d_g, d_g + h->n_params, s, true);
 }
 
-static int enqueue_schur_prepare(pcs_engine *h, double *d_packed, const uint8_t *d_fixed, const double *d_lambda, double *d_linvt, double *d_u,
+static int enqueue_schur_prepare(const BlockLayout &L, double *d_packed, const uint8_t *d_fixed, const double *d_lambda, double *d_linvt, double *d_u,
                                  double *d_V, double *d_S, double *d_rhs, double *d_dvec, double *d_gm, int32_t *d_status, hipStream_t s, const int32_t *d_stop,
                                  double *d_fill = nullptr, int64_t fill_n = 0, const int32_t *d_sel = nullptr, int64_t alt = 0) {
-    const BlockLayout L = block_layout(h);
     SchurArgs a{};
     a.sel = d_sel; a.alt = alt;
     a.fill = reinterpret_cast<uint64_t *>(d_fill); a.fill_n = d_fill ? fill_n : 0;
@@ -1955,6 +1954,11 @@ static int enqueue_schur_prepare(pcs_engine *h, double *d_packed, const uint8_t 
     }
     return PCS_OK;
 }
+static int enqueue_schur_prepare(pcs_engine *h, double *d_packed, const uint8_t *d_fixed, const double *d_lambda, double *d_linvt, double *d_u,
+                                 double *d_V, double *d_S, double *d_rhs, double *d_dvec, double *d_gm, int32_t *d_status, hipStream_t s, const int32_t *d_stop,
+                                 double *d_fill = nullptr, int64_t fill_n = 0, const int32_t *d_sel = nullptr, int64_t alt = 0) {
+    return enqueue_schur_prepare(block_layout(h), d_packed, d_fixed, d_lambda, d_linvt, d_u, d_V, d_S, d_rhs, d_dvec, d_gm, d_status, s, d_stop, d_fill, fill_n, d_sel, alt);
+}
 
 int pcs_schur_prepare(pcs_engine *h, double *d_packed, const uint8_t *d_fixed, const double *d_lambda, double *d_linvt, double *d_u,
                       double *d_V, double *d_S, double *d_rhs, double *d_dvec, double *d_gm, int32_t *d_status, void *stream) {
@@ -1978,10 +1982,9 @@ int pcs_lm_decide(pcs_engine *h, const double *d_cost_old, const double *d_cost_
     return PCS_OK;
 }
 
-static int enqueue_schur_finish(pcs_engine *h, const double *d_linvt, const double *d_u, const double *d_w, const double *d_xlead, const uint8_t *d_fixed,
+static int enqueue_schur_finish(const BlockLayout &L, const double *d_linvt, const double *d_u, const double *d_w, const double *d_xlead, const uint8_t *d_fixed,
                                 double *d_delta, const double *d_ps_in, double *d_ps_out, hipStream_t s, const int32_t *d_stop, const int32_t *d_sel = nullptr,
                                 double *d_vote = nullptr, int64_t vote_alt = 0, const int32_t *d_status = nullptr) {
-    const BlockLayout L = block_layout(h);
     SchurBackArgs a{};
     a.sel = d_sel; a.vote = d_vote; a.vote_alt = vote_alt; a.status = d_status;
     a.linvt = d_linvt; a.u = d_u; a.w = d_w; a.xl = d_xlead; a.fixed = d_fixed; a.delta = d_delta;
@@ -1994,6 +1997,11 @@ static int enqueue_schur_finish(pcs_engine *h, const double *d_linvt, const doub
     else hipLaunchKernelGGL(schur_back_kernel<3>, grid, dim3(256), 0, s, a);
     HIPCHK(hipGetLastError());
     return PCS_OK;
+}
+static int enqueue_schur_finish(pcs_engine *h, const double *d_linvt, const double *d_u, const double *d_w, const double *d_xlead, const uint8_t *d_fixed,
+                                double *d_delta, const double *d_ps_in, double *d_ps_out, hipStream_t s, const int32_t *d_stop, const int32_t *d_sel = nullptr,
+                                double *d_vote = nullptr, int64_t vote_alt = 0, const int32_t *d_status = nullptr) {
+    return enqueue_schur_finish(block_layout(h), d_linvt, d_u, d_w, d_xlead, d_fixed, d_delta, d_ps_in, d_ps_out, s, d_stop, d_sel, d_vote, vote_alt, d_status);
 }
 
 int pcs_schur_finish(pcs_engine *h, const double *d_linvt, const double *d_u, const double *d_w, const double *d_xlead, const uint8_t *d_fixed,
@@ -2261,7 +2269,7 @@ static int enqueue_schur_finish_fused(pcs_engine *h, const pcs_lm_buffers *b, hi
 // decision INCLUDING the loop's termination rules, the state flip of an accepted trial and the read-back of the twelve numbers the host
 // follows the loop with.  A sharded loop puts its all-reduce of the trial state between the two, on the same stream.  Every kernel starts
 // with PCS_STOP_GUARD on flags[0], so the host may queue trial t + 1 before it has read the verdict of trial t.
-static int lm_check(pcs_engine *h, const pcs_lm_buffers *b, const char *who) {
+static int lm_check(const void *h, const pcs_lm_buffers *b, const char *who) {
     if (!h || !b || !b->packed[0] || !b->packed[1] || !b->ps[0] || !b->ps[1] || !b->flags || !b->fixed || !b->lambda || !b->linvt || !b->u || !b->V || !b->S || !b->rhs ||
         !b->dvec || !b->gm || !b->status || !b->xlead || !b->w || !b->spd_work || !b->delta || !b->ctrl || !b->stats)
         return fail(PCS_ERR_ARG, "%s: bad arguments", who);
@@ -2326,20 +2334,15 @@ int pcs_lm_trial_build(pcs_engine *h, const pcs_lm_buffers *b, void *stream) {
     return enqueue_normal(h, b->ps[1], b->packed[1], g_new, g_new + h->n_params, s, true, stop, sel, -alt_ps, -alt_pk);
 }
 
-int pcs_lm_trial_finish(pcs_engine *h, const pcs_lm_buffers *b, void *stream) {
-    int rc = lm_check(h, b, "pcs_lm_trial_finish");
-    if (rc) return rc;
-    HIPCHK(hipSetDevice(h->device));
-    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
-    const BlockLayout L = block_layout(h);
-    const int64_t n_packed = L.a_len() + L.b_len() + L.c_len() + h->n_params + 1;
+// The second half of a trial for a state of n_packed doubles ([blocks | g | cost]; pcs_engine and pcs_genchain alike).
+static int enqueue_lm_finish(int n_cu, int64_t n_params, int64_t n_packed, const pcs_lm_buffers *b, hipStream_t s) {
     const bool fixed_buffer = (b->mode & PCS_LM_FIXED_TRIAL_BUFFER) != 0;
     LmDecideArgs a{};
     a.tail[0] = b->packed[0] + n_packed - 1; a.tail[1] = b->packed[1] + n_packed - 1;
     a.ps2[0] = b->ps[0]; a.ps2[1] = b->ps[1];
     a.sel = b->flags + 2;
     a.dvec = b->dvec; a.gm = b->gm; a.delta = b->delta; a.fixed = b->fixed; a.status = b->status; a.lambda = b->lambda; a.stats = b->stats;
-    a.n_params = h->n_params;
+    a.n_params = n_params;
     a.ctrl = b->ctrl; a.stop_flag = b->flags; a.accept_flag = b->flags + 1;
     a.use_votes = (b->mode & PCS_LM_VOTES) ? 1 : 0;
     a.keep_sel = fixed_buffer ? 1 : 0;
@@ -2362,13 +2365,21 @@ int pcs_lm_trial_finish(pcs_engine *h, const pcs_lm_buffers *b, void *stream) {
     hipLaunchKernelGGL(lm_decide_kernel, dim3(1), dim3(1024), 0, s, a);
     HIPCHK(hipGetLastError());
     if (b->stats_host && !stats_mapped) HIPCHK(hipMemcpyAsync(b->stats_host, b->stats, sizeof(double) * LM_STATS, hipMemcpyDeviceToHost, s));
-    if (fixed_buffer) {   // sharded loop: the trial state sits in the buffer the all-reduce was queued on — an accepted one is copied over the current state
-        const int copy_blocks = (int)std::min<int64_t>((n_packed / 2 + 255) / 256 + 1, (int64_t)h->n_cu * 8);
+    if (fixed_buffer) {   // the trial state sits in a fixed buffer (the one a sharded loop's all-reduce was queued on) — an accepted one is copied over the current state
+        const int copy_blocks = (int)std::min<int64_t>((n_packed / 2 + 255) / 256 + 1, (int64_t)n_cu * 8);
         hipLaunchKernelGGL(lm_accept_kernel, dim3((unsigned)copy_blocks), dim3(256), 0, s, (const int32_t *)(b->flags + 1), (const double *)b->packed[1], b->packed[0], n_packed,
-                           (const double *)b->ps[1], b->ps[0], h->n_params);
+                           (const double *)b->ps[1], b->ps[0], n_params);
         HIPCHK(hipGetLastError());
     }
     return PCS_OK;
+}
+
+int pcs_lm_trial_finish(pcs_engine *h, const pcs_lm_buffers *b, void *stream) {
+    int rc = lm_check(h, b, "pcs_lm_trial_finish");
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(h->device));
+    const BlockLayout L = block_layout(h);
+    return enqueue_lm_finish(h->n_cu, h->n_params, L.a_len() + L.b_len() + L.c_len() + h->n_params + 1, b, stream ? (hipStream_t)stream : h->stream);
 }
 
 int pcs_lm_trial(pcs_engine *h, const pcs_lm_buffers *b, void *stream) {

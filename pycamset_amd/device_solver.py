@@ -133,10 +133,13 @@ REGION_LIMIT = 2 ** 32     # doubles per region of the packed buffer: the build 
 
 
 def blocked_fits(engine) -> bool:
-    """Can ``linear_solver='auto'`` take the blocked normal equations + Schur / Cholesky step on this engine?  False for generated
-    chains (no block-reduced build: they use the products of csrc/ba_blockrow.hpp), for leading groups beyond LEAD_LIMIT, for
-    buffers beyond BLOCKED_BYTES_LIMIT and for any single region A / B / C of 2^32 doubles or more (the build would refuse it)."""
+    """Can ``linear_solver='auto'`` take the blocked normal equations + Schur / Cholesky step on this engine?  False for leading
+    groups beyond LEAD_LIMIT, for buffers beyond BLOCKED_BYTES_LIMIT and for any single region A / B / C of 2^32 doubles or more (the
+    build would refuse it).  A generated chain has the DENSE form of the same state (every parameter leading, csrc/ba_blockgram.hpp):
+    the same limits apply to its n_params, plus the contraction's own (FP64 block rows of at most 63 columns)."""
     if not hasattr(engine, "normal_layout"):
+        return False
+    if hasattr(engine, "dense_lm_supported") and not engine.dense_lm_supported():
         return False
     lay = engine.normal_layout()
     n_lead, n_trail, tb = lay["n_lead"], lay["n_trail"], lay["tb"]
@@ -403,7 +406,8 @@ def _lm_loop_device(ne: BlockedNormalEquations, ps0: np.ndarray, *, max_iter, ft
             b.delta, b.ctrl = ne.delta.data_ptr(), ctrl.data_ptr()
             b.stats, b.stats_host = stats_dev.data_ptr(), stats_host[k % ring].data_ptr()
             b.spd_algorithm = SPD_ALGORITHMS[ne.spd_algorithm]
-            b.mode = (LM_FIXED_TRIAL_BUFFER | LM_VOTES) if sharded else 0
+            # a fixed trial buffer: where a collective is queued on it (sharded) or the build reads its string from a fixed address (generated chains)
+            b.mode = (LM_FIXED_TRIAL_BUFFER | LM_VOTES) if sharded else LM_FIXED_TRIAL_BUFFER if getattr(eng, "lm_fixed_trial_buffer", False) else 0
             b.free_idx, b.n_free, b.result_host = ne.free_idx.data_ptr(), n_free, result_host.data_ptr()
             b.syrk_work, b.syrk_work_len = ne.syrk_work.data_ptr(), ne.syrk_work_len
             return b
@@ -686,7 +690,8 @@ def lm_solve(handler, x0, *, max_iter: int = 50, ftol: float = 1e-8, xtol: float
         eng = op_fun._engine_for(dd)
         op_fun._bind_template(eng, handler._template_arg())
         if linear_solver == "auto":   # blocked J^T J while its regions fit comfortably; beyond that matrix-free CG
-            linear_solver = "cholesky" if blocked_fits(eng) else "pcg"
+            # (a generated chain's dense form has no order-deterministic sums: sharded over ranks it keeps the CG on all-reduced products)
+            linear_solver = "cholesky" if blocked_fits(eng) and (reduce_fn is None or not getattr(eng, "lm_fixed_trial_buffer", False)) else "pcg"
         if linear_solver == "cholesky":
             # the solver's device workspace (two packed states, V, S, a stream) lives with the engine: a second solve on the same
             # table and mask — the usual case: a calibration re-run with other start values or tolerances — allocates nothing

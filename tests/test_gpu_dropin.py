@@ -833,10 +833,57 @@ def test_generated_chain_products_and_device_lm_reach_the_scipy_solution(golden_
     # (2) the solve
     ref = least_squares(loss_fn, prob.x0.copy(), jac=jac_fn, x_scale="jac", max_nfev=40)
     res = lm_solve(prob, prob.x0.copy(), max_iter=40)
+    # round 5: "auto" is the EXACT step on the chain's dense normal equations, steered by the device (csrc/ba_blockgram.hpp +
+    # pcs_genchain_lm_trial): one factorisation per evaluated trial, not conjugate gradients on products with the host in between
+    assert res.n_jtjv == res.nfev - 1 and res.nfev <= 12, (res.n_jtjv, res.nfev)
     assert res.history == sorted(res.history, reverse=True)
     assert res.cost <= ref.cost * (1 + 1e-3), (res.cost, ref.cost)
     assert abs(0.5 * np.sum(loss_fn(res.x) ** 2) - res.cost) <= 1e-9 * res.cost
     assert res.cost < 0.05 * res.history[0]
+    # ... and the inexact path is still there on request, ending at the same cost
+    cg = lm_solve(prob, prob.x0.copy(), max_iter=40, linear_solver="pcg")
+    assert cg.n_jtjv > cg.nfev and abs(cg.cost - res.cost) <= 1e-3 * res.cost, (cg.cost, res.cost)
+
+
+@pytest.mark.parametrize("tag", ["generic_proj_rigid_free", "generic_proj_extr_rigid_template", "generic_proj_template", "generic_proj_rigid_extr_free",
+                                 "user_cam_scale", "user_division", "user_board_flex"])
+def test_generated_chain_dense_normal_equations_match_the_reference_jacobian(golden_dir, tag):
+    """Round 5 (csrc/ba_blockgram.hpp): [J^T J | J^T r | sum r^2] of a generated chain, contracted on the device from its block rows,
+    against the SAME products of the reference generator's own CSR Jacobian and residual (the fixtures of make_golden.py) — the four
+    shipped compositions and the three chains with user blocks; three of the seven have columns linked to the KEY (free points:
+    a different global column per detection), which take the per-detection path of the kernel."""
+    import torch
+    from scipy.sparse import csr_array
+    from pycamset_amd import function_blocks as fb
+    g = np.load(golden_dir / f"{tag}.npz")
+    ub = H.user_blocks(fb)
+    names = [str(n) for n in g["blocks"]]
+    op = fb.optimisation_function([ub[n]() if n in ub else getattr(fb, n)() for n in names])
+    assert op.chain == "generated"
+    det, ps = g["detections"], g["param_str"]
+    eng = op._engine_for(det)
+    if op.templated:
+        op._bind_template(eng, g["points"])
+    lay = eng.normal_layout()
+    n = eng.n_params
+    assert eng.dense_lm_supported() and lay == dict(n_lead=n, n_trail=0, tb=3, packed_len=n * n + n + 1, n_params=n)
+    dev = torch.device("cuda", eng.device)
+    ps_dev = torch.from_numpy(np.ascontiguousarray(ps[:n])).to(dev)
+    packed = torch.full((lay["packed_len"],), np.nan, dtype=torch.float64, device=dev)      # the build zeroes its output itself
+    torch.cuda.synchronize()
+    eng.normal_blocks_device(ps_dev.data_ptr(), packed.data_ptr())
+    eng.synchronize()
+    out = packed.cpu().numpy()
+    A, grad, cost = out[: n * n].reshape(n, n), out[n * n: n * n + n], out[-1]
+    Jc = csr_array((g["data_all"], g["indices_all"], g["indptr_all"]), shape=(2 * det.shape[0], n))
+    r = g["resid"].ravel()
+    want = (Jc.T @ Jc).toarray()
+    assert np.max(np.abs(np.triu(A) - np.triu(want))) <= 1e-11 * np.max(np.abs(want))
+    assert np.all(np.tril(A, -1) == 0)                                                    # only the upper triangle is written
+    assert np.max(np.abs(grad - Jc.T @ r)) <= 1e-11 * np.max(np.abs(Jc.T @ r))
+    assert abs(cost - r @ r) <= 1e-12 * (r @ r)
+    key_linked = any(str(b) == "free_point" for b in names)
+    assert key_linked == (tag in ("generic_proj_rigid_free", "generic_proj_rigid_extr_free", "user_division"))
 
 
 def test_templated_user_source_through_the_device_lm(golden_dir):
@@ -870,6 +917,7 @@ def test_templated_user_source_through_the_device_lm(golden_dir):
     loss_fn, jac_fn = prob.make_loss_fun(), prob.make_loss_jac()
     ref = least_squares(loss_fn, prob.x0.copy(), jac=jac_fn, x_scale="jac", max_nfev=40)
     res = lm_solve(prob, prob.x0.copy(), max_iter=40)
+    assert res.n_jtjv == res.nfev - 1                                    # the exact step of round 5 (dense normal equations of the generated chain)
     assert res.history == sorted(res.history, reverse=True)
     assert res.cost <= ref.cost * (1 + 1e-3), (res.cost, ref.cost)
     assert abs(0.5 * np.sum(loss_fn(res.x) ** 2) - res.cost) <= 1e-9 * res.cost
