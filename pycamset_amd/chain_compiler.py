@@ -558,7 +558,7 @@ class ChainEngine:
 
     # -- the exact LM step: dense normal equations + the device-steered trial (csrc/ba_blockgram.hpp; device_solver.BlockedNormalEquations) ----
     lm_fixed_trial_buffer = True   # the generated kernel reads its string from a fixed address: trials are built at ps[1] into packed[1]
-    DENSE_OPTIONS = ("spd_timeout_us", "timing")
+    DENSE_OPTIONS = ("spd_timeout_us", "timing", "gram_debug")
 
     def dense_lm_supported(self) -> bool:
         """Does the contraction of csrc/ba_blockgram.hpp take this chain?  FP64 block rows of at most 63 columns, n_params <= 65 535."""

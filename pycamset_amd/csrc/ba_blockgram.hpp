@@ -20,7 +20,8 @@
 //   * columns linked to the KEY (free points, per-point user parameters) differ from detection to detection: their products are
 //     taken per detection by the lanes (one detection each) and added one by one — (key columns) x P atomics per detection, only for
 //     chains that have such columns;
-//   * sums meet in f64 atomics on A / g / cost (zeroed by the caller): at most (P + 1)^2 / 2 per segment.
+//   * the segments of a workgroup (16 waves for P < 32) combine in LDS before they go out: sums meet in f64 atomics on A / g / cost
+//     (zeroed by the caller), (P + 1)^2 / 2 per group of segments with the same camera (and image, for entries of image-linked columns).
 // On MI355X an FP64 MFMA issues at the rate of the FP64 vector pipe (2 048 flop in 64 cycles); what the matrix cores save here is the
 // cross-lane reduction — 64 detections' products land summed in the accumulators.
 #pragma once
@@ -47,17 +48,29 @@ struct BlockGramArgs {
     int32_t blk_col0[BLOCKROW_MAX_BLOCKS], blk_np[BLOCKROW_MAX_BLOCKS], blk_link[BLOCKROW_MAX_BLOCKS];   // link: 0 camera, 1 image, 2 key
     int64_t blk_start[BLOCKROW_MAX_BLOCKS];
     const int32_t *stop;    // optional LM stop word (ba_schur.hpp PCS_STOP_GUARD)
+    int32_t debug;          // measurements only (option "gram_debug"): 1 = no flush, 2 = no contraction
 };
 
 using gram_d4 = __attribute__((ext_vector_type(4))) double;
 
-// NB = column blocks of 16 covering the P + 1 columns (block rows + the residual column)
+constexpr int gram_blocks(int nb) { return nb * (nb + 1) / 2; }                       // upper column blocks of 16 x 16
+constexpr int gram_waves(int nb) { return nb <= 2 ? 16 : nb == 3 ? 8 : 4; }          // waves per workgroup: their Gram matrices fit 96 KB of LDS
+constexpr int gram_unroll(int nb) { return nb <= 2 ? 8 : nb == 3 ? 4 : 2; }          // contraction steps (4 rows each) whose loads are in flight together
+
+// NB = column blocks of 16 covering the P + 1 columns (block rows + the residual column).  One wave = one segment; the WAVES segments
+// of a workgroup are consecutive in the table, so they mostly share the camera and often the image: their Gram matrices meet in LDS and
+// ONE wave per group of equal (camera) / (camera, image) adds the group's sum to global memory — flushing every segment on its own made
+// the atomics the larger part of the kernel (1e6 detections, 32 cameras: 125 us of 230; each camera's 15 x 15 block is hit by all of its
+// ~400 segments).
 template <int NB>
-__global__ __launch_bounds__(256) void blockrow_gram_kernel(const BlockGramArgs a) {
+__global__ __launch_bounds__(64 * gram_waves(NB)) void blockrow_gram_kernel(const BlockGramArgs a) {
     if (a.stop && *a.stop) return;
+    constexpr int WAVES = gram_waves(NB), NE = gram_blocks(NB) * 256, UNROLL = gram_unroll(NB);
     // per local column: base (global column of entity 0), multiplier (parameters per entity), link
     __shared__ int64_t col_base[GRAM_MAX_COLS];
     __shared__ int32_t col_mul[GRAM_MAX_COLS], col_link[GRAM_MAX_COLS];
+    __shared__ int32_t seg_cam[WAVES], seg_img[WAVES];
+    extern __shared__ double gram_lds[];   // WAVES x NE
     if (threadIdx.x < GRAM_MAX_COLS) {
         const int p = threadIdx.x;
         int64_t base = 0;
@@ -66,11 +79,11 @@ __global__ __launch_bounds__(256) void blockrow_gram_kernel(const BlockGramArgs 
             if (p >= a.blk_col0[b] && p < a.blk_col0[b] + a.blk_np[b]) { base = a.blk_start[b] + (p - a.blk_col0[b]); mul = a.blk_np[b]; link = a.blk_link[b]; }
         col_base[p] = base; col_mul[p] = mul; col_link[p] = link;
     }
-    __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int s_id = blockIdx.x * 4 + wave;
-    if (s_id >= a.n_seg) return;
-    const int first = a.seg[4 * s_id], count = a.seg[4 * s_id + 1], cam = a.seg[4 * s_id + 2], img = a.seg[4 * s_id + 3];
+    const int s_id = blockIdx.x * WAVES + wave;
+    const bool have = s_id < a.n_seg;
+    const int first = have ? a.seg[4 * s_id] : 0, count = have ? a.seg[4 * s_id + 1] : 0, cam = have ? a.seg[4 * s_id + 2] : -1, img = have ? a.seg[4 * s_id + 3] : -1;
+    if (lane == 0) { seg_cam[wave] = cam; seg_img[wave] = img; }
     const int P = a.P;
     const int64_t row0 = 2 * (int64_t)first, row_end = row0 + 2 * (int64_t)count;
     const int lr = lane >> 4, lc = lane & 15;
@@ -94,11 +107,17 @@ __global__ __launch_bounds__(256) void blockrow_gram_kernel(const BlockGramArgs 
             v[cb] = x;
         }
     };
-    constexpr int UNROLL = 4;   // steps (16 rows) whose loads are in flight together
     for (int64_t r = row0 + lr; r - lr < row_end; r += 4 * UNROLL) {
         double v[UNROLL][NB];
 #pragma unroll
         for (int t = 0; t < UNROLL; ++t) fetch(r + 4 * t, v[t]);
+        if (a.debug & 2) {
+#pragma unroll
+            for (int t = 0; t < UNROLL; ++t)
+#pragma unroll
+                for (int i = 0; i < NB; ++i) acc[i][i][0] += v[t][i];
+            continue;
+        }
 #pragma unroll
         for (int t = 0; t < UNROLL; ++t)
 #pragma unroll
@@ -106,41 +125,79 @@ __global__ __launch_bounds__(256) void blockrow_gram_kernel(const BlockGramArgs 
 #pragma unroll
                 for (int j = i; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(v[t][i], v[t][j], acc[i][j], 0, 0, 0);
     }
+    if (a.debug & 1) {
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int j = i; j < NB; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (s == 1.2345e301) a.cost[0] = s;
+        return;
+    }
 
-    // ---- flush: acc[i][j][q] = G[16 i + lane / 16 + 4 q][16 j + lane % 16] ---------------------------------------------------------
-    auto gcol = [&](const int p, const int key) -> int64_t {
-        const int link = col_link[p];
-        return col_base[p] + (int64_t)col_mul[p] * (link == 0 ? cam : link == 1 ? img : key);
-    };
-    const int64_t n = a.n_params;
+    // ---- the waves' matrices into LDS: entry e = block x 256 + q x 64 + lane  <->  G[16 i + lane / 16 + 4 q][16 j + lane % 16] -------
+    {
+        double *mine = gram_lds + wave * NE;
+        int blk = 0;
 #pragma unroll
-    for (int i = 0; i < NB; ++i)
+        for (int i = 0; i < NB; ++i)
 #pragma unroll
-        for (int j = i; j < NB; ++j)
+            for (int j = i; j < NB; ++j) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int p = 16 * i + lr + 4 * q, c = 16 * j + lc;
-                if (p > c || c > P) continue;
-                const double val = acc[i][j][q];
-                if (p == P) {   // (residual, residual)
-                    unsafeAtomicAdd(a.cost, val);
-                    continue;
-                }
-                if (col_link[p] == 2) continue;   // key-linked columns: per detection, below
-                const int64_t gp = gcol(p, 0);
-                if (c == P) {
-                    unsafeAtomicAdd(a.g + gp, val);
-                    continue;
-                }
-                if (col_link[c] == 2) continue;
-                const int64_t gc = gcol(c, 0);
-                unsafeAtomicAdd(a.A + (gp < gc ? gp * n + gc : gc * n + gp), val);
+                for (int q = 0; q < 4; ++q) mine[blk * 256 + q * 64 + lane] = acc[i][j][q];
+                ++blk;
             }
+    }
+    __syncthreads();
+
+    // ---- flush: one (wave, entry) pair per thread and pass; the first wave of a group of equal keys adds the group's sum ---------------
+    const int64_t n = a.n_params;
+    for (int idx = threadIdx.x; idx < WAVES * NE; idx += 64 * WAVES) {
+        const int w = idx / NE, e = idx - w * NE;
+        const int wc = seg_cam[w];
+        if (wc < 0) continue;
+        const int blk = e >> 8, q = (e >> 6) & 3, ln = e & 63;
+        int bi = 0, bj = blk;                      // block index -> (bi, bj), bi <= bj, row-major over the upper triangle
+        while (bj >= NB - bi) { bj -= NB - bi; ++bi; }
+        bj += bi;
+        const int p = 16 * bi + (ln >> 4) + 4 * q, c = 16 * bj + (ln & 15);
+        if (p > c || c > P) continue;
+        const bool resid_pair = p == P;            // (residual, residual): the cost — one group per workgroup
+        if (!resid_pair && (col_link[p] == 2 || (c < P && col_link[c] == 2))) continue;    // key-linked columns: per detection, below
+        const bool by_img = !resid_pair && (col_link[p] == 1 || (c < P && col_link[c] == 1));
+        const int wi = seg_img[w];
+        // leader of its group?  (groups are runs of consecutive waves with the same key; the table order makes equal keys consecutive)
+        if (w > 0) {
+            const bool same = resid_pair ? seg_cam[w - 1] >= 0 : (seg_cam[w - 1] == wc && (!by_img || seg_img[w - 1] == wi));
+            if (same) continue;
+        }
+        double sum = gram_lds[idx];
+        for (int w2 = w + 1; w2 < WAVES; ++w2) {
+            const bool same = resid_pair ? seg_cam[w2] >= 0 : (seg_cam[w2] == wc && (!by_img || seg_img[w2] == wi));
+            if (!same) break;
+            sum += gram_lds[w2 * NE + e];
+        }
+        if (resid_pair) {
+            unsafeAtomicAdd(a.cost, sum);
+            continue;
+        }
+        const int64_t gp = col_base[p] + (int64_t)col_mul[p] * (col_link[p] == 0 ? wc : wi);
+        if (c == P) {
+            unsafeAtomicAdd(a.g + gp, sum);
+            continue;
+        }
+        const int64_t gc = col_base[c] + (int64_t)col_mul[c] * (col_link[c] == 0 ? wc : wi);
+        unsafeAtomicAdd(a.A + (gp < gc ? gp * n + gc : gc * n + gp), sum);
+    }
 
     // ---- key-linked columns: one detection per lane ------------------------------------------------------------------------------
     bool any_key = false;
     for (int p = 0; p < P; ++p) any_key = any_key || col_link[p] == 2;
-    if (!any_key) return;
+    if (!any_key || !have) return;
+    auto gcol = [&](const int p, const int key) -> int64_t {
+        const int link = col_link[p];
+        return col_base[p] + (int64_t)col_mul[p] * (link == 0 ? cam : link == 1 ? img : key);
+    };
     for (int d0 = 0; d0 < count; d0 += 64) {
         const int d = d0 + lane;
         if (d >= count) break;

@@ -536,12 +536,23 @@ struct SchurBackArgs {
     double *vote;
     int64_t vote_alt;
     const int32_t *status;
+    // optional: zero_n doubles at `zero` (16-byte aligned) are set to 0 on the way — the trial state a dense build sums into right after
+    // this kernel (pcs_genchain_lm_trial_build: the two fill launches of a hipMemsetAsync cost a small trial 9 us)
+    double *zero;
+    int64_t zero_n;
 };
 
 template <int TB>
 __global__ __launch_bounds__(256) void schur_back_kernel(const SchurBackArgs a0) {
     PCS_STOP_GUARD(a0);
     SchurBackArgs a = a0;
+    if (a.zero) {
+        using D2 = __attribute__((ext_vector_type(2))) double;
+        const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (int64_t)gridDim.x * blockDim.x;
+        D2 *z = reinterpret_cast<D2 *>(a.zero);
+        for (int64_t i = t0; i < a.zero_n / 2; i += nt) z[i] = D2{0.0, 0.0};
+        if (t0 == 0 && (a.zero_n & 1)) a.zero[a.zero_n - 1] = 0.0;
+    }
     const bool flipped = a.sel && *a.sel;
     if (flipped && a.ps_out) { a.ps_in = a0.ps_out; a.ps_out = const_cast<double *>(a0.ps_in); }
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

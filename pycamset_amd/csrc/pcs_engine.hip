@@ -1984,15 +1984,19 @@ int pcs_lm_decide(pcs_engine *h, const double *d_cost_old, const double *d_cost_
 
 static int enqueue_schur_finish(const BlockLayout &L, const double *d_linvt, const double *d_u, const double *d_w, const double *d_xlead, const uint8_t *d_fixed,
                                 double *d_delta, const double *d_ps_in, double *d_ps_out, hipStream_t s, const int32_t *d_stop, const int32_t *d_sel = nullptr,
-                                double *d_vote = nullptr, int64_t vote_alt = 0, const int32_t *d_status = nullptr) {
+                                double *d_vote = nullptr, int64_t vote_alt = 0, const int32_t *d_status = nullptr, double *d_zero = nullptr, int64_t zero_n = 0,
+                                int n_cu = 256) {
     SchurBackArgs a{};
+    a.zero = d_zero; a.zero_n = d_zero ? zero_n : 0;
     a.sel = d_sel; a.vote = d_vote; a.vote_alt = vote_alt; a.status = d_status;
     a.linvt = d_linvt; a.u = d_u; a.w = d_w; a.xl = d_xlead; a.fixed = d_fixed; a.delta = d_delta;
     a.ps_in = d_ps_in; a.ps_out = d_ps_out;
     a.n_lead = L.n_lead; a.n_ent = L.n_ent; a.trail_off = L.trail_off;
     a.stop = d_stop;
     const int64_t n = std::max(L.n_lead, L.n_ent);
-    const dim3 grid((unsigned)((n + 255) / 256));
+    // with a buffer to zero on the way: enough workgroups for that as well (8 doubles per thread and pass, at most four workgroups per CU)
+    const int64_t zero_blocks = a.zero ? std::min<int64_t>((a.zero_n / 8 + 255) / 256, (int64_t)n_cu * 4) : 0;
+    const dim3 grid((unsigned)std::max<int64_t>((n + 255) / 256, zero_blocks));
     if (L.tb == 6) hipLaunchKernelGGL(schur_back_kernel<6>, grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(schur_back_kernel<3>, grid, dim3(256), 0, s, a);
     HIPCHK(hipGetLastError());
