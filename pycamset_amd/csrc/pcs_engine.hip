@@ -427,7 +427,10 @@ int pcs_tri_group_device(pcs_triangulator *t, int64_t n, const int32_t *d_cam, c
     if (rc) return rc;
     rc = tri_grow((void **)&t->d_uv, &t->uv_capacity, n, 2 * sizeof(double));
     if (rc) return rc;
-    rc = tri_grow((void **)&t->d_start, &t->pts_capacity, n / 2 + 2, sizeof(int64_t));
+    // one entry per kept run + 1.  A GROUPED table has at most n / 2 kept runs, but whether it is grouped is only known afterwards: in a table
+    // whose features interleave every row can be the head of a kept run (writes up to start[n]; sized for n / 2 + 2 until this was found
+    // by a fault in the full test suite — alone, the overrun stayed inside the allocation)
+    rc = tri_grow((void **)&t->d_start, &t->pts_capacity, n + 2, sizeof(int64_t));
     if (rc) return rc;
     rc = tri_grow((void **)&t->d_count, &t->count_capacity, n_features, sizeof(int32_t));
     if (rc) return rc;
