@@ -491,6 +491,7 @@ __global__ __launch_bounds__(256) void tri_group_count_kernel(const TriGroupArgs
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n) return;
     const int32_t f = a.feat[i];
+    if ((uint32_t)f >= (uint64_t)a.n_features) return;   // not a feature id (the caller's contract): the row is dropped, nothing is addressed with it
     if (atomicAdd(a.count + f, 1) == 0) atomicAdd(reinterpret_cast<unsigned long long *>(a.totals + 3), 1ull);   // a feature's first row
     if (i == 0 || a.feat[i - 1] != f) atomicAdd(reinterpret_cast<unsigned long long *>(a.totals + 2), 1ull);     // a run's first row
 }
@@ -498,6 +499,7 @@ __global__ __launch_bounds__(256) void tri_group_count_kernel(const TriGroupArgs
 __device__ __forceinline__ uint64_t tri_group_flags(const TriGroupArgs &a, const int64_t i) {
     if (i >= a.n) return 0;
     const int32_t f = a.feat[i];
+    if ((uint32_t)f >= (uint64_t)a.n_features) return 0;
     const bool keep = a.count[f] >= 2;
     const bool head = i == 0 || a.feat[i - 1] != f;
     return (keep ? 1ull : 0ull) | ((keep && head) ? (1ull << 32) : 0ull);
