@@ -370,14 +370,18 @@ int pcs_genchain_linearize(pcs_genchain *h, const double *param_str);
 int pcs_genchain_matfree(pcs_genchain *h, int op, const double *in, double *out, double *cost);
 /* The exact Levenberg-Marquardt step for ANY generated chain (round 5; csrc/ba_blockgram.hpp).  Replaces what scipy's trf does with the
  * CSR Jacobian of a composed chain (optimisation_handling.py:88-98) for chains the three hand-fused engines do not cover — user blocks
- * included.  The packed state is [A | g | cost]: A = J^T J DENSE (n_params x n_params, upper triangle written), i.e. pcs_normal_layout's
- * form with every parameter in the leading group: out5 = {n_params, 0, 3, n_params^2 + n_params + 1, n_params}.
+ * included.  The packed state is pcs_normal_layout's [A | B | C | g | cost] (pcs_genchain_normal_layout: same out5).  A chain whose LAST
+ * parameter group is one rigid transform per image (6) or one point per key (3) has that group as the trailing entities — B and the
+ * tb x tb blocks of C are filled, the dense factorisation is of the leading part only (Schur step, like the hand-fused chains); every
+ * other chain, and any chain after pcs_genchain_set_option("dense_normal", 1), has every parameter leading: A = J^T J DENSE
+ * (n_params x n_params, upper triangle written), out5 = {n_params, 0, 3, n_params^2 + n_params + 1, n_params}.
  * pcs_genchain_normal_blocks_device evaluates the chain at d_param_str (block rows into the handle's buffers) and contracts them on the
  * FP64 matrix cores.  pcs_genchain_lm_trial_build / _finish / pcs_genchain_lm_trial are pcs_lm_trial_build / _finish / pcs_lm_trial for
  * the handle (same pcs_lm_buffers — V, linvt, u, w: one double each —, same decision, read-back and stop word); mode must hold
  * PCS_LM_FIXED_TRIAL_BUFFER (the generated kernel reads its string from a fixed address: the trial is built at ps[1] into packed[1],
  * an accepted one is copied over state 0).  Limits: FP64 chains, row length <= 63, n_params <= PCS_NORMAL_MAX_PARAMS.
- * Options (pcs_genchain_set_option): "spd_timeout_us" (as pcs_set_option), "timing" (0: no start / stop events around evaluations). */
+ * Options (pcs_genchain_set_option): "spd_timeout_us" (as pcs_set_option), "timing" (0: no start / stop events around evaluations),
+ * "dense_normal" (above; changes the layout: set it before buffers are sized), "gram_debug" (measurements only). */
 int pcs_genchain_normal_layout(const pcs_genchain *h, int64_t *out5);
 int pcs_genchain_normal_blocks_device(pcs_genchain *h, const double *d_param_str, double *d_packed, void *stream);
 int pcs_genchain_lm_trial_build(pcs_genchain *h, const pcs_lm_buffers *b, void *stream);

@@ -558,14 +558,16 @@ class ChainEngine:
 
     # -- the exact LM step: dense normal equations + the device-steered trial (csrc/ba_blockgram.hpp; device_solver.BlockedNormalEquations) ----
     lm_fixed_trial_buffer = True   # the generated kernel reads its string from a fixed address: trials are built at ps[1] into packed[1]
-    DENSE_OPTIONS = ("spd_timeout_us", "timing", "gram_debug")
+    DENSE_OPTIONS = ("spd_timeout_us", "timing", "gram_debug", "dense_normal")
 
     def dense_lm_supported(self) -> bool:
         """Does the contraction of csrc/ba_blockgram.hpp take this chain?  FP64 block rows of at most 63 columns, n_params <= 65 535."""
         return self.dtype == "f64" and self.P + 1 <= 64 and self.n_params <= 65535
 
     def normal_layout(self) -> dict:
-        """{n_lead, n_trail, tb, packed_len, n_params} of the packed state [A | g | cost]: every parameter in the leading group, A dense."""
+        """{n_lead, n_trail, tb, packed_len, n_params} of the packed state [A | B | C | g | cost] (include/pcs_hip.h): the chain's LAST
+        parameter group as trailing entities when it is one rigid transform per image or one point per key (Schur step on the leading
+        part), else — or with ``set_option("dense_normal", 1)`` — every parameter leading and A dense."""
         out = (c_int64 * 5)()
         check(lib().pcs_genchain_normal_layout(self._h, out))
         return dict(n_lead=int(out[0]), n_trail=int(out[1]), tb=int(out[2]), packed_len=int(out[3]), n_params=int(out[4]))

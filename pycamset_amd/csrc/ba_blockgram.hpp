@@ -42,8 +42,14 @@ struct BlockGramArgs {
     const double *J;        // 2N x P dense block rows, u row then v row
     const double *resid;    // N x 2
     const int32_t *seg;     // n_seg x 4: first detection, count, camera, image
-    double *A, *g, *cost;   // n_params x n_params (upper triangle written), n_params, 1 — zeroed by the caller
-    int64_t n_params;
+    double *A, *g, *cost;   // n_lead x n_lead (upper triangle written), n_params, 1 — zeroed by the caller
+    // Blocked form (a chain whose LAST parameter group is one rigid transform per image or one point per key — ba_schur.hpp's trailing
+    // entities): products of two leading columns go to A, leading x trailing to B (n_lead x n_trail, row-major), two trailing columns
+    // (always the same entity: a detection has one image and one key) to the entity's tb x tb block of C (upper triangle).
+    // Dense form: trail_off = n_lead = n_params, B and C unused.
+    double *B, *C;
+    int64_t n_params, n_lead, n_trail, trail_off;
+    int32_t tb;
     int32_t P, n_seg, n_blocks;
     int32_t blk_col0[BLOCKROW_MAX_BLOCKS], blk_np[BLOCKROW_MAX_BLOCKS], blk_link[BLOCKROW_MAX_BLOCKS];   // link: 0 camera, 1 image, 2 key
     int64_t blk_start[BLOCKROW_MAX_BLOCKS];
@@ -56,6 +62,21 @@ using gram_d4 = __attribute__((ext_vector_type(4))) double;
 constexpr int gram_blocks(int nb) { return nb * (nb + 1) / 2; }                       // upper column blocks of 16 x 16
 constexpr int gram_waves(int nb) { return nb <= 2 ? 16 : nb == 3 ? 8 : 4; }          // waves per workgroup: their Gram matrices fit 96 KB of LDS
 constexpr int gram_unroll(int nb) { return nb <= 2 ? 8 : nb == 3 ? 4 : 2; }          // contraction steps (4 rows each) whose loads are in flight together
+
+// where the product of the global columns gp and gc goes (see BlockGramArgs); a parameter that two blocks share (one group, two
+// local columns: afb:160-163) meets itself off the local diagonal: that product belongs to the diagonal entry TWICE
+__device__ __forceinline__ void gram_add(const BlockGramArgs &a, const int64_t gp, const int64_t gc, const bool same_local, double val) {
+    if (gp == gc && !same_local) val += val;
+    const int64_t lo = gp < gc ? gp : gc, hi = gp < gc ? gc : gp;
+    if (hi < a.trail_off) {
+        unsafeAtomicAdd(a.A + lo * a.n_lead + hi, val);
+    } else if (lo < a.trail_off) {
+        unsafeAtomicAdd(a.B + lo * a.n_trail + (hi - a.trail_off), val);
+    } else {
+        const int64_t tl = lo - a.trail_off, th = hi - a.trail_off, e = tl / a.tb;
+        unsafeAtomicAdd(a.C + e * a.tb * a.tb + (tl - e * a.tb) * a.tb + (th - e * a.tb), val);
+    }
+}
 
 // NB = column blocks of 16 covering the P + 1 columns (block rows + the residual column).  One wave = one segment; the WAVES segments
 // of a workgroup are consecutive in the table, so they mostly share the camera and often the image: their Gram matrices meet in LDS and
@@ -151,7 +172,6 @@ __global__ __launch_bounds__(64 * gram_waves(NB)) void blockrow_gram_kernel(cons
     __syncthreads();
 
     // ---- flush: one (wave, entry) pair per thread and pass; the first wave of a group of equal keys adds the group's sum ---------------
-    const int64_t n = a.n_params;
     for (int idx = threadIdx.x; idx < WAVES * NE; idx += 64 * WAVES) {
         const int w = idx / NE, e = idx - w * NE;
         const int wc = seg_cam[w];
@@ -187,7 +207,7 @@ __global__ __launch_bounds__(64 * gram_waves(NB)) void blockrow_gram_kernel(cons
             continue;
         }
         const int64_t gc = col_base[c] + (int64_t)col_mul[c] * (col_link[c] == 0 ? wc : wi);
-        unsafeAtomicAdd(a.A + (gp < gc ? gp * n + gc : gc * n + gp), sum);
+        gram_add(a, gp, gc, p == c, sum);
     }
 
     // ---- key-linked columns: one detection per lane ------------------------------------------------------------------------------
@@ -213,8 +233,7 @@ __global__ __launch_bounds__(64 * gram_waves(NB)) void blockrow_gram_kernel(cons
             unsafeAtomicAdd(a.g + gp, pu * ru + pv * rv);
             for (int c = 0; c < P; ++c) {
                 if (col_link[c] == 2 && c < p) continue;   // a pair of key-linked columns is taken once
-                const int64_t gc = gcol(c, key);
-                unsafeAtomicAdd(a.A + (gp < gc ? gp * n + gc : gc * n + gp), pu * ju[c] + pv * jv[c]);
+                gram_add(a, gp, gcol(c, key), p == c, pu * ju[c] + pv * jv[c]);
             }
         }
     }

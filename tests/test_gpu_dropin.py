@@ -702,6 +702,30 @@ def test_generated_chain_options_counts_shared_groups_and_errors():
         fd = (op.make_full_loss_fn(det, 1)(pp)[d0] - op.make_full_loss_fn(det, 1)(pm)[d0]) / (2 * h)
         analytic = J[d0, :, [c for c in range(24) if cols[d0, c] == gi]].sum(axis=0)
         assert np.max(np.abs(fd - analytic)) <= 1e-5 * max(1.0, np.max(np.abs(analytic))), (col, fd, analytic)
+    # the dense / blocked normal equations of the chain with the SHARED group: the product of its two local columns belongs to the
+    # diagonal entry twice (csrc/ba_blockgram.hpp gram_add); scipy's CSR sums the duplicate column entries of a row the same way
+    import torch
+    from scipy.sparse import csr_array
+    eng1 = op._engine_for(det)
+    for dense in (0, 1):
+        eng1.set_option("dense_normal", dense)
+        lay = eng1.normal_layout()
+        nl, nt, tb, n1 = lay["n_lead"], lay["n_trail"], lay["tb"], eng1.n_params
+        assert (nt > 0) == (dense == 0)
+        ps_dev = torch.from_numpy(np.ascontiguousarray(ps[:n1])).cuda()
+        packed = torch.empty(lay["packed_len"], dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        eng1.normal_blocks_device(ps_dev.data_ptr(), packed.data_ptr())
+        eng1.synchronize()
+        out = packed.cpu().numpy()
+        Jc = csr_array((np.asarray(data).ravel(), idx, ptr), shape=(2 * det.shape[0], n1))
+        want = (Jc.T @ Jc).toarray()
+        A = out[: nl * nl].reshape(nl, nl)
+        assert np.max(np.abs(np.triu(A) - np.triu(want[:nl, :nl]))) <= 1e-11 * np.max(np.abs(want))
+        if nt:
+            assert np.max(np.abs(out[nl * nl: nl * nl + nl * nt].reshape(nl, nt) - want[:nl, nl:])) <= 1e-11 * np.max(np.abs(want))
+        assert np.max(np.abs(out[-(n1 + 1): -1] - Jc.T @ r.ravel())) <= 1e-11 * np.max(np.abs(Jc.T @ r.ravel()))
+    eng1.set_option("dense_normal", 0)
     # (2) explicit counts: a trailing image and key without detections still get their place in the string
     op2 = fb.optimisation_function([fb.projection(), fb.rigidTform3d(), fb.free_point()], counts=(3, 7, 10))
     eng = op2._engine_for(det)
@@ -864,26 +888,67 @@ def test_generated_chain_dense_normal_equations_match_the_reference_jacobian(gol
     eng = op._engine_for(det)
     if op.templated:
         op._bind_template(eng, g["points"])
-    lay = eng.normal_layout()
     n = eng.n_params
-    assert eng.dense_lm_supported() and lay == dict(n_lead=n, n_trail=0, tb=3, packed_len=n * n + n + 1, n_params=n)
     dev = torch.device("cuda", eng.device)
     ps_dev = torch.from_numpy(np.ascontiguousarray(ps[:n])).to(dev)
-    packed = torch.full((lay["packed_len"],), np.nan, dtype=torch.float64, device=dev)      # the build zeroes its output itself
-    torch.cuda.synchronize()
-    eng.normal_blocks_device(ps_dev.data_ptr(), packed.data_ptr())
-    eng.synchronize()
-    out = packed.cpu().numpy()
-    A, grad, cost = out[: n * n].reshape(n, n), out[n * n: n * n + n], out[-1]
     Jc = csr_array((g["data_all"], g["indices_all"], g["indptr_all"]), shape=(2 * det.shape[0], n))
     r = g["resid"].ravel()
     want = (Jc.T @ Jc).toarray()
-    assert np.max(np.abs(np.triu(A) - np.triu(want))) <= 1e-11 * np.max(np.abs(want))
-    assert np.all(np.tril(A, -1) == 0)                                                    # only the upper triangle is written
-    assert np.max(np.abs(grad - Jc.T @ r)) <= 1e-11 * np.max(np.abs(Jc.T @ r))
-    assert abs(cost - r @ r) <= 1e-12 * (r @ r)
+    assert eng.dense_lm_supported()
+
+    def build_and_check(e):
+        """[A | B | C | g | cost] of engine `e` against the reference's products, whatever its layout"""
+        lay = e.normal_layout()
+        nl, nt, tb = lay["n_lead"], lay["n_trail"], lay["tb"]
+        assert nl + nt == n and lay["packed_len"] == nl * nl + nl * nt + nt * tb + n + 1
+        packed = torch.full((lay["packed_len"],), np.nan, dtype=torch.float64, device=dev)      # the build zeroes its output itself
+        torch.cuda.synchronize()
+        e.normal_blocks_device(ps_dev.data_ptr(), packed.data_ptr())
+        e.synchronize()
+        out = packed.cpu().numpy()
+        A = out[: nl * nl].reshape(nl, nl)
+        B = out[nl * nl: nl * nl + nl * nt].reshape(nl, nt)
+        C = out[nl * nl + nl * nt: nl * nl + nl * nt + nt * tb].reshape(-1, tb, tb)
+        grad, cost = out[-(n + 1): -1], out[-1]
+        scale = np.max(np.abs(want))
+        assert np.max(np.abs(np.triu(A) - np.triu(want[:nl, :nl]))) <= 1e-11 * scale
+        assert np.all(np.tril(A, -1) == 0)                                                    # only the upper triangle is written
+        if nt:
+            assert np.max(np.abs(B - want[:nl, nl:])) <= 1e-11 * scale
+            T = want[nl:, nl:].copy()
+            for ent in range(nt // tb):                                                       # the trailing part is block diagonal ...
+                blk = T[ent * tb: (ent + 1) * tb, ent * tb: (ent + 1) * tb]
+                assert np.max(np.abs(np.triu(C[ent]) - np.triu(blk))) <= 1e-11 * scale and np.all(np.tril(C[ent], -1) == 0)
+                blk[:] = 0.0
+            assert np.all(T == 0.0)                                                           # ... and nothing else: two entities never share a detection
+        assert np.max(np.abs(grad - Jc.T @ r)) <= 1e-11 * np.max(np.abs(Jc.T @ r))
+        assert abs(cost - r @ r) <= 1e-12 * (r @ r)
+        return out, lay
+
+    out, lay = build_and_check(eng)
+    # chains whose LAST parameter group is one rigid transform per image / one point per key get the blocked form (Schur step on the
+    # leading part only), everything else — the board-flex source: five parameters per image — the dense one
+    blocked = {"generic_proj_rigid_free": 3, "generic_proj_extr_rigid_template": 6, "generic_proj_template": 6, "generic_proj_rigid_extr_free": 3,
+               "user_cam_scale": 6, "user_division": 3}
+    assert (lay["n_trail"] > 0) == (tag in blocked) and (tag not in blocked or lay["tb"] == blocked[tag])
+    if tag in blocked:   # the dense form of the same chain on request
+        eng.set_option("dense_normal", 1)
+        _, lay_d = build_and_check(eng)
+        assert lay_d["n_trail"] == 0 and lay_d["n_lead"] == n
+        eng.set_option("dense_normal", 0)
     key_linked = any(str(b) == "free_point" for b in names)
     assert key_linked == (tag in ("generic_proj_rigid_free", "generic_proj_rigid_extr_free", "user_division"))
+    # the rows of the table in ANY order: the host cuts it into segments of one (camera, image) pair wherever they lie (a shuffled table
+    # degenerates to short segments), the sums are the same
+    perm = np.random.default_rng(3).permutation(det.shape[0])
+    op2 = fb.optimisation_function([ub[n_]() if n_ in ub else getattr(fb, n_)() for n_ in names])
+    eng2 = op2._engine_for(np.ascontiguousarray(det[perm]))
+    if op2.templated:
+        op2._bind_template(eng2, g["points"])
+    Jc = Jc[np.stack([2 * perm, 2 * perm + 1], axis=1).ravel()]
+    r = r.reshape(-1, 2)[perm].ravel()
+    out2, _ = build_and_check(eng2)
+    assert np.max(np.abs(out2 - out)) <= 1e-11 * np.max(np.abs(out))
 
 
 def test_templated_user_source_through_the_device_lm(golden_dir):
