@@ -60,7 +60,9 @@ struct BlockGramArgs {
 using gram_d4 = __attribute__((ext_vector_type(4))) double;
 
 constexpr int gram_blocks(int nb) { return nb * (nb + 1) / 2; }                       // upper column blocks of 16 x 16
-constexpr int gram_waves(int nb) { return nb <= 2 ? 16 : nb == 3 ? 8 : 4; }          // waves per workgroup: their Gram matrices fit 96 KB of LDS
+constexpr int gram_waves(int nb) { return nb == 1 ? 16 : nb == 2 ? 8 : 4; }         // waves per workgroup: their Gram matrices take 32 / 48 / 48 / 80 KB of LDS — two or three
+                                                                                     // workgroups per CU, so that one's flush runs under another's loads (16 waves = 96 KB for nb = 2, one
+                                                                                     // workgroup per CU: 182 us on rig-32 with P = 17)
 constexpr int gram_unroll(int nb) { return nb <= 2 ? 8 : nb == 3 ? 4 : 2; }          // contraction steps (4 rows each) whose loads are in flight together
 
 // where the product of the global columns gp and gc goes (see BlockGramArgs); a parameter that two blocks share (one group, two

@@ -4,7 +4,7 @@ equations from the block rows, csrc/ba_blockgram.hpp + pcs_genchain_lm_trial) ag
 default (products of csrc/ba_blockrow.hpp, the host between every two) and — on small rigs — scipy's trf on the same closures
 (optimisation_handling.py:88-98).  The chain is `projection + extrinsic3D + rigidTform3d + board_flex`: the user-written templated
 source of tests/helpers.py (a board that bends, one flex model per image) on the rigs of BASELINE's configs.
-    python tools/genchain_lm.py --config 1 2 3 [--trace]"""
+    python tools/genchain_lm.py --config 1 2 3 [--chain division] [--dense] [--trace]"""
 import argparse
 import sys
 import time
@@ -23,31 +23,44 @@ from pycamset_amd import handlers, synthetic
 from pycamset_amd.device_solver import lm_solve
 
 
-def problem(number: int):
+def problem(number: int, which: str):
+    """`flex`: projection + extrinsic3D + rigidTform3d + board_flex (a user-written templated source, five parameters per image: the
+    DENSE form of the normal equations); `division`: division_projection + extrinsic3D + template_points (a user-written lens model in
+    place of the shipped projection; the chain ends in one rigid transform per image: the BLOCKED form, Schur step)."""
     rig = synthetic.config_rig(number)
     ub = H.user_blocks(fb)
     rng = np.random.default_rng(6)
-
-    def chain():
-        return fb.projection() + fb.extrinsic3D() + fb.rigidTform3d() + ub["board_flex"]()
-
-    op = chain()
-    flex = np.concatenate([rng.uniform(0.98, 1.02, (rig.n_imgs, 2)), rng.normal(0, 1e-3, (rig.n_imgs, 2)), rng.normal(0, 0.3, (rig.n_imgs, 1))], axis=1)
+    fix_ext = np.ones((rig.n_cams, 6), dtype=bool)
+    fix_ext[0] = False
     det = rig.detections.copy()
-    ps_true = op.build_param_list(rig.intr_true, rig.extr_true, rig.poses_true, flex)
-    uv = op.make_full_loss_fn(det, 1)(ps_true, rig.points) + det[:, 3:]
+    if which == "flex":
+        def chain():
+            return fb.projection() + fb.extrinsic3D() + fb.rigidTform3d() + ub["board_flex"]()
+
+        flex = np.concatenate([rng.uniform(0.98, 1.02, (rig.n_imgs, 2)), rng.normal(0, 1e-3, (rig.n_imgs, 2)), rng.normal(0, 0.3, (rig.n_imgs, 1))], axis=1)
+        truth = [rig.intr_true, rig.extr_true, rig.poses_true, flex]
+        free_flex = np.zeros((rig.n_imgs, 5), dtype=bool)
+        free_flex[:, 4] = True
+        start = [rig.intr_true * (1 + 1e-3 * rng.standard_normal(rig.intr_true.shape)), rig.extr_true + 1e-3 * rng.standard_normal(rig.extr_true.shape),
+                 rig.poses_true + 1e-3 * rng.standard_normal(rig.poses_true.shape), flex.copy()]
+        start[3][:, 4] = 0.0
+        unfixed = [None, fix_ext, None, free_flex]
+    else:
+        def chain():
+            return ub["division_projection"]() + fb.extrinsic3D() + fb.template_points()
+
+        div = np.concatenate([rig.intr_true[:, :4], rng.normal(0, 0.05, (rig.n_cams, 1))], axis=1)      # fx, cx, fy, cy, k
+        truth = [div, rig.extr_true, rig.poses_true]
+        start = [div * (1 + 1e-3 * rng.standard_normal(div.shape)), rig.extr_true + 1e-3 * rng.standard_normal(rig.extr_true.shape),
+                 rig.poses_true + 1e-3 * rng.standard_normal(rig.poses_true.shape)]
+        unfixed = [None, fix_ext, None]
+    start[1][0] = rig.extr_true[0]
+    op = chain()
+    uv = op.make_full_loss_fn(det, 1)(op.build_param_list(*truth), rig.points) + det[:, 3:]
     det[:, 3:] = uv + rng.normal(0, 0.3, uv.shape)
     op.engine.close()
     op = chain()
-    fix_ext = np.ones((rig.n_cams, 6), dtype=bool)
-    fix_ext[0] = False
-    free_flex = np.zeros((rig.n_imgs, 5), dtype=bool)
-    free_flex[:, 4] = True
-    start = [rig.intr_true * (1 + 1e-3 * rng.standard_normal(rig.intr_true.shape)), rig.extr_true + 1e-3 * rng.standard_normal(rig.extr_true.shape),
-             rig.poses_true + 1e-3 * rng.standard_normal(rig.poses_true.shape), flex.copy()]
-    start[1][0] = rig.extr_true[0]
-    start[3][:, 4] = 0.0
-    prob = handlers.ChainProblem(op, det, start, template=rig.points, unfixed=[None, fix_ext, None, free_flex])
+    prob = handlers.ChainProblem(op, det, start, template=rig.points, unfixed=unfixed)
     return rig, op, prob
 
 
@@ -58,12 +71,18 @@ def main():
     ap.add_argument("--max-iter", type=int, default=40)
     ap.add_argument("--phases", action="store_true", help="time the build with parts of the contraction switched off")
     ap.add_argument("--no-cg", action="store_true")
+    ap.add_argument("--chain", choices=("flex", "division"), default="flex")
+    ap.add_argument("--dense", action="store_true", help="the dense form of the normal equations also where the chain has the blocked one")
     a = ap.parse_args()
     for number in a.config:
-        rig, op, prob = problem(number)
+        rig, op, prob = problem(number, a.chain)
         eng = op._engine_for(prob._flat_detections())
+        if a.dense:
+            eng.set_option("dense_normal", 1)
         n_free = prob.x0.shape[0]
-        print(f"config {number}: {rig.n_cams} cameras, {rig.n_imgs} images, N = {rig.n_det}, row length {eng.P}, {eng.n_params} parameters ({n_free} free)", flush=True)
+        lay = eng.normal_layout()
+        print(f"config {number}, {eng.chain}: {rig.n_cams} cameras, {rig.n_imgs} images, N = {rig.n_det}, row length {eng.P}, {eng.n_params} parameters "
+              f"({n_free} free), normal equations: {lay['n_lead']} leading + {lay['n_trail']} trailing", flush=True)
         lm_solve(prob, prob.x0.copy(), max_iter=a.max_iter)     # warm-up: compiled chain, solver state, page-locked read-back
         torch.cuda.synchronize()
         best, res = np.inf, None
