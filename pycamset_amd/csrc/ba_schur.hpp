@@ -661,25 +661,27 @@ __global__ __launch_bounds__(1024) void lm_decide_kernel(const LmDecideArgs a) {
         ss += d * d;
         if (!a.fixed[i]) xx += ps[i] * ps[i];
     }
-    // five reductions through LDS (sum, sum, max, sum, sum): four arrays, the fifth reuses the first after a barrier
-    red[0][tid] = gd; red[1][tid] = dd; red[2][tid] = gmax; red[3][tid] = xx;
-    __syncthreads();
-    for (int s = 512; s > 0; s >>= 1) {
-        if (tid < s) {
-            red[0][tid] += red[0][tid + s];
-            red[1][tid] += red[1][tid + s];
-            red[2][tid] = fmax(red[2][tid], red[2][tid + s]);
-            red[3][tid] += red[3][tid + s];
-        }
-        __syncthreads();
+    // five reductions (sum, sum, max, sum, sum): inside each wave by lane exchange, across the sixteen waves through LDS — ONE barrier
+    // (binary trees through LDS with a barrier per level, until round 5: twenty-two barriers of 1024 threads, ~2.5 us of the 8)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        gd += __shfl_xor(gd, off);
+        dd += __shfl_xor(dd, off);
+        gmax = fmax(gmax, __shfl_xor(gmax, off));
+        xx += __shfl_xor(xx, off);
+        ss += __shfl_xor(ss, off);
     }
-    const double s_gd = red[0][0], s_dd = red[1][0], s_gmax = red[2][0], s_xx = red[3][0];
+    if ((tid & 63) == 0) {
+        const int w = tid >> 6;
+        red[0][w] = gd; red[0][16 + w] = dd; red[0][32 + w] = gmax; red[0][48 + w] = xx; red[0][64 + w] = ss;
+    }
     __syncthreads();
-    red[0][tid] = ss;
-    __syncthreads();
-    for (int s = 512; s > 0; s >>= 1) {
-        if (tid < s) red[0][tid] += red[0][tid + s];
-        __syncthreads();
+    double s_gd = 0.0, s_dd = 0.0, s_gmax = 0.0, s_xx = 0.0, s_ss = 0.0;
+    if (tid == 0) {
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {   // a fixed order: the same bits on every run (deterministic mode relies on it)
+            s_gd += red[0][w]; s_dd += red[0][16 + w]; s_gmax = fmax(s_gmax, red[0][32 + w]); s_xx += red[0][48 + w]; s_ss += red[0][64 + w];
+        }
     }
     if (tid == 0) {
         const double pred = 0.5 * (lam * s_dd - s_gd);
@@ -688,7 +690,7 @@ __global__ __launch_bounds__(1024) void lm_decide_kernel(const LmDecideArgs a) {
         const double rho = pred > 0.0 ? actual / pred : -1.0;
         bool acc = ok && c_new == c_new && fabs(c_new) < 1.0e300 && actual > 0.0;
         const double factor = (cv[10] > 0.0 && cv[11] > 0.0 && rho > cv[10]) ? cv[11] : rho > 0.75 ? 1.0 / 3.0 : rho > 0.25 ? 1.0 : 2.0;
-        const double rel_drop = actual / (0.5 * c_old), step_norm = sqrt(red[0][0]), x_norm = sqrt(s_xx);
+        const double rel_drop = actual / (0.5 * c_old), step_norm = sqrt(s_ss), x_norm = sqrt(s_xx);
         double code = 0.0, trial_no = 0.0;
         // the dense solve did not complete (ba_chol_persist.hpp's time limit) — here, or on some rank of a sharded loop: the host repeats the trial
         const bool void_trial = (st & 4) != 0 || votes > 0.0;
