@@ -993,6 +993,51 @@ def test_templated_user_source_through_the_device_lm(golden_dir):
         (fb.projection() + ub["board_flex"]() + fb.free_point()).chain
 
 
+def test_user_lens_model_with_free_points_through_the_blocked_device_lm():
+    """A generated chain whose LAST group is one point per key: `division_projection + extrinsic3D + rigidTform3d + free_point` — a
+    user-written lens model AND free points — takes the blocked normal equations with the points as trailing entities (tb = 3: the
+    Schur step of the self / free chains, here fed by csrc/ba_blockgram.hpp's per-detection path for key-linked columns).  Poses held at
+    their values (they fix the frame), lens, extrinsics and every point free: `lm_solve` ends where scipy's trf on the same closures
+    ends, with one factorisation of the LEADING part per evaluation."""
+    from pycamset_amd import function_blocks as fb
+    from pycamset_amd.device_solver import lm_solve
+    ub = H.user_blocks(fb)
+    rig = synthetic.make_rig("div-free", 4, 10, synthetic.charuco_points(7, 8.0), seed=63, visibility=0.9)
+    det = rig.detections
+    rng = np.random.default_rng(7)
+
+    def chain():
+        return ub["division_projection"]() + fb.extrinsic3D() + fb.rigidTform3d() + fb.free_point()
+
+    op = chain()
+    assert op.chain == "generated"
+    div = np.concatenate([rig.intr_true[:, :4], rng.normal(0, 0.05, (rig.n_cams, 1))], axis=1)      # fx, cx, fy, cy, k
+    uv = op.make_full_loss_fn(det, 1)(op.build_param_list(div, rig.extr_true, rig.poses_true, rig.points)) + det[:, 3:]
+    det = det.copy()
+    det[:, 3:] = uv + rng.normal(0, 0.3, uv.shape)
+    op = chain()
+    start = [div * (1 + 1e-3 * rng.standard_normal(div.shape)), rig.extr_true + 1e-3 * rng.standard_normal(rig.extr_true.shape),
+             rig.poses_true.copy(), rig.points + rng.normal(0, 2e-4, rig.points.shape)]
+    prob = handlers.ChainProblem(op, det, start, unfixed=[None, None, np.zeros_like(rig.poses_true, dtype=bool), None])
+    eng = op._engine_for(prob._flat_detections())
+    lay = eng.normal_layout()
+    assert (lay["n_lead"], lay["n_trail"], lay["tb"]) == (rig.n_cams * 11 + rig.n_imgs * 6, 3 * rig.n_keys, 3)
+    loss_fn, jac_fn = prob.make_loss_fun(), prob.make_loss_jac()
+    ref = least_squares(loss_fn, prob.x0.copy(), jac=jac_fn, x_scale="jac", max_nfev=40)
+    res = lm_solve(prob, prob.x0.copy(), max_iter=40)
+    assert res.n_jtjv == res.nfev - 1 and res.nfev <= 15, (res.n_jtjv, res.nfev)
+    assert res.history == sorted(res.history, reverse=True)
+    assert res.cost <= ref.cost * (1 + 1e-3), (res.cost, ref.cost)
+    assert abs(0.5 * np.sum(loss_fn(res.x) ** 2) - res.cost) <= 1e-9 * res.cost
+    assert res.cost < 0.2 * res.history[0], (res.cost, res.history[0])
+    # the dense form of the same problem walks to the same cost
+    op_d = chain()
+    prob_d = handlers.ChainProblem(op_d, det, start, unfixed=[None, None, np.zeros_like(rig.poses_true, dtype=bool), None])
+    op_d._engine_for(prob_d._flat_detections()).set_option("dense_normal", 1)
+    res_d = lm_solve(prob_d, prob_d.x0.copy(), max_iter=40)
+    assert abs(res_d.cost - res.cost) <= 1e-6 * res.cost, (res_d.cost, res.cost)
+
+
 def test_generated_kernel_for_the_template_chain_against_the_hand_fused_one(capsys):
     """The chain compiler applied to `projection + extrinsic3D + template_points` itself (bypassing the hand-fused fast path):
     same function as ba_eval_kernel on the headline rig (N = 1e6) — values to 1e-12 of the row scale, golden parity on the

@@ -72,6 +72,7 @@ def main():
     ap.add_argument("--phases", action="store_true", help="time the build with parts of the contraction switched off")
     ap.add_argument("--no-cg", action="store_true")
     ap.add_argument("--chain", choices=("flex", "division"), default="flex")
+    ap.add_argument("--two-launch", action="store_true", help="slab preparation as a launch of its own in front of the evaluation")
     ap.add_argument("--dense", action="store_true", help="the dense form of the normal equations also where the chain has the blocked one")
     a = ap.parse_args()
     for number in a.config:
@@ -79,6 +80,8 @@ def main():
         eng = op._engine_for(prob._flat_detections())
         if a.dense:
             eng.set_option("dense_normal", 1)
+        if a.two_launch:
+            eng.set_one_launch(False)
         n_free = prob.x0.shape[0]
         lay = eng.normal_layout()
         print(f"config {number}, {eng.chain}: {rig.n_cams} cameras, {rig.n_imgs} images, N = {rig.n_det}, row length {eng.P}, {eng.n_params} parameters "
