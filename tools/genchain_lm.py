@@ -45,6 +45,15 @@ def problem(number: int, which: str):
                  rig.poses_true + 1e-3 * rng.standard_normal(rig.poses_true.shape), flex.copy()]
         start[3][:, 4] = 0.0
         unfixed = [None, fix_ext, None, free_flex]
+    elif which == "divfree":   # the lens model AND free points (key-linked trailing entities); the poses hold the frame
+        def chain():
+            return ub["division_projection"]() + fb.extrinsic3D() + fb.rigidTform3d() + fb.free_point()
+
+        div = np.concatenate([rig.intr_true[:, :4], rng.normal(0, 0.05, (rig.n_cams, 1))], axis=1)
+        truth = [div, rig.extr_true, rig.poses_true, rig.points]
+        start = [div * (1 + 1e-3 * rng.standard_normal(div.shape)), rig.extr_true + 1e-3 * rng.standard_normal(rig.extr_true.shape),
+                 rig.poses_true.copy(), rig.points + rng.normal(0, 2e-4, rig.points.shape)]
+        unfixed = [None, None, np.zeros_like(rig.poses_true, dtype=bool), None]
     else:
         def chain():
             return ub["division_projection"]() + fb.extrinsic3D() + fb.template_points()
@@ -54,13 +63,15 @@ def problem(number: int, which: str):
         start = [div * (1 + 1e-3 * rng.standard_normal(div.shape)), rig.extr_true + 1e-3 * rng.standard_normal(rig.extr_true.shape),
                  rig.poses_true + 1e-3 * rng.standard_normal(rig.poses_true.shape)]
         unfixed = [None, fix_ext, None]
-    start[1][0] = rig.extr_true[0]
+    if which != "divfree":
+        start[1][0] = rig.extr_true[0]
     op = chain()
-    uv = op.make_full_loss_fn(det, 1)(op.build_param_list(*truth), rig.points) + det[:, 3:]
+    tm = (rig.points,) if op.templated else ()
+    uv = op.make_full_loss_fn(det, 1)(op.build_param_list(*truth), *tm) + det[:, 3:]
     det[:, 3:] = uv + rng.normal(0, 0.3, uv.shape)
     op.engine.close()
     op = chain()
-    prob = handlers.ChainProblem(op, det, start, template=rig.points, unfixed=unfixed)
+    prob = handlers.ChainProblem(op, det, start, template=rig.points if op.templated else None, unfixed=unfixed)
     return rig, op, prob
 
 
@@ -71,7 +82,7 @@ def main():
     ap.add_argument("--max-iter", type=int, default=40)
     ap.add_argument("--phases", action="store_true", help="time the build with parts of the contraction switched off")
     ap.add_argument("--no-cg", action="store_true")
-    ap.add_argument("--chain", choices=("flex", "division"), default="flex")
+    ap.add_argument("--chain", choices=("flex", "division", "divfree"), default="flex")
     ap.add_argument("--two-launch", action="store_true", help="slab preparation as a launch of its own in front of the evaluation")
     ap.add_argument("--dense", action="store_true", help="the dense form of the normal equations also where the chain has the blocked one")
     a = ap.parse_args()
