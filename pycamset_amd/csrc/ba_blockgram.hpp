@@ -17,9 +17,13 @@
 //   * operands straight from global memory in v_mfma_f64_16x16x4's layout: lane l holds element [row 4 s + l / 16][column 16 c + l % 16]
 //     of the segment's rows — four row pieces of 128 bytes per load instruction, no LDS staging; the residual rides along as column P
 //     (G[p][P] = g_p, G[P][P] = the cost), so one contraction yields all three outputs;
-//   * columns linked to the KEY (free points, per-point user parameters) differ from detection to detection: their products are
-//     taken per detection by the lanes (one detection each) and added one by one — (key columns) x P atomics per detection, only for
-//     chains that have such columns;
+//   * columns linked to the KEY (free points, per-point user parameters) differ from detection to detection in that order.  A product
+//     of two columns is a sum over detections that share the entities of BOTH columns, so every pair of columns has a table order in
+//     which its destination is constant over runs: pairs of camera / image columns in the table's own order (runs of one (camera,
+//     image) pair: pass 0), pairs that involve a key column and otherwise the camera in (camera, key) order (pass 1), image x key pairs
+//     in (image, key) order (pass 2).  The host sorts the detections for passes 1 and 2 (an index per detection; rows are gathered
+//     through it) and cuts each order into segments; the kernel is the same in every pass and flushes only the pairs that belong to
+//     it.  (First version: key columns per detection with atomics — 60 per detection at P = 20: 2.4 ms of a 2.6 ms build on rig-32.)
 //   * the segments of a workgroup (16 waves for P < 32) combine in LDS before they go out: sums meet in f64 atomics on A / g / cost
 //     (zeroed by the caller), (P + 1)^2 / 2 per group of segments with the same camera (and image, for entries of image-linked columns).
 // On MI355X an FP64 MFMA issues at the rate of the FP64 vector pipe (2 048 flop in 64 cycles); what the matrix cores save here is the
@@ -36,12 +40,16 @@ namespace pcs {
 
 constexpr int GRAM_SEG = 128;        // detections per segment at most (256 rows = 64 contraction steps)
 constexpr int GRAM_MAX_COLS = 64;    // P + 1 <= 64: four column blocks of 16
+constexpr int GRAM_SEG_WORDS = 5;
 
 struct BlockGramArgs {
     DetTable tab;
     const double *J;        // 2N x P dense block rows, u row then v row
     const double *resid;    // N x 2
-    const int32_t *seg;     // n_seg x 4: first detection, count, camera, image
+    const int32_t *seg;     // n_seg x GRAM_SEG_WORDS: first position (in `order`, or the detection itself), count, camera, image, key — -1 where the
+                            // entity varies inside the segment (the pass does not hold it)
+    const int32_t *order;   // passes 1 and 2: position -> detection; NULL = the table's own order
+    int32_t pass;           // 0 (camera, image), 1 (camera, key), 2 (image, key): which pairs of columns this launch flushes
     double *A, *g, *cost;   // n_lead x n_lead (upper triangle written), n_params, 1 — zeroed by the caller
     // Blocked form (a chain whose LAST parameter group is one rigid transform per image or one point per key — ba_schur.hpp's trailing
     // entities): products of two leading columns go to A, leading x trailing to B (n_lead x n_trail, row-major), two trailing columns
@@ -85,6 +93,12 @@ __device__ __forceinline__ void gram_add(const BlockGramArgs &a, const int64_t g
 // ONE wave per group of equal (camera) / (camera, image) adds the group's sum to global memory — flushing every segment on its own made
 // the atomics the larger part of the kernel (1e6 detections, 32 cameras: 125 us of 230; each camera's 15 x 15 block is hit by all of its
 // ~400 segments).
+// which pass sums the product of two columns with links lp and lc (0 camera, 1 image, 2 key; -1: the residual column, no entity)
+__device__ __forceinline__ int gram_pass_of(const int lp, const int lc) {
+    const bool key = lp == 2 || lc == 2, img = lp == 1 || lc == 1;
+    return !key ? 0 : !img ? 1 : 2;
+}
+
 template <int NB>
 __global__ __launch_bounds__(64 * gram_waves(NB)) void blockrow_gram_kernel(const BlockGramArgs a) {
     if (a.stop && *a.stop) return;
@@ -92,7 +106,7 @@ __global__ __launch_bounds__(64 * gram_waves(NB)) void blockrow_gram_kernel(cons
     // per local column: base (global column of entity 0), multiplier (parameters per entity), link
     __shared__ int64_t col_base[GRAM_MAX_COLS];
     __shared__ int32_t col_mul[GRAM_MAX_COLS], col_link[GRAM_MAX_COLS];
-    __shared__ int32_t seg_cam[WAVES], seg_img[WAVES];
+    __shared__ int32_t seg_id[3][WAVES];   // camera, image, key of the waves' segments (-1: varies / no segment)
     extern __shared__ double gram_lds[];   // WAVES x NE
     if (threadIdx.x < GRAM_MAX_COLS) {
         const int p = threadIdx.x;
@@ -105,10 +119,11 @@ __global__ __launch_bounds__(64 * gram_waves(NB)) void blockrow_gram_kernel(cons
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int s_id = blockIdx.x * WAVES + wave;
     const bool have = s_id < a.n_seg;
-    const int first = have ? a.seg[4 * s_id] : 0, count = have ? a.seg[4 * s_id + 1] : 0, cam = have ? a.seg[4 * s_id + 2] : -1, img = have ? a.seg[4 * s_id + 3] : -1;
-    if (lane == 0) { seg_cam[wave] = cam; seg_img[wave] = img; }
+    const int32_t *sg = a.seg + (int64_t)GRAM_SEG_WORDS * (have ? s_id : 0);
+    const int first = have ? sg[0] : 0, count = have ? sg[1] : 0;
+    if (lane < 3) seg_id[lane][wave] = have ? sg[2 + lane] : -1;
     const int P = a.P;
-    const int64_t row0 = 2 * (int64_t)first, row_end = row0 + 2 * (int64_t)count;
+    const int n_rows = 2 * count;
     const int lr = lane >> 4, lc = lane & 15;
 
     // ---- the contraction: G = [J r]' [J r] over the segment's rows, upper column blocks -------------------------------------------
@@ -117,8 +132,15 @@ __global__ __launch_bounds__(64 * gram_waves(NB)) void blockrow_gram_kernel(cons
     for (int i = 0; i < NB; ++i)
 #pragma unroll
         for (int j = 0; j < NB; ++j) acc[i][j] = gram_d4{0.0, 0.0, 0.0, 0.0};
-    auto fetch = [&](const int64_t row, double (&v)[NB]) {
-        const bool in = row < row_end;
+    // row q of the segment = component q & 1 of its detection q >> 1; in the table's order the detections are consecutive, in a sorted
+    // order they are looked up (four per load instruction: the lanes of a quarter wave share one)
+    auto fetch = [&](const int q, double (&v)[NB]) {
+        const bool in = q < n_rows;
+        int64_t row = 0;
+        if (in) {
+            const int64_t pos = (int64_t)first + (q >> 1);
+            row = 2 * (a.order ? (int64_t)a.order[pos] : pos) + (q & 1);
+        }
 #pragma unroll
         for (int cb = 0; cb < NB; ++cb) {
             const int col = 16 * cb + lc;
@@ -130,10 +152,10 @@ __global__ __launch_bounds__(64 * gram_waves(NB)) void blockrow_gram_kernel(cons
             v[cb] = x;
         }
     };
-    for (int64_t r = row0 + lr; r - lr < row_end; r += 4 * UNROLL) {
+    for (int q0 = 0; q0 < n_rows; q0 += 4 * UNROLL) {
         double v[UNROLL][NB];
 #pragma unroll
-        for (int t = 0; t < UNROLL; ++t) fetch(r + 4 * t, v[t]);
+        for (int t = 0; t < UNROLL; ++t) fetch(q0 + 4 * t + lr, v[t]);
         if (a.debug & 2) {
 #pragma unroll
             for (int t = 0; t < UNROLL; ++t)
@@ -174,70 +196,37 @@ __global__ __launch_bounds__(64 * gram_waves(NB)) void blockrow_gram_kernel(cons
     __syncthreads();
 
     // ---- flush: one (wave, entry) pair per thread and pass; the first wave of a group of equal keys adds the group's sum ---------------
+    // (a group = consecutive waves whose segments agree in the entities of BOTH columns of the entry; the sorted orders make equal ones
+    // consecutive)
     for (int idx = threadIdx.x; idx < WAVES * NE; idx += 64 * WAVES) {
         const int w = idx / NE, e = idx - w * NE;
-        const int wc = seg_cam[w];
-        if (wc < 0) continue;
+        if (seg_id[0][w] < 0 && seg_id[1][w] < 0 && seg_id[2][w] < 0) continue;   // no segment
         const int blk = e >> 8, q = (e >> 6) & 3, ln = e & 63;
         int bi = 0, bj = blk;                      // block index -> (bi, bj), bi <= bj, row-major over the upper triangle
         while (bj >= NB - bi) { bj -= NB - bi; ++bi; }
         bj += bi;
         const int p = 16 * bi + (ln >> 4) + 4 * q, c = 16 * bj + (ln & 15);
         if (p > c || c > P) continue;
-        const bool resid_pair = p == P;            // (residual, residual): the cost — one group per workgroup
-        if (!resid_pair && (col_link[p] == 2 || (c < P && col_link[c] == 2))) continue;    // key-linked columns: per detection, below
-        const bool by_img = !resid_pair && (col_link[p] == 1 || (c < P && col_link[c] == 1));
-        const int wi = seg_img[w];
-        // leader of its group?  (groups are runs of consecutive waves with the same key; the table order makes equal keys consecutive)
-        if (w > 0) {
-            const bool same = resid_pair ? seg_cam[w - 1] >= 0 : (seg_cam[w - 1] == wc && (!by_img || seg_img[w - 1] == wi));
-            if (same) continue;
-        }
+        const int lp = p < P ? col_link[p] : -1, lcn = c < P ? col_link[c] : -1;
+        if (gram_pass_of(lp, lcn) != a.pass) continue;
+        const int ip = lp < 0 ? 0 : seg_id[lp][w], ic = lcn < 0 ? 0 : seg_id[lcn][w];   // the entities of the two columns in wave w's segment
+        auto same = [&](const int w2) {
+            if (seg_id[0][w2] < 0 && seg_id[1][w2] < 0 && seg_id[2][w2] < 0) return false;
+            return (lp < 0 || seg_id[lp][w2] == ip) && (lcn < 0 || seg_id[lcn][w2] == ic);
+        };
+        if (w > 0 && same(w - 1)) continue;        // not the leader of its group
         double sum = gram_lds[idx];
-        for (int w2 = w + 1; w2 < WAVES; ++w2) {
-            const bool same = resid_pair ? seg_cam[w2] >= 0 : (seg_cam[w2] == wc && (!by_img || seg_img[w2] == wi));
-            if (!same) break;
-            sum += gram_lds[w2 * NE + e];
-        }
-        if (resid_pair) {
+        for (int w2 = w + 1; w2 < WAVES && same(w2); ++w2) sum += gram_lds[w2 * NE + e];
+        if (p == P) {                              // (residual, residual): the cost
             unsafeAtomicAdd(a.cost, sum);
             continue;
         }
-        const int64_t gp = col_base[p] + (int64_t)col_mul[p] * (col_link[p] == 0 ? wc : wi);
+        const int64_t gp = col_base[p] + (int64_t)col_mul[p] * ip;
         if (c == P) {
             unsafeAtomicAdd(a.g + gp, sum);
             continue;
         }
-        const int64_t gc = col_base[c] + (int64_t)col_mul[c] * (col_link[c] == 0 ? wc : wi);
-        gram_add(a, gp, gc, p == c, sum);
-    }
-
-    // ---- key-linked columns: one detection per lane ------------------------------------------------------------------------------
-    bool any_key = false;
-    for (int p = 0; p < P; ++p) any_key = any_key || col_link[p] == 2;
-    if (!any_key || !have) return;
-    auto gcol = [&](const int p, const int key) -> int64_t {
-        const int link = col_link[p];
-        return col_base[p] + (int64_t)col_mul[p] * (link == 0 ? cam : link == 1 ? img : key);
-    };
-    for (int d0 = 0; d0 < count; d0 += 64) {
-        const int d = d0 + lane;
-        if (d >= count) break;
-        const int64_t i = (int64_t)first + d;
-        int c_, im_, key;
-        load_indices(a.tab, i, c_, im_, key);
-        const double *ju = a.J + 2 * i * (int64_t)P, *jv = ju + P;
-        const double ru = a.resid[2 * i], rv = a.resid[2 * i + 1];
-        for (int p = 0; p < P; ++p) {
-            if (col_link[p] != 2) continue;
-            const double pu = ju[p], pv = jv[p];
-            const int64_t gp = gcol(p, key);
-            unsafeAtomicAdd(a.g + gp, pu * ru + pv * rv);
-            for (int c = 0; c < P; ++c) {
-                if (col_link[c] == 2 && c < p) continue;   // a pair of key-linked columns is taken once
-                gram_add(a, gp, gcol(c, key), p == c, pu * ju[c] + pv * jv[c]);
-            }
-        }
+        gram_add(a, gp, col_base[c] + (int64_t)col_mul[c] * ic, p == c, sum);
     }
 }
 
