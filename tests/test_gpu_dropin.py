@@ -875,7 +875,8 @@ def test_generated_chain_dense_normal_equations_match_the_reference_jacobian(gol
     """Round 5 (csrc/ba_blockgram.hpp): [J^T J | J^T r | sum r^2] of a generated chain, contracted on the device from its block rows,
     against the SAME products of the reference generator's own CSR Jacobian and residual (the fixtures of make_golden.py) — the four
     shipped compositions and the three chains with user blocks; three of the seven have columns linked to the KEY (free points:
-    a different global column per detection), which take the per-detection path of the kernel."""
+    a different global column per detection), whose products are summed in (camera, key) and (image, key) order (passes 1 and 2 of
+    the kernel); six of the seven end in a group that makes trailing entities (blocked form), board_flex stays dense."""
     import torch
     from scipy.sparse import csr_array
     from pycamset_amd import function_blocks as fb
