@@ -994,6 +994,54 @@ def test_templated_user_source_through_the_device_lm(golden_dir):
         (fb.projection() + ub["board_flex"]() + fb.free_point()).chain
 
 
+@pytest.mark.parametrize("n_rigid", [2, 5])
+def test_normal_equations_of_a_long_generated_chain_with_three_and_four_column_blocks(n_rigid):
+    """Block rows of 34 / 52 columns (+ the residual column: three / four column blocks of 16 — the NB = 3 and NB = 4 instances of
+    blockrow_gram_kernel, four waves per workgroup): `projection + cam_scale + extrinsic3D + rigidTform3d x n + template_points` — a
+    user block, a SHARED pose group (n local column sets for ONE parameter group: every pair of them meets on the group's diagonal
+    block twice) and one more per-image transform — against the products of the chain's own CSR closure (scipy sums the duplicate
+    column entries of a row)."""
+    import torch
+    from scipy.sparse import csr_array
+    from pycamset_amd import function_blocks as fb
+    ub = H.user_blocks(fb)
+    rig = synthetic.make_rig("long-chain", 3, 6, synthetic.charuco_points(5, 8.0), seed=64, visibility=0.9)
+    det = rig.detections
+    rng = np.random.default_rng(8)
+    op = fb.optimisation_function([fb.projection(), ub["cam_scale"](), fb.extrinsic3D()] + [fb.rigidTform3d() for _ in range(n_rigid)] + [fb.template_points()])
+    assert op.chain == "generated"
+    small = np.concatenate([rng.normal(0, 0.02, (rig.n_imgs, 3)), rng.normal(0, 0.002, (rig.n_imgs, 3))], axis=1) / n_rigid
+    ps = op.build_param_list(rig.intr, rng.uniform(0.9, 1.1, (rig.n_cams, 1)), rig.extr, small, rig.poses)
+    r = op.make_full_loss_fn(det, 1)(ps, rig.points)
+    data, idx, ptr = op.make_jacobean(det, 1)(ps, rig.points)
+    eng = op._engine_for(det)
+    assert eng.P == 9 + 1 + 6 + 6 * n_rigid + 6 and eng.dense_lm_supported()
+    n = eng.n_params
+    Jc = csr_array((np.asarray(data).ravel(), idx, ptr), shape=(2 * det.shape[0], n))
+    want, gwant = (Jc.T @ Jc).toarray(), Jc.T @ np.asarray(r).ravel()
+    for dense in (0, 1):
+        eng.set_option("dense_normal", dense)
+        lay = eng.normal_layout()
+        nl, nt, tb = lay["n_lead"], lay["n_trail"], lay["tb"]
+        assert (nt, tb) == ((6 * rig.n_imgs, 6) if not dense else (0, 3))
+        ps_dev = torch.from_numpy(np.ascontiguousarray(ps[:n])).cuda()
+        packed = torch.empty(lay["packed_len"], dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        eng.normal_blocks_device(ps_dev.data_ptr(), packed.data_ptr())
+        eng.synchronize()
+        out = packed.cpu().numpy()
+        scale = np.max(np.abs(want))
+        assert np.max(np.abs(np.triu(out[: nl * nl].reshape(nl, nl)) - np.triu(want[:nl, :nl]))) <= 1e-11 * scale
+        if nt:
+            assert np.max(np.abs(out[nl * nl: nl * nl + nl * nt].reshape(nl, nt) - want[:nl, nl:])) <= 1e-11 * scale
+            C = out[nl * nl + nl * nt: nl * nl + nl * nt + nt * tb].reshape(-1, tb, tb)
+            for e in range(nt // tb):
+                assert np.max(np.abs(np.triu(C[e]) - np.triu(want[nl + e * tb: nl + (e + 1) * tb, nl + e * tb: nl + (e + 1) * tb]))) <= 1e-11 * scale
+        assert np.max(np.abs(out[-(n + 1): -1] - gwant)) <= 1e-11 * np.max(np.abs(gwant))
+        assert abs(out[-1] - np.sum(np.asarray(r) ** 2)) <= 1e-12 * np.sum(np.asarray(r) ** 2)
+    eng.set_option("dense_normal", 0)
+
+
 def test_user_lens_model_with_free_points_through_the_blocked_device_lm():
     """A generated chain whose LAST group is one point per key: `division_projection + extrinsic3D + rigidTform3d + free_point` — a
     user-written lens model AND free points — takes the blocked normal equations with the points as trailing entities (tb = 3: the
