@@ -388,6 +388,15 @@ int pcs_genchain_lm_trial_build(pcs_genchain *h, const pcs_lm_buffers *b, void *
 int pcs_genchain_lm_trial_finish(pcs_genchain *h, const pcs_lm_buffers *b, void *stream);
 int pcs_genchain_lm_trial(pcs_genchain *h, const pcs_lm_buffers *b, void *stream);
 int pcs_genchain_set_option(pcs_genchain *h, const char *key, int64_t value);
+/* The pieces of a trial as calls of their own — pcs_schur_prepare / pcs_schur_finish / pcs_lm_decide for the handle's layout — for a
+ * loop the host steers (a sharded solve with a host-staged collective); pcs_schur_syrk, pcs_dense_spd_solve and pcs_schur_vtx take
+ * sizes, not handles, and serve both kinds of handle. */
+int pcs_genchain_schur_prepare(pcs_genchain *h, double *d_packed, const uint8_t *d_fixed, const double *d_lambda, double *d_linvt, double *d_u,
+                               double *d_V, double *d_S, double *d_rhs, double *d_dvec, double *d_gm, int32_t *d_status, void *stream);
+int pcs_genchain_schur_finish(pcs_genchain *h, const double *d_linvt, const double *d_u, const double *d_w, const double *d_xlead, const uint8_t *d_fixed,
+                              double *d_delta, const double *d_ps_in, double *d_ps_out, void *stream);
+int pcs_genchain_lm_decide(pcs_genchain *h, const double *d_cost_old, const double *d_cost_new, const double *d_dvec, const double *d_gm, const double *d_delta,
+                           const double *d_ps, const uint8_t *d_fixed, int32_t *d_status, double *d_lambda, double *d_stats, void *stream);
 int pcs_genchain_device_buffers(pcs_genchain *h, void **d_resid, void **d_jac);
 int pcs_genchain_synchronize(pcs_genchain *h, void *stream);
 int pcs_genchain_last_kernel_ms(pcs_genchain *h, float *slab_prep_ms, float *eval_ms);

@@ -97,6 +97,9 @@ SYMBOLS = {
     "pcs_genchain_lm_trial_build": (c_int, [_P, _P, _P]),
     "pcs_genchain_lm_trial_finish": (c_int, [_P, _P, _P]),
     "pcs_genchain_set_option": (c_int, [_P, c_char_p, c_int64]),
+    "pcs_genchain_schur_prepare": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "pcs_genchain_schur_finish": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "pcs_genchain_lm_decide": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pcs_genchain_device_buffers": (c_int, [_P, POINTER(_P), POINTER(_P)]),
     "pcs_genchain_synchronize": (c_int, [_P, _P]),
     "pcs_genchain_last_kernel_ms": (c_int, [_P, POINTER(c_float), POINTER(c_float)]),

@@ -593,6 +593,23 @@ class ChainEngine:
 
         check(lib().pcs_genchain_lm_trial_finish(self._h, byref(buffers), _stream_arg(stream)))
 
+    def schur_prepare(self, d_packed, d_fixed, d_lambda, d_linvt, d_u, d_V, d_S, d_rhs, d_dvec, d_gm, d_status, stream=None):
+        from .engine import _stream_arg
+
+        check(lib().pcs_genchain_schur_prepare(self._h, *(c_void_p(p) for p in (d_packed, d_fixed, d_lambda, d_linvt, d_u, d_V, d_S, d_rhs, d_dvec, d_gm, d_status)),
+                                               _stream_arg(stream)))
+
+    def schur_finish(self, d_linvt, d_u, d_w, d_xlead, d_fixed, d_delta, d_ps_in=0, d_ps_out=0, stream=None):
+        from .engine import _stream_arg
+
+        check(lib().pcs_genchain_schur_finish(self._h, *(c_void_p(p) for p in (d_linvt, d_u, d_w, d_xlead, d_fixed, d_delta, d_ps_in, d_ps_out)), _stream_arg(stream)))
+
+    def lm_decide(self, d_cost_old, d_cost_new, d_dvec, d_gm, d_delta, d_ps, d_fixed, d_status, d_lambda, d_stats, stream=None):
+        from .engine import _stream_arg
+
+        check(lib().pcs_genchain_lm_decide(self._h, *(c_void_p(p) for p in (d_cost_old, d_cost_new, d_dvec, d_gm, d_delta, d_ps, d_fixed, d_status, d_lambda, d_stats)),
+                                           _stream_arg(stream)))
+
     def set_option(self, key: str, value: int):
         """Engine's option interface as far as the LM driver uses it: "spd_timeout_us" and "timing" reach the handle; "timing_every"
         maps to "timing"; "lazy_done_event" has nothing to switch here; "deterministic" cannot be switched ON (the contraction of a

@@ -323,7 +323,8 @@ def _lm_solve_blocked(ne: BlockedNormalEquations, ps0: np.ndarray, *, max_iter, 
         # no rank can take another branch than its peers — unless the engine cannot (the (image, key) pass of the self chain with more
         # than 64 cameras keeps its atomics, csrc/ba_reduce.hpp): then the ranks adopt one consensus step per trial, host-steered.
         sharded = ne.reduce_fn is not None
-        det_ok = not (eng.chain == "self" and eng.n_cams > DET_SELF_CAM_LIMIT)
+        # (generated chains: the contraction of their block rows sums with atomics, csrc/ba_blockgram.hpp — no deterministic mode either)
+        det_ok = not (eng.chain == "self" and eng.n_cams > DET_SELF_CAM_LIMIT) and not getattr(eng, "lm_fixed_trial_buffer", False)
         device_steered = not sharded or (getattr(ne.reduce_fn, "on_device", False) and det_ok)
         loop = _lm_loop_device if device_steered else _lm_loop_blocked
         saved_det = eng.option("deterministic", 0)
@@ -690,8 +691,7 @@ def lm_solve(handler, x0, *, max_iter: int = 50, ftol: float = 1e-8, xtol: float
         eng = op_fun._engine_for(dd)
         op_fun._bind_template(eng, handler._template_arg())
         if linear_solver == "auto":   # blocked J^T J while its regions fit comfortably; beyond that matrix-free CG
-            # (a generated chain's dense form has no order-deterministic sums: sharded over ranks it keeps the CG on all-reduced products)
-            linear_solver = "cholesky" if blocked_fits(eng) and (reduce_fn is None or not getattr(eng, "lm_fixed_trial_buffer", False)) else "pcg"
+            linear_solver = "cholesky" if blocked_fits(eng) else "pcg"
         if linear_solver == "cholesky":
             # the solver's device workspace (two packed states, V, S, a stream) lives with the engine: a second solve on the same
             # table and mask — the usual case: a calibration re-run with other start values or tolerances — allocates nothing

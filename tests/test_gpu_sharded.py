@@ -188,6 +188,37 @@ def _worker(rank, world, port, out_dir, backend="gloo"):
         # self-calibration has a flat valley (gauge + point/pose trade-offs) and the J^T products sum with
         # f64 atomics in arrival order, so after 15 iterations the two runs agree in cost, not bit for bit
         assert abs(rs.cost - r1.cost) <= 1e-3 * r1.cost and rs.cost < 0.01 * rs.history[0], (rs.cost, r1.cost, rs.history[0])
+        # (5) a GENERATED chain sharded (round 5): `projection + extrinsic3D + rigidTform3d + template_points` — two per-image transforms,
+        # the last one the trailing entities of the blocked normal equations (csrc/ba_blockgram.hpp).  Every rank contracts the block rows
+        # of ITS shard, the packed [A | B | C | g | cost] is all-reduced, the exact step follows on every rank; the contraction sums with
+        # atomics (no deterministic mode), so the loop is host-steered and the ranks adopt one consensus step per trial.
+        from pycamset_amd import function_blocks as fb
+
+        def gen_problem(rows):
+            op_g = fb.optimisation_function([fb.projection(), fb.extrinsic3D(), fb.rigidTform3d(), fb.template_points()], counts=counts, device=device)
+            assert op_g.chain == "generated"
+            rng_g = np.random.default_rng(5)
+            second = np.concatenate([rng_g.normal(0, 0.02, (rig.n_imgs, 3)), rng_g.normal(0, 0.002, (rig.n_imgs, 3))], axis=1)
+            fix_ext = np.ones((rig.n_cams, 6), dtype=bool)
+            fix_ext[0] = False
+            start = [rig.intr, rig.extr.copy(), second, rig.poses]
+            start[1][0] = rig.extr_true[0]
+            # the middle transform is held (it is redundant with the pose behind it): the problem is the template chain's, through the generator
+            return handlers.ChainProblem(op_g, rows, start, template=rig.points, unfixed=[None, fix_ext, np.zeros((rig.n_imgs, 6), dtype=bool), None])
+
+        g_shard, g_full = gen_problem(mine), gen_problem(det)
+        calls = []
+        original = ds.BlockedNormalEquations._consensus_step
+        ds.BlockedNormalEquations._consensus_step = lambda self, *a: calls.append(1) or original(self, *a)
+        try:
+            rg = lm_solve(g_shard, g_shard.x0.copy(), max_iter=20, reduce_fn=mat_reduce)
+        finally:
+            ds.BlockedNormalEquations._consensus_step = original
+        rg1 = lm_solve(g_full, g_full.x0.copy(), max_iter=20)
+        assert calls and rg.n_jtjv == rg.nfev - 1, (len(calls), rg.n_jtjv, rg.nfev)        # exact steps, consensus per trial
+        assert abs(rg.cost - rg1.cost) <= 1e-6 * rg1.cost and rg.cost < 0.01 * rg.history[0], (rg.cost, rg1.cost, rg.history[0])
+        dist.all_gather_object(gathered, (rg.x, rg.nit, rg.nfev, rg.status))
+        assert all(np.array_equal(gathered[0][0], g[0]) and gathered[0][1:] == g[1:] for g in gathered)
         Path(out_dir, f"ok{rank}").write_text("ok")
     finally:
         dist.destroy_process_group()
