@@ -134,28 +134,42 @@ __global__ __launch_bounds__(64 * gram_waves(NB)) void blockrow_gram_kernel(cons
         for (int j = 0; j < NB; ++j) acc[i][j] = gram_d4{0.0, 0.0, 0.0, 0.0};
     // row q of the segment = component q & 1 of its detection q >> 1; in the table's order the detections are consecutive, in a sorted
     // order they are looked up (four per load instruction: the lanes of a quarter wave share one)
-    auto fetch = [&](const int q, double (&v)[NB]) {
-        const bool in = q < n_rows;
-        int64_t row = 0;
-        if (in) {
-            const int64_t pos = (int64_t)first + (q >> 1);
-            row = 2 * (a.order ? (int64_t)a.order[pos] : pos) + (q & 1);
-        }
-#pragma unroll
-        for (int cb = 0; cb < NB; ++cb) {
-            const int col = 16 * cb + lc;
-            double x = 0.0;
-            if (in) {
-                if (col < P) x = a.J[row * P + col];
-                else if (col == P) x = a.resid[row];
-            }
-            v[cb] = x;
-        }
-    };
+    // The rows of UNROLL steps first (passes 1 and 2 look the detections up: ONE uniform branch around all of those loads — with the
+    // look-up inside every step's fetch the operand loads sat in basic blocks of their own and no longer overlapped: + 76 us on rig-32),
+    // then all the operand loads together.
     for (int q0 = 0; q0 < n_rows; q0 += 4 * UNROLL) {
+        int64_t rows[UNROLL];
+        bool ins[UNROLL];
+#pragma unroll
+        for (int t = 0; t < UNROLL; ++t) {
+            const int q = q0 + 4 * t + lr;
+            ins[t] = q < n_rows;
+            rows[t] = 2 * ((int64_t)first + (q >> 1)) + (q & 1);
+        }
+        if (a.order) {
+#pragma unroll
+            for (int t = 0; t < UNROLL; ++t) {
+                const int q = q0 + 4 * t + lr;
+                rows[t] = 2 * (int64_t)a.order[(int64_t)first + (ins[t] ? (q >> 1) : 0)] + (q & 1);   // unconditional (see below): lanes past the end look up the first
+            }
+        }
+        // every lane loads — from its element, or from a.J[0] where it has none (masked afterwards): loads under per-lane conditions
+        // become branches, and hipcc joins branches with `s_waitcnt vmcnt(0)` — the sixteen loads of a round then went out one by one
+        // (+ 100 us on rig-32)
         double v[UNROLL][NB];
 #pragma unroll
-        for (int t = 0; t < UNROLL; ++t) fetch(q0 + 4 * t + lr, v[t]);
+        for (int t = 0; t < UNROLL; ++t)
+#pragma unroll
+            for (int cb = 0; cb < NB; ++cb) {
+                const int col = 16 * cb + lc;
+                const bool use = ins[t] && col <= P;
+                const double *src = col < P ? a.J + rows[t] * P + col : a.resid + rows[t];
+                v[t][cb] = *(use ? src : a.J);
+            }
+#pragma unroll
+        for (int t = 0; t < UNROLL; ++t)
+#pragma unroll
+            for (int cb = 0; cb < NB; ++cb) v[t][cb] = (ins[t] && 16 * cb + lc <= P) ? v[t][cb] : 0.0;
         if (a.debug & 2) {
 #pragma unroll
             for (int t = 0; t < UNROLL; ++t)

@@ -2217,9 +2217,8 @@ static int enqueue_dense_spd(int device, int64_t n, double *d_S, int64_t ld, con
 }
 
 // The fused forms of the trial's small kernels (csrc/ba_lm_fused.hpp).
-static int enqueue_schur_prep_fused(pcs_engine *h, const pcs_lm_buffers *b, hipStream_t s, const int32_t *d_stop, const int32_t *d_sel, int64_t alt,
+static int enqueue_schur_prep_fused(const BlockLayout &L, const pcs_lm_buffers *b, hipStream_t s, const int32_t *d_stop, const int32_t *d_sel, int64_t alt,
                                     double *d_fill, int64_t fill_n) {
-    const BlockLayout L = block_layout(h);
     SchurArgs a{};
     a.sel = d_sel; a.alt = alt;
     a.fill = reinterpret_cast<uint64_t *>(d_fill); a.fill_n = d_fill ? fill_n : 0;
@@ -2298,7 +2297,7 @@ int pcs_lm_trial_build(pcs_engine *h, const pcs_lm_buffers *b, void *stream) {
     // fused: the two launches in front of the matrix products as one, the three behind the dense solve as one (csrc/ba_lm_fused.hpp); they
     // need every trailing entity to have leading rows to ride on and the normal equations' prologue to be theirs to replace
     const bool fused = h->fused_trial && L.n_lead > 0 && L.n_ent > 0 && h->n > 0;
-    if (fused) rc = enqueue_schur_prep_fused(h, b, s, stop, sel, alt_pk, prefill ? b->spd_work : nullptr, prefill ? cp_work_doubles((L.n_lead + 31) / 32) : 0);
+    if (fused) rc = enqueue_schur_prep_fused(L, b, s, stop, sel, alt_pk, prefill ? b->spd_work : nullptr, prefill ? cp_work_doubles((L.n_lead + 31) / 32) : 0);
     else rc = enqueue_schur_prepare(h, b->packed[0], b->fixed, b->lambda, b->linvt, b->u, b->V, b->S, b->rhs, b->dvec, b->gm, b->status, s, stop,
                                     prefill ? b->spd_work : nullptr, prefill ? cp_work_doubles((L.n_lead + 31) / 32) : 0, sel, alt_pk);
     if (rc) return rc;
