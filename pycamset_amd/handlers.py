@@ -334,13 +334,18 @@ class ChainProblem:
         prob = ChainProblem(op, detections, [intr, extr, poses_a, poses_b], template=points,
                             unfixed=[None, None, None, mask_b])            # one array per block, like build_param_list
         res  = lm_solve(prob, prob.x0)                                     # J stays on the device
+        res, slabs = run_bundle_adjustment(prob, solver="device")          # the reference's caller (optimisation_handling.py:52-117)
         scipy.optimize.least_squares(prob.make_loss_fun(), prob.x0, jac=prob.make_loss_jac(), x_scale='jac')
 
     ``slabs``: one array per argument of ``build_param_list`` (afb:669-681), i.e. per parameter GROUP in string order (blocks that
     share a parameter object share one array); ``unfixed``: a boolean array per slab (None = all free).  The free vector ``x`` is the
     concatenation of the slabs' free entries in string order."""
 
-    def __init__(self, op_fun, detections, slabs, *, template=None, unfixed=None):
+    def __init__(self, op_fun, detections, slabs, *, template=None, unfixed=None, options=None):
+        # what optimisation_handling.run_bundle_adjustment reads from a handler (oh:52-117): the reference's option names and defaults
+        # (template_handler.py:110-118)
+        self.problem_opts = {"verbosity": 0, "max_nfev": 100}
+        self.problem_opts.update(options or {})
         self.op_fun = op_fun
         self.det = np.ascontiguousarray(detections, dtype=np.float64)
         self.slabs = [np.array(s, dtype=np.float64) for s in slabs]
@@ -350,6 +355,13 @@ class ChainProblem:
         self.unfixed = [np.ones(s.shape, dtype=bool) if m is None else np.broadcast_to(np.asarray(m, dtype=bool), s.shape).copy() for s, m in zip(self.slabs, masks)]
         self.template = None if template is None else np.ascontiguousarray(template, dtype=np.float64).reshape(-1, 3)
         self.x0 = np.concatenate([s[m] for s, m in zip(self.slabs, self.unfixed)])
+
+    # -- what run_bundle_adjustment asks of a handler (oh:24-49) ------------------------------------------------------------------------
+    def get_initial_params(self):
+        return self.x0.copy()
+
+    def can_make_jac(self):
+        return True
 
     # -- what lm_solve asks of a handler ---------------------------------------------------------------------------------------------
     def _flat_detections(self):

@@ -1079,6 +1079,12 @@ def test_user_lens_model_with_free_points_through_the_blocked_device_lm():
     assert res.cost <= ref.cost * (1 + 1e-3), (res.cost, ref.cost)
     assert abs(0.5 * np.sum(loss_fn(res.x) ** 2) - res.cost) <= 1e-9 * res.cost
     assert res.cost < 0.2 * res.history[0], (res.cost, res.history[0])
+    # the reference's caller (optimisation_handling.py:52-117) takes the composed problem like a handler: both solvers, the slabs back
+    from pycamset_amd.optimisation_handling import run_bundle_adjustment
+    prob_c = handlers.ChainProblem(chain(), det, start, unfixed=[None, None, np.zeros_like(rig.poses_true, dtype=bool), None], options={"max_nfev": 40})
+    res_c, slabs_c = run_bundle_adjustment(prob_c, solver="device")
+    assert abs(res_c.cost - res.cost) <= 1e-9 * res.cost and len(slabs_c) == 4 and slabs_c[3].shape == rig.points.shape
+    assert np.array_equal(slabs_c[2], rig.poses_true)                                  # the held poses come back untouched
     # the dense form of the same problem walks to the same cost
     op_d = chain()
     prob_d = handlers.ChainProblem(op_d, det, start, unfixed=[None, None, np.zeros_like(rig.poses_true, dtype=bool), None])
