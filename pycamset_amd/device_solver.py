@@ -696,10 +696,13 @@ def lm_solve(handler, x0, *, max_iter: int = 50, ftol: float = 1e-8, xtol: float
             # the solver's device workspace (two packed states, V, S, a stream) lives with the engine: a second solve on the same
             # table and mask — the usual case: a calibration re-run with other start values or tolerances — allocates nothing
             mask = np.asarray(handler._jac_mask(), dtype=bool)
-            key = (hash(mask.tobytes()), id(reduce_fn))
+            # (... and layout: a generated chain changes it with set_option("dense_normal", ...) — buffers sized for the other form would be overrun)
+            key = (hash(mask.tobytes()), id(reduce_fn), tuple(sorted(eng.normal_layout().items())))
             cache = eng.__dict__.setdefault("_blocked_solvers", {})
             ne = cache.get(key)
             if ne is None:
+                for old in cache.values():   # a speculative trial of the solver state being dropped may still be draining: its buffers go back to the allocator after that
+                    old.stream.synchronize()
                 cache.clear()
                 ne = cache[key] = BlockedNormalEquations(eng, mask, reduce_fn=reduce_fn)
             ne.spd_algorithm = "auto"
