@@ -195,7 +195,7 @@ __global__ __launch_bounds__(1024) void schur_finish_kernel(const SchurFinishArg
                 if (TB == 3 && a.copy_points) a.points[3 * e + i] = pv;     // self / free chain: the trailing entities are the points
             }
         }
-        if (TB == 6) {                                                       // template chain: the trailing entities are the poses — their slabs
+        if (TB == 6 && a.pose_slab) {                                        // template chain: the trailing entities are the poses — their slabs (a generated chain: none)
             __syncthreads();
             if (tid < ECB * POSE_STRIDE) {
                 const int el = tid / POSE_STRIDE, slot = tid % POSE_STRIDE;

@@ -2241,26 +2241,32 @@ static int enqueue_schur_prep_fused(const BlockLayout &L, const pcs_lm_buffers *
     return PCS_OK;
 }
 
-static int enqueue_schur_finish_fused(pcs_engine *h, const pcs_lm_buffers *b, hipStream_t s, const int32_t *d_stop, const int32_t *d_sel, int64_t alt_pk,
-                                      int64_t n_packed) {
-    const BlockLayout L = block_layout(h);
+// what schur_finish_kernel prepares for the build that follows it, beyond the step itself: the hand-fused engines' slabs and point copy
+// (a generated chain has its own preparation: all of it empty)
+struct FinishSlabs {
+    double *cam_slab = nullptr, *pose_slab = nullptr, *points = nullptr;
+    int64_t n_cams = 0, n_imgs = 0, n_keys = 0, extr_off = 0, pose_off = 0, point_off = 0;
+    bool has_pose = false, copy_points = false;
+};
+static int enqueue_schur_finish_fused(const BlockLayout &L, int64_t n_params, int n_cu, const FinishSlabs &fs, const pcs_lm_buffers *b, hipStream_t s, const int32_t *d_stop,
+                                      const int32_t *d_sel, int64_t alt_pk, int64_t n_packed) {
     SchurFinishArgs a{};
     a.V = b->V; a.xl = b->xlead; a.n_lead = (int32_t)L.n_lead; a.n_trail = (int32_t)L.n_trail; a.ldv = (int32_t)std::max<int64_t>(1, L.n_trail);
     a.linvt = b->linvt; a.u = b->u; a.fixed = b->fixed; a.delta = b->delta; a.ps_in = b->ps[0]; a.ps_out = b->ps[1];
     a.n_ent = L.n_ent; a.trail_off = L.trail_off;
     a.stop = d_stop; a.sel = d_sel;
     a.vote = (b->mode & PCS_LM_VOTES) ? b->packed[1] + n_packed : nullptr; a.vote_alt = -alt_pk; a.status = b->status;
-    a.cam_slab = (double *)h->d_cam_slab; a.pose_slab = (double *)h->d_pose_slab; a.points = (double *)h->d_points;
-    a.n_cams = (int32_t)h->n_cams; a.n_imgs = (int32_t)h->n_imgs; a.n_keys = (int32_t)h->n_keys;
-    a.has_pose = h->chain != PCS_CHAIN_FREE; a.copy_points = h->chain != PCS_CHAIN_TEMPLATE;
-    a.extr_off = h->extr_off; a.pose_off = h->pose_off; a.point_off = h->point_off;
-    a.Hm = b->packed[1]; a.n_h = L.a_len() + L.b_len() + L.c_len(); a.g = a.Hm + a.n_h; a.n_g = h->n_params; a.cost = a.g + h->n_params; a.alt_out = -alt_pk;
+    a.cam_slab = fs.cam_slab; a.pose_slab = fs.pose_slab; a.points = fs.points;
+    a.n_cams = (int32_t)fs.n_cams; a.n_imgs = (int32_t)fs.n_imgs; a.n_keys = (int32_t)fs.n_keys;
+    a.has_pose = fs.has_pose; a.copy_points = fs.copy_points;
+    a.extr_off = fs.extr_off; a.pose_off = fs.pose_off; a.point_off = fs.point_off;
+    a.Hm = b->packed[1]; a.n_h = L.a_len() + L.b_len() + L.c_len(); a.g = a.Hm + a.n_h; a.n_g = n_params; a.cost = a.g + n_params; a.alt_out = -alt_pk;
     const int ecb = finish_ecb(L.tb);
     const int64_t w_blocks = (L.n_ent + ecb - 1) / ecb;
-    const bool lead_poses = a.has_pose && h->pose_off < L.trail_off;
-    const int64_t lead_threads = std::max<int64_t>(L.n_lead, (int64_t)h->n_cams * CAM_STRIDE + (lead_poses ? (int64_t)h->n_imgs * POSE_STRIDE : 0));
+    const bool lead_poses = a.has_pose && fs.pose_off < L.trail_off;
+    const int64_t lead_threads = std::max<int64_t>(L.n_lead, fs.n_cams * CAM_STRIDE + (lead_poses ? fs.n_imgs * POSE_STRIDE : 0));
     const int64_t lead_blocks = std::max<int64_t>(1, (lead_threads + 1023) / 1024);
-    const int64_t zero_blocks = std::min<int64_t>((a.n_h / 2 + 1023) / 1024 + 1, (int64_t)h->n_cu * 4);
+    const int64_t zero_blocks = std::min<int64_t>((a.n_h / 2 + 1023) / 1024 + 1, (int64_t)n_cu * 4);
     a.w_blocks = (int32_t)w_blocks; a.lead_blocks = (int32_t)lead_blocks;
     const int64_t grid = w_blocks + lead_blocks + zero_blocks;
     if (grid > INT32_MAX) return fail(PCS_ERR_ARG, "pcs_lm_trial_build: the system is too large for one launch of the step's completion");
@@ -2268,6 +2274,15 @@ static int enqueue_schur_finish_fused(pcs_engine *h, const pcs_lm_buffers *b, hi
     else hipLaunchKernelGGL(schur_finish_kernel<3>, dim3((unsigned)grid), dim3(1024), 0, s, a);
     HIPCHK(hipGetLastError());
     return PCS_OK;
+}
+static int enqueue_schur_finish_fused(pcs_engine *h, const pcs_lm_buffers *b, hipStream_t s, const int32_t *d_stop, const int32_t *d_sel, int64_t alt_pk,
+                                      int64_t n_packed) {
+    FinishSlabs fs;
+    fs.cam_slab = (double *)h->d_cam_slab; fs.pose_slab = (double *)h->d_pose_slab; fs.points = (double *)h->d_points;
+    fs.n_cams = h->n_cams; fs.n_imgs = h->n_imgs; fs.n_keys = h->n_keys;
+    fs.has_pose = h->chain != PCS_CHAIN_FREE; fs.copy_points = h->chain != PCS_CHAIN_TEMPLATE;
+    fs.extr_off = h->extr_off; fs.pose_off = h->pose_off; fs.point_off = h->point_off;
+    return enqueue_schur_finish_fused(block_layout(h), h->n_params, h->n_cu, fs, b, s, d_stop, d_sel, alt_pk, n_packed);
 }
 
 // One whole Levenberg-Marquardt trial in two halves (round 5; pcs_lm_trial = both): BUILD = the damped Schur step from the current state at
