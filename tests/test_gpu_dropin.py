@@ -1042,6 +1042,59 @@ def test_normal_equations_of_a_long_generated_chain_with_three_and_four_column_b
     eng.set_option("dense_normal", 0)
 
 
+@pytest.mark.parametrize("blocks", [("projection", "extrinsic3D", "rigidTform3d", "template_points"), ("projection", "rigidTform3d", "extrinsic3D", "free_point")])
+def test_generated_chain_normal_equations_on_ragged_tables(blocks):
+    """The contraction on tables that are NOT the reference's tidy product: 1, 2, 63, 64, 65, 129 and all rows drawn at random from a
+    sparse rig (cameras and images without any row, runs of one row), in random order, with explicit counts (trailing entities nobody
+    observes keep their empty blocks) — against J'J assembled on the host from the chain's own dense block rows."""
+    import torch
+    from pycamset_amd import function_blocks as fb
+    rig = synthetic.make_rig("ragged", 5, 9, synthetic.charuco_points(6, 8.0), seed=65, visibility=0.5)
+    counts = (rig.n_cams + 1, rig.n_imgs + 2, rig.n_keys + 3)                  # one camera, two images, three keys nobody sees
+    rng = np.random.default_rng(9)
+    small = np.concatenate([rng.normal(0, 0.02, (counts[1], 3)), rng.normal(0, 0.002, (counts[1], 3))], axis=1)
+    pad = lambda a, n: np.concatenate([a, np.zeros((n - a.shape[0],) + a.shape[1:])])   # noqa: E731
+    intr, extr, poses, pts = pad(rig.intr, counts[0]), pad(rig.extr, counts[0]), pad(rig.poses, counts[1]), pad(rig.points, counts[2])
+    intr[-1, :4] = [1000.0, 500.0, 1000.0, 500.0]
+    for n_rows in (1, 2, 63, 64, 65, 129, rig.detections.shape[0]):
+        rows = rng.choice(rig.detections.shape[0], size=n_rows, replace=False)
+        det = np.ascontiguousarray(rig.detections[rows])
+        op = fb.optimisation_function([getattr(fb, b)() for b in blocks], counts=counts)
+        assert op.chain == "generated"
+        slabs = [intr, extr, small, poses] if blocks[-1] == "template_points" else [intr, small, extr, pts]
+        ps = op.build_param_list(*slabs)
+        tm = (pts,) if op.templated else ()
+        r = np.asarray(op.make_full_loss_fn(det, 1)(ps, *tm))
+        eng = op._engine_for(det)
+        _, j = eng.eval(ps[: eng.n_params], want_resid=False, want_jac=True)
+        cols = eng.block_param_inds()
+        n = eng.n_params
+        Jd = np.zeros((2 * n_rows, n))
+        for k in range(cols.shape[1]):                                             # duplicates (none here) would add up
+            np.add.at(Jd, (2 * np.arange(n_rows), cols[:, k]), j[0::2, k])
+            np.add.at(Jd, (2 * np.arange(n_rows) + 1, cols[:, k]), j[1::2, k])
+        want, gwant = Jd.T @ Jd, Jd.T @ r.ravel()
+        lay = eng.normal_layout()
+        nl, nt, tb = lay["n_lead"], lay["n_trail"], lay["tb"]
+        assert nt == (6 * counts[1] if blocks[-1] == "template_points" else 3 * counts[2])
+        ps_dev = torch.from_numpy(np.ascontiguousarray(ps[:n])).cuda()
+        packed = torch.full((lay["packed_len"],), np.nan, dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        eng.normal_blocks_device(ps_dev.data_ptr(), packed.data_ptr())
+        eng.synchronize()
+        out = packed.cpu().numpy()
+        scale = max(np.max(np.abs(want)), 1e-300)
+        assert np.all(np.isfinite(out))
+        assert np.max(np.abs(np.triu(out[: nl * nl].reshape(nl, nl)) - np.triu(want[:nl, :nl]))) <= 1e-11 * scale, n_rows
+        assert np.max(np.abs(out[nl * nl: nl * nl + nl * nt].reshape(nl, nt) - want[:nl, nl:])) <= 1e-11 * scale, n_rows
+        C = out[nl * nl + nl * nt: nl * nl + nl * nt + nt * tb].reshape(-1, tb, tb)
+        for e in range(nt // tb):
+            assert np.max(np.abs(np.triu(C[e]) - np.triu(want[nl + e * tb: nl + (e + 1) * tb, nl + e * tb: nl + (e + 1) * tb]))) <= 1e-11 * scale, (n_rows, e)
+        assert np.max(np.abs(out[-(n + 1): -1] - gwant)) <= 1e-11 * max(np.max(np.abs(gwant)), 1e-300), n_rows
+        assert abs(out[-1] - np.sum(r ** 2)) <= 1e-12 * np.sum(r ** 2), n_rows
+        op.engine.close()
+
+
 def test_user_lens_model_with_free_points_through_the_blocked_device_lm():
     """A generated chain whose LAST group is one point per key: `division_projection + extrinsic3D + rigidTform3d + free_point` — a
     user-written lens model AND free points — takes the blocked normal equations with the points as trailing entities (tb = 3: the
