@@ -377,7 +377,8 @@ int pcs_genchain_matfree(pcs_genchain *h, int op, const double *in, double *out,
  * (n_params x n_params, upper triangle written), out5 = {n_params, 0, 3, n_params^2 + n_params + 1, n_params}.
  * pcs_genchain_normal_blocks_device evaluates the chain at d_param_str (block rows into the handle's buffers) and contracts them on the
  * FP64 matrix cores.  pcs_genchain_lm_trial_build / _finish / pcs_genchain_lm_trial are pcs_lm_trial_build / _finish / pcs_lm_trial for
- * the handle (same pcs_lm_buffers — V, linvt, u, w: one double each —, same decision, read-back and stop word); mode must hold
+ * the handle (same pcs_lm_buffers, sized from pcs_genchain_normal_layout like pcs_normal_layout's — in the dense form V, linvt, u and w hold
+ * one double each —, same decision, read-back and stop word); mode must hold
  * PCS_LM_FIXED_TRIAL_BUFFER (the generated kernel reads its string from a fixed address: the trial is built at ps[1] into packed[1],
  * an accepted one is copied over state 0).  Limits: FP64 chains, row length <= 63, n_params <= PCS_NORMAL_MAX_PARAMS.
  * Options (pcs_genchain_set_option): "spd_timeout_us" (as pcs_set_option), "timing" (0: no start / stop events around evaluations),
