@@ -560,6 +560,10 @@ class ChainEngine:
     lm_fixed_trial_buffer = True   # the generated kernel reads its string from a fixed address: trials are built at ps[1] into packed[1]
     DENSE_OPTIONS = ("spd_timeout_us", "timing", "gram_debug", "dense_normal")
 
+    def deterministic_supported(self) -> bool:
+        """The ordered sums write every destination from ONE pair of local columns: no two blocks may share a parameter group."""
+        return len(set(self.spec.group_of_block)) == len(self.spec.blocks)
+
     def dense_lm_supported(self) -> bool:
         """Does the contraction of csrc/ba_blockgram.hpp take this chain?  FP64 block rows of at most 63 columns, n_params <= 65 535."""
         return self.dtype == "f64" and self.P + 1 <= 64 and self.n_params <= 65535
@@ -611,13 +615,14 @@ class ChainEngine:
                                            _stream_arg(stream)))
 
     def set_option(self, key: str, value: int):
-        """Engine's option interface as far as the LM driver uses it: "spd_timeout_us" and "timing" reach the handle; "timing_every"
-        maps to "timing"; "lazy_done_event" has nothing to switch here; "deterministic" cannot be switched ON (the contraction of a
-        generated chain's block rows sums with atomics)."""
+        """Engine's option interface as far as the LM driver uses it: "spd_timeout_us", "timing" and "deterministic" (the ORDERED
+        contraction of csrc/ba_blockgram.hpp: every sum in a fixed order, the same bits on every run) reach the handle; "timing_every"
+        maps to "timing"; "lazy_done_event" has nothing to switch here."""
         value = int(value)
         if key == "deterministic":
-            if value:
-                raise NotImplementedError("generated chains have no order-deterministic normal equations (csrc/ba_blockgram.hpp sums with atomics)")
+            if value and not self.deterministic_supported():
+                raise NotImplementedError("deterministic mode: blocks that share a parameter group are not supported in the ordered sums (csrc/ba_blockgram.hpp)")
+            check(lib().pcs_genchain_set_option(self._h, b"deterministic", value))
         elif key == "timing_every":
             check(lib().pcs_genchain_set_option(self._h, b"timing", int(value != 0)))
         elif key in self.DENSE_OPTIONS:

@@ -63,6 +63,15 @@ struct BlockGramArgs {
     int64_t blk_start[BLOCKROW_MAX_BLOCKS];
     const int32_t *stop;    // optional LM stop word (ba_schur.hpp PCS_STOP_GUARD)
     int32_t debug;          // measurements only (option "gram_debug"): 1 = no flush, 2 = no contraction
+    // ORDERED mode (option "deterministic"): the contraction stores every segment's matrix, raw, to ws[segment][entry] instead of
+    // flushing it; blockrow_gram_reduce_kernel then adds the segments of a GROUP (consecutive segments that agree in the entities of an
+    // entry's two columns) in table order — one thread per (group, entry), plain stores, the same bits on every run.  The passes of this
+    // mode are chosen so that every pair of columns has its groups consecutive: DET orders (major, minor) = (camera, image), (image,
+    // camera), (key, camera), (image, key); see gram_pass_of_det.
+    double *ws;
+    const int32_t *grp[2];  // [0]: groups by the pass's MAJOR entity, [1]: by (major, minor): pairs (first segment, one past the last)
+    int32_t n_grp[2];
+    int32_t det;            // 1: `pass` counts the DET orders
 };
 
 using gram_d4 = __attribute__((ext_vector_type(4))) double;
@@ -99,6 +108,20 @@ __device__ __forceinline__ int gram_pass_of(const int lp, const int lc) {
     return !key ? 0 : !img ? 1 : 2;
 }
 
+// ORDERED mode: the pass (0 (camera, image), 1 (image, camera), 2 (key, camera), 3 (image, key) — major entity first) in which the groups of a
+// pair of columns are consecutive, and which grouping it needs there: 0 = by the major entity, 1 = by (major, minor), 2 = everything
+// (the cost).  `keys`: the chain has key-linked columns (then image-only pairs ride in pass 3 and pass 1 does not exist).
+__device__ __forceinline__ void gram_pass_of_det(const int lp, const int lc, const bool keys, int &pass, int &cat) {
+    const bool cam = lp == 0 || lc == 0, img = lp == 1 || lc == 1, key = lp == 2 || lc == 2;
+    if (!cam && !img && !key) { pass = 0; cat = 2; return; }
+    if (key) {
+        if (img) { pass = 3; cat = 1; }              // (image, key)
+        else { pass = 2; cat = cam ? 1 : 0; }        // (key, camera) / (key, key)
+        return;
+    }
+    if (img && !cam) { pass = keys ? 3 : 1; cat = 0; return; }   // (image, image): image-major orders
+    pass = 0; cat = img ? 1 : 0;                     // (camera, image) / (camera, camera)
+}
 template <int NB>
 __global__ __launch_bounds__(64 * gram_waves(NB)) void blockrow_gram_kernel(const BlockGramArgs a) {
     if (a.stop && *a.stop) return;
@@ -194,6 +217,21 @@ __global__ __launch_bounds__(64 * gram_waves(NB)) void blockrow_gram_kernel(cons
         return;
     }
 
+    if (a.ws) {   // ORDERED mode: the segment's matrix as it is, to its place in the workspace (coalesced 512-byte stores)
+        if (have) {
+            double *mine = a.ws + (int64_t)s_id * NE + lane;
+            int blk = 0;
+#pragma unroll
+            for (int i = 0; i < NB; ++i)
+#pragma unroll
+                for (int j = i; j < NB; ++j) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) mine[blk * 256 + q * 64] = acc[i][j][q];
+                    ++blk;
+                }
+        }
+        return;
+    }
     // ---- the waves' matrices into LDS: entry e = block x 256 + q x 64 + lane  <->  G[16 i + lane / 16 + 4 q][16 j + lane % 16] -------
     {
         double *mine = gram_lds + wave * NE;
@@ -241,6 +279,67 @@ __global__ __launch_bounds__(64 * gram_waves(NB)) void blockrow_gram_kernel(cons
             continue;
         }
         gram_add(a, gp, col_base[c] + (int64_t)col_mul[c] * ic, p == c, sum);
+    }
+}
+
+// ORDERED mode, second step: one workgroup per group of segments (grid = n_grp[0] + n_grp[1] + 1: groups by the major entity, by (major,
+// minor), and one workgroup for the cost), one thread per entry: the segments' values in table order, four interleaved partial sums (a
+// FIXED tree: the same bits whatever the schedule), one plain add to the destination — nothing else writes it: every pair of columns
+// belongs to one pass and one grouping, every destination to one pair (chains whose blocks share a parameter group are refused in this
+// mode: two local pairs would meet in one destination).
+template <int NB>
+__global__ __launch_bounds__(256) void blockrow_gram_reduce_kernel(const BlockGramArgs a, const int32_t keys) {
+    if (a.stop && *a.stop) return;
+    constexpr int NE = gram_blocks(NB) * 256;
+    __shared__ int64_t col_base[GRAM_MAX_COLS];
+    __shared__ int32_t col_mul[GRAM_MAX_COLS], col_link[GRAM_MAX_COLS];
+    if (threadIdx.x < GRAM_MAX_COLS) {
+        const int p = threadIdx.x;
+        int64_t base = 0;
+        int32_t mul = 0, link = -1;
+        for (int b = 0; b < a.n_blocks; ++b)
+            if (p >= a.blk_col0[b] && p < a.blk_col0[b] + a.blk_np[b]) { base = a.blk_start[b] + (p - a.blk_col0[b]); mul = a.blk_np[b]; link = a.blk_link[b]; }
+        col_base[p] = base; col_mul[p] = mul; col_link[p] = link;
+    }
+    __syncthreads();
+    const int gb = blockIdx.x;
+    int cat, lo, hi;
+    if (gb < a.n_grp[0]) { cat = 0; lo = a.grp[0][2 * gb]; hi = a.grp[0][2 * gb + 1]; }
+    else if (gb < a.n_grp[0] + a.n_grp[1]) { cat = 1; lo = a.grp[1][2 * (gb - a.n_grp[0])]; hi = a.grp[1][2 * (gb - a.n_grp[0]) + 1]; }
+    else { cat = 2; lo = 0; hi = a.n_seg; }
+    const int32_t *sg = a.seg + (int64_t)GRAM_SEG_WORDS * lo;
+    const int ids[3] = {sg[2], sg[3], sg[4]};
+    const int P = a.P;
+    for (int e = threadIdx.x; e < NE; e += 256) {
+        const int blk = e >> 8, q = (e >> 6) & 3, ln = e & 63;
+        int bi = 0, bj = blk;
+        while (bj >= NB - bi) { bj -= NB - bi; ++bi; }
+        bj += bi;
+        const int p = 16 * bi + (ln >> 4) + 4 * q, c = 16 * bj + (ln & 15);
+        if (p > c || c > P) continue;
+        const int lp = p < P ? col_link[p] : -1, lcn = c < P ? col_link[c] : -1;
+        int pass, pc;
+        gram_pass_of_det(lp, lcn, keys != 0, pass, pc);
+        if (pass != a.pass || pc != cat) continue;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        const double *w = a.ws + (int64_t)lo * NE + e;
+        int s = lo;
+        for (; s + 4 <= hi; s += 4, w += 4 * (int64_t)NE) { s0 += w[0]; s1 += w[NE]; s2 += w[2 * (int64_t)NE]; s3 += w[3 * (int64_t)NE]; }
+        for (; s < hi; ++s, w += NE) s0 += w[0];
+        const double sum = (s0 + s1) + (s2 + s3);
+        if (p == P) { *a.cost += sum; continue; }
+        const int64_t gp = col_base[p] + (int64_t)col_mul[p] * ids[lp];
+        if (c == P) { a.g[gp] += sum; continue; }
+        const int64_t gc = col_base[c] + (int64_t)col_mul[c] * ids[lcn];
+        const int64_t lo_c = gp < gc ? gp : gc, hi_c = gp < gc ? gc : gp;
+        double *dst;
+        if (hi_c < a.trail_off) dst = a.A + lo_c * a.n_lead + hi_c;
+        else if (lo_c < a.trail_off) dst = a.B + lo_c * a.n_trail + (hi_c - a.trail_off);
+        else {
+            const int64_t tl = lo_c - a.trail_off, th = hi_c - a.trail_off, en = tl / a.tb;
+            dst = a.C + en * a.tb * a.tb + (tl - en * a.tb) * a.tb + (th - en * a.tb);
+        }
+        *dst += sum;
     }
 }
 

@@ -323,8 +323,8 @@ def _lm_solve_blocked(ne: BlockedNormalEquations, ps0: np.ndarray, *, max_iter, 
         # no rank can take another branch than its peers — unless the engine cannot (the (image, key) pass of the self chain with more
         # than 64 cameras keeps its atomics, csrc/ba_reduce.hpp): then the ranks adopt one consensus step per trial, host-steered.
         sharded = ne.reduce_fn is not None
-        # (generated chains: the contraction of their block rows sums with atomics, csrc/ba_blockgram.hpp — no deterministic mode either)
-        det_ok = not (eng.chain == "self" and eng.n_cams > DET_SELF_CAM_LIMIT) and not getattr(eng, "lm_fixed_trial_buffer", False)
+        # (generated chains: the ordered contraction of csrc/ba_blockgram.hpp, unless two blocks share a parameter group)
+        det_ok = not (eng.chain == "self" and eng.n_cams > DET_SELF_CAM_LIMIT) and getattr(eng, "deterministic_supported", lambda: True)()
         device_steered = not sharded or (getattr(ne.reduce_fn, "on_device", False) and det_ok)
         loop = _lm_loop_device if device_steered else _lm_loop_blocked
         saved_det = eng.option("deterministic", 0)

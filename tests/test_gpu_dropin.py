@@ -726,6 +726,9 @@ def test_generated_chain_options_counts_shared_groups_and_errors():
             assert np.max(np.abs(out[nl * nl: nl * nl + nl * nt].reshape(nl, nt) - want[:nl, nl:])) <= 1e-11 * np.max(np.abs(want))
         assert np.max(np.abs(out[-(n1 + 1): -1] - Jc.T @ r.ravel())) <= 1e-11 * np.max(np.abs(Jc.T @ r.ravel()))
     eng1.set_option("dense_normal", 0)
+    assert not eng1.deterministic_supported()                               # two local columns per parameter: the ordered sums refuse the chain
+    with pytest.raises(NotImplementedError, match="share a parameter group"):
+        eng1.set_option("deterministic", 1)
     # (2) explicit counts: a trailing image and key without detections still get their place in the string
     op2 = fb.optimisation_function([fb.projection(), fb.rigidTform3d(), fb.free_point()], counts=(3, 7, 10))
     eng = op2._engine_for(det)
@@ -864,6 +867,13 @@ def test_generated_chain_products_and_device_lm_reach_the_scipy_solution(golden_
     assert res.cost <= ref.cost * (1 + 1e-3), (res.cost, ref.cost)
     assert abs(0.5 * np.sum(loss_fn(res.x) ** 2) - res.cost) <= 1e-9 * res.cost
     assert res.cost < 0.05 * res.history[0]
+    # deterministic mode for a generated chain: two solves, the same bits
+    eng.set_option("deterministic", 1)
+    d1 = lm_solve(prob, prob.x0.copy(), max_iter=40)
+    d2 = lm_solve(prob, prob.x0.copy(), max_iter=40)
+    eng.set_option("deterministic", 0)
+    assert np.array_equal(d1.x, d2.x) and d1.cost == d2.cost and (d1.nit, d1.nfev) == (d2.nit, d2.nfev)
+    assert abs(d1.cost - res.cost) <= 1e-9 * res.cost
     # ... and the inexact path is still there on request, ending at the same cost
     cg = lm_solve(prob, prob.x0.copy(), max_iter=40, linear_solver="pcg")
     assert cg.n_jtjv > cg.nfev and abs(cg.cost - res.cost) <= 1e-3 * res.cost, (cg.cost, res.cost)
@@ -937,6 +947,15 @@ def test_generated_chain_dense_normal_equations_match_the_reference_jacobian(gol
         _, lay_d = build_and_check(eng)
         assert lay_d["n_trail"] == 0 and lay_d["n_lead"] == n
         eng.set_option("dense_normal", 0)
+    # ORDERED mode (set_option("deterministic", 1)): the segments' matrices go to a workspace and are added group by group in table
+    # order — the same matrix, and the same BITS on every build (the default mode's atomics leave the last bits to the schedule)
+    assert eng.deterministic_supported()
+    eng.set_option("deterministic", 1)
+    od1, _ = build_and_check(eng)
+    od2, _ = build_and_check(eng)
+    assert np.array_equal(od1, od2)
+    assert np.max(np.abs(od1 - out)) <= 1e-12 * np.max(np.abs(out))
+    eng.set_option("deterministic", 0)
     key_linked = any(str(b) == "free_point" for b in names)
     assert key_linked == (tag in ("generic_proj_rigid_free", "generic_proj_rigid_extr_free", "user_division"))
     # the rows of the table in ANY order: the host cuts it into segments of one (camera, image) pair wherever they lie (a shuffled table

@@ -190,8 +190,9 @@ def _worker(rank, world, port, out_dir, backend="gloo"):
         assert abs(rs.cost - r1.cost) <= 1e-3 * r1.cost and rs.cost < 0.01 * rs.history[0], (rs.cost, r1.cost, rs.history[0])
         # (5) a GENERATED chain sharded (round 5): `projection + extrinsic3D + rigidTform3d + template_points` — two per-image transforms,
         # the last one the trailing entities of the blocked normal equations (csrc/ba_blockgram.hpp).  Every rank contracts the block rows
-        # of ITS shard, the packed [A | B | C | g | cost] is all-reduced, the exact step follows on every rank; the contraction sums with
-        # atomics (no deterministic mode), so the loop is host-steered and the ranks adopt one consensus step per trial.
+        # of ITS shard — in the ORDERED mode lm_solve switches on for a sharded loop —, the packed [A | B | C | g | cost] is all-reduced and
+        # the exact step follows on every rank with the same bits: no consensus step (a chain whose blocks share a parameter group has no
+        # ordered mode and would take one).
         from pycamset_amd import function_blocks as fb
 
         def gen_problem(rows):
@@ -215,7 +216,7 @@ def _worker(rank, world, port, out_dir, backend="gloo"):
         finally:
             ds.BlockedNormalEquations._consensus_step = original
         rg1 = lm_solve(g_full, g_full.x0.copy(), max_iter=20)
-        assert calls and rg.n_jtjv == rg.nfev - 1, (len(calls), rg.n_jtjv, rg.nfev)        # exact steps, consensus per trial
+        assert not calls and rg.n_jtjv == rg.nfev - 1, (len(calls), rg.n_jtjv, rg.nfev)    # exact steps, no consensus: ordered sums on every rank
         assert abs(rg.cost - rg1.cost) <= 1e-6 * rg1.cost and rg.cost < 0.01 * rg.history[0], (rg.cost, rg1.cost, rg.history[0])
         dist.all_gather_object(gathered, (rg.x, rg.nit, rg.nfev, rg.status))
         assert all(np.array_equal(gathered[0][0], g[0]) and gathered[0][1:] == g[1:] for g in gathered)
