@@ -282,25 +282,32 @@ __global__ __launch_bounds__(64 * gram_waves(NB)) void blockrow_gram_kernel(cons
     }
 }
 
-// ORDERED mode, second step: one workgroup per group of segments (grid = n_grp[0] + n_grp[1] + 1: groups by the major entity, by (major,
-// minor), and one workgroup for the cost), one thread per entry: the segments' values in table order, four interleaved partial sums (a
-// FIXED tree: the same bits whatever the schedule), one plain add to the destination — nothing else writes it: every pair of columns
-// belongs to one pass and one grouping, every destination to one pair (chains whose blocks share a parameter group are refused in this
-// mode: two local pairs would meet in one destination).
+// ORDERED mode, second step: one workgroup per group of segments (grid = n_grp[0] + n_grp[1] (+ 1 in pass 0: the cost); groups by the
+// major entity, by (major, minor)).  The workgroup first lists the entries that belong to its (pass, grouping); then, sixteen entries at a
+// time, sixteen SLICES of the group's segments are summed side by side (a slice = a fixed contiguous sixteenth, four interleaved partial
+// sums inside it) and joined in slice order — a FIXED tree: the same bits whatever the schedule — and one plain add goes to the
+// destination.  Nothing else writes it: every pair of columns belongs to one pass and one grouping, every destination to one pair (chains
+// whose blocks share a parameter group are refused in this mode: two local pairs would meet in one destination).  A camera's group is
+// hundreds of segments long: walked by one thread per entry (first version) the reductions took 0.9 ms of rig-32's build.
 template <int NB>
 __global__ __launch_bounds__(256) void blockrow_gram_reduce_kernel(const BlockGramArgs a, const int32_t keys) {
     if (a.stop && *a.stop) return;
     constexpr int NE = gram_blocks(NB) * 256;
     __shared__ int64_t col_base[GRAM_MAX_COLS];
     __shared__ int32_t col_mul[GRAM_MAX_COLS], col_link[GRAM_MAX_COLS];
-    if (threadIdx.x < GRAM_MAX_COLS) {
-        const int p = threadIdx.x;
+    __shared__ int16_t list[NE];
+    __shared__ int32_t n_list;
+    __shared__ double red[16][17];
+    const int tid = threadIdx.x;
+    if (tid < GRAM_MAX_COLS) {
+        const int p = tid;
         int64_t base = 0;
         int32_t mul = 0, link = -1;
         for (int b = 0; b < a.n_blocks; ++b)
             if (p >= a.blk_col0[b] && p < a.blk_col0[b] + a.blk_np[b]) { base = a.blk_start[b] + (p - a.blk_col0[b]); mul = a.blk_np[b]; link = a.blk_link[b]; }
         col_base[p] = base; col_mul[p] = mul; col_link[p] = link;
     }
+    if (tid == 0) n_list = 0;
     __syncthreads();
     const int gb = blockIdx.x;
     int cat, lo, hi;
@@ -310,36 +317,66 @@ __global__ __launch_bounds__(256) void blockrow_gram_reduce_kernel(const BlockGr
     const int32_t *sg = a.seg + (int64_t)GRAM_SEG_WORDS * lo;
     const int ids[3] = {sg[2], sg[3], sg[4]};
     const int P = a.P;
-    for (int e = threadIdx.x; e < NE; e += 256) {
+    auto decode = [&](const int e, int &p, int &c) {
         const int blk = e >> 8, q = (e >> 6) & 3, ln = e & 63;
         int bi = 0, bj = blk;
         while (bj >= NB - bi) { bj -= NB - bi; ++bi; }
         bj += bi;
-        const int p = 16 * bi + (ln >> 4) + 4 * q, c = 16 * bj + (ln & 15);
+        p = 16 * bi + (ln >> 4) + 4 * q; c = 16 * bj + (ln & 15);
+    };
+    // the entries of this (pass, grouping): their order in the list is of no consequence (every entry is summed on its own)
+    for (int e = tid; e < NE; e += 256) {
+        int p, c;
+        decode(e, p, c);
         if (p > c || c > P) continue;
-        const int lp = p < P ? col_link[p] : -1, lcn = c < P ? col_link[c] : -1;
         int pass, pc;
-        gram_pass_of_det(lp, lcn, keys != 0, pass, pc);
-        if (pass != a.pass || pc != cat) continue;
+        gram_pass_of_det(p < P ? col_link[p] : -1, c < P ? col_link[c] : -1, keys != 0, pass, pc);
+        if (pass == a.pass && pc == cat) list[atomicAdd(&n_list, 1)] = (int16_t)e;
+    }
+    __syncthreads();
+    const int n_valid = n_list;
+    const int col = tid & 15, slice = tid >> 4;
+    const int len = hi - lo, per = (len + 15) / 16;
+    const int s_lo = lo + slice * per, s_hi = min(hi, s_lo + per);
+    for (int base = 0; base < n_valid; base += 16) {
+        const int idx = base + col;
+        const int e = idx < n_valid ? list[idx] : 0;
         double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-        const double *w = a.ws + (int64_t)lo * NE + e;
-        int s = lo;
-        for (; s + 4 <= hi; s += 4, w += 4 * (int64_t)NE) { s0 += w[0]; s1 += w[NE]; s2 += w[2 * (int64_t)NE]; s3 += w[3 * (int64_t)NE]; }
-        for (; s < hi; ++s, w += NE) s0 += w[0];
-        const double sum = (s0 + s1) + (s2 + s3);
-        if (p == P) { *a.cost += sum; continue; }
-        const int64_t gp = col_base[p] + (int64_t)col_mul[p] * ids[lp];
-        if (c == P) { a.g[gp] += sum; continue; }
-        const int64_t gc = col_base[c] + (int64_t)col_mul[c] * ids[lcn];
-        const int64_t lo_c = gp < gc ? gp : gc, hi_c = gp < gc ? gc : gp;
-        double *dst;
-        if (hi_c < a.trail_off) dst = a.A + lo_c * a.n_lead + hi_c;
-        else if (lo_c < a.trail_off) dst = a.B + lo_c * a.n_trail + (hi_c - a.trail_off);
-        else {
-            const int64_t tl = lo_c - a.trail_off, th = hi_c - a.trail_off, en = tl / a.tb;
-            dst = a.C + en * a.tb * a.tb + (tl - en * a.tb) * a.tb + (th - en * a.tb);
+        if (idx < n_valid && s_lo < s_hi) {
+            const double *w = a.ws + (int64_t)s_lo * NE + e;
+            int s = s_lo;
+            for (; s + 4 <= s_hi; s += 4, w += 4 * (int64_t)NE) { s0 += w[0]; s1 += w[NE]; s2 += w[2 * (int64_t)NE]; s3 += w[3 * (int64_t)NE]; }
+            for (; s < s_hi; ++s, w += NE) s0 += w[0];
         }
-        *dst += sum;
+        red[slice][col] = (s0 + s1) + (s2 + s3);
+        __syncthreads();
+        if (slice == 0 && idx < n_valid) {
+            double sum = 0.0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) sum += red[q][col];   // slice order
+            int p, c;
+            decode(e, p, c);
+            if (p == P) {
+                *a.cost += sum;
+            } else {
+                const int64_t gp = col_base[p] + (int64_t)col_mul[p] * ids[col_link[p]];
+                if (c == P) {
+                    a.g[gp] += sum;
+                } else {
+                    const int64_t gc = col_base[c] + (int64_t)col_mul[c] * ids[col_link[c]];
+                    const int64_t lo_c = gp < gc ? gp : gc, hi_c = gp < gc ? gc : gp;
+                    double *dst;
+                    if (hi_c < a.trail_off) dst = a.A + lo_c * a.n_lead + hi_c;
+                    else if (lo_c < a.trail_off) dst = a.B + lo_c * a.n_trail + (hi_c - a.trail_off);
+                    else {
+                        const int64_t tl = lo_c - a.trail_off, th = hi_c - a.trail_off, en = tl / a.tb;
+                        dst = a.C + en * a.tb * a.tb + (tl - en * a.tb) * a.tb + (th - en * a.tb);
+                    }
+                    *dst += sum;
+                }
+            }
+        }
+        __syncthreads();
     }
 }
 

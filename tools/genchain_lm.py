@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--no-cg", action="store_true")
     ap.add_argument("--chain", choices=("flex", "division", "divfree"), default="flex")
     ap.add_argument("--two-launch", action="store_true", help="slab preparation as a launch of its own in front of the evaluation")
+    ap.add_argument("--deterministic", action="store_true", help="the ordered contraction and step (the same bits on every run)")
     ap.add_argument("--dense", action="store_true", help="the dense form of the normal equations also where the chain has the blocked one")
     a = ap.parse_args()
     for number in a.config:
@@ -93,6 +94,8 @@ def main():
             eng.set_option("dense_normal", 1)
         if a.two_launch:
             eng.set_one_launch(False)
+        if a.deterministic:
+            eng.set_option("deterministic", 1)
         n_free = prob.x0.shape[0]
         lay = eng.normal_layout()
         print(f"config {number}, {eng.chain}: {rig.n_cams} cameras, {rig.n_imgs} images, N = {rig.n_det}, row length {eng.P}, {eng.n_params} parameters "
