@@ -382,7 +382,10 @@ int pcs_genchain_matfree(pcs_genchain *h, int op, const double *in, double *out,
  * PCS_LM_FIXED_TRIAL_BUFFER (the generated kernel reads its string from a fixed address: the trial is built at ps[1] into packed[1],
  * an accepted one is copied over state 0).  Limits: FP64 chains, row length <= 63, n_params <= PCS_NORMAL_MAX_PARAMS.
  * Options (pcs_genchain_set_option): "spd_timeout_us" (as pcs_set_option), "timing" (0: no start / stop events around evaluations),
- * "dense_normal" (above; changes the layout: set it before buffers are sized), "gram_debug" (measurements only). */
+ * "dense_normal" (above; changes the layout: set it before buffers are sized), "deterministic" (1: the ORDERED contraction — every
+ * segment's matrix to a workspace, groups of consecutive segments added in table order, the K split of schur_syrk through
+ * pcs_lm_buffers.syrk_work: the same bits on every run; refused for chains whose blocks share a parameter group),
+ * "gram_debug" (measurements only). */
 int pcs_genchain_normal_layout(const pcs_genchain *h, int64_t *out5);
 int pcs_genchain_normal_blocks_device(pcs_genchain *h, const double *d_param_str, double *d_packed, void *stream);
 int pcs_genchain_lm_trial_build(pcs_genchain *h, const pcs_lm_buffers *b, void *stream);

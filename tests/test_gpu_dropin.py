@@ -1157,6 +1157,25 @@ def test_user_lens_model_with_free_points_through_the_blocked_device_lm():
     res_c, slabs_c = run_bundle_adjustment(prob_c, solver="device")
     assert abs(res_c.cost - res.cost) <= 1e-9 * res.cost and len(slabs_c) == 4 and slabs_c[3].shape == rig.points.shape
     assert np.array_equal(slabs_c[2], rig.poses_true)                                  # the held poses come back untouched
+    # the SHARDED form of the device-steered loop on one rank, for a generated chain: a stream-ordered stand-in for the collective
+    # (reduce_fn.on_device, what RCCL is) — lm_solve switches the ordered contraction on and queues build -> collective -> decision per trial
+    import torch
+    queued = []
+
+    def in_stream_sum(t):
+        queued.append((t.data_ptr(), torch.cuda.current_stream().cuda_stream))
+        t.mul_(1.0)
+        return t
+
+    in_stream_sum.on_device = True
+    prob_s = handlers.ChainProblem(chain(), det, start, unfixed=[None, None, np.zeros_like(rig.poses_true, dtype=bool), None])
+    res_s = lm_solve(prob_s, prob_s.x0.copy(), max_iter=40, reduce_fn=in_stream_sum)
+    eng_s = prob_s.op_fun._engine_for(prob_s._flat_detections())
+    ne_s = [v for v in eng_s.__dict__["_blocked_solvers"].values() if v.reduce_fn is in_stream_sum][0]
+    assert abs(res_s.cost - res.cost) <= 1e-9 * res.cost and res_s.nit == res.nit, (res_s.cost, res.cost, res_s.nit, res.nit)
+    assert queued[0][0] == ne_s.packed[0].data_ptr() and {q[0] for q in queued[1:]} == {ne_s.packed[1].data_ptr()}
+    assert all(q[1] == ne_s.stream.cuda_stream for q in queued) and res_s.nfev <= len(queued) <= res_s.nfev + 1
+    assert eng_s.option("deterministic", 0) == 0                                      # switched back after the loop
     # the dense form of the same problem walks to the same cost
     op_d = chain()
     prob_d = handlers.ChainProblem(op_d, det, start, unfixed=[None, None, np.zeros_like(rig.poses_true, dtype=bool), None])
