@@ -66,11 +66,13 @@ struct BlockGramArgs {
     // ORDERED mode (option "deterministic"): the contraction stores every segment's matrix, raw, to ws[segment][entry] instead of
     // flushing it; blockrow_gram_reduce_kernel then adds the segments of a GROUP (consecutive segments that agree in the entities of an
     // entry's two columns) in table order — one thread per (group, entry), plain stores, the same bits on every run.  The passes of this
-    // mode are chosen so that every pair of columns has its groups consecutive: DET orders (major, minor) = (camera, image), (image,
-    // camera), (key, camera), (image, key); see gram_pass_of_det.
+    // mode are chosen so that every pair of columns has its groups consecutive — DET orders (major, minor) = (camera, image), (key, camera),
+    // (image, key); see gram_pass_of_det — or, for the image x image pairs of a chain without key columns, listed (grp[2] + gidx).
     double *ws;
-    const int32_t *grp[2];  // [0]: groups by the pass's MAJOR entity, [1]: by (major, minor): pairs (first segment, one past the last)
-    int32_t n_grp[2];
+    const int32_t *grp[3];  // [0]: groups by the pass's MAJOR entity, [1]: by (major, minor): pairs (first segment, one past the last);
+                            // [2]: groups by the MINOR entity — their segments are not consecutive: pairs (first, one past the last) into `gidx`
+    const int32_t *gidx;    // segment ids of the minor-entity groups, group after group, each in table order
+    int32_t n_grp[3];
     int32_t det;            // 1: `pass` counts the DET orders
 };
 
@@ -108,9 +110,10 @@ __device__ __forceinline__ int gram_pass_of(const int lp, const int lc) {
     return !key ? 0 : !img ? 1 : 2;
 }
 
-// ORDERED mode: the pass (0 (camera, image), 1 (image, camera), 2 (key, camera), 3 (image, key) — major entity first) in which the groups of a
-// pair of columns are consecutive, and which grouping it needs there: 0 = by the major entity, 1 = by (major, minor), 2 = everything
-// (the cost).  `keys`: the chain has key-linked columns (then image-only pairs ride in pass 3 and pass 1 does not exist).
+// ORDERED mode: the pass (0 (camera, image), 2 (key, camera), 3 (image, key) — major entity first; 1 is not used) in which the groups of a
+// pair of columns can be walked in a fixed order, and which grouping it needs there: 0 = by the major entity, 1 = by (major, minor),
+// 2 = everything (the cost), 3 = by the MINOR entity (segments listed through an index: not consecutive).  `keys`: the chain has
+// key-linked columns (then image-only pairs ride in pass 3, where the image is the major entity).
 __device__ __forceinline__ void gram_pass_of_det(const int lp, const int lc, const bool keys, int &pass, int &cat) {
     const bool cam = lp == 0 || lc == 0, img = lp == 1 || lc == 1, key = lp == 2 || lc == 2;
     if (!cam && !img && !key) { pass = 0; cat = 2; return; }
@@ -119,9 +122,10 @@ __device__ __forceinline__ void gram_pass_of_det(const int lp, const int lc, con
         else { pass = 2; cat = cam ? 1 : 0; }        // (key, camera) / (key, key)
         return;
     }
-    if (img && !cam) { pass = keys ? 3 : 1; cat = 0; return; }   // (image, image): image-major orders
+    if (img && !cam) { pass = keys ? 3 : 0; cat = keys ? 0 : 3; return; }   // (image, image): image-major order, or the (camera, image) order through the list
     pass = 0; cat = img ? 1 : 0;                     // (camera, image) / (camera, camera)
 }
+
 template <int NB>
 __global__ __launch_bounds__(64 * gram_waves(NB)) void blockrow_gram_kernel(const BlockGramArgs a) {
     if (a.stop && *a.stop) return;
@@ -282,8 +286,8 @@ __global__ __launch_bounds__(64 * gram_waves(NB)) void blockrow_gram_kernel(cons
     }
 }
 
-// ORDERED mode, second step: one workgroup per group of segments (grid = n_grp[0] + n_grp[1] (+ 1 in pass 0: the cost); groups by the
-// major entity, by (major, minor)).  The workgroup first lists the entries that belong to its (pass, grouping); then, sixteen entries at a
+// ORDERED mode, second step: one workgroup per group of segments (grid = n_grp[0] + n_grp[1] + n_grp[2] (+ 1 in pass 0: the cost); groups by
+// the major entity, by (major, minor), by the minor entity through the list).  The workgroup first lists the entries that belong to its (pass, grouping); then, sixteen entries at a
 // time, sixteen SLICES of the group's segments are summed side by side (a slice = a fixed contiguous sixteenth, four interleaved partial
 // sums inside it) and joined in slice order — a FIXED tree: the same bits whatever the schedule — and one plain add goes to the
 // destination.  Nothing else writes it: every pair of columns belongs to one pass and one grouping, every destination to one pair (chains
@@ -311,10 +315,12 @@ __global__ __launch_bounds__(256) void blockrow_gram_reduce_kernel(const BlockGr
     __syncthreads();
     const int gb = blockIdx.x;
     int cat, lo, hi;
+    const int32_t *via = nullptr;   // cat 3: position -> segment
     if (gb < a.n_grp[0]) { cat = 0; lo = a.grp[0][2 * gb]; hi = a.grp[0][2 * gb + 1]; }
     else if (gb < a.n_grp[0] + a.n_grp[1]) { cat = 1; lo = a.grp[1][2 * (gb - a.n_grp[0])]; hi = a.grp[1][2 * (gb - a.n_grp[0]) + 1]; }
+    else if (gb < a.n_grp[0] + a.n_grp[1] + a.n_grp[2]) { cat = 3; lo = a.grp[2][2 * (gb - a.n_grp[0] - a.n_grp[1])]; hi = a.grp[2][2 * (gb - a.n_grp[0] - a.n_grp[1]) + 1]; via = a.gidx; }
     else { cat = 2; lo = 0; hi = a.n_seg; }
-    const int32_t *sg = a.seg + (int64_t)GRAM_SEG_WORDS * lo;
+    const int32_t *sg = a.seg + (int64_t)GRAM_SEG_WORDS * (via ? via[lo] : lo);
     const int ids[3] = {sg[2], sg[3], sg[4]};
     const int P = a.P;
     auto decode = [&](const int e, int &p, int &c) {
@@ -343,10 +349,19 @@ __global__ __launch_bounds__(256) void blockrow_gram_reduce_kernel(const BlockGr
         const int e = idx < n_valid ? list[idx] : 0;
         double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
         if (idx < n_valid && s_lo < s_hi) {
-            const double *w = a.ws + (int64_t)s_lo * NE + e;
-            int s = s_lo;
-            for (; s + 4 <= s_hi; s += 4, w += 4 * (int64_t)NE) { s0 += w[0]; s1 += w[NE]; s2 += w[2 * (int64_t)NE]; s3 += w[3 * (int64_t)NE]; }
-            for (; s < s_hi; ++s, w += NE) s0 += w[0];
+            if (via) {   // listed segments
+                int s = s_lo;
+                for (; s + 4 <= s_hi; s += 4) {
+                    s0 += a.ws[(int64_t)via[s] * NE + e]; s1 += a.ws[(int64_t)via[s + 1] * NE + e];
+                    s2 += a.ws[(int64_t)via[s + 2] * NE + e]; s3 += a.ws[(int64_t)via[s + 3] * NE + e];
+                }
+                for (; s < s_hi; ++s) s0 += a.ws[(int64_t)via[s] * NE + e];
+            } else {
+                const double *w = a.ws + (int64_t)s_lo * NE + e;
+                int s = s_lo;
+                for (; s + 4 <= s_hi; s += 4, w += 4 * (int64_t)NE) { s0 += w[0]; s1 += w[NE]; s2 += w[2 * (int64_t)NE]; s3 += w[3 * (int64_t)NE]; }
+                for (; s < s_hi; ++s, w += NE) s0 += w[0];
+            }
         }
         red[slice][col] = (s0 + s1) + (s2 + s3);
         __syncthreads();
