@@ -7,14 +7,19 @@ mkdir -p $OUT
 what=${@:-times trace}
 for w in $what; do
   case $w in
-    times) timeout -k 10 800 python tools/genchain_lm.py --config 1 2 3 > $OUT/genchain_lm.log 2>&1 ;;
+    times)
+      timeout -k 10 800 python tools/genchain_lm.py --config 1 2 3 2>&1 | grep -v amdgpu > $OUT/genchain_lm.log
+      timeout -k 10 500 python tools/genchain_lm.py --config 1 2 3 --chain division 2>&1 | grep -v amdgpu > $OUT/genchain_division.log
+      for c in division flex divfree; do timeout -k 10 300 python tools/genchain_lm.py --config 1 2 3 --chain $c --no-cg --phases 2>&1 | grep -v amdgpu; done > $OUT/genchain_final_phases.log
+      for c in division flex divfree; do timeout -k 10 300 python tools/genchain_lm.py --config 1 2 3 --chain $c --no-cg --deterministic 2>&1 | grep -v amdgpu; done > $OUT/genchain_deterministic.log ;;
     trace)
       cd /tmp && export TMPDIR=/tmp
-      for c in 1 3; do
-        rm -rf /tmp/gtrace_$c
-        timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/gtrace_$c -o t -- python3 $OLDPWD/tools/genchain_lm.py --config $c --trace > $OUT/genchain_trace_c$c.log 2>&1 < /dev/null
-        f=$(find /tmp/gtrace_$c -name "*kernel_stats.csv" | head -1)
-        cp "$f" $OUT/genchain_c${c}_kernel_stats.csv
+      for spec in "1 flex c1" "3 flex c3" "3 division division_c3"; do
+        set -- $spec
+        rm -rf /tmp/gtrace_$3
+        timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/gtrace_$3 -o t -- python3 $OLDPWD/tools/genchain_lm.py --config $1 --chain $2 --trace > $OUT/genchain_trace_$3.log 2>&1 < /dev/null
+        f=$(find /tmp/gtrace_$3 -name "*kernel_stats.csv" | head -1)
+        cp "$f" $OUT/genchain_$3_kernel_stats.csv
       done
       cd $OLDPWD ;;
   esac
