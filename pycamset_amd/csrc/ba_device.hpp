@@ -317,4 +317,66 @@ __device__ __forceinline__ void eval_detection(SlabPtrC cs, SlabPtrP ps, const T
     }
 }
 
+// J_i dv WITHOUT forming J_i: the directional derivative of one detection's projection along dv (forward mode), for a tile whose
+// detections share camera and image.  Same chain rule as eval_detection, applied to a vector instead of to the identity:
+//   d X_w = M_p X + dv_pt (+ R_p dv_X)         M_p = sum_a dv_pr[a] dR_p[a]   (the caller forms M_e and M_p once per tile)
+//   d X_c = M_e X_w + dv_et + R_e d X_w        M_e = sum_a dv_er[a] dR_e[a]
+//   d(u, v) = A_x d X_c + A_p dv_intr
+// ~110 FP64 operations per detection where the 2 x P block and its product with dv take ~340.  (Round 5; the matrix-free J v is
+// issue-bound in the evaluation: DESIGN section 4.)
+//   cs / ps : camera / pose slab (R, t and the nine intrinsics are read; the dR blocks are not)
+//   M       : M_e (entries 0-8, row-major) and M_p (9-17)
+//   vi      : dv of the nine intrinsics; vet / vpt: dv of the extrinsic / pose translation; vX: dv of the point (chains S and F)
+template <int CHAIN, typename SlabPtrC, typename SlabPtrP, typename MatPtr, typename VecPtr>
+__device__ __forceinline__ void eval_detection_jvp(SlabPtrC cs, SlabPtrP ps, const double X0, const double X1, const double X2, MatPtr M, VecPtr vi,
+                                                   VecPtr vet, VecPtr vpt, const double vX0, const double vX1, const double vX2, double &du, double &dv) {
+    double Xw0, Xw1, Xw2, dW0, dW1, dW2;
+    if constexpr (CHAIN != CHAIN_FREE) {
+        const double r0 = ps[POSE_R + 0], r1 = ps[POSE_R + 1], r2 = ps[POSE_R + 2];
+        const double r3 = ps[POSE_R + 3], r4 = ps[POSE_R + 4], r5 = ps[POSE_R + 5];
+        const double r6 = ps[POSE_R + 6], r7 = ps[POSE_R + 7], r8 = ps[POSE_R + 8];
+        Xw0 = r0 * X0 + r1 * X1 + r2 * X2 + ps[POSE_T + 0];
+        Xw1 = r3 * X0 + r4 * X1 + r5 * X2 + ps[POSE_T + 1];
+        Xw2 = r6 * X0 + r7 * X1 + r8 * X2 + ps[POSE_T + 2];
+        dW0 = M[9] * X0 + M[10] * X1 + M[11] * X2 + vpt[0];
+        dW1 = M[12] * X0 + M[13] * X1 + M[14] * X2 + vpt[1];
+        dW2 = M[15] * X0 + M[16] * X1 + M[17] * X2 + vpt[2];
+        if constexpr (CHAIN == CHAIN_SELF) {
+            dW0 += r0 * vX0 + r1 * vX1 + r2 * vX2;
+            dW1 += r3 * vX0 + r4 * vX1 + r5 * vX2;
+            dW2 += r6 * vX0 + r7 * vX1 + r8 * vX2;
+        }
+    } else {
+        Xw0 = X0; Xw1 = X1; Xw2 = X2;
+        dW0 = vX0; dW1 = vX1; dW2 = vX2;
+    }
+    const double e0 = cs[CAM_R + 0], e1 = cs[CAM_R + 1], e2 = cs[CAM_R + 2];
+    const double e3 = cs[CAM_R + 3], e4 = cs[CAM_R + 4], e5 = cs[CAM_R + 5];
+    const double e6 = cs[CAM_R + 6], e7 = cs[CAM_R + 7], e8 = cs[CAM_R + 8];
+    const double x = e0 * Xw0 + e1 * Xw1 + e2 * Xw2 + cs[CAM_T + 0];
+    const double y = e3 * Xw0 + e4 * Xw1 + e5 * Xw2 + cs[CAM_T + 1];
+    const double z = e6 * Xw0 + e7 * Xw1 + e8 * Xw2 + cs[CAM_T + 2];
+    const double dx = M[0] * Xw0 + M[1] * Xw1 + M[2] * Xw2 + vet[0] + e0 * dW0 + e1 * dW1 + e2 * dW2;
+    const double dy = M[3] * Xw0 + M[4] * Xw1 + M[5] * Xw2 + vet[1] + e3 * dW0 + e4 * dW1 + e5 * dW2;
+    const double dz = M[6] * Xw0 + M[7] * Xw1 + M[8] * Xw2 + vet[2] + e6 * dW0 + e7 * dW1 + e8 * dW2;
+    const double fx = cs[0], fy = cs[2];
+    const double k0 = cs[4], k1 = cs[5], p0 = cs[6], p1 = cs[7], k2 = cs[8];
+    const double iz = 1.0 / z;
+    const double a = x * iz, b = y * iz;
+    const double a2 = a * a, b2 = b * b, ab = a * b;
+    const double r2 = a2 + b2, r4 = r2 * r2, r6 = r4 * r2;
+    const double kup = 1.0 + k0 * r2 + k1 * r4 + k2 * r6;
+    const double dk = k0 + 2.0 * k1 * r2 + 3.0 * k2 * r4;
+    const double ua = fx * (kup + 2.0 * a2 * dk + 2.0 * p0 * b + 6.0 * p1 * a);
+    const double cross = 2.0 * (ab * dk + p0 * a + p1 * b);
+    const double ub = fx * cross, va = fy * cross;
+    const double vb = fy * (kup + 2.0 * b2 * dk + 6.0 * p0 * b + 2.0 * p1 * a);
+    const double da = (dx - a * dz) * iz, db = (dy - b * dz) * iz;
+    const double xD = a * kup + 2.0 * p0 * ab + p1 * (r2 + 2.0 * a2);
+    const double yD = b * kup + p0 * (r2 + 2.0 * b2) + 2.0 * p1 * ab;
+    // A_p dv_intr: [xD, 1, 0, 0, fx a r2, fx a r4, 2 fx ab, fx (r2 + 2 a2), fx a r6] and the v row likewise (eval_detection's J[0..8], J[P..P+8])
+    du = ua * da + ub * db + xD * vi[0] + vi[1] + fx * (a * (r2 * vi[4] + r4 * vi[5] + r6 * vi[8]) + 2.0 * ab * vi[6] + (r2 + 2.0 * a2) * vi[7]);
+    dv = va * da + vb * db + yD * vi[2] + vi[3] + fy * (b * (r2 * vi[4] + r4 * vi[5] + r6 * vi[8]) + (r2 + 2.0 * b2) * vi[6] + 2.0 * ab * vi[7]);
+}
+
 }  // namespace pcs

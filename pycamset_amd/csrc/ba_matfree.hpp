@@ -106,6 +106,65 @@ __global__ __launch_bounds__(256) void ba_matfree_kernel(const MatfreeArgs a) {
         int c, im, k;
         load_indices(a.tab, ic, c, im, k);
         const double2v m = load_uv(a.tab, ic);
+        if constexpr (OP == OP_JV) {
+            // J v WITHOUT J: forward mode (eval_detection_jvp, ba_device.hpp: a third of the arithmetic of the 2 x P block and its product).
+            // A tile of the reference's table order lies inside a run of one (camera, image) pair or across ONE run boundary (four tiles in
+            // ten on rig-32, runs of 156): the derivative is taken with the first lane's pair and, across a boundary, once more with the
+            // last lane's — every lane keeps its own pair's — so that R, t, the intrinsics and v's camera / image entries always come
+            // through scalar loads (48 values per pair: they fit the SGPRs, unlike the 87 of a full Jacobian) and no lane ever loads a
+            // slab of its own (87 per-lane loads per straddling tile: what the kernel's time went to, whatever was done to the one-pair
+            // tiles — DESIGN section 4).  The two 3 x 3 matrices the rotations' derivatives contract to with v (M_e, M_p) are formed once
+            // per tile and pair: lane q < 36 holds one entry (three multiply-adds from its own loads of a dR block), read by v_readlane.
+            const int c0 = __builtin_amdgcn_readfirstlane(c), im0 = __builtin_amdgcn_readfirstlane(im);
+            const int c1 = __builtin_amdgcn_readlane(c, 63), im1 = __builtin_amdgcn_readlane(im, 63);
+            const bool in_a = c == c0 && im == im0;
+            if (__all(in_a || (c == c1 && im == im1))) {
+                const bool two = c0 != c1 || im0 != im1;
+                const T X0 = points[3 * k], X1 = points[3 * k + 1], X2 = points[3 * k + 2];
+                const double *vin = a.vin;
+                const int64_t cEa = a.extr_off + 6 * (int64_t)c0, cPa = a.pose_off + 6 * (int64_t)im0;
+                const int64_t cEb = a.extr_off + 6 * (int64_t)c1, cPb = a.pose_off + 6 * (int64_t)im1;
+                double mval = 0.0;
+                {
+                    const int l36 = min(lane, 35), half = l36 >= 18 ? 1 : 0, q18 = l36 - 18 * half;
+                    const bool cam_part = q18 < 9;
+                    const int q = cam_part ? q18 : q18 - 9;
+                    const int cc = half ? c1 : c0, ii = half ? im1 : im0;
+                    const T *dr = cam_part ? cam_slab + cc * CAM_STRIDE + CAM_DR : pose_slab + ii * POSE_STRIDE + POSE_DR;
+                    const double *vr = cam_part ? vin + (half ? cEb : cEa) : vin + (half ? cPb : cPa);
+                    if (CHAIN != CHAIN_FREE || cam_part) mval = dr[q] * vr[0] + dr[9 + q] * vr[1] + dr[18 + q] * vr[2];
+                }
+                double vX0 = 0.0, vX1 = 0.0, vX2 = 0.0;
+                if constexpr (CHAIN != CHAIN_TEMPLATE) {
+                    const int64_t cXl = a.point_off + 3 * (int64_t)k;
+                    vX0 = vin[cXl]; vX1 = vin[cXl + 1]; vX2 = vin[cXl + 2];
+                }
+                struct LaneMat {   // M_e, M_p of one pair inside the lanes' values
+                    double v;
+                    int off;
+                    __device__ __forceinline__ double operator[](const int j) const { return readlane_scalar(v, off + j); }
+                };
+                double du, dv;
+                eval_detection_jvp<CHAIN>(ScalarSlab(cam_slab + c0 * CAM_STRIDE), ScalarSlab(pose_slab + im0 * POSE_STRIDE), X0, X1, X2, LaneMat{mval, 0},
+                                          ScalarSlab(vin + 9 * (int64_t)c0), ScalarSlab(vin + cEa + 3), ScalarSlab(vin + (CHAIN != CHAIN_FREE ? cPa + 3 : 0)),
+                                          vX0, vX1, vX2, du, dv);
+                if (two) {
+                    double du1, dv1;
+                    eval_detection_jvp<CHAIN>(ScalarSlab(cam_slab + c1 * CAM_STRIDE), ScalarSlab(pose_slab + im1 * POSE_STRIDE), X0, X1, X2, LaneMat{mval, 18},
+                                              ScalarSlab(vin + 9 * (int64_t)c1), ScalarSlab(vin + cEb + 3), ScalarSlab(vin + (CHAIN != CHAIN_FREE ? cPb + 3 : 0)),
+                                              vX0, vX1, vX2, du1, dv1);
+                    du = in_a ? du : du1;
+                    dv = in_a ? dv : dv1;
+                }
+                if (valid) {
+                    D2 q2;
+                    q2.x = du;
+                    q2.y = dv;
+                    reinterpret_cast<D2 *>(a.vout)[i] = q2;
+                }
+                continue;
+            }
+        }
         T u, v;
         T J[P2];
         {
