@@ -223,55 +223,61 @@ __global__ __launch_bounds__(256) void ba_matfree_kernel(const MatfreeArgs a) {
         if constexpr (LDS_ACC) {
             // tile sums through the wave-private LDS panel (see the header)
             double *red = lds_acc + ((a.n_params + 1) & ~1) + wave * RED_PANEL;
-            const int c0 = __builtin_amdgcn_readfirstlane(c);
-            const int im0 = __builtin_amdgcn_readfirstlane(im);
-            const bool cam_uni = __all(!valid || c == c0);
-            const bool img_uni = (CHAIN != CHAIN_FREE) && __all(!valid || im == im0);
-            if (cam_uni) {
+            // The tile's (camera, image) pairs: the first lane's (A) and the last lane's (B).  A tile of the reference's table order lies
+            // inside one run (A = B) or across one boundary, the lanes of A first.  Every lane parks its contributions in the panel; the 63
+            // summing lanes split what they add up by pair (rows below n_a: pair A) and send each part to its pair's entries.  (Until round
+            // 5 a straddling tile — four in ten on rig-32 — added lane by lane: 21 x 64 LDS atomics on a handful of addresses;
+            // SQ_LDS_BANK_CONFLICT was as large as SQ_ACTIVE_INST_LDS, profiles/r05/matfree_jtjv_sq_b.json.)  Other tiles: lane by lane.
+            const int ca = __builtin_amdgcn_readfirstlane(c), ima = __builtin_amdgcn_readfirstlane(im);
+            const int cb = __builtin_amdgcn_readlane(c, 63), imb = __builtin_amdgcn_readlane(im, 63);
+            const bool in_a = c == ca && im == ima;
+            const uint64_t mask_a = __ballot(in_a);
+            const int n_a = __builtin_popcountll(mask_a);
+            const bool two_pair = __all(in_a || (c == cb && im == imb)) && mask_a == (n_a == 64 ? ~0ull : (1ull << n_a) - 1ull);
+            constexpr int NRED = (CHAIN != CHAIN_FREE) ? RED_COLS : 15;   // columns summed over the tile: camera (+ pose)
+            if (two_pair) {
 #pragma unroll
-                for (int j = 0; j < 15; ++j) red[j * RED_STRIDE + lane] = valid ? g[j] : 0.0;
-            } else if (valid) {
+                for (int j = 0; j < NRED; ++j) red[j * RED_STRIDE + lane] = valid ? g[j] : 0.0;
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                asm volatile("" ::: "memory");
+                {
+                    const int col = lane % RED_COLS, grp = lane / RED_COLS;  // lane 63: grp 3 -> idle
+                    if (grp < 3 && col < NRED) {
+                        // 22 independent reads first, then the adds: as a plain loop hipcc emits read - wait - add
+                        // per row (22 exposed LDS latencies per tile).  Rows past 63 (third group) are clamped and masked.
+                        const int r0 = grp * 22;
+                        const double *colp = red + col * RED_STRIDE;
+                        double vals[22];
+#pragma unroll
+                        for (int t = 0; t < 22; ++t) vals[t] = colp[min(r0 + t, 63)];
+                        asm volatile("" ::: "memory");
+                        double sum_a = 0.0, sum_b = 0.0;
+#pragma unroll
+                        for (int t = 0; t < 22; ++t) {
+                            const double x = (r0 + t < 64) ? vals[t] : 0.0;
+                            sum_a += (r0 + t < n_a) ? x : 0.0;
+                            sum_b += (r0 + t < n_a) ? 0.0 : x;
+                        }
+                        const int64_t dst_a = col < 9 ? 9 * (int64_t)ca + col : col < 15 ? a.extr_off + 6 * (int64_t)ca + (col - 9) : a.pose_off + 6 * (int64_t)ima + (col - 15);
+                        const int64_t dst_b = col < 9 ? 9 * (int64_t)cb + col : col < 15 ? a.extr_off + 6 * (int64_t)cb + (col - 9) : a.pose_off + 6 * (int64_t)imb + (col - 15);
+                        if (r0 < n_a) unsafeAtomicAdd(lds_acc + dst_a, sum_a);
+                        if (r0 + 22 > n_a && n_a < 64) unsafeAtomicAdd(lds_acc + dst_b, sum_b);
+                    }
+                }
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                asm volatile("" ::: "memory");
+            } else if (valid) {   // a third pair, or the pairs interleaved (not the reference's table order)
 #pragma unroll
                 for (int j = 0; j < 9; ++j) unsafeAtomicAdd(lds_acc + cI + j, g[j]);
 #pragma unroll
                 for (int j = 0; j < 6; ++j) unsafeAtomicAdd(lds_acc + cE + j, g[9 + j]);
-            }
-            if constexpr (CHAIN != CHAIN_FREE) {
-                if (img_uni) {
-#pragma unroll
-                    for (int j = 15; j < 21; ++j) red[j * RED_STRIDE + lane] = valid ? g[j] : 0.0;
-                } else if (valid) {
+                if constexpr (CHAIN != CHAIN_FREE) {
 #pragma unroll
                     for (int j = 0; j < 6; ++j) unsafeAtomicAdd(lds_acc + cP + j, g[15 + j]);
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            {
-                const int col = lane % RED_COLS, grp = lane / RED_COLS;  // lane 63: grp 3 -> idle
-                const bool is_cam = col < 15;
-                if (grp < 3 && (is_cam ? cam_uni : img_uni)) {
-                    // 22 independent reads first, then the adds: as a plain loop hipcc emits read - wait - add
-                    // per row (22 exposed LDS latencies per tile).  Rows past 63 (third group) are clamped and masked.
-                    const int r0 = grp * 22;
-                    const double *colp = red + col * RED_STRIDE;
-                    double vals[22];
-#pragma unroll
-                    for (int t = 0; t < 22; ++t) vals[t] = colp[min(r0 + t, 63)];
-                    asm volatile("" ::: "memory");
-                    double sum = 0.0;
-#pragma unroll
-                    for (int t = 0; t < 22; ++t) sum += (r0 + t < 64) ? vals[t] : 0.0;
-                    const int64_t dst = col < 9 ? 9 * (int64_t)c0 + col
-                                      : is_cam  ? a.extr_off + 6 * (int64_t)c0 + (col - 9)
-                                                : a.pose_off + 6 * (int64_t)im0 + (col - 15);
-                    unsafeAtomicAdd(lds_acc + dst, sum);
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             if constexpr (CHAIN != CHAIN_TEMPLATE) {
                 constexpr int o = (CHAIN == CHAIN_SELF) ? 21 : 15;
                 if (valid) {
