@@ -253,11 +253,16 @@ __global__ __launch_bounds__(256) void ba_matfree_kernel(const MatfreeArgs a) {
                         for (int t = 0; t < 22; ++t) vals[t] = colp[min(r0 + t, 63)];
                         asm volatile("" ::: "memory");
                         double sum_a = 0.0, sum_b = 0.0;
+                        if (n_a == 64) {   // one pair (wave-uniform): a plain sum
 #pragma unroll
-                        for (int t = 0; t < 22; ++t) {
-                            const double x = (r0 + t < 64) ? vals[t] : 0.0;
-                            sum_a += (r0 + t < n_a) ? x : 0.0;
-                            sum_b += (r0 + t < n_a) ? 0.0 : x;
+                            for (int t = 0; t < 22; ++t) sum_a += (r0 + t < 64) ? vals[t] : 0.0;
+                        } else {
+#pragma unroll
+                            for (int t = 0; t < 22; ++t) {
+                                const double x = (r0 + t < 64) ? vals[t] : 0.0;
+                                sum_a += (r0 + t < n_a) ? x : 0.0;
+                                sum_b += (r0 + t < n_a) ? 0.0 : x;
+                            }
                         }
                         const int64_t dst_a = col < 9 ? 9 * (int64_t)ca + col : col < 15 ? a.extr_off + 6 * (int64_t)ca + (col - 9) : a.pose_off + 6 * (int64_t)ima + (col - 15);
                         const int64_t dst_b = col < 9 ? 9 * (int64_t)cb + col : col < 15 ? a.extr_off + 6 * (int64_t)cb + (col - 9) : a.pose_off + 6 * (int64_t)imb + (col - 15);
